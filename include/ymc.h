@@ -1,0 +1,220 @@
+/*
+ * ymc.h -- C ABI of the MI355X chain-ensemble library (libymc.so).
+ *
+ * The reference (rkutri/yagre-mcmc) has no FFI: its hot path is the Python
+ * loop MetropolisHastings.run (yagremcmc/chain/metropolisHastings.py:103-120)
+ * over plug-in objects.  This header is the boundary a binding for that path
+ * targets: plain pointers and sizes, opaque handles, int status codes, no
+ * exceptions, no callbacks into the caller.  Each entry point names the
+ * reference interface it stands in for.  The shipped binding is ctypes
+ * (yagre-mcmc_amd/_ffi.py); INTEGRATION.md shows the stub a maintainer of the
+ * reference would add.
+ *
+ * Ownership: the caller owns every host buffer; the library owns all device
+ * memory.  Handles are not thread-safe; one host thread drives one context.
+ * All functions return YMC_OK (0) or a negative ymc_status;
+ * ymc_last_error() gives the message of the calling thread's last failure.
+ */
+#ifndef YMC_H
+#define YMC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YMC_ABI_VERSION 1
+
+typedef enum ymc_status {
+    YMC_OK = 0,
+    YMC_ERR_INVALID = -1,      /* bad argument / inconsistent description (ValueError in the reference's builders, builder.py:44-50) */
+    YMC_ERR_DEVICE = -2,       /* HIP runtime error */
+    YMC_ERR_UNSUPPORTED = -3,  /* a plug-in combination that has no device lowering */
+    YMC_ERR_CAPACITY = -4,     /* record buffers full */
+    YMC_ERR_COMM = -5          /* RCCL error */
+} ymc_status;
+
+/* ---- densities: lowered forms of DensityInterface.evaluate_log ---------
+ * (yagremcmc/statistics/interface.py:6-10) */
+typedef enum ymc_density_kind {
+    /* GaussianTargetDensity2d (test/testSetup.py:32-40), any dim <= 8:
+     * -0.5 * (log_norm + |(x - mean) whiten|^2) */
+    YMC_DENSITY_GAUSS_WHITENED = 1,
+    /* GaussianTargetDensity1d (test/testSetup.py:15-25): -0.5 (mean-x)^2 / variance */
+    YMC_DENSITY_GAUSS_ISO1D = 2,
+    /* UnnormalisedPosterior (chain/target.py:19-22) of an
+     * AdditiveGaussianNoiseLikelihood (statistics/likelihood.py:49-87) over
+     * ExampleLinearModelSolver (exampleSetup.py:42-47) and a Gaussian prior
+     * (statistics/gaussian.py:19-24); diagonal covariances */
+    YMC_DENSITY_POSTERIOR_LINEAR = 3,
+    /* the same over LotkaVolterraSolver (test/testSetup.py:61-141) with the
+     * ODE integrated by fixed-step RK4 */
+    YMC_DENSITY_POSTERIOR_LV = 4
+} ymc_density_kind;
+
+typedef struct ymc_density_desc {
+    int32_t kind;                  /* ymc_density_kind */
+    int32_t dim;                   /* parameter dimension d */
+    const double *mean;            /* GAUSS_*: [d] */
+    const double *whiten;          /* GAUSS_WHITENED: [d][d] row-major */
+    double log_norm;               /* GAUSS_WHITENED: rank*log(2 pi) + log pdet */
+    double variance;               /* GAUSS_ISO1D */
+    int32_t n_data;                /* POSTERIOR_*: rows of Data.array (statistics/data.py:4-23) */
+    int32_t data_dim;              /* POSTERIOR_*: columns */
+    const double *data;            /* [n_data][data_dim] */
+    const double *noise_precision; /* [data_dim]   (covariance.py:36-37) */
+    const double *prior_mean;      /* [d] */
+    const double *prior_precision; /* [d] */
+    const double *fwd_matrix;      /* POSTERIOR_LINEAR: A [data_dim][d] */
+    const double *fwd_shift;       /* POSTERIOR_LINEAR: b [data_dim] */
+    const double *design;          /* POSTERIOR_LV: [n_data][2] initial conditions */
+    double t_final;                /* POSTERIOR_LV */
+    double alpha;
+    double gamma;
+    int32_t rk4_steps;
+    int32_t reserved_;
+} ymc_density_desc;
+
+typedef enum ymc_method {
+    YMC_METHOD_MRW = 1,   /* MetropolisedRandomWalk, chain/method/mrw.py:41-57 */
+    YMC_METHOD_MLDA2 = 2  /* MLDA with one surrogate, chain/method/mlda.py:100-110,146-154 */
+} ymc_method;
+
+typedef enum ymc_state_eq {
+    YMC_EQ_EXACT = 0,   /* ParameterVector.__eq__, parameter/vector.py:37-45 */
+    YMC_EQ_ISCLOSE = 1  /* ScalarParameter.__eq__,  parameter/scalar.py:39-44 */
+} ymc_state_eq;
+
+/* What MRWBuilder / MLDABuilder.build_method() assemble (mrw.py:60-91,
+ * mlda.py:157-344), lowered to numbers. */
+typedef struct ymc_problem_desc {
+    int32_t method;                /* ymc_method */
+    int32_t state_eq;              /* ymc_state_eq */
+    ymc_density_desc target;       /* the (fine) target density */
+    ymc_density_desc surrogate;    /* MLDA2: the coarse density (same kind and dim) */
+    int32_t sub_chain_length;      /* MLDA2: subChainLengths[0] */
+    int32_t reserved_;
+    const double *proposal_sigma;  /* [d]: sqrt(reciprocal(precision)) of the proposal covariance (covariance.py:51-52) */
+} ymc_problem_desc;
+
+/* record_flags */
+#define YMC_RECORD_TRAJECTORY 1u  /* Chain.append, chain/chain.py:17-18 */
+#define YMC_RECORD_ACCEPT 2u      /* AcceptanceRateDiagnostics.process, chain/diagnostics.py:48-54 */
+#define YMC_RECORD_LOGPOST 4u     /* log-density of every recorded state (parity checks) */
+#define YMC_RECORD_SUB_ACCEPT 8u  /* MLDA2: outcomes of the coarse sub-steps */
+#define YMC_RECORD_MOMENTS 16u    /* FullDiagnostics' Welford accumulator, chain/diagnostics.py:91-94 */
+
+/* per-chain status bits */
+#define YMC_CHAIN_NONFINITE 1u    /* a proposal's log-density was not finite; it was rejected */
+
+/* MetropolisHastings.run(chainLength, initialState) for n_chains chains
+ * (metropolisHastings.py:103-110): chain k of this run is GLOBAL chain
+ * chain_offset + k of the ensemble and draws from that id's stream. */
+typedef struct ymc_run_desc {
+    uint64_t seed;
+    uint64_t chain_offset;
+    uint64_t n_chains;
+    const double *initial_state;   /* [x0_rows][d] */
+    uint64_t x0_rows;              /* 1 (broadcast) or n_chains */
+    uint64_t record_capacity;      /* transitions the record buffers hold */
+    uint32_t record_flags;
+    uint32_t reserved_;
+} ymc_run_desc;
+
+typedef struct ymc_device_info {
+    char name[128];
+    char arch[64];
+    int32_t compute_units;
+    int32_t clock_mhz;
+    uint64_t hbm_bytes;
+} ymc_device_info;
+
+typedef struct ymc_ctx ymc_ctx;
+typedef struct ymc_problem ymc_problem;
+typedef struct ymc_run ymc_run;
+typedef struct ymc_comm ymc_comm;
+
+int ymc_abi_version(void);
+const char *ymc_last_error(void);
+int ymc_device_count(int *count);
+
+int ymc_ctx_create(int device, ymc_ctx **out);
+int ymc_ctx_destroy(ymc_ctx *ctx);
+int ymc_ctx_device_info(const ymc_ctx *ctx, ymc_device_info *out);
+
+/* ChainBuilder.build_method(), chain/builder.py:72-83 */
+int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem **out);
+int ymc_problem_destroy(ymc_problem *problem);
+
+/* MetropolisHastings.run, entry part (:103-110): stores the initial states as
+ * record row 0 is NOT done -- the record holds the state AFTER each
+ * transition; the caller keeps x0. */
+int ymc_run_create(ymc_ctx *ctx, const ymc_problem *problem, const ymc_run_desc *desc, ymc_run **out);
+int ymc_run_destroy(ymc_run *run);
+
+/* The hot loop, metropolisHastings.py:112-120: `nsteps` more transitions of
+ * every chain (MLDA2: fine steps).  Asynchronous on the run's stream. */
+int ymc_run_advance(ymc_run *run, uint64_t nsteps);
+int ymc_run_sync(ymc_run *run);
+/* average device time of the advance kernel launches since the last call, by
+ * HIP events on the run's stream; resets the accumulator */
+int ymc_run_kernel_time_ms(ymc_run *run, double *avg_ms, uint64_t *launches);
+/* forget recorded rows (chain state is kept), so the buffers can be refilled */
+int ymc_run_rewind_record(ymc_run *run);
+int ymc_run_steps_done(const ymc_run *run, uint64_t *total, uint64_t *recorded);
+
+/* Chain.trajectory (chain/chain.py:9-11): rows [first, first+n) of the record,
+ * dst[n][n_chains][d] */
+int ymc_run_fetch_trajectory(ymc_run *run, uint64_t first, uint64_t n, double *dst, size_t dst_bytes);
+/* AcceptanceRateDiagnostics._decisions (chain/diagnostics.py:22): dst[n][n_chains] */
+int ymc_run_fetch_accept(ymc_run *run, uint64_t first, uint64_t n, uint8_t *dst, size_t dst_bytes);
+int ymc_run_fetch_logpost(ymc_run *run, uint64_t first, uint64_t n, double *dst, size_t dst_bytes);
+/* dst[n][sub_chain_length][n_chains] */
+int ymc_run_fetch_sub_accept(ymc_run *run, uint64_t first, uint64_t n, uint8_t *dst, size_t dst_bytes);
+/* current state [n_chains][d] and its log-density [n_chains] (either may be NULL) */
+int ymc_run_fetch_state(ymc_run *run, double *state, double *logpost);
+/* per-chain summary: accepted transitions, Welford n / mean / M2
+ * (statistics/estimation.py:4-58), status bits; any pointer may be NULL */
+int ymc_run_fetch_summary(ymc_run *run, uint64_t *accepted, uint64_t *wf_n, double *wf_mean,
+                          double *wf_m2, uint32_t *status);
+
+/* DensityInterface.evaluate_log for a batch: which = 0 target, 1 surrogate.
+ * x[n][d] -> out[n], status[n] (may be NULL) */
+int ymc_logdensity_eval(ymc_ctx *ctx, const ymc_problem *problem, int which, uint64_t n,
+                        const double *x, double *out, uint32_t *status);
+/* ForwardModel.evaluate (model/forwardModel.py:10-19) for a batch:
+ * x[n][d] -> out[n][m], m = data_dim (linear) or 2*n_data (Lotka-Volterra) */
+int ymc_forward_eval(ymc_ctx *ctx, const ymc_problem *problem, int which, uint64_t n,
+                     const double *x, double *out);
+
+/* parity hooks: the device's draws and elementary functions, bit-for-bit
+ * comparable with the CPU build of csrc/ymc_numerics.h.
+ * xi[nt][K][d], u[nt][K]; fn: 0 log, 1 exp, 2 sincospi (y0 = sin, y1 = cos),
+ * 3 sqrt, 4 x / y1_in (y1 holds the divisor on entry) */
+int ymc_rng_fill(ymc_ctx *ctx, uint64_t seed, uint64_t chain0, uint64_t K, uint64_t t0, uint64_t nt,
+                 int32_t d, double *xi, double *u);
+int ymc_numerics_eval(ymc_ctx *ctx, int fn, uint64_t n, const double *x, double *y0, double *y1);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI --------------------
+ * The ensemble shards by contiguous blocks of global chain ids; nothing is
+ * exchanged while sampling.  The single collective is the gather of the
+ * per-chain summaries at the end. */
+#define YMC_UNIQUE_ID_BYTES 128
+int ymc_comm_unique_id(void *id, size_t id_bytes);
+int ymc_comm_create(ymc_ctx *ctx, const void *id, size_t id_bytes, int nranks, int rank, ymc_comm **out);
+int ymc_comm_destroy(ymc_comm *comm);
+int ymc_comm_barrier(ymc_comm *comm);
+int ymc_comm_allreduce_max(ymc_comm *comm, double *value);
+/* words per chain of a packed summary record: 3*d + 5 (state, logpost,
+ * accepted, wf_n, wf_mean, wf_m2, status), all 8-byte words */
+int ymc_summary_words(const ymc_run *run, uint64_t *words);
+/* ncclAllGather of the packed summaries of `run` (every rank passes the same
+ * n_chains); dst[nranks][n_chains][words] on every rank */
+int ymc_comm_allgather_summary(ymc_comm *comm, ymc_run *run, uint64_t *dst, size_t dst_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YMC_H */

@@ -1,0 +1,274 @@
+"""ctypes front end of the CPU checker (oracle/ymc_oracle.c).
+
+TEST INFRASTRUCTURE: only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg import this module.  The product (yagre-mcmc_amd/) never
+does; its MH path fails loudly when the HIP library is missing.
+
+A "problem" here is a plain dict (see `gauss_whitened`, `gauss_iso1d`,
+`posterior_linear`, `posterior_lv`), deliberately independent of the product's
+ctypes structures.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libymc_oracle.so")
+
+GAUSS_WHITENED, GAUSS_ISO1D, POST_LINEAR, POST_LV = 1, 2, 3, 4
+EQ_EXACT, EQ_ISCLOSE = 0, 1
+STATUS_NONFINITE = 1
+
+_dp = C.POINTER(C.c_double)
+
+
+class _Density(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("dim", C.c_int32),
+        ("mean", _dp), ("whiten", _dp), ("log_norm", C.c_double),
+        ("variance", C.c_double),
+        ("n_data", C.c_int32), ("data_dim", C.c_int32),
+        ("data", _dp), ("noise_precision", _dp), ("prior_mean", _dp), ("prior_precision", _dp),
+        ("fwd_matrix", _dp), ("fwd_shift", _dp),
+        ("design", _dp), ("t_final", C.c_double), ("alpha", C.c_double), ("gamma", C.c_double),
+        ("rk4_steps", C.c_int32),
+    ]
+
+
+def build(force=False):
+    """Compile oracle/libymc_oracle.so with gcc (recipe: oracle/Makefile)."""
+    if force and os.path.exists(_LIB_PATH):
+        os.remove(_LIB_PATH)
+    subprocess.check_call(["make", "-s", "-C", _HERE, "libymc_oracle.so"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.ymo_max_threads.restype = C.c_int32
+        _lib.ymo_forward.restype = C.c_int
+    return _lib
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def _vp(a):
+    return C.c_void_p(a.ctypes.data) if a is not None else None
+
+
+# ---------------------------------------------------------------------------
+# problem dictionaries
+# ---------------------------------------------------------------------------
+
+def gauss_whitened(mean, whiten, log_norm):
+    mean = _f64(mean).reshape(-1)
+    return dict(kind=GAUSS_WHITENED, dim=mean.size, mean=mean,
+                whiten=_f64(whiten).reshape(mean.size, mean.size), log_norm=float(log_norm))
+
+
+def gauss_from_cov(mean, cov):
+    """Whitening data of scipy.stats.multivariate_normal(mean, cov) the way
+    scipy's CovViaPSD forms it (eigh; U = V / sqrt(w); log_pdet = sum log w)."""
+    mean = _f64(mean).reshape(-1)
+    cov = _f64(cov).reshape(mean.size, mean.size)
+    w, v = np.linalg.eigh(cov)
+    whiten = v * np.sqrt(1.0 / w)
+    log_norm = mean.size * np.log(2.0 * np.pi) + np.sum(np.log(w))
+    return gauss_whitened(mean, whiten, log_norm)
+
+
+def gauss_iso1d(mean, variance):
+    return dict(kind=GAUSS_ISO1D, dim=1, mean=_f64([mean]).reshape(-1), variance=float(variance))
+
+
+def _posterior_common(kind, dim, data, noise_precision, prior_mean, prior_precision):
+    data = _f64(data)
+    assert data.ndim == 2
+    return dict(kind=kind, dim=int(dim), data=data, n_data=data.shape[0], data_dim=data.shape[1],
+                noise_precision=_f64(noise_precision).reshape(-1),
+                prior_mean=_f64(prior_mean).reshape(-1),
+                prior_precision=_f64(prior_precision).reshape(-1))
+
+
+def posterior_linear(A, b, data, noise_precision, prior_mean, prior_precision):
+    A = _f64(A)
+    p = _posterior_common(POST_LINEAR, A.shape[1], data, noise_precision, prior_mean, prior_precision)
+    assert A.shape[0] == p["data_dim"]
+    p.update(fwd_matrix=A, fwd_shift=_f64(b).reshape(-1))
+    return p
+
+
+def posterior_lv(design, t_final, alpha, gamma, rk4_steps, data, noise_precision, prior_mean,
+                 prior_precision):
+    design = _f64(design)
+    p = _posterior_common(POST_LV, 2, data, noise_precision, prior_mean, prior_precision)
+    assert design.shape == (p["n_data"], 2) and p["data_dim"] == 2
+    p.update(design=design, t_final=float(t_final), alpha=float(alpha), gamma=float(gamma),
+             rk4_steps=int(rk4_steps))
+    return p
+
+
+def _lower(p):
+    """dict -> (_Density, keepalive)"""
+    d = _Density()
+    d.kind, d.dim = p["kind"], p["dim"]
+    keep = []
+    for name in ("mean", "whiten", "data", "noise_precision", "prior_mean", "prior_precision",
+                 "fwd_matrix", "fwd_shift", "design"):
+        if name in p:
+            arr = _f64(p[name])
+            keep.append(arr)
+            setattr(d, name, _ptr(arr))
+    for name in ("log_norm", "variance", "t_final", "alpha", "gamma"):
+        if name in p:
+            setattr(d, name, p[name])
+    for name in ("n_data", "data_dim", "rk4_steps"):
+        if name in p:
+            setattr(d, name, p[name])
+    return d, keep
+
+
+# ---------------------------------------------------------------------------
+# numeric-spec hooks
+# ---------------------------------------------------------------------------
+
+def philox(ctr, key):
+    c = np.asarray(ctr, dtype=np.uint32)
+    k = np.asarray(key, dtype=np.uint32)
+    out = np.zeros(4, dtype=np.uint32)
+    lib().ymo_philox(_vp(c), _vp(k), _vp(out))
+    return out
+
+
+def _vec1(fn, x):
+    x = _f64(x).reshape(-1)
+    y = np.empty_like(x)
+    fn(C.c_int64(x.size), _ptr(x), _ptr(y))
+    return y
+
+
+def log(x):
+    return _vec1(lib().ymo_log_v, x)
+
+
+def exp(x):
+    return _vec1(lib().ymo_exp_v, x)
+
+
+def sincospi(x):
+    x = _f64(x).reshape(-1)
+    s, c = np.empty_like(x), np.empty_like(x)
+    lib().ymo_sincospi_v(C.c_int64(x.size), _ptr(x), _ptr(s), _ptr(c))
+    return s, c
+
+
+def rng_fill(seed, chain0, K, t0, nt, d, normals=True, uniforms=True):
+    """xi[nt][K][d], u[nt][K] -- the draws of chains chain0..chain0+K-1."""
+    xi = np.empty((nt, K, d)) if normals else None
+    u = np.empty((nt, K)) if uniforms else None
+    lib().ymo_rng_fill(C.c_uint64(seed), C.c_uint64(chain0), C.c_int64(K), C.c_uint64(t0),
+                       C.c_int64(nt), C.c_int32(d), _ptr(xi), _ptr(u))
+    return xi, u
+
+
+# ---------------------------------------------------------------------------
+# densities
+# ---------------------------------------------------------------------------
+
+def logdensity(problem, x):
+    d, keep = _lower(problem)
+    x = _f64(x).reshape(-1, problem["dim"])
+    out = np.empty(x.shape[0])
+    status = np.zeros(x.shape[0], dtype=np.uint32)
+    lib().ymo_logdensity(C.byref(d), C.c_int64(x.shape[0]), _ptr(x), _ptr(out), _vp(status))
+    return out, status
+
+
+def forward(problem, x):
+    d, keep = _lower(problem)
+    x = _f64(x).reshape(-1, problem["dim"])
+    m = problem["n_data"] * 2 if problem["kind"] == POST_LV else problem["data_dim"]
+    out = np.empty((x.shape[0], m))
+    bad = lib().ymo_forward(C.byref(d), C.c_int64(x.shape[0]), _ptr(x), _ptr(out))
+    if bad < 0:
+        raise ValueError("problem has no forward map")
+    return out
+
+
+# ---------------------------------------------------------------------------
+# chain ensembles
+# ---------------------------------------------------------------------------
+
+class Ensemble:
+    """K chains advanced by the oracle; mirrors the state a device run carries."""
+
+    def __init__(self, target, sigma, x0, seed, chain0=0, eq_mode=EQ_EXACT, surrogate=None,
+                 sub_chain_length=0, nthreads=1):
+        self.target, self.surrogate = target, surrogate
+        self.S = int(sub_chain_length)
+        self.d = target["dim"]
+        x0 = _f64(x0)
+        if x0.ndim == 1:
+            x0 = x0.reshape(1, -1)
+        self.K = x0.shape[0]
+        self.x = x0.copy()
+        self.sigma = _f64(sigma).reshape(-1)
+        assert self.sigma.size == self.d and x0.shape[1] == self.d
+        self.seed, self.chain0, self.eq_mode = int(seed), int(chain0), int(eq_mode)
+        self.nthreads = int(nthreads)
+        self.t = 0  # MRW: transitions done; MLDA2: fine steps done
+        self.lp, self.status0 = logdensity(target, self.x)
+        self.lpc = logdensity(surrogate, self.x)[0] if surrogate is not None else None
+        self.acc_count = np.zeros(self.K, dtype=np.uint64)
+        self.wf_n = np.zeros(self.K, dtype=np.uint64)
+        self.wf_mean = np.zeros((self.K, self.d))
+        self.wf_m2 = np.zeros((self.K, self.d))
+        self.status = np.zeros(self.K, dtype=np.uint32)
+
+    def advance(self, nsteps, record=True, want_margin=False, want_sub=False):
+        K, d = self.K, self.d
+        traj = np.empty((nsteps, K, d)) if record else None
+        acc = np.empty((nsteps, K), dtype=np.uint8) if record else None
+        lp_out = np.empty((nsteps, K)) if record else None
+        margin = np.empty((nsteps, K)) if want_margin else None
+        tgt, keep = _lower(self.target)
+        out = dict(traj=traj, acc=acc, logpost=lp_out, margin=margin)
+        if self.surrogate is None:
+            lib().ymo_mrw_advance(
+                C.byref(tgt), _ptr(self.sigma), C.c_int32(self.eq_mode), C.c_uint64(self.seed),
+                C.c_uint64(self.chain0), C.c_int64(K), C.c_uint64(self.t), C.c_int64(nsteps),
+                _ptr(self.x), _ptr(self.lp), _vp(self.acc_count), _vp(self.wf_n),
+                _ptr(self.wf_mean), _ptr(self.wf_m2), _vp(self.status), _ptr(traj), _vp(acc),
+                _ptr(lp_out), _ptr(margin), C.c_int32(self.nthreads))
+        else:
+            sur, keep2 = _lower(self.surrogate)
+            sub = np.empty((nsteps, self.S, K), dtype=np.uint8) if want_sub else None
+            out["sub_acc"] = sub
+            lib().ymo_mlda2_advance(
+                C.byref(tgt), C.byref(sur), _ptr(self.sigma), C.c_int32(self.S),
+                C.c_int32(self.eq_mode), C.c_uint64(self.seed), C.c_uint64(self.chain0),
+                C.c_int64(K), C.c_uint64(self.t), C.c_int64(nsteps), _ptr(self.x), _ptr(self.lp),
+                _ptr(self.lpc), _vp(self.acc_count), _vp(self.wf_n), _ptr(self.wf_mean),
+                _ptr(self.wf_m2), _vp(self.status), _ptr(traj), _vp(acc), _vp(sub), _ptr(lp_out),
+                _ptr(margin), C.c_int32(self.nthreads))
+        self.t += nsteps
+        return out
+
+
+def max_threads():
+    return int(lib().ymo_max_threads())

@@ -1,0 +1,518 @@
+/*
+ * ymc_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A plain-C, one-chain-at-a-time restatement of the reference's
+ * Metropolis-Hastings hot path (rkutri/yagre-mcmc @ 2025-01-03), used only as
+ * the checker for the HIP kernels: tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it; nothing under yagre-mcmc_amd/
+ * does.  Every function cites the reference file:line it follows.
+ *
+ * Parity status: PINNED.  tests/golden/make_golden.py imports the reference
+ * in the build container, replays this file's random draws into the
+ * unmodified reference classes and stores the reference's trajectories,
+ * accept decisions and log-densities as .npz files under tests/golden/;
+ * tests/test_oracle_golden.py checks this restatement against them (masks and
+ * trajectories bit-exact, log-densities <= 1e-12 relative).
+ *
+ * Arithmetic: IEEE binary64, compiled with -ffp-contract=off; random draws
+ * and elementary functions come from yagre-mcmc_amd/csrc/ymc_numerics.h (the
+ * numeric specification shared with the device code, itself pinned against
+ * libm/mpmath and the Random123 known-answer vectors in
+ * tests/test_numerics.py), so the GPU path can be compared bit-for-bit.
+ *
+ * The one deliberate deviation from the reference is documented at
+ * ymo_accept(): a non-finite proposal log-density is rejected and flagged
+ * instead of being accepted through the reference's NaN hole (mrw.py:57).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../yagre-mcmc_amd/csrc/ymc_numerics.h"
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define YMO_DMAX 256  /* largest parameter dimension the oracle handles */
+#define YMO_MMAX 256  /* largest forward-map output dimension */
+
+enum {
+    YMO_GAUSS_WHITENED = 1, /* testSetup.py:32-40  GaussianTargetDensity2d (any d) */
+    YMO_GAUSS_ISO1D = 2,    /* testSetup.py:15-25  GaussianTargetDensity1d */
+    YMO_POST_LINEAR = 3,    /* target.py:19-22 over exampleSetup.py:42-47 */
+    YMO_POST_LV = 4         /* target.py:19-22 over testSetup.py:96-141 (RK4 in place of solve_ivp) */
+};
+
+enum { YMO_EQ_EXACT = 0, YMO_EQ_ISCLOSE = 1 };
+
+enum { YMO_STATUS_NONFINITE = 1 };
+
+typedef struct ymo_density {
+    int32_t kind;
+    int32_t dim;
+    /* GAUSS_WHITENED: logpi = -0.5 * (log_norm + |(x-mean) U|^2), U = whiten (dim x dim, row-major) */
+    const double *mean;
+    const double *whiten;
+    double log_norm;
+    /* GAUSS_ISO1D */
+    double variance;
+    /* POST_*: Gaussian-noise likelihood + Gaussian prior, diagonal covariances */
+    int32_t n_data;
+    int32_t data_dim;
+    const double *data;            /* n_data x data_dim, row-major (data.py:4-23) */
+    const double *noise_precision; /* data_dim (covariance.py:36-37) */
+    const double *prior_mean;      /* dim */
+    const double *prior_precision; /* dim */
+    /* POST_LINEAR: G(theta) = A theta + b */
+    const double *fwd_matrix;      /* data_dim x dim, row-major */
+    const double *fwd_shift;       /* data_dim */
+    /* POST_LV */
+    const double *design;          /* n_data x 2 initial conditions */
+    double t_final, alpha, gamma;
+    int32_t rk4_steps;
+} ymo_density;
+
+/* ---------------------------------------------------------------------- */
+/* numeric-spec hooks (so tests can pin ymc_numerics.h against libm etc.)   */
+/* ---------------------------------------------------------------------- */
+
+void ymo_philox(const uint32_t *ctr, const uint32_t *key, uint32_t *out)
+{
+    ymc_u32x4 b = ymc_philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
+    memcpy(out, b.v, sizeof b.v);
+}
+
+void ymo_log_v(int64_t n, const double *x, double *y)
+{
+    for (int64_t i = 0; i < n; ++i) y[i] = ymc_log(x[i]);
+}
+
+void ymo_exp_v(int64_t n, const double *x, double *y)
+{
+    for (int64_t i = 0; i < n; ++i) y[i] = ymc_exp(x[i]);
+}
+
+void ymo_sincospi_v(int64_t n, const double *x, double *s, double *c)
+{
+    for (int64_t i = 0; i < n; ++i) ymc_sincospi(x[i], &s[i], &c[i]);
+}
+
+/*
+ * The draws chain `chain0 + k` consumes in transitions t0 .. t0+nt-1:
+ *   xi[t][k][0..d-1]  replaces standard_normal(d)      (gaussian.py:63)
+ *   u[t][k]           replaces uniform(0,1,size=1)[0]  (metropolisHastings.py:68)
+ */
+void ymo_rng_fill(uint64_t seed, uint64_t chain0, int64_t K, uint64_t t0, int64_t nt, int32_t d,
+                  double *xi, double *u)
+{
+    for (int64_t t = 0; t < nt; ++t) {
+        for (int64_t k = 0; k < K; ++k) {
+            uint32_t chain = (uint32_t)(chain0 + (uint64_t)k);
+            if (u) u[t * K + k] = ymc_draw_uniform(seed, chain, t0 + (uint64_t)t);
+            if (xi) {
+                double *row = xi + (t * K + k) * (int64_t)d;
+                for (int32_t j = 0; 2 * j < d; ++j) {
+                    double z0, z1;
+                    ymc_draw_normal_pair(seed, chain, t0 + (uint64_t)t, (uint32_t)j, &z0, &z1);
+                    row[2 * j] = z0;
+                    if (2 * j + 1 < d) row[2 * j + 1] = z1;
+                }
+            }
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------- */
+/* densities                                                              */
+/* ---------------------------------------------------------------------- */
+
+/* CovarianceMatrix.induced_norm_squared with a diagonal precision:
+ * covariance.py:19-22 (np.dot(x, Px)) and :54-55 (Px = precision * x). */
+static double ymo_diag_norm_sq(const double *x, const double *prec, int32_t n)
+{
+    double acc = 0.0;
+    for (int32_t j = 0; j < n; ++j) {
+        double px = prec[j] * x[j];
+        acc = acc + x[j] * px;
+    }
+    return acc;
+}
+
+/* GaussianDensity.evaluate_log, gaussian.py:19-24: -0.5 |x - mean|^2_{Sigma^-1},
+ * no normalising constant. */
+static double ymo_gaussian_prior_log(const ymo_density *p, const double *theta)
+{
+    double x[YMO_DMAX];
+    for (int32_t j = 0; j < p->dim; ++j) x[j] = theta[j] - p->prior_mean[j];
+    return -0.5 * ymo_diag_norm_sq(x, p->prior_precision, p->dim);
+}
+
+/* ExampleLinearModelSolver.invoke, exampleSetup.py:42-47: A @ theta + b.
+ * The dot product is a k-ordered fma chain (the canonical order of the
+ * ensemble; BLAS' own order is unspecified). */
+static void ymo_forward_linear(const ymo_density *p, const double *theta, double *F)
+{
+    for (int32_t m = 0; m < p->data_dim; ++m) {
+        const double *row = p->fwd_matrix + (int64_t)m * p->dim;
+        double acc = 0.0;
+        for (int32_t j = 0; j < p->dim; ++j) acc = ymc_fma(row[j], theta[j], acc);
+        F[m] = acc + p->fwd_shift[m];
+    }
+}
+
+/* LotkaVolterraSolver.flow__, testSetup.py:96-99 */
+static void ymo_lv_flow(double x, double y, double alpha, double beta, double gamma, double delta,
+                        double *dx, double *dy)
+{
+    *dx = alpha * x - beta * x * y;
+    *dy = delta * x * y - gamma * y;
+}
+
+/* LotkaVolterraParameter.evaluate (testSetup.py:56-58: exp of the coefficient)
+ * + LotkaVolterraSolver.interpolate/invoke (testSetup.py:101-141): one ODE
+ * solve per design row, final state only (:139).  The reference integrates
+ * with scipy's adaptive solve_ivp; the ensemble fixes classical RK4 with
+ * rk4_steps equal steps (BASELINE.json north_star), so this is the build's
+ * integrator, checked against the reference solver to ~1e-3 in
+ * tests/test_oracle_golden.py.  Returns 0 on success, 1 if any output is
+ * non-finite (EvaluationStatus.FAILURE, evaluation.py:4-9). */
+static int ymo_forward_lv(const ymo_density *p, const double *theta, double *F)
+{
+    double beta = ymc_exp(theta[0]);
+    double delta = ymc_exp(theta[1]);
+    double alpha = p->alpha, gamma = p->gamma;
+    double h = p->t_final / (double)p->rk4_steps;
+    double h2 = 0.5 * h;
+    double h6 = h / 6.0;
+    int bad = 0;
+    for (int32_t n = 0; n < p->n_data; ++n) {
+        double x = p->design[2 * n], y = p->design[2 * n + 1];
+        for (int32_t s = 0; s < p->rk4_steps; ++s) {
+            double k1x, k1y, k2x, k2y, k3x, k3y, k4x, k4y;
+            ymo_lv_flow(x, y, alpha, beta, gamma, delta, &k1x, &k1y);
+            ymo_lv_flow(x + h2 * k1x, y + h2 * k1y, alpha, beta, gamma, delta, &k2x, &k2y);
+            ymo_lv_flow(x + h2 * k2x, y + h2 * k2y, alpha, beta, gamma, delta, &k3x, &k3y);
+            ymo_lv_flow(x + h * k3x, y + h * k3y, alpha, beta, gamma, delta, &k4x, &k4y);
+            x = x + h6 * ((k1x + 2.0 * k2x) + (2.0 * k3x + k4x));
+            y = y + h6 * ((k1y + 2.0 * k2y) + (2.0 * k3y + k4y));
+        }
+        F[2 * n] = x;
+        F[2 * n + 1] = y;
+        if (!(fabs(x) <= 1.79769313486231570815e308) || !(fabs(y) <= 1.79769313486231570815e308))
+            bad = 1;
+    }
+    return bad;
+}
+
+/* AdditiveGaussianNoiseLikelihood.compute_log_likelihood, likelihood.py:77-84:
+ *   residual = fmEval - data.array          (:74-75, broadcast over rows)
+ *   per row   noise.induced_norm_squared    (:33-39, noise.py:21-22)
+ *   logL = -0.5 * sum(rows)                 (:80)
+ * F is (data_dim,) for the linear map (one evaluation, broadcast against every
+ * data row) and (n_data, data_dim) for Lotka-Volterra (row i pairs with D_i). */
+static double ymo_log_likelihood(const ymo_density *p, const double *F, int per_row_eval)
+{
+    double total = 0.0;
+    double r[YMO_MMAX];
+    for (int32_t i = 0; i < p->n_data; ++i) {
+        const double *Fi = per_row_eval ? F + (int64_t)i * p->data_dim : F;
+        const double *Di = p->data + (int64_t)i * p->data_dim;
+        for (int32_t j = 0; j < p->data_dim; ++j) r[j] = Fi[j] - Di[j];
+        total = total + ymo_diag_norm_sq(r, p->noise_precision, p->data_dim);
+    }
+    return -0.5 * total;
+}
+
+/* DensityInterface.evaluate_log (statistics/interface.py:6-10) for the lowered
+ * target kinds.  *status gets YMO_STATUS_NONFINITE or'ed in when the forward
+ * map fails; the value is then -inf. */
+static double ymo_logdensity_one(const ymo_density *p, const double *x, uint32_t *status)
+{
+    switch (p->kind) {
+    case YMO_GAUSS_WHITENED: {
+        /* GaussianTargetDensity2d.evaluate_log, testSetup.py:38-40 ->
+         * scipy.stats.multivariate_normal.logpdf:
+         *   dev = x - mean; maha = sum(square(dev @ U)); -0.5*(rank*log(2pi) + log_pdet + maha)
+         * with U the whitening matrix of scipy's CovViaPSD and
+         * log_norm = rank*log(2pi) + log_pdet precomputed on the host. */
+        double dev[YMO_DMAX];
+        int32_t d = p->dim;
+        for (int32_t i = 0; i < d; ++i) dev[i] = x[i] - p->mean[i];
+        double maha = 0.0;
+        for (int32_t j = 0; j < d; ++j) {
+            double w = dev[0] * p->whiten[j];
+            for (int32_t i = 1; i < d; ++i) w = w + dev[i] * p->whiten[(int64_t)i * d + j];
+            maha = (j == 0) ? w * w : maha + w * w;
+        }
+        return -0.5 * (p->log_norm + maha);
+    }
+    case YMO_GAUSS_ISO1D: {
+        /* GaussianTargetDensity1d.evaluate_log, testSetup.py:22-25:
+         *   -0.5 * square(mean - x) / var */
+        double t = p->mean[0] - x[0];
+        return (-0.5 * (t * t)) / p->variance;
+    }
+    case YMO_POST_LINEAR: {
+        /* UnnormalisedPosterior.evaluate_log, target.py:19-22: logL + log prior */
+        double F[YMO_MMAX];
+        ymo_forward_linear(p, x, F);
+        return ymo_log_likelihood(p, F, 0) + ymo_gaussian_prior_log(p, x);
+    }
+    case YMO_POST_LV: {
+        double F[YMO_MMAX];
+        if (ymo_forward_lv(p, x, F)) {
+            /* ForwardModel.evaluate raises on failure (forwardModel.py:15-19);
+             * per-chain equivalent: flag the chain, reject the proposal. */
+            if (status) *status |= YMO_STATUS_NONFINITE;
+            return -INFINITY;
+        }
+        return ymo_log_likelihood(p, F, 1) + ymo_gaussian_prior_log(p, x);
+    }
+    default:
+        if (status) *status |= YMO_STATUS_NONFINITE;
+        return NAN;
+    }
+}
+
+void ymo_logdensity(const ymo_density *p, int64_t n, const double *x, double *out, uint32_t *status)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        uint32_t st = 0;
+        out[i] = ymo_logdensity_one(p, x + i * (int64_t)p->dim, &st);
+        if (status) status[i] = st;
+    }
+}
+
+/* the forward map alone (ForwardModel.evaluate, forwardModel.py:10-19) */
+int ymo_forward(const ymo_density *p, int64_t n, const double *x, double *out)
+{
+    int bad = 0;
+    int64_t m = (p->kind == YMO_POST_LV) ? (int64_t)p->n_data * 2 : p->data_dim;
+    for (int64_t i = 0; i < n; ++i) {
+        if (p->kind == YMO_POST_LINEAR) ymo_forward_linear(p, x + i * p->dim, out + i * m);
+        else if (p->kind == YMO_POST_LV) bad |= ymo_forward_lv(p, x + i * p->dim, out + i * m);
+        else return -1;
+    }
+    return bad;
+}
+
+/* ---------------------------------------------------------------------- */
+/* one chain: proposal, accept/reject, diagnostics                        */
+/* ---------------------------------------------------------------------- */
+
+/* ParameterVector.__eq__ (vector.py:37-45: numpy.array_equal) or
+ * ScalarParameter.__eq__ (scalar.py:39-44: math.isclose, rel_tol 1e-9). */
+static int ymo_states_equal(const double *a, const double *b, int32_t d, int eq_mode)
+{
+    if (eq_mode == YMO_EQ_ISCLOSE) {
+        double x = a[0], y = b[0];
+        if (x == y) return 1;
+        if (isinf(x) || isinf(y)) return 0;
+        double diff = fabs(y - x);
+        return (diff <= fabs(1e-9 * y)) || (diff <= fabs(1e-9 * x));
+    }
+    for (int32_t j = 0; j < d; ++j)
+        if (!(a[j] == b[j])) return 0;
+    return 1;
+}
+
+/* MRWProposal.generate_proposal (mrw.py:32-38) -> Gaussian.generate_realisation
+ * (gaussian.py:61-66) with DiagonalCovarianceMatrix.apply_chol_factor
+ * (covariance.py:51-52): y = x + sigma * xi, separate multiply and add.
+ * sigma = sqrt(reciprocal(precision)) is formed on the host exactly as NumPy
+ * does. */
+static void ymo_propose(const double *x, const double *sigma, uint64_t seed, uint32_t chain,
+                        uint64_t t, int32_t d, double *y)
+{
+    for (int32_t j = 0; 2 * j < d; ++j) {
+        double z0, z1;
+        ymc_draw_normal_pair(seed, chain, t, (uint32_t)j, &z0, &z1);
+        y[2 * j] = x[2 * j] + sigma[2 * j] * z0;
+        if (2 * j + 1 < d) y[2 * j + 1] = x[2 * j + 1] + sigma[2 * j + 1] * z1;
+    }
+}
+
+/* MetropolisHastings._accept_reject, metropolisHastings.py:55-73, given the
+ * log of the acceptance ratio:
+ *   a = exp(log_ratio); a = a if a < 1 else 1      (mrw.py:54-57, mlda.py:148-154)
+ *   u = uniform();  ACCEPTED iff u <= a            (:68-70)
+ * Deviation: the reference's `a if a < 1. else 1.` turns a NaN ratio into
+ * a = 1 (always accepted).  Here a proposal whose log-density is not finite
+ * (NaN, or -inf from a failed forward solve) is rejected and the chain is
+ * flagged YMO_STATUS_NONFINITE.  `margin` receives |u - a| (SURVEY.md
+ * section 7, "Accept test form"). */
+static int ymo_accept(double log_ratio, int proposal_finite, uint64_t seed, uint32_t chain,
+                      uint64_t t, uint32_t *status, double *margin)
+{
+    if (!proposal_finite) {
+        *status |= YMO_STATUS_NONFINITE;
+        if (margin) *margin = INFINITY;
+        return 0;
+    }
+    double a = ymc_exp(log_ratio);
+    a = (a < 1.0) ? a : 1.0;
+    double u = ymc_draw_uniform(seed, chain, t);
+    if (margin) *margin = fabs(u - a);
+    return u <= a;
+}
+
+/* WelfordAccumulator.update, estimation.py:36-53 */
+static void ymo_welford(const double *x, int32_t d, uint64_t *n, double *mean, double *m2)
+{
+    *n += 1;
+    double dn = (double)*n;
+    for (int32_t j = 0; j < d; ++j) {
+        double delta = x[j] - mean[j];
+        mean[j] = mean[j] + delta / dn;
+        double delta2 = x[j] - mean[j];
+        m2[j] = m2[j] + delta * delta2;
+    }
+}
+
+static int ymo_is_finite(double v) { return fabs(v) <= 1.79769313486231570815e308; }
+
+/*
+ * MetropolisHastings.run, metropolisHastings.py:103-120, for K independent
+ * chains of the Metropolised random walk (mrw.py:41-57), advanced by `nsteps`
+ * transitions t0 .. t0+nsteps-1 from the carried state.
+ *
+ *   x[K][d], lp[K]             state and logpi(state), updated in place
+ *   acc_count[K]               accepted transitions (diagnostics.py:48-54)
+ *   wf_n[K], wf_mean, wf_m2    FullDiagnostics' Welford over the
+ *                              PRE-transition state (diagnostics.py:91-94)
+ *   status[K]                  or'ed YMO_STATUS_*
+ *   traj[nsteps][K][d]         state after each transition (:75-76), or NULL
+ *   acc[nsteps][K]             0/1 outcome (transition.py:3-4), or NULL
+ *   lp_out[nsteps][K]          logpi(state after the transition), or NULL
+ *   margin[nsteps][K]          |u - a| (inf where no uniform was drawn), or NULL
+ */
+void ymo_mrw_advance(const ymo_density *tgt, const double *sigma, int32_t eq_mode, uint64_t seed,
+                     uint64_t chain0, int64_t K, uint64_t t0, int64_t nsteps, double *x, double *lp,
+                     uint64_t *acc_count, uint64_t *wf_n, double *wf_mean, double *wf_m2,
+                     uint32_t *status, double *traj, uint8_t *acc, double *lp_out, double *margin,
+                     int32_t nthreads)
+{
+    int32_t d = tgt->dim;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
+#endif
+    for (int64_t k = 0; k < K; ++k) {
+        uint32_t chain = (uint32_t)(chain0 + (uint64_t)k);
+        double xs[YMO_DMAX], y[YMO_DMAX];
+        memcpy(xs, x + k * d, sizeof(double) * (size_t)d);
+        double lpx = lp[k];
+        uint32_t st = status ? status[k] : 0;
+        for (int64_t n = 0; n < nsteps; ++n) {
+            uint64_t t = t0 + (uint64_t)n;
+            ymo_propose(xs, sigma, seed, chain, t, d, y);       /* :116-117 */
+            int accepted = 0;
+            double mg = INFINITY;
+            double lpy = lpx;
+            if (!ymo_states_equal(y, xs, d, eq_mode)) {          /* :60-61 */
+                lpy = ymo_logdensity_one(tgt, y, &st);
+                accepted = ymo_accept(lpy - lpx, ymo_is_finite(lpy), seed, chain, t, &st, &mg);
+            }
+            if (wf_n) ymo_welford(xs, d, &wf_n[k], wf_mean + k * d, wf_m2 + k * d);
+            if (accepted) {                                      /* :79-92 */
+                memcpy(xs, y, sizeof(double) * (size_t)d);
+                lpx = lpy;
+                if (acc_count) acc_count[k] += 1;
+            }
+            if (traj) memcpy(traj + (n * K + k) * d, xs, sizeof(double) * (size_t)d);
+            if (acc) acc[n * K + k] = (uint8_t)accepted;
+            if (lp_out) lp_out[n * K + k] = lpx;
+            if (margin) margin[n * K + k] = mg;
+        }
+        memcpy(x + k * d, xs, sizeof(double) * (size_t)d);
+        lp[k] = lpx;
+        if (status) status[k] = st;
+    }
+}
+
+/*
+ * Two-level delayed acceptance: MLDA (mlda.py:120-154) with one surrogate,
+ * i.e. MLDAProposal.generate_proposal's nSurrogates == 1 branch (:102-110):
+ * the proposal of fine step n is the end point of an S-step random walk on
+ * the surrogate density started at the fine state, and it is accepted with
+ *   min(1, exp(pi_f(y) + pi_c(x) - pi_c(y) - pi_f(x)))        (:146-154)
+ * Transition numbering: t = n*(S+1) + s, s < S coarse, s == S fine.
+ * The surrogate's diagnostics are DummyDiagnostics by default (:271-280), so
+ * only fine-level outcomes are accumulated; sub_acc[nsteps][S][K] (optional)
+ * exposes the coarse outcomes for parity checks.
+ *   lpf[K], lpc[K]   fine / coarse log-density of the carried fine state
+ */
+void ymo_mlda2_advance(const ymo_density *fine, const ymo_density *coarse, const double *sigma,
+                       int32_t S, int32_t eq_mode, uint64_t seed, uint64_t chain0, int64_t K,
+                       uint64_t n0, int64_t nsteps, double *x, double *lpf, double *lpc,
+                       uint64_t *acc_count, uint64_t *wf_n, double *wf_mean, double *wf_m2,
+                       uint32_t *status, double *traj, uint8_t *acc, uint8_t *sub_acc,
+                       double *lp_out, double *margin, int32_t nthreads)
+{
+    int32_t d = fine->dim;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
+#endif
+    for (int64_t k = 0; k < K; ++k) {
+        uint32_t chain = (uint32_t)(chain0 + (uint64_t)k);
+        double xs[YMO_DMAX], z[YMO_DMAX], y[YMO_DMAX];
+        memcpy(xs, x + k * d, sizeof(double) * (size_t)d);
+        double lpfx = lpf[k], lpcx = lpc[k];
+        uint32_t st = status ? status[k] : 0;
+        for (int64_t n = 0; n < nsteps; ++n) {
+            uint64_t tbase = (n0 + (uint64_t)n) * (uint64_t)(S + 1);
+            /* surrogate.run(S+1, state): metropolisHastings.py:103-120 on pi_c */
+            memcpy(z, xs, sizeof(double) * (size_t)d);
+            double lpcz = lpcx;
+            for (int32_t s = 0; s < S; ++s) {
+                uint64_t t = tbase + (uint64_t)s;
+                ymo_propose(z, sigma, seed, chain, t, d, y);
+                int a = 0;
+                if (!ymo_states_equal(y, z, d, eq_mode)) {
+                    double lpcy = ymo_logdensity_one(coarse, y, &st);
+                    a = ymo_accept(lpcy - lpcz, ymo_is_finite(lpcy), seed, chain, t, &st, NULL);
+                    if (a) {
+                        memcpy(z, y, sizeof(double) * (size_t)d);
+                        lpcz = lpcy;
+                    }
+                }
+                if (sub_acc) sub_acc[(n * S + s) * K + k] = (uint8_t)a;
+            }
+            /* fine accept/reject of y = z, metropolisHastings.py:55-73 + mlda.py:146-154 */
+            int accepted = 0;
+            double mg = INFINITY;
+            double lpfy = lpfx;
+            if (!ymo_states_equal(z, xs, d, eq_mode)) {
+                lpfy = ymo_logdensity_one(fine, z, &st);
+                double log_ratio = ((lpfy + lpcx) - lpcz) - lpfx;
+                accepted = ymo_accept(log_ratio, ymo_is_finite(lpfy) && ymo_is_finite(lpcz), seed,
+                                      chain, tbase + (uint64_t)S, &st, &mg);
+            }
+            if (wf_n) ymo_welford(xs, d, &wf_n[k], wf_mean + k * d, wf_m2 + k * d);
+            if (accepted) {
+                memcpy(xs, z, sizeof(double) * (size_t)d);
+                lpfx = lpfy;
+                lpcx = lpcz;
+                if (acc_count) acc_count[k] += 1;
+            }
+            if (traj) memcpy(traj + (n * K + k) * d, xs, sizeof(double) * (size_t)d);
+            if (acc) acc[n * K + k] = (uint8_t)accepted;
+            if (lp_out) lp_out[n * K + k] = lpfx;
+            if (margin) margin[n * K + k] = mg;
+        }
+        memcpy(x + k * d, xs, sizeof(double) * (size_t)d);
+        lpf[k] = lpfx;
+        lpc[k] = lpcx;
+        if (status) status[k] = st;
+    }
+}
+
+int32_t ymo_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,441 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures of tests/golden/ from the LIVE reference.
+
+Runs only in the build container (needs /root/reference on PYTHONPATH):
+
+    PYTHONPATH=/root/reference MPLBACKEND=Agg python tests/golden/make_golden.py
+
+For every fixture the UNMODIFIED reference classes are built through the
+reference's own builders and run one chain at a time; the only intervention is
+that the two module-level names the reference draws random numbers through,
+
+    yagremcmc.statistics.gaussian.standard_normal      (gaussian.py:2,63)
+    yagremcmc.chain.metropolisHastings.uniform          (metropolisHastings.py:2,68)
+
+are rebound to closures replaying the ensemble's counter-based stream
+(csrc/ymc_numerics.h, evaluated here through oracle.rng_fill) by ADDRESS:
+the normals of transition t, and -- only if the reference asks for it -- the
+uniform of transition t.  What is stored is data: the inputs of each problem
+and the reference's outputs (trajectories, accept decisions, log-densities,
+diagnostics).  Nothing of the reference's source travels.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import oracle  # noqa: E402  (draw stream + RK4 plug-in only)
+
+import yagremcmc.chain.metropolisHastings as ref_mh  # noqa: E402
+import yagremcmc.statistics.gaussian as ref_gaussian  # noqa: E402
+from yagremcmc.chain.diagnostics import AcceptanceRateDiagnostics, FullDiagnostics  # noqa: E402
+from yagremcmc.chain.method.mlda import MLDABuilder  # noqa: E402
+from yagremcmc.chain.method.mrw import MRWBuilder  # noqa: E402
+from yagremcmc.model.evaluation import EvaluationStatus  # noqa: E402
+from yagremcmc.model.forwardModel import ForwardModel  # noqa: E402
+from yagremcmc.model.interface import SolverInterface  # noqa: E402
+from yagremcmc.parameter.scalar import ScalarParameter  # noqa: E402
+from yagremcmc.parameter.vector import ParameterVector  # noqa: E402
+from yagremcmc.statistics.bayesModel import BayesianRegressionModel  # noqa: E402
+from yagremcmc.statistics.covariance import (DiagonalCovarianceMatrix,  # noqa: E402
+                                             IIDCovarianceMatrix)
+from yagremcmc.statistics.data import Data  # noqa: E402
+from yagremcmc.statistics.gaussian import Gaussian  # noqa: E402
+from yagremcmc.statistics.likelihood import AdditiveGaussianNoiseLikelihood  # noqa: E402
+from yagremcmc.statistics.noise import CentredGaussianNoise  # noqa: E402
+from yagremcmc.test.testSetup import (GaussianTargetDensity1d, GaussianTargetDensity2d,  # noqa: E402
+                                      LotkaVolterraParameter, LotkaVolterraSolver)
+
+sys.path.insert(0, "/root/reference")
+from exampleSetup import ExampleLinearModelSolver  # noqa: E402
+
+
+class Replay:
+    """Serves the ensemble's draws of one chain to the reference by address."""
+
+    def __init__(self, seed, chain, dim, n_transitions, sub_chain_length=0):
+        self.S = sub_chain_length
+        self.xi, self.u = oracle.rng_fill(seed, chain, 1, 0, n_transitions, dim)
+        self.xi, self.u = self.xi[:, 0, :], self.u[:, 0]
+        self.normal_calls = 0
+        self.t_last = None
+        self.fine = False
+        self.used_u = []
+
+    def _t_of_call(self, c):
+        if self.S == 0:
+            return c
+        return (c // self.S) * (self.S + 1) + (c % self.S)
+
+    def standard_normal(self, size=None):
+        t = self._t_of_call(self.normal_calls)
+        self.normal_calls += 1
+        self.t_last = t
+        out = self.xi[t].copy()
+        assert size is None or int(size) == out.size
+        return out
+
+    def uniform(self, low=0.0, high=1.0, size=None):
+        if self.S == 0:
+            t = self.t_last
+        elif self.fine:
+            # fine accept/reject of the fine step whose sub-chain just ended
+            t = (self.t_last // (self.S + 1)) * (self.S + 1) + self.S
+        else:
+            t = self.t_last
+        self.used_u.append(t)
+        return np.array([self.u[t]])
+
+    def install(self):
+        ref_gaussian.standard_normal = self.standard_normal
+        ref_mh.uniform = self.uniform
+
+
+def mark_fine_level(mc, replay):
+    """Tell the replay when the FINE chain's _accept_reject is drawing."""
+    inner = mc._accept_reject
+
+    def wrapped(proposal, state):
+        replay.fine = True
+        try:
+            return inner(proposal, state)
+        finally:
+            replay.fine = False
+
+    mc._accept_reject = wrapped
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def eval_log_along(target, traj, make_param):
+    return np.array([float(np.asarray(target.evaluate_log(make_param(s))).reshape(-1)[0])
+                     for s in traj])
+
+
+def scipy_whitening(density2d):
+    co = density2d.dist_.cov_object
+    return (np.array(density2d.dist_.mean, dtype=float), np.array(co._LP, dtype=float),
+            float(co.rank * np.log(2.0 * np.pi) + co._log_pdet))
+
+
+def sigma_of(cov):
+    # covariance.py:51-52: sqrt(reciprocal(precision)), precision = reciprocal(var)
+    return np.sqrt(np.reciprocal(cov._precision))
+
+
+# ---------------------------------------------------------------------------
+# F1: example_mcmc_1d.py shape -- 1 chain, 1-D Gaussian target, ScalarParameter
+# ---------------------------------------------------------------------------
+
+def fixture_f1():
+    seed, n = 20250103, 10000
+    mean, var, prop_var, x0 = 1.5, 1.0, 1.5, -3.0
+    target = GaussianTargetDensity1d(ScalarParameter(np.array([mean])), var)
+    cov = IIDCovarianceMatrix(1, prop_var)
+    from yagremcmc.chain.method.mrw import MetropolisedRandomWalk
+    diag = FullDiagnostics()
+    mc = MetropolisedRandomWalk(target, cov, diag)
+    rp = Replay(seed, 0, 1, n - 1)
+    rp.install()
+    mc.run(n, ScalarParameter(np.array([x0])), verbose=False)
+    traj = np.array(mc.chain.trajectory).reshape(n, 1, 1)
+    acc = np.array(diag._diagnostics._decisions, dtype=np.uint8).reshape(n - 1, 1)
+    lp = eval_log_along(target, traj[:, 0, :], lambda s: ScalarParameter(np.array(s))).reshape(n, 1)
+    np.savez_compressed(
+        os.path.join(HERE, "f1_mrw_1d.npz"), seed=seed, n_states=n, mean=mean, variance=var,
+        sigma=sigma_of(cov), x0=np.array([[x0]]), traj=traj, acc=acc, logpost=lp,
+        acc_rate=diag.global_acceptance_rate(), wf_mean=np.array(diag.mean()),
+        wf_var=np.array(diag.marginal_variance()))
+    print("F1", acc.mean())
+
+
+# ---------------------------------------------------------------------------
+# F2 (+F6): example_mcmc_2d_singleLevel.py shape -- 2-D Gaussian, MRW
+# ---------------------------------------------------------------------------
+
+TGT_MEAN = np.array([1.0, 1.5])
+TGT_COV = np.array([[2.4, -0.5], [-0.5, 0.7]])
+
+
+def run_mrw_2d(name, seed, K, n, proposal_cov, x0):
+    target = GaussianTargetDensity2d(ParameterVector(TGT_MEAN.copy()), TGT_COV.copy())
+    mu, U, c = scipy_whitening(target)
+    traj = np.empty((n, K, 2))
+    acc = np.empty((n - 1, K), dtype=np.uint8)
+    lp = np.empty((n, K))
+    margin = np.empty((n - 1, K))
+    rate = np.empty(K)
+    wmean = np.empty((K, 2))
+    wvar = np.empty((K, 2))
+    sig = sigma_of(proposal_cov)
+    for k in range(K):
+        b = MRWBuilder()
+        b.explicitTarget = target
+        b.proposalCovariance = proposal_cov
+        b.diagnostics = FullDiagnostics()
+        mc = b.build_method()
+        rp = Replay(seed, k, 2, n - 1)
+        rp.install()
+        mc.run(n, ParameterVector(x0.copy()), verbose=False)
+        traj[:, k, :] = np.array(mc.chain.trajectory)
+        acc[:, k] = mc.diagnostics._diagnostics._decisions
+        lp[:, k] = eval_log_along(target, traj[:, k, :], lambda s: ParameterVector(np.array(s)))
+        # margin |u - a| of every decision, from reference values
+        props = traj[:-1, k, :] + sig * rp.xi
+        lpp = eval_log_along(target, props, lambda s: ParameterVector(np.array(s)))
+        a = np.minimum(np.exp(lpp - lp[:-1, k]), 1.0)
+        margin[:, k] = np.abs(rp.u - a)
+        rate[k] = mc.diagnostics.global_acceptance_rate()
+        wmean[k] = mc.diagnostics.mean()
+        wvar[k] = mc.diagnostics.marginal_variance()
+    np.savez_compressed(
+        os.path.join(HERE, name), seed=seed, n_states=n, mean=mu, whiten=U, log_norm=c,
+        cov=TGT_COV, sigma=sig, x0=np.tile(x0, (K, 1)), traj=traj, acc=acc, logpost=lp,
+        min_margin=margin.min(), acc_rate=rate, wf_mean=wmean, wf_var=wvar)
+    print(name, acc.mean(), "min margin", margin.min())
+
+
+# ---------------------------------------------------------------------------
+# F5: example_mcmc_2d_twoLevel.py shape -- two-level delayed acceptance, S = 6
+# ---------------------------------------------------------------------------
+
+def fixture_f5():
+    seed, K, n, S = 20250105, 64, 1000, 6
+    x0 = np.array([-8.0, -7.0])
+    sur_mean = TGT_MEAN + np.array([0.15, -0.2])
+    sur_cov = 2.0 * TGT_COV + np.array([[0.1, 1.2], [1.2, 0.05]])
+    fine = GaussianTargetDensity2d(ParameterVector(TGT_MEAN.copy()), TGT_COV.copy())
+    coarse = GaussianTargetDensity2d(ParameterVector(sur_mean.copy()), sur_cov.copy())
+    mu_f, U_f, c_f = scipy_whitening(fine)
+    mu_c, U_c, c_c = scipy_whitening(coarse)
+    cov = IIDCovarianceMatrix(2, 1.0)
+    traj = np.empty((n, K, 2))
+    acc = np.empty((n - 1, K), dtype=np.uint8)
+    sub = np.empty((n - 1, S, K), dtype=np.uint8)
+    lp = np.empty((n, K))
+    for k in range(K):
+        b = MLDABuilder()
+        b.explicitTarget = fine
+        b.surrogateTargets = [coarse]
+        b.baseProposalCovariance = cov
+        b.subChainLengths = [S]
+        b.surrogateDiagnostics = [AcceptanceRateDiagnostics()]
+        mc = b.build_method()
+        rp = Replay(seed, k, 2, (n - 1) * (S + 1), sub_chain_length=S)
+        rp.install()
+        mark_fine_level(mc, rp)
+        mc.run(n, ParameterVector(x0.copy()), verbose=False)
+        traj[:, k, :] = np.array(mc.chain.trajectory)
+        acc[:, k] = mc.diagnostics._decisions
+        sub[:, :, k] = np.array(mc.surrogate(0).diagnostics._decisions,
+                                dtype=np.uint8).reshape(n - 1, S)
+        lp[:, k] = eval_log_along(fine, traj[:, k, :], lambda s: ParameterVector(np.array(s)))
+    np.savez_compressed(
+        os.path.join(HERE, "f5_mlda2_2d.npz"), seed=seed, n_states=n, S=S,
+        fine_mean=mu_f, fine_whiten=U_f, fine_log_norm=c_f, fine_cov=TGT_COV,
+        coarse_mean=mu_c, coarse_whiten=U_c, coarse_log_norm=c_c, coarse_cov=sur_cov,
+        sigma=sigma_of(cov), x0=np.tile(x0, (K, 1)), traj=traj, acc=acc, sub_acc=sub, logpost=lp)
+    print("F5", acc.mean(), sub.mean())
+
+
+# ---------------------------------------------------------------------------
+# F3: linear forward model posterior (likelihood.py:49-87 over exampleSetup.py)
+# ---------------------------------------------------------------------------
+
+def linear_problem(d, n_data, gen_seed):
+    """C3-shaped synthetic problem: A ~ N(0,1)/sqrt(d) etc."""
+    z, _ = oracle.rng_fill(gen_seed, 0, d + 3 + n_data, 0, 1, d, uniforms=False)
+    z = z[0]
+    A = z[:d] / np.sqrt(d)
+    b = z[d]
+    theta_true = z[d + 1]
+    noise_var = 0.3
+    data = np.array([A @ theta_true + b + np.sqrt(noise_var) * z[d + 3 + i] for i in range(n_data)])
+    return A, b, data, noise_var
+
+
+def build_linear_reference(A, b, data, noise_var, prior_mean, prior_var):
+    d = A.shape[1]
+    solver = ExampleLinearModelSolver(A, b)
+    like = AdditiveGaussianNoiseLikelihood(
+        Data(data), ForwardModel(solver), CentredGaussianNoise(IIDCovarianceMatrix(A.shape[0], noise_var)))
+    prior = Gaussian(ParameterVector(prior_mean.copy()), IIDCovarianceMatrix(d, prior_var))
+    return BayesianRegressionModel(like, prior)
+
+
+def run_mrw_model(model, seed, K, n, prop_cov, x0, make_param=ParameterVector, keep_traj=None):
+    d = x0.size
+    traj = np.empty((n, K, d))
+    acc = np.empty((n - 1, K), dtype=np.uint8)
+    lp = np.empty((n, K))
+    for k in range(K):
+        b = MRWBuilder()
+        b.bayesModel = model
+        b.proposalCovariance = prop_cov
+        mc = b.build_method()
+        rp = Replay(seed, k, d, n - 1)
+        rp.install()
+        mc.run(n, make_param(x0.copy()), verbose=False)
+        traj[:, k, :] = np.array(mc.chain.trajectory)
+        acc[:, k] = mc.diagnostics._decisions
+        lp[:, k] = eval_log_along(mc.target, traj[:, k, :], lambda s: make_param(np.array(s)))
+    return traj, acc, lp
+
+
+def fixture_f3():
+    d, n_data, seed, K, n = 128, 5, 20250107, 16, 500
+    A, b, data, noise_var = linear_problem(d, n_data, 7)
+    prior_mean, prior_var, prop_var = np.zeros(d), 5.0, 1.1e-3
+    model = build_linear_reference(A, b, data, noise_var, prior_mean, prior_var)
+    prop_cov = IIDCovarianceMatrix(d, prop_var)
+    traj, acc, lp = run_mrw_model(model, seed, K, n, prop_cov, np.zeros(d))
+    np.savez_compressed(
+        os.path.join(HERE, "f3_linear_d128.npz"), seed=seed, n_states=n, A=A, b=b, data=data,
+        noise_precision=np.reciprocal(np.full(d, noise_var)), prior_mean=prior_mean,
+        prior_precision=np.reciprocal(np.full(d, prior_var)), sigma=sigma_of(prop_cov),
+        x0=np.zeros((K, d)), traj_head=traj[:, :2, :], traj_sha256=sha(traj), acc=acc, logpost=lp)
+    print("F3", acc.mean())
+
+
+def fixture_f3b():
+    """The shipped 2x2 example model (example_inference_linearModel_twoLevel.py:24-82)."""
+    from numpy.random import seed as np_seed, standard_normal
+    np_seed(2222)
+    A = np.array([[1.4, -0.2], [-0.6, 0.7]])
+    b = np.zeros(2)
+    true = np.array([1.5, 0.5])
+    sd = np.sqrt(0.3)
+    data = np.array([A @ true + b + sd * standard_normal(2) for _ in range(5)])
+    prior_mean = true + np.array([-0.2, 0.4])
+    model = build_linear_reference(A, b, data, sd ** 2, prior_mean, 5.0)
+    g = np.linspace(-2.0, 4.0, 25)
+    grid = np.array([[x, y] for x in g for y in g])
+    from yagremcmc.chain.target import UnnormalisedPosterior
+    post = UnnormalisedPosterior(model.likelihood, model.prior)
+    vals = np.array([post.evaluate_log(ParameterVector(p)) for p in grid])
+    seed, K, n = 20250108, 8, 500
+    prop_cov = IIDCovarianceMatrix(2, 0.5)
+    traj, acc, lp = run_mrw_model(model, seed, K, n, prop_cov, np.array([0.0, 0.0]))
+    np.savez_compressed(
+        os.path.join(HERE, "f3b_linear_2x2.npz"), seed=seed, n_states=n, A=A, b=b, data=data,
+        noise_precision=np.reciprocal(np.full(2, sd ** 2)), prior_mean=prior_mean,
+        prior_precision=np.reciprocal(np.full(2, 5.0)), sigma=sigma_of(prop_cov),
+        x0=np.zeros((K, 2)), grid=grid, grid_logpost=vals, traj=traj, acc=acc, logpost=lp)
+    print("F3b", acc.mean())
+
+
+# ---------------------------------------------------------------------------
+# F4: Lotka-Volterra (test_inference_mcmc_singleLevel.py:28-73 wiring)
+# ---------------------------------------------------------------------------
+
+class RK4LotkaVolterraSolver(SolverInterface):
+    """The build's fixed-step RK4 integrator as a reference SolverInterface
+    plug-in, so the reference LOOP can be replayed with the build's forward
+    map (loop parity exact; the integrator itself is checked separately)."""
+
+    def __init__(self, problem):
+        self._p = problem
+        self._theta = None
+        self._eval = None
+        self._status = EvaluationStatus.NONE
+
+    @property
+    def status(self):
+        return self._status
+
+    @property
+    def evaluation(self):
+        return self._eval
+
+    def interpolate(self, parameter):
+        self._theta = np.array(parameter.coefficient, dtype=float)
+
+    def invoke(self):
+        out = oracle.forward(self._p, self._theta)
+        self._eval = out.reshape(self._p["n_data"], 2)
+        self._status = (EvaluationStatus.SUCCESS if np.all(np.isfinite(out))
+                        else EvaluationStatus.FAILURE)
+
+
+def fixture_f4():
+    cfg = {'T': 6., 'alpha': 0.8, 'gamma': 0.4, 'nData': 5, 'dataDim': 2,
+           'solver': 'LSODA', 'rtol': 1e-4}
+    design = np.array([[0.1, 0.9], [0.5, 0.5], [1., 0.5], [0.5, 1.], [2.5, 1.5]])
+    ref_solver = LotkaVolterraSolver(design, cfg)
+    tight = LotkaVolterraSolver(design, dict(cfg, solver='DOP853', rtol=1e-12))
+    # forward map at 32 parameter values around the test's posterior bulk
+    zz, uu = oracle.rng_fill(4444, 0, 32, 0, 1, 2)
+    thetas = np.log(np.array([0.4, 0.6])) + 0.25 * zz[0]
+    f_ref = np.empty((32, 5, 2))
+    f_tight = np.empty((32, 5, 2))
+    for i, th in enumerate(thetas):
+        p = LotkaVolterraParameter.from_coefficient(th)
+        for s, out in ((ref_solver, f_ref), (tight, f_tight)):
+            s.interpolate(p)
+            s.invoke()
+            assert s.status == EvaluationStatus.SUCCESS
+            out[i] = s.evaluation
+    # synthetic data from the tight solver + stream noise
+    truth = np.log(np.array([0.4, 0.6]))
+    tight.interpolate(LotkaVolterraParameter.from_coefficient(truth))
+    tight.invoke()
+    noise_var = 0.05
+    zn, _ = oracle.rng_fill(5555, 0, 5, 0, 1, 2, uniforms=False)
+    data = tight.evaluation + np.sqrt(noise_var) * zn[0]
+    prior_mean, prior_var = np.zeros(2), 0.02
+    problem = oracle.posterior_lv(design, cfg['T'], cfg['alpha'], cfg['gamma'], 50, data,
+                                  np.reciprocal(np.full(2, noise_var)), prior_mean,
+                                  np.reciprocal(np.full(2, prior_var)))
+    like = AdditiveGaussianNoiseLikelihood(
+        Data(data), ForwardModel(RK4LotkaVolterraSolver(problem)),
+        CentredGaussianNoise(IIDCovarianceMatrix(2, noise_var)))
+    prior = Gaussian(LotkaVolterraParameter.from_coefficient(prior_mean.copy()),
+                     IIDCovarianceMatrix(2, prior_var))
+    model = BayesianRegressionModel(like, prior)
+    seed, K, n = 20250104, 16, 300
+    prop_cov = DiagonalCovarianceMatrix(np.array([0.02, 0.01]))
+    x0 = np.array([-0.6, -0.3])
+    traj, acc, lp = run_mrw_model(model, seed, K, n, prop_cov, x0,
+                                  make_param=LotkaVolterraParameter.from_coefficient)
+    np.savez_compressed(
+        os.path.join(HERE, "f4_lotka_volterra.npz"), seed=seed, n_states=n, design=design,
+        t_final=cfg['T'], alpha=cfg['alpha'], gamma=cfg['gamma'], rk4_steps=50, data=data,
+        noise_precision=np.reciprocal(np.full(2, noise_var)), prior_mean=prior_mean,
+        prior_precision=np.reciprocal(np.full(2, prior_var)), sigma=sigma_of(prop_cov),
+        x0=np.tile(x0, (K, 1)), thetas=thetas, forward_lsoda_rtol1e4=f_ref,
+        forward_dop853_rtol1e12=f_tight, traj=traj, acc=acc, logpost=lp)
+    print("F4", acc.mean(), "RK4-50 vs DOP853:",
+          np.abs(oracle.forward(problem, thetas).reshape(32, 5, 2) - f_tight).max(),
+          "LSODA vs DOP853:", np.abs(f_ref - f_tight).max())
+
+
+def main():
+    which = sys.argv[1:] or ["f1", "f2", "f2b", "f3", "f3b", "f4", "f5"]
+    if "f1" in which:
+        fixture_f1()
+    if "f2" in which:
+        run_mrw_2d("f2_mrw_2d.npz", 20250102, 64, 2000, IIDCovarianceMatrix(2, 1.0),
+                   np.array([-8.0, -7.0]))
+    if "f2b" in which:
+        run_mrw_2d("f2b_mrw_2d_indep.npz", 20250112, 8, 500,
+                   DiagonalCovarianceMatrix(np.array([TGT_COV[0, 0], TGT_COV[1, 1]])),
+                   np.array([0.5, 0.25]))
+    if "f3" in which:
+        fixture_f3()
+    if "f3b" in which:
+        fixture_f3b()
+    if "f4" in which:
+        fixture_f4()
+    if "f5" in which:
+        fixture_f5()
+
+
+if __name__ == "__main__":
+    main()

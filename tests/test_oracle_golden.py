@@ -1,0 +1,148 @@
+"""The CPU restatement (oracle/) against the golden vectors the LIVE reference
+produced (tests/golden/make_golden.py): accept decisions and trajectories
+bit-exact, log-densities to 1e-12 relative, diagnostics bit-exact."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+
+LP_RTOL = 1e-12
+
+
+def _check(out, g, n, lp_rtol=LP_RTOL):
+    assert np.array_equal(out["acc"], g["acc"])
+    if "traj" in g:
+        assert np.array_equal(out["traj"], g["traj"][1:])
+    want = g["logpost"][1:]
+    assert np.abs(out["logpost"] - want).max() <= lp_rtol * np.abs(want).max()
+    rel = np.abs(out["logpost"] - want) / np.maximum(np.abs(want), 1e-300)
+    assert rel.max() <= 1e-9
+
+
+def test_f1_mrw_1d_scalar_parameter(golden):
+    g = golden("f1_mrw_1d.npz")
+    n = int(g["n_states"])
+    e = o.Ensemble(o.gauss_iso1d(float(g["mean"]), float(g["variance"])), g["sigma"], g["x0"],
+                   int(g["seed"]), eq_mode=o.EQ_ISCLOSE)
+    out = e.advance(n - 1)
+    _check(out, g, n)
+    # FullDiagnostics: rate, Welford mean and unbiased variance (estimation.py:11-53)
+    assert e.acc_count[0] / (n - 1) == float(g["acc_rate"])
+    assert np.array_equal(e.wf_mean[0], g["wf_mean"].reshape(-1))
+    assert np.array_equal(e.wf_m2[0] / (float(e.wf_n[0]) - 1.0), g["wf_var"].reshape(-1))
+
+
+@pytest.mark.parametrize("name", ["f2_mrw_2d.npz", "f2b_mrw_2d_indep.npz"])
+def test_f2_mrw_2d(golden, name):
+    g = golden(name)
+    n = int(g["n_states"])
+    p = o.gauss_whitened(g["mean"], g["whiten"], float(g["log_norm"]))
+    e = o.Ensemble(p, g["sigma"], g["x0"], int(g["seed"]))
+    out = e.advance(n - 1, want_margin=True)
+    _check(out, g, n)
+    assert np.array_equal(e.acc_count / (n - 1), g["acc_rate"])
+    assert np.array_equal(e.wf_mean, g["wf_mean"])
+    assert np.array_equal(e.wf_m2 / (e.wf_n[:, None] - 1.0), g["wf_var"])
+    # no decision in the fixture is closer than 1e-9 to the threshold
+    assert float(g["min_margin"]) > 1e-9 and out["margin"].min() > 1e-9
+    # two half-length advances == one full one (state carried exactly)
+    e2 = o.Ensemble(p, g["sigma"], g["x0"], int(g["seed"]))
+    a = e2.advance((n - 1) // 2)
+    b = e2.advance(n - 1 - (n - 1) // 2)
+    assert np.array_equal(np.concatenate([a["traj"], b["traj"]]), out["traj"])
+    # whitening recomputed from the covariance agrees with scipy's to rounding
+    p2 = o.gauss_from_cov(g["mean"], g["cov"])
+    lp2, _ = o.logdensity(p2, g["traj"][:, 0, :])
+    assert np.abs(lp2 - g["logpost"][:, 0]).max() <= 1e-12 * np.abs(g["logpost"]).max()
+
+
+def test_f3_linear_d128(golden):
+    g = golden("f3_linear_d128.npz")
+    n = int(g["n_states"])
+    p = o.posterior_linear(g["A"], g["b"], g["data"], g["noise_precision"], g["prior_mean"],
+                           g["prior_precision"])
+    e = o.Ensemble(p, g["sigma"], g["x0"], int(g["seed"]))
+    out = e.advance(n - 1)
+    _check(out, g, n)
+    assert np.array_equal(out["traj"][:, :2, :], g["traj_head"][1:])
+    full = np.concatenate([g["x0"][None], out["traj"]])
+    assert hashlib.sha256(np.ascontiguousarray(full).tobytes()).hexdigest() == str(g["traj_sha256"])
+
+
+def test_f3b_linear_2x2_example(golden):
+    g = golden("f3b_linear_2x2.npz")
+    n = int(g["n_states"])
+    p = o.posterior_linear(g["A"], g["b"], g["data"], g["noise_precision"], g["prior_mean"],
+                           g["prior_precision"])
+    lp, st = o.logdensity(p, g["grid"])
+    assert (st == 0).all()
+    assert np.abs(lp - g["grid_logpost"]).max() <= 1e-12 * np.abs(g["grid_logpost"]).max()
+    e = o.Ensemble(p, g["sigma"], g["x0"], int(g["seed"]))
+    _check(e.advance(n - 1), g, n)
+
+
+def test_f4_lotka_volterra(golden):
+    g = golden("f4_lotka_volterra.npz")
+    n = int(g["n_states"])
+    p = o.posterior_lv(g["design"], float(g["t_final"]), float(g["alpha"]), float(g["gamma"]),
+                       int(g["rk4_steps"]), g["data"], g["noise_precision"], g["prior_mean"],
+                       g["prior_precision"])
+    # forward map: RK4-50 against the reference's own solver (LSODA rtol 1e-4,
+    # test_solver_invoke.py:64-94 uses rtol 1e-3) and a tight DOP853 solution
+    f = o.forward(p, g["thetas"]).reshape(-1, 5, 2)
+    assert np.allclose(f, g["forward_lsoda_rtol1e4"], rtol=1e-3, atol=5e-3)
+    assert np.abs(f - g["forward_dop853_rtol1e12"]).max() < 1e-4
+    # loop parity: the reference loop ran with this RK4 as its solver plug-in
+    e = o.Ensemble(p, g["sigma"], g["x0"], int(g["seed"]))
+    out = e.advance(n - 1)
+    _check(out, g, n)
+    assert (e.status == 0).all()
+
+
+def test_f4_nonfinite_forward_is_rejected_and_flagged(golden):
+    g = golden("f4_lotka_volterra.npz")
+    p = o.posterior_lv(g["design"], 10.0, 0.8, 0.4, 50, g["data"], g["noise_precision"],
+                       g["prior_mean"], g["prior_precision"])
+    # the example's stiff start (example_inference_lotkaVolterra_singleLevel.py:106)
+    lp, st = o.logdensity(p, np.array([[-7.0, 2.8]]))
+    assert st[0] & o.STATUS_NONFINITE and lp[0] == -np.inf
+
+
+def test_f5_two_level_delayed_acceptance(golden):
+    g = golden("f5_mlda2_2d.npz")
+    n, S = int(g["n_states"]), int(g["S"])
+    fine = o.gauss_whitened(g["fine_mean"], g["fine_whiten"], float(g["fine_log_norm"]))
+    coarse = o.gauss_whitened(g["coarse_mean"], g["coarse_whiten"], float(g["coarse_log_norm"]))
+    e = o.Ensemble(fine, g["sigma"], g["x0"], int(g["seed"]), surrogate=coarse, sub_chain_length=S)
+    out = e.advance(n - 1, want_sub=True)
+    _check(out, g, n)
+    assert np.array_equal(out["sub_acc"], g["sub_acc"])
+
+
+def test_perfect_surrogate_accepts_everything(golden):
+    """test_mlda.py:94-130: coarse == fine => every fine proposal that moved is accepted."""
+    g = golden("f5_mlda2_2d.npz")
+    fine = o.gauss_whitened(g["fine_mean"], g["fine_whiten"], float(g["fine_log_norm"]))
+    e = o.Ensemble(fine, g["sigma"], g["x0"][:16], 99, surrogate=fine, sub_chain_length=4)
+    out = e.advance(400, want_sub=True)
+    moved = out["sub_acc"].any(axis=1)
+    assert np.array_equal(out["acc"].astype(bool), moved)
+
+
+def test_threads_do_not_change_results(golden):
+    g = golden("f2_mrw_2d.npz")
+    p = o.gauss_whitened(g["mean"], g["whiten"], float(g["log_norm"]))
+    a = o.Ensemble(p, g["sigma"], g["x0"], 5, nthreads=1).advance(200)
+    b = o.Ensemble(p, g["sigma"], g["x0"], 5, nthreads=4).advance(200)
+    assert np.array_equal(a["traj"], b["traj"]) and np.array_equal(a["acc"], b["acc"])
+
+
+def test_sharding_by_global_chain_id(golden):
+    g = golden("f2_mrw_2d.npz")
+    p = o.gauss_whitened(g["mean"], g["whiten"], float(g["log_norm"]))
+    whole = o.Ensemble(p, g["sigma"], g["x0"], 5).advance(100)
+    lo = o.Ensemble(p, g["sigma"], g["x0"][:40], 5, chain0=0).advance(100)
+    hi = o.Ensemble(p, g["sigma"], g["x0"][40:], 5, chain0=40).advance(100)
+    assert np.array_equal(np.concatenate([lo["traj"], hi["traj"]], axis=1), whole["traj"])

@@ -1,0 +1,286 @@
+/*
+ * ymc_numerics.h -- the normative numeric specification of the chain-ensemble
+ * hot path: counter-based random draws and the fp64 elementary functions the
+ * Metropolis-Hastings kernels use.
+ *
+ * Everything in this header is written with IEEE-754 binary64 basic operations
+ * only (+, -, *, /, sqrt, fma -- each correctly rounded) and integer
+ * arithmetic.  The same source is compiled for gfx950 by hipcc (device code of
+ * the HIP kernels) and for x86-64 by gcc (oracle/, the CPU checker).  Both are
+ * built with -ffp-contract=off, and every fused multiply-add below is an
+ * explicit ymc_fma(), so the two produce IDENTICAL bits.  That is what makes
+ * accept masks and trajectories comparable bit-for-bit between the GPU and the
+ * CPU restatement ("Bit-exact masks require bit-exact
+ * states" / "Whose normals?").
+ *
+ * The reference (yagremcmc) draws from NumPy's global legacy generator:
+ *   xi = standard_normal(d)            yagremcmc/statistics/gaussian.py:63
+ *   u  = uniform(0, 1, size=1)[0]      yagremcmc/chain/metropolisHastings.py:68
+ * A Mersenne-Twister stream cannot be sharded over 10^5..10^6 chains, so the
+ * ensemble replaces it by a pure function  (seed, chain, transition) -> draws
+ * defined here; parity with the reference is established on identical injected
+ * draws (tests/golden/make_golden.py replays this stream into the reference).
+ */
+#ifndef YMC_NUMERICS_H
+#define YMC_NUMERICS_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define YMC_FN __host__ __device__ static inline __attribute__((always_inline))
+#else
+#define YMC_FN static inline __attribute__((always_inline))
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* bit helpers                                                              */
+/* ------------------------------------------------------------------------ */
+
+YMC_FN double ymc_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+YMC_FN uint64_t ymc_bits(double x)
+{
+    uint64_t u;
+    __builtin_memcpy(&u, &x, sizeof u);
+    return u;
+}
+
+YMC_FN double ymc_from_bits(uint64_t u)
+{
+    double x;
+    __builtin_memcpy(&x, &u, sizeof x);
+    return x;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as   */
+/* easy as 1, 2, 3", SC'11).  Pinned by the Random123 known-answer vectors  */
+/* in tests/test_numerics.py.                                               */
+/* ------------------------------------------------------------------------ */
+
+#define YMC_PHILOX_M0 0xD2511F53u
+#define YMC_PHILOX_M1 0xCD9E8D57u
+#define YMC_PHILOX_W0 0x9E3779B9u
+#define YMC_PHILOX_W1 0xBB67AE85u
+
+typedef struct ymc_u32x4 {
+    uint32_t v[4];
+} ymc_u32x4;
+
+YMC_FN ymc_u32x4 ymc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                   uint32_t k0, uint32_t k1)
+{
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)YMC_PHILOX_M0 * c0;
+        uint64_t p1 = (uint64_t)YMC_PHILOX_M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += YMC_PHILOX_W0;
+        k1 += YMC_PHILOX_W1;
+    }
+    ymc_u32x4 out;
+    out.v[0] = c0; out.v[1] = c1; out.v[2] = c2; out.v[3] = c3;
+    return out;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Draw addressing.                                                         */
+/*                                                                          */
+/* A chain consumes draws per MH *transition*.  Transitions of one chain    */
+/* are numbered t = 0, 1, 2, ... (for the single-level random walk t is the */
+/* step index; for two-level delayed acceptance with sub-chain length S,    */
+/* fine step n owns t = n*(S+1) + s, s = 0..S-1 the coarse sub-steps and    */
+/* s = S the fine accept/reject).  Every draw is addressed, never           */
+/* sequenced, so the reference's "proposal == state => no uniform drawn"    */
+/* rule (metropolisHastings.py:60-61) does not shift any later draw.        */
+/*                                                                          */
+/*   key     = (seed[31:0], seed[63:32])                                    */
+/*   uniform of transition t:  counter (chain, 0, p[31:0], p[63:32]),       */
+/*       p = t >> 1; words {0,1} serve even t, words {2,3} odd t            */
+/*   normals 2j, 2j+1 of transition t:                                      */
+/*       counter (chain, 1 + j, t[31:0], t[63:32]); Box-Muller on the block */
+/* chain is the GLOBAL chain id, so a chain's stream does not depend on how */
+/* the ensemble is sharded over GPUs.                                       */
+/* ------------------------------------------------------------------------ */
+
+/* 53-bit mantissa from two words -> [0,1) on the 2^-53 grid */
+YMC_FN double ymc_u01_co(uint32_t lo, uint32_t hi)
+{
+    uint64_t m = (((uint64_t)hi << 32) | lo) >> 11;
+    return (double)m * 0x1p-53;
+}
+
+/* 53-bit mantissa from two words -> (0,1] on the 2^-53 grid */
+YMC_FN double ymc_u01_oc(uint32_t lo, uint32_t hi)
+{
+    uint64_t m = ((((uint64_t)hi << 32) | lo) >> 11) + 1u;
+    return (double)m * 0x1p-53;
+}
+
+YMC_FN ymc_u32x4 ymc_uniform_block(uint64_t seed, uint32_t chain, uint64_t t)
+{
+    uint64_t p = t >> 1;
+    return ymc_philox4x32_10(chain, 0u, (uint32_t)p, (uint32_t)(p >> 32),
+                             (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+YMC_FN double ymc_uniform_from_block(ymc_u32x4 b, uint64_t t)
+{
+    return (t & 1u) ? ymc_u01_co(b.v[2], b.v[3]) : ymc_u01_co(b.v[0], b.v[1]);
+}
+
+/* the accept/reject uniform of transition t (u ~ U[0,1), metropolisHastings.py:68) */
+YMC_FN double ymc_draw_uniform(uint64_t seed, uint32_t chain, uint64_t t)
+{
+    return ymc_uniform_from_block(ymc_uniform_block(seed, chain, t), t);
+}
+
+/* ------------------------------------------------------------------------ */
+/* log(x), x a positive normal double.  Argument reduction to               */
+/* [sqrt(2)/2, sqrt(2)) and the s = f/(2+f) series (the classic fdlibm      */
+/* scheme); < 1 ulp.                                                        */
+/* ------------------------------------------------------------------------ */
+YMC_FN double ymc_log(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01; /* 0x3fe62e42fee00000 */
+    const double ln2_lo = 1.90821492927058770002e-10; /* 0x3dea39ef35793c76 */
+    const double Lg1 = 6.666666666666735130e-01;
+    const double Lg2 = 3.999999999940941908e-01;
+    const double Lg3 = 2.857142874366239149e-01;
+    const double Lg4 = 2.222219843214978396e-01;
+    const double Lg5 = 1.818357216161805012e-01;
+    const double Lg6 = 1.531383769920937332e-01;
+    const double Lg7 = 1.479819860511658591e-01;
+
+    uint64_t ix = ymc_bits(x);
+    uint32_t hx = (uint32_t)(ix >> 32);
+    int32_t k = (int32_t)(hx >> 20) - 1023;
+    hx &= 0x000fffffu;
+    uint32_t i = (hx + 0x95f64u) & 0x100000u;
+    k += (int32_t)(i >> 20);
+    ix = ((uint64_t)(hx | (i ^ 0x3ff00000u)) << 32) | (ix & 0xffffffffu);
+    double f = ymc_from_bits(ix) - 1.0;
+    double dk = (double)k;
+
+    double s = f / (2.0 + f);
+    double z = s * s;
+    double w = z * z;
+    double t1 = w * ymc_fma(w, ymc_fma(w, Lg6, Lg4), Lg2);
+    double t2 = z * ymc_fma(w, ymc_fma(w, ymc_fma(w, Lg7, Lg5), Lg3), Lg1);
+    double R = t2 + t1;
+    double hfsq = 0.5 * f * f;
+    return dk * ln2_hi - ((hfsq - ymc_fma(s, hfsq + R, dk * ln2_lo)) - f);
+}
+
+/* ------------------------------------------------------------------------ */
+/* exp(x) for any double.  x = k ln2 + r, |r| <= ln2/2; degree-13 Taylor    */
+/* polynomial in r by Horner/fma; 2^k applied through the exponent field.   */
+/* Tables: tools/gen_numerics_tables.py.  < 1 ulp (tests/test_numerics.py). */
+/* ------------------------------------------------------------------------ */
+YMC_FN double ymc_scale2(double p, int32_t k) /* p * 2^k, result must be normal */
+{
+    return ymc_from_bits(ymc_bits(p) + ((uint64_t)(int64_t)k << 52));
+}
+
+YMC_FN double ymc_exp(double x)
+{
+    const double inv_ln2 = 0x1.71547652b82fep+0;
+    const double ln2_hi = 0x1.62e42fee00000p-1;
+    const double ln2_lo = 0x1.a39ef35793c76p-33;
+
+    if (!(x == x)) return x;                          /* NaN */
+    if (x > 0x1.62e42fefa39efp+9) return __builtin_inf();
+    if (x < -745.2) return 0.0;
+
+    double kd = __builtin_rint(x * inv_ln2);
+    int32_t k = (int32_t)kd;
+    double r = ymc_fma(-kd, ln2_hi, x);
+    r = ymc_fma(-kd, ln2_lo, r);
+
+    double p = 0x1.6124613a86d09p-33;                 /* 1/13! */
+    p = ymc_fma(p, r, 0x1.1eed8eff8d898p-29);         /* 1/12! */
+    p = ymc_fma(p, r, 0x1.ae64567f544e4p-26);         /* 1/11! */
+    p = ymc_fma(p, r, 0x1.27e4fb7789f5cp-22);         /* 1/10! */
+    p = ymc_fma(p, r, 0x1.71de3a556c734p-19);         /* 1/9!  */
+    p = ymc_fma(p, r, 0x1.a01a01a01a01ap-16);         /* 1/8!  */
+    p = ymc_fma(p, r, 0x1.a01a01a01a01ap-13);         /* 1/7!  */
+    p = ymc_fma(p, r, 0x1.6c16c16c16c17p-10);         /* 1/6!  */
+    p = ymc_fma(p, r, 0x1.1111111111111p-7);          /* 1/5!  */
+    p = ymc_fma(p, r, 0x1.5555555555555p-5);          /* 1/4!  */
+    p = ymc_fma(p, r, 0x1.5555555555555p-3);          /* 1/3!  */
+    p = ymc_fma(p, r, 0.5);
+    p = ymc_fma(p, r, 1.0);
+    p = ymc_fma(p, r, 1.0);                           /* p in [0.70, 1.42] */
+
+    if (k < -1021) return ymc_scale2(p, k + 1000) * 0x1p-1000;
+    if (k > 1022) return ymc_scale2(p, k - 2) * 4.0;
+    return ymc_scale2(p, k);
+}
+
+/* ------------------------------------------------------------------------ */
+/* sin(pi t), cos(pi t) for |t| < 2^30.  t = q/2 + r exactly, |r| <= 1/4;   */
+/* odd/even Taylor polynomials in r with coefficients pi^n/n! rounded to    */
+/* nearest (tools/gen_numerics_tables.py), then the quadrant fix-up.        */
+/* ------------------------------------------------------------------------ */
+YMC_FN void ymc_sincospi(double t, double *sn, double *cs)
+{
+    double qd = __builtin_rint(t + t);
+    double r = ymc_fma(-0.5, qd, t);                  /* exact */
+    int32_t q = (int32_t)qd;
+    double r2 = r * r;
+
+    double ps = 0x1.aaec32af93359p-21;                /* +pi^17/17! */
+    ps = ymc_fma(ps, r2, -0x1.6fadb9f155744p-16);
+    ps = ymc_fma(ps, r2, 0x1.e8f434d018d63p-12);
+    ps = ymc_fma(ps, r2, -0x1.e3074fde8871fp-8);
+    ps = ymc_fma(ps, r2, 0x1.50783487ee782p-4);
+    ps = ymc_fma(ps, r2, -0x1.32d2cce62bd86p-1);
+    ps = ymc_fma(ps, r2, 0x1.466bc6775aae2p+1);
+    ps = ymc_fma(ps, r2, -0x1.4abbce625be53p+2);
+    ps = ymc_fma(ps, r2, 0x1.921fb54442d18p+1);       /* pi */
+    double s = ps * r;
+
+    double pc = 0x1.20c62c2f2d7f5p-18;                /* +pi^16/16! */
+    pc = ymc_fma(pc, r2, -0x1.b6e24f44b128fp-14);
+    pc = ymc_fma(pc, r2, 0x1.f9d38a3763cc3p-10);
+    pc = ymc_fma(pc, r2, -0x1.a6d1f2a204a8cp-6);
+    pc = ymc_fma(pc, r2, 0x1.e1f506891babbp-3);
+    pc = ymc_fma(pc, r2, -0x1.55d3c7e3cbffap+0);
+    pc = ymc_fma(pc, r2, 0x1.03c1f081b5ac4p+2);
+    pc = ymc_fma(pc, r2, -0x1.3bd3cc9be45dep+2);
+    double c = ymc_fma(pc, r2, 1.0);
+
+    /* quadrant q mod 4: 0 -> (s,c); 1 -> (c,-s); 2 -> (-s,-c); 3 -> (-c,s) */
+    double so = (q & 1) ? c : s;
+    double co = (q & 1) ? s : c;
+    if (q & 2) so = -so;
+    if ((q + 1) & 2) co = -co;
+    *sn = so;
+    *cs = co;
+}
+
+/* ------------------------------------------------------------------------ */
+/* The normal pair (2j, 2j+1) of transition t: Box-Muller on one Philox     */
+/* block.  Replaces numpy.random.standard_normal(d) (gaussian.py:63).       */
+/* ------------------------------------------------------------------------ */
+YMC_FN void ymc_draw_normal_pair(uint64_t seed, uint32_t chain, uint64_t t, uint32_t j,
+                                 double *z0, double *z1)
+{
+    ymc_u32x4 b = ymc_philox4x32_10(chain, 1u + j, (uint32_t)t, (uint32_t)(t >> 32),
+                                    (uint32_t)seed, (uint32_t)(seed >> 32));
+    double u1 = ymc_u01_oc(b.v[0], b.v[1]);           /* (0,1] */
+    double u2 = ymc_u01_co(b.v[2], b.v[3]);           /* [0,1) */
+    double rad = __builtin_sqrt(-2.0 * ymc_log(u1));
+    double sn, cs;
+    ymc_sincospi(u2 + u2, &sn, &cs);
+    *z0 = rad * cs;
+    *z1 = rad * sn;
+}
+
+#endif /* YMC_NUMERICS_H */
