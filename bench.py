@@ -1,0 +1,299 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MH steps/s of the chain-ensemble hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One bench "step" = one launch of the fused propose/evaluate/accept/record
+kernel advancing every chain of this rank by --transitions MH transitions
+(full trajectory + accept mask + FullDiagnostics' Welford moments, i.e. what
+example_mcmc_2d_singleLevel.py records).  Default workload = BASELINE.json
+configs[1]: the 2-D Gaussian target, random-walk proposal, 65 536 chains per
+GPU.  For N > 1 the driver launches one process per GPU (torchrun env:
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); chains shard by global chain id,
+nothing is exchanged while sampling (weak scaling), and the single collective
+is an RCCL all-gather of the per-chain summaries after the timed region.
+No PyTorch anywhere: the host drives libymc.so through ctypes.
+
+Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes per
+launch ((8 d + 1) B per transition per chain) / average kernel
+time measured with HIP events on the kernel's stream.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c5", "c4"])
+    ap.add_argument("--chains", type=int, default=0, help="chains per GPU (default: the workload's)")
+    ap.add_argument("--transitions", type=int, default=0, help="MH transitions per chain per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-moments", action="store_true")
+    return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------
+# synthetic workloads
+# ---------------------------------------------------------------------------
+
+TGT_MEAN = np.array([1.0, 1.5])
+TGT_COV = np.array([[2.4, -0.5], [-0.5, 0.7]])
+
+
+def whitening(mean, cov):
+    w, v = np.linalg.eigh(cov)
+    return v * np.sqrt(1.0 / w), float(mean.size * np.log(2.0 * np.pi) + np.sum(np.log(w)))
+
+
+def lv_problem_arrays():
+    rng = np.random.default_rng(1111)
+    design = rng.uniform(0.5, 1.5, size=(10, 2))
+    return design
+
+
+def make_workload(name, ffi, ctx, lowering):
+    """-> (problem, x0 (1,d), default chains/GPU, default transitions/step, description, d, oracle problem)"""
+    from oracle import oracle  # only to describe the same problem to the cpu_baseline leg
+    if name in ("c2", "c5"):
+        U, c = whitening(TGT_MEAN, TGT_COV)
+        fine = lowering.Lowered(ffi.GAUSS_WHITENED, 2)
+        fine.set_array("mean", TGT_MEAN)
+        fine.set_array("whiten", U)
+        fine.desc.log_norm = c
+        sigma = np.sqrt(np.reciprocal(np.reciprocal(np.full(2, 1.0))))
+        x0 = np.array([[-8.0, -7.0]])
+        o_fine = oracle.gauss_whitened(TGT_MEAN, U, c)
+        if name == "c2":
+            prob = lowering.make_problem(ctx, ffi.METHOD_MRW, fine, sigma)
+            return (prob, x0, 65536, 1000, "C2: 2-D Gaussian target (example_mcmc_2d_singleLevel.py), "
+                    "random-walk proposal var 1.0, x0=(-8,-7)", 2, dict(target=o_fine, sigma=sigma))
+        cm = TGT_MEAN + np.array([0.15, -0.2])
+        cc = 2.0 * TGT_COV + np.array([[0.1, 1.2], [1.2, 0.05]])
+        Uc, c_c = whitening(cm, cc)
+        coarse = lowering.Lowered(ffi.GAUSS_WHITENED, 2)
+        coarse.set_array("mean", cm)
+        coarse.set_array("whiten", Uc)
+        coarse.desc.log_norm = c_c
+        prob = lowering.make_problem(ctx, ffi.METHOD_MLDA2, fine, sigma, surrogate=coarse, sub_chain_length=6)
+        return (prob, x0, 131072, 200, "C5: two-level delayed acceptance (example_mcmc_2d_twoLevel.py), S=6",
+                2, dict(target=o_fine, sigma=sigma, surrogate=oracle.gauss_whitened(cm, Uc, c_c), S=6))
+    # c4: Lotka-Volterra, nData=10, T=10, RK4 x 50
+    design = lv_problem_arrays()
+    truth = np.log(np.array([0.4, 0.6]))
+    noise_prec, prior_mean, prior_prec = np.reciprocal(np.full(2, 0.04)), np.zeros(2), np.reciprocal(np.full(2, 1.4))
+    o_prob = oracle.posterior_lv(design, 10.0, 0.8, 0.4, 50, np.zeros((10, 2)), noise_prec, prior_mean, prior_prec)
+    clean = oracle.forward(o_prob, truth).reshape(10, 2)
+    data = clean + np.sqrt(0.04) * np.random.default_rng(2222).standard_normal((10, 2))
+    o_prob = oracle.posterior_lv(design, 10.0, 0.8, 0.4, 50, data, noise_prec, prior_mean, prior_prec)
+    low = lowering.Lowered(ffi.POSTERIOR_LV, 2)
+    low.desc.n_data, low.desc.data_dim = 10, 2
+    for k, v in (("data", data), ("noise_precision", noise_prec), ("prior_mean", prior_mean),
+                 ("prior_precision", prior_prec), ("design", design)):
+        low.set_array(k, v)
+    low.desc.t_final, low.desc.alpha, low.desc.gamma, low.desc.rk4_steps = 10.0, 0.8, 0.4, 50
+    sigma = np.sqrt(np.reciprocal(np.reciprocal(np.full(2, 0.15))))
+    prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, sigma)
+    return (prob, np.array([[-0.6, -0.3]]), 16384, 100,
+            "C4: Lotka-Volterra posterior, nData=10, T=10, RK4 x 50", 2, dict(target=o_prob, sigma=sigma))
+
+
+# ---------------------------------------------------------------------------
+# rendezvous of the RCCL unique id without PyTorch: rank 0 publishes it in a
+# file keyed by the launcher's pid and MASTER_PORT, the other ranks poll for it
+# ---------------------------------------------------------------------------
+
+def exchange_unique_id(ffi, rank):
+    key = f"{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}"
+    path = os.path.join("/tmp", f"ymc_rdzv_{key}")
+    if rank == 0:
+        uid = ffi.Communicator.unique_id()
+        tmp = path + f".{os.getpid()}"
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)
+        return uid, path
+    deadline = time.time() + 300
+    while time.time() < deadline:
+        try:
+            with open(path, "rb") as f:
+                uid = f.read()
+            if len(uid) == ffi.UNIQUE_ID_BYTES:
+                return uid, path
+        except FileNotFoundError:
+            pass
+        time.sleep(0.05)
+    raise RuntimeError("rank 0 never published the RCCL unique id")
+
+
+def cpu_baseline(wl, d):
+    """The oracle (CPU restatement, kind "port") timed on the host cores on a
+    bounded sample of the same workload: same target, same recording, fewer
+    chains and transitions (~10-20 s of CPU work)."""
+    from oracle import oracle
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+    x0 = wl.get("x0")
+
+    def ensemble(K, threads):
+        return oracle.Ensemble(wl["target"], wl["sigma"], np.tile(x0, (K, 1)), 20250103,
+                               surrogate=wl.get("surrogate"), sub_chain_length=wl.get("S", 0), nthreads=threads)
+
+    def timed(K, T, threads, min_seconds):
+        e = ensemble(K, threads)
+        bufs = e.advance(T)          # untimed: faults the record buffers in, like the GPU warm-up
+        reps, t = 0, time.perf_counter()
+        while True:
+            e.advance(T, reuse=bufs)
+            reps += 1
+            dt = time.perf_counter() - t
+            if dt >= min_seconds:
+                return K * T * reps / dt, reps, dt
+
+    T = 500
+    K = 1024 * cores             # 25 B per transition of record: ~100 MB per 8 cores
+    rate, reps, dt = timed(K, T, cores, 10.0)
+    K1 = 1024
+    rate1, reps1, dt1 = timed(K1, T, 1, 4.0)
+    return {"value": rate, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"{K} chains x {T} transitions x {reps} passes of the same workload (trajectory, mask, log-density and "
+                      f"moments recorded, record buffers resident), {cores} OpenMP threads, {dt:.1f} s",
+            "single_thread_steps_per_s": rate1,
+            "reference_single_core_steps_per_s_survey_container": 2.2e4}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched as N processes (torch.distributed.run / torchrun)")
+        args.gpus = world
+
+    from yagremcmc_amd import _ffi as ffi, lowering
+    from yagremcmc_amd.diagnostics import merge_welford
+    ctx = ffi.Context(local_rank if world > 1 else 0)
+    info = ctx.info()
+    prob, x0, def_chains, def_T, desc, d, wl = make_workload(args.workload, ffi, ctx, lowering)
+    wl["x0"] = x0
+    K = args.chains or def_chains
+    T = args.transitions or def_T
+    flags = ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT | (0 if args.no_moments else ffi.RECORD_MOMENTS)
+    run = ffi.Run(prob, 20250103, K, x0, T, flags, chain_offset=rank * K)
+
+    comm = None
+    if world > 1:
+        uid, path = exchange_unique_id(ffi, rank)
+        comm = ffi.Communicator(ctx, uid, world, rank)
+
+    def barrier():
+        run.sync()
+        if comm is not None:
+            comm.barrier()
+
+    for _ in range(args.warmup):
+        run.rewind_record()
+        run.advance(T)
+    run.sync()
+    run.kernel_time_ms()  # drop warm-up launches from the kernel-time average
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run.rewind_record()
+        run.advance(T)
+    run.sync()
+    elapsed = time.perf_counter() - t0
+    if comm is not None:
+        elapsed = comm.allreduce_max(elapsed)
+    kernel_ms, launches = run.kernel_time_ms()
+
+    # the single collective of the run: gather the per-chain summaries
+    gather_ms = None
+    if comm is not None:
+        tg = time.perf_counter()
+        packed = comm.allgather_summary(run)  # (world, K, 3d+5) u64
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        flat = packed.reshape(world * K, -1)
+        if rank == 0:
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+    else:
+        s = run.summary()
+        x, lp = run.state()
+        flat = None
+
+    if rank != 0:
+        return
+
+    total_steps = run.steps_done()[0]
+    if flat is not None:
+        accepted = flat[:, d + 1].astype(np.float64)
+        wf_n = flat[:, d + 2]
+        wf_mean = flat[:, d + 3:2 * d + 3].view(np.float64)
+        wf_m2 = flat[:, 2 * d + 3:3 * d + 3].view(np.float64)
+        status = flat[:, 3 * d + 3]
+    else:
+        accepted, wf_n, wf_mean, wf_m2, status = (s["accepted"].astype(np.float64), s["wf_n"], s["wf_mean"],
+                                                  s["wf_m2"], s["status"])
+    pooled = merge_welford(wf_n, wf_mean, wf_m2) if not args.no_moments else (0, None, None)
+
+    transitions = float(world) * K * T * args.steps
+    value = transitions / elapsed
+    bytes_per_transition = 8 * d + 1
+    launch_bytes = K * T * bytes_per_transition
+    achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            rec = json.load(open(tpath)).get(f"{args.workload}_K{K}_T{T}")
+            traffic = rec["hbm_bytes_per_launch"] if rec else None
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "MH steps/sec (whole node)", "value": value, "unit": "steps/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": desc, "chains_per_gpu": K, "chains_total": world * K,
+                   "transitions_per_step": T, "record": "trajectory f64 [T][K][d] + accept u8 [T][K]"
+                   + ("" if args.no_moments else " + Welford moments"), "parallelism": f"chains sharded over {world} GPU(s)",
+                   "rng": "Philox4x32-10, seed 20250103, keyed by global chain id"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "kernel_ms_avg": kernel_ms, "launches_timed": launches,
+                     "algorithmic_bytes_per_launch": launch_bytes,
+                     "note": "per GPU (rank 0); bytes = (8 d + 1) per transition per chain; the kernel is fp64-VALU "
+                             "bound (Philox + Box-Muller + exp per transition), see DESIGN.md"},
+        "hbm_gb_per_s_whole_node": world * achieved,
+        "kernel_steps_per_s_per_gpu": K * T / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0,
+        "acceptance_rate": float(accepted.sum() / (len(accepted) * total_steps)),
+        "pooled_mean": None if pooled[1] is None else [float(v) for v in pooled[1]],
+        "chains_flagged_nonfinite": int((status != 0).sum()),
+        "gather_ms": gather_ms,
+        "device": info,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(wl, d)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

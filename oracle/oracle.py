@@ -240,11 +240,18 @@ class Ensemble:
         self.wf_m2 = np.zeros((self.K, self.d))
         self.status = np.zeros(self.K, dtype=np.uint32)
 
-    def advance(self, nsteps, record=True, want_margin=False, want_sub=False):
+    def advance(self, nsteps, record=True, want_margin=False, want_sub=False, reuse=None):
+        """`reuse`: the dict a previous advance of the same length returned; its
+        arrays are overwritten (lets a timing run write into pages that are
+        already resident)."""
         K, d = self.K, self.d
-        traj = np.empty((nsteps, K, d)) if record else None
-        acc = np.empty((nsteps, K), dtype=np.uint8) if record else None
-        lp_out = np.empty((nsteps, K)) if record else None
+        if reuse is not None:
+            traj, acc, lp_out = reuse["traj"], reuse["acc"], reuse["logpost"]
+            assert traj.shape == (nsteps, K, d)
+        else:
+            traj = np.empty((nsteps, K, d)) if record else None
+            acc = np.empty((nsteps, K), dtype=np.uint8) if record else None
+            lp_out = np.empty((nsteps, K)) if record else None
         margin = np.empty((nsteps, K)) if want_margin else None
         tgt, keep = _lower(self.target)
         out = dict(traj=traj, acc=acc, logpost=lp_out, margin=margin)

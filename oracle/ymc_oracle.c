@@ -373,6 +373,13 @@ static void ymo_welford(const double *x, int32_t d, uint64_t *n, double *mean, d
 
 static int ymo_is_finite(double v) { return fabs(v) <= 1.79769313486231570815e308; }
 
+/* chains per cache block of the ensemble loops */
+static int64_t ymo_block_size(int32_t d)
+{
+    int64_t b = 512 / (d > 0 ? d : 1);
+    return b < 1 ? 1 : (b > 64 ? 64 : b);
+}
+
 /*
  * MetropolisHastings.run, metropolisHastings.py:103-120, for K independent
  * chains of the Metropolised random walk (mrw.py:41-57), advanced by `nsteps`
@@ -395,39 +402,44 @@ void ymo_mrw_advance(const ymo_density *tgt, const double *sigma, int32_t eq_mod
                      int32_t nthreads)
 {
     int32_t d = tgt->dim;
+    /* chains are independent, so they are walked in blocks (a block's record
+     * rows are contiguous: cache-friendly on the CPU); per chain the order of
+     * operations is exactly the reference's loop */
+    const int64_t block = ymo_block_size(d);
+    const int64_t nblocks = (K + block - 1) / block;
 #ifdef _OPENMP
-#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(dynamic, 1)
 #endif
-    for (int64_t k = 0; k < K; ++k) {
-        uint32_t chain = (uint32_t)(chain0 + (uint64_t)k);
-        double xs[YMO_DMAX], y[YMO_DMAX];
-        memcpy(xs, x + k * d, sizeof(double) * (size_t)d);
-        double lpx = lp[k];
-        uint32_t st = status ? status[k] : 0;
+    for (int64_t kb = 0; kb < nblocks; ++kb) {
+        const int64_t k_lo = kb * block, k_hi = (k_lo + block < K) ? k_lo + block : K;
+        double y[YMO_DMAX];
         for (int64_t n = 0; n < nsteps; ++n) {
             uint64_t t = t0 + (uint64_t)n;
-            ymo_propose(xs, sigma, seed, chain, t, d, y);       /* :116-117 */
-            int accepted = 0;
-            double mg = INFINITY;
-            double lpy = lpx;
-            if (!ymo_states_equal(y, xs, d, eq_mode)) {          /* :60-61 */
-                lpy = ymo_logdensity_one(tgt, y, &st);
-                accepted = ymo_accept(lpy - lpx, ymo_is_finite(lpy), seed, chain, t, &st, &mg);
+            for (int64_t k = k_lo; k < k_hi; ++k) {
+                uint32_t chain = (uint32_t)(chain0 + (uint64_t)k);
+                double *xs = x + k * d;
+                uint32_t st = status ? status[k] : 0;
+                ymo_propose(xs, sigma, seed, chain, t, d, y);       /* :116-117 */
+                int accepted = 0;
+                double mg = INFINITY;
+                double lpy = lp[k];
+                if (!ymo_states_equal(y, xs, d, eq_mode)) {          /* :60-61 */
+                    lpy = ymo_logdensity_one(tgt, y, &st);
+                    accepted = ymo_accept(lpy - lp[k], ymo_is_finite(lpy), seed, chain, t, &st, &mg);
+                }
+                if (wf_n) ymo_welford(xs, d, &wf_n[k], wf_mean + k * d, wf_m2 + k * d);
+                if (accepted) {                                      /* :79-92 */
+                    memcpy(xs, y, sizeof(double) * (size_t)d);
+                    lp[k] = lpy;
+                    if (acc_count) acc_count[k] += 1;
+                }
+                if (status) status[k] = st;
+                if (traj) memcpy(traj + (n * K + k) * d, xs, sizeof(double) * (size_t)d);
+                if (acc) acc[n * K + k] = (uint8_t)accepted;
+                if (lp_out) lp_out[n * K + k] = lp[k];
+                if (margin) margin[n * K + k] = mg;
             }
-            if (wf_n) ymo_welford(xs, d, &wf_n[k], wf_mean + k * d, wf_m2 + k * d);
-            if (accepted) {                                      /* :79-92 */
-                memcpy(xs, y, sizeof(double) * (size_t)d);
-                lpx = lpy;
-                if (acc_count) acc_count[k] += 1;
-            }
-            if (traj) memcpy(traj + (n * K + k) * d, xs, sizeof(double) * (size_t)d);
-            if (acc) acc[n * K + k] = (uint8_t)accepted;
-            if (lp_out) lp_out[n * K + k] = lpx;
-            if (margin) margin[n * K + k] = mg;
         }
-        memcpy(x + k * d, xs, sizeof(double) * (size_t)d);
-        lp[k] = lpx;
-        if (status) status[k] = st;
     }
 }
 
@@ -451,60 +463,61 @@ void ymo_mlda2_advance(const ymo_density *fine, const ymo_density *coarse, const
                        double *lp_out, double *margin, int32_t nthreads)
 {
     int32_t d = fine->dim;
+    const int64_t block = ymo_block_size(d);
+    const int64_t nblocks = (K + block - 1) / block;
 #ifdef _OPENMP
-#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(dynamic, 1)
 #endif
-    for (int64_t k = 0; k < K; ++k) {
-        uint32_t chain = (uint32_t)(chain0 + (uint64_t)k);
-        double xs[YMO_DMAX], z[YMO_DMAX], y[YMO_DMAX];
-        memcpy(xs, x + k * d, sizeof(double) * (size_t)d);
-        double lpfx = lpf[k], lpcx = lpc[k];
-        uint32_t st = status ? status[k] : 0;
+    for (int64_t kb = 0; kb < nblocks; ++kb) {
+        const int64_t k_lo = kb * block, k_hi = (k_lo + block < K) ? k_lo + block : K;
+        double z[YMO_DMAX], y[YMO_DMAX];
         for (int64_t n = 0; n < nsteps; ++n) {
             uint64_t tbase = (n0 + (uint64_t)n) * (uint64_t)(S + 1);
-            /* surrogate.run(S+1, state): metropolisHastings.py:103-120 on pi_c */
-            memcpy(z, xs, sizeof(double) * (size_t)d);
-            double lpcz = lpcx;
-            for (int32_t s = 0; s < S; ++s) {
-                uint64_t t = tbase + (uint64_t)s;
-                ymo_propose(z, sigma, seed, chain, t, d, y);
-                int a = 0;
-                if (!ymo_states_equal(y, z, d, eq_mode)) {
-                    double lpcy = ymo_logdensity_one(coarse, y, &st);
-                    a = ymo_accept(lpcy - lpcz, ymo_is_finite(lpcy), seed, chain, t, &st, NULL);
-                    if (a) {
-                        memcpy(z, y, sizeof(double) * (size_t)d);
-                        lpcz = lpcy;
+            for (int64_t k = k_lo; k < k_hi; ++k) {
+                uint32_t chain = (uint32_t)(chain0 + (uint64_t)k);
+                double *xs = x + k * d;
+                uint32_t st = status ? status[k] : 0;
+                /* surrogate.run(S+1, state): metropolisHastings.py:103-120 on pi_c */
+                memcpy(z, xs, sizeof(double) * (size_t)d);
+                double lpcz = lpc[k];
+                for (int32_t s = 0; s < S; ++s) {
+                    uint64_t t = tbase + (uint64_t)s;
+                    ymo_propose(z, sigma, seed, chain, t, d, y);
+                    int a = 0;
+                    if (!ymo_states_equal(y, z, d, eq_mode)) {
+                        double lpcy = ymo_logdensity_one(coarse, y, &st);
+                        a = ymo_accept(lpcy - lpcz, ymo_is_finite(lpcy), seed, chain, t, &st, NULL);
+                        if (a) {
+                            memcpy(z, y, sizeof(double) * (size_t)d);
+                            lpcz = lpcy;
+                        }
                     }
+                    if (sub_acc) sub_acc[(n * S + s) * K + k] = (uint8_t)a;
                 }
-                if (sub_acc) sub_acc[(n * S + s) * K + k] = (uint8_t)a;
+                /* fine accept/reject of y = z, metropolisHastings.py:55-73 + mlda.py:146-154 */
+                int accepted = 0;
+                double mg = INFINITY;
+                double lpfy = lpf[k];
+                if (!ymo_states_equal(z, xs, d, eq_mode)) {
+                    lpfy = ymo_logdensity_one(fine, z, &st);
+                    double log_ratio = ((lpfy + lpc[k]) - lpcz) - lpf[k];
+                    accepted = ymo_accept(log_ratio, ymo_is_finite(lpfy) && ymo_is_finite(lpcz), seed,
+                                          chain, tbase + (uint64_t)S, &st, &mg);
+                }
+                if (wf_n) ymo_welford(xs, d, &wf_n[k], wf_mean + k * d, wf_m2 + k * d);
+                if (accepted) {
+                    memcpy(xs, z, sizeof(double) * (size_t)d);
+                    lpf[k] = lpfy;
+                    lpc[k] = lpcz;
+                    if (acc_count) acc_count[k] += 1;
+                }
+                if (status) status[k] = st;
+                if (traj) memcpy(traj + (n * K + k) * d, xs, sizeof(double) * (size_t)d);
+                if (acc) acc[n * K + k] = (uint8_t)accepted;
+                if (lp_out) lp_out[n * K + k] = lpf[k];
+                if (margin) margin[n * K + k] = mg;
             }
-            /* fine accept/reject of y = z, metropolisHastings.py:55-73 + mlda.py:146-154 */
-            int accepted = 0;
-            double mg = INFINITY;
-            double lpfy = lpfx;
-            if (!ymo_states_equal(z, xs, d, eq_mode)) {
-                lpfy = ymo_logdensity_one(fine, z, &st);
-                double log_ratio = ((lpfy + lpcx) - lpcz) - lpfx;
-                accepted = ymo_accept(log_ratio, ymo_is_finite(lpfy) && ymo_is_finite(lpcz), seed,
-                                      chain, tbase + (uint64_t)S, &st, &mg);
-            }
-            if (wf_n) ymo_welford(xs, d, &wf_n[k], wf_mean + k * d, wf_m2 + k * d);
-            if (accepted) {
-                memcpy(xs, z, sizeof(double) * (size_t)d);
-                lpfx = lpfy;
-                lpcx = lpcz;
-                if (acc_count) acc_count[k] += 1;
-            }
-            if (traj) memcpy(traj + (n * K + k) * d, xs, sizeof(double) * (size_t)d);
-            if (acc) acc[n * K + k] = (uint8_t)accepted;
-            if (lp_out) lp_out[n * K + k] = lpfx;
-            if (margin) margin[n * K + k] = mg;
         }
-        memcpy(x + k * d, xs, sizeof(double) * (size_t)d);
-        lpf[k] = lpfx;
-        lpc[k] = lpcx;
-        if (status) status[k] = st;
     }
 }
 

@@ -1,0 +1,177 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol
+include/ymc.h declares; host logic (lowering, builder validation, diagnostics
+pooling) behaves; nothing here launches a kernel."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ffi():
+    import __graft_entry__ as entry
+    entry.build()
+    from yagremcmc_amd import _ffi
+    return _ffi
+
+
+def test_library_exports_every_declared_symbol(ffi):
+    header = open(os.path.join(ROOT, "include", "ymc.h")).read()
+    declared = set(re.findall(r"^(?:int|const char \*)\s*\*?(ymc_[a-z0-9_]+)\(", header, flags=re.M))
+    assert len(declared) >= 30
+    handle = ffi.lib()
+    for name in sorted(declared):
+        assert hasattr(handle, name), f"libymc.so does not export {name}"
+    assert declared == set(ffi.EXPORTED_SYMBOLS)
+    assert handle.ymc_abi_version() == ffi.ABI_VERSION
+
+
+def test_struct_layouts_match_the_header(ffi):
+    import ctypes as C
+    # sizes computed from the header's field lists (LP64)
+    assert C.sizeof(ffi.DensityDesc) == 8 + 2 * 8 + 16 + 8 + 7 * 8 + 24 + 8
+    assert C.sizeof(ffi.ProblemDesc) == 8 + 2 * C.sizeof(ffi.DensityDesc) + 8 + 8
+    assert C.sizeof(ffi.RunDesc) == 7 * 8
+    assert C.sizeof(ffi.DeviceInfo) == 128 + 64 + 8 + 8
+
+
+def test_no_gpu_means_loud_failure_not_fallback(ffi):
+    """On a box without a GPU the MH path must raise, never compute on the CPU."""
+    try:
+        n = ffi.device_count()
+    except ffi.YmcError as e:
+        assert e.code == ffi.ERR_DEVICE
+        n = 0
+    if n > 0:
+        pytest.skip("a GPU is present")
+    from yagremcmc_amd import MRWBuilder
+    from yagremcmc_amd.parameter.vector import ParameterVector
+    from yagremcmc_amd.statistics.covariance import IIDCovarianceMatrix
+    from yagremcmc_amd.test.testSetup import GaussianTargetDensity2d
+    b = MRWBuilder()
+    b.explicitTarget = GaussianTargetDensity2d(ParameterVector(np.zeros(2)), np.eye(2))
+    b.proposalCovariance = IIDCovarianceMatrix(2, 1.0)
+    with pytest.raises(ffi.YmcError):
+        b.build_method().run(10, ParameterVector(np.zeros(2)), verbose=False)
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing in the package may import, load or include it."""
+    pkg = os.path.join(ROOT, "yagre-mcmc_amd")
+    bad = re.compile(r"(^\s*(from|import)\s+oracle\b)|libymc_oracle|#include\s*[\"<][^\">]*oracle", re.M)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                assert not bad.search(open(os.path.join(dirpath, f)).read()), f"{f} uses the oracle"
+
+
+def test_builder_validation_messages(ffi):
+    """test_builder.py:7-33 and builder.py:42-50 / mlda.py:218-269"""
+    from yagremcmc_amd import MLDABuilder, MRWBuilder
+    b = MRWBuilder()
+    b.bayesModel = object()
+    with pytest.raises(ValueError, match="Proposal Covariance not set for MRW"):
+        b.build_method()
+    b = MRWBuilder()
+    b.proposalCovariance = object()
+    with pytest.raises(ValueError, match="Either bayesian model or explicit target"):
+        b.build_method()
+    b.bayesModel, b.explicitTarget = object(), object()
+    with pytest.raises(ValueError, match="Only one of bayes model or explicit target"):
+        b.build_method()
+    m = MLDABuilder()
+    with pytest.raises(ValueError, match="Coarse proposal covariance not set for MLDA"):
+        m.build_method()
+    m.baseProposalCovariance = object()
+    with pytest.raises(ValueError, match="Subchain lengths not set for MLDA"):
+        m.build_method()
+    m.subChainLengths = [6]
+    m.explicitTarget = object()
+    with pytest.raises(ValueError, match="Surrogate targets not set for MLDA"):
+        m.build_method()
+    m.surrogateTargets = [object(), object()]
+    with pytest.raises(ValueError, match="Number of sub-chain lengths does not match"):
+        m.build_method()
+
+
+def test_lowering_of_plugins_and_duck_typed_reference_objects(ffi):
+    from yagremcmc_amd import lowering
+    from yagremcmc_amd.plugins import (AdditiveGaussianNoiseLikelihood, CentredGaussianNoise, Data,
+                                       DiagonalCovarianceMatrix, ExampleLinearModelSolver, ForwardModel,
+                                       Gaussian, GaussianTargetDensity1d, GaussianTargetDensity2d,
+                                       IIDCovarianceMatrix, LotkaVolterraSolver, ParameterVector,
+                                       ScalarParameter, UnnormalisedPosterior)
+    cov = np.array([[2.4, -0.5], [-0.5, 0.7]])
+    t = GaussianTargetDensity2d(ParameterVector(np.array([1.0, 1.5])), cov)
+    low = lowering.lower_density(t)
+    assert low.desc.kind == ffi.GAUSS_WHITENED and low.desc.dim == 2
+    # U U^T = Sigma^-1 and log_norm = d log 2pi + log det
+    assert np.allclose(t.whiten_ @ t.whiten_.T, np.linalg.inv(cov))
+    assert np.isclose(low.desc.log_norm, 2 * np.log(2 * np.pi) + np.log(np.linalg.det(cov)))
+    low = lowering.lower_density(GaussianTargetDensity1d(ScalarParameter(np.array([1.5])), 2.0))
+    assert low.desc.kind == ffi.GAUSS_ISO1D and low.desc.variance == 2.0
+    # sigma is sqrt(reciprocal(reciprocal(var))), not sqrt(var)
+    var = np.array([0.1, 0.7, 3.3])
+    assert np.array_equal(lowering.proposal_sigma(DiagonalCovarianceMatrix(var), 3),
+                          np.sqrt(np.reciprocal(np.reciprocal(var))))
+    with pytest.raises(ValueError):
+        lowering.proposal_sigma(IIDCovarianceMatrix(2, 1.0), 3)
+    # posterior over the linear solver
+    A, b = np.arange(6.0).reshape(3, 2), np.ones(3)
+    like = AdditiveGaussianNoiseLikelihood(Data(np.zeros((4, 3))), ForwardModel(ExampleLinearModelSolver(A, b)),
+                                           CentredGaussianNoise(IIDCovarianceMatrix(3, 0.5)))
+    prior = Gaussian(ParameterVector(np.zeros(2)), IIDCovarianceMatrix(2, 5.0))
+    low = lowering.lower_density(UnnormalisedPosterior(like, prior))
+    assert (low.desc.kind, low.desc.dim, low.desc.n_data, low.desc.data_dim) == (ffi.POSTERIOR_LINEAR, 2, 4, 3)
+    # Lotka-Volterra
+    cfg = {'T': 6., 'alpha': 0.8, 'gamma': 0.4, 'nData': 5, 'dataDim': 2, 'solver': 'LSODA', 'rtol': 1e-4}
+    like = AdditiveGaussianNoiseLikelihood(Data(np.zeros((5, 2))), ForwardModel(LotkaVolterraSolver(np.ones((5, 2)), cfg)),
+                                           CentredGaussianNoise(IIDCovarianceMatrix(2, 0.05)))
+    low = lowering.lower_density(UnnormalisedPosterior(like, prior))
+    assert (low.desc.kind, low.desc.rk4_steps, low.desc.t_final) == (ffi.POSTERIOR_LV, 50, 6.0)
+    # objects of the reference's own classes are recognised by name + attributes
+    RefCov = type("IIDCovarianceMatrix", (), {})
+    rc = RefCov()
+    rc._precision = np.reciprocal(np.full(2, 0.25))
+    assert np.array_equal(lowering.proposal_sigma(rc, 2), np.full(2, 0.5))
+    RefT1 = type("GaussianTargetDensity1d", (), {})
+    r1 = RefT1()
+    r1.mean_, r1.var_ = ScalarParameter(np.array([0.5])), 1.5
+    assert lowering.lower_density(r1).desc.variance == 1.5
+    # anything else raises: no hidden CPU path
+    with pytest.raises(lowering.UnsupportedPlugin):
+        lowering.lower_density(object())
+    Dense = type("DenseCovarianceMatrix", (), {"cholFactor_": np.eye(2)})
+    with pytest.raises(lowering.UnsupportedPlugin):
+        lowering.proposal_sigma(Dense(), 2)
+    assert lowering.state_eq_of(ScalarParameter(np.array([1.0]))) == ffi.EQ_ISCLOSE
+    assert lowering.state_eq_of(ParameterVector(np.array([1.0, 2.0]))) == ffi.EQ_EXACT
+
+
+def test_parameter_objects_behave_like_the_reference():
+    from yagremcmc_amd.plugins import ParameterVector, ScalarParameter
+    a, b = ParameterVector(np.array([1.0, 2.0])), ParameterVector(np.array([1.0, 2.0]))
+    assert a == b and a.dimension == 2 and not (a == ParameterVector(np.array([1.0, 2.0 + 1e-15])))
+    assert a.clone_with(np.array([3.0, 4.0])).coefficient[0] == 3.0
+    with pytest.raises(ValueError):
+        a.clone_with([3.0, 4.0])
+    s = ScalarParameter(np.array([1.0]))
+    assert s == ScalarParameter(np.array([1.0 + 1e-12])) and s.dimension == 1
+    with pytest.raises(Exception):
+        ScalarParameter(1.0)
+
+
+def test_welford_pooling_matches_numpy():
+    """test_diagnostics.py:32-66 on the pooled (Chan) merge"""
+    from yagremcmc_amd.diagnostics import merge_welford
+    rng = np.random.default_rng(3)
+    data = rng.normal(size=(7, 500, 3)) * np.array([1.0, 5.0, 0.1]) + np.array([0.0, 3.0, -2.0])
+    n = np.full(7, 500)
+    mean = data.mean(axis=1)
+    m2 = ((data - mean[:, None]) ** 2).sum(axis=1)
+    N, pm, pm2 = merge_welford(n, mean, m2)
+    flat = data.reshape(-1, 3)
+    assert N == 3500 and np.allclose(pm, flat.mean(axis=0)) and np.allclose(pm2 / (N - 1), flat.var(axis=0, ddof=1))

@@ -1,0 +1,334 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and with the
+golden vectors of the live reference.  Bar: accept masks, trajectories,
+diagnostics AND log-densities bit-exact against the oracle (same numeric
+spec); against the reference's own outputs masks/trajectories bit-exact and
+log-densities within 1e-12 relative (north_star asks 1e-6)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as o  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ffi():
+    from yagremcmc_amd import _ffi
+    assert _ffi.device_count() >= 1
+    return _ffi
+
+
+@pytest.fixture(scope="module")
+def ctx(ffi):
+    return ffi.default_context(0)
+
+
+ALL = None
+
+
+def _flags(ffi, moments=True, sub=False):
+    f = ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT | ffi.RECORD_LOGPOST
+    if moments:
+        f |= ffi.RECORD_MOMENTS
+    if sub:
+        f |= ffi.RECORD_SUB_ACCEPT
+    return f
+
+
+def _gauss_low(ffi, mean, whiten, log_norm):
+    from yagremcmc_amd import lowering
+    low = lowering.Lowered(ffi.GAUSS_WHITENED, int(np.size(mean)))
+    low.set_array("mean", np.asarray(mean).reshape(-1))
+    low.set_array("whiten", whiten)
+    low.desc.log_norm = float(log_norm)
+    return low
+
+
+def _posterior_low(ffi, kind, dim, g, **extra):
+    from yagremcmc_amd import lowering
+    low = lowering.Lowered(kind, dim)
+    data = np.asarray(g["data"])
+    low.desc.n_data, low.desc.data_dim = data.shape
+    low.set_array("data", data)
+    low.set_array("noise_precision", g["noise_precision"])
+    low.set_array("prior_mean", g["prior_mean"])
+    low.set_array("prior_precision", g["prior_precision"])
+    for k, v in extra.items():
+        if isinstance(v, np.ndarray):
+            low.set_array(k, v)
+        else:
+            setattr(low.desc, k, v)
+    return low
+
+
+def _device_run(ffi, ctx, low, sigma, x0, seed, nsteps, method=None, sur=None, S=0, eq=None, chain0=0,
+                moments=True, splits=1):
+    from yagremcmc_amd import lowering
+    method = method or ffi.METHOD_MRW
+    prob = lowering.make_problem(ctx, method, low, sigma, eq if eq is not None else ffi.EQ_EXACT,
+                                 surrogate=sur, sub_chain_length=S)
+    K = x0.shape[0]
+    run = ffi.Run(prob, seed, K, x0, nsteps, _flags(ffi, moments, sub=(method == ffi.METHOD_MLDA2)), chain0)
+    base, rem = divmod(nsteps, splits)
+    for i in range(splits):
+        run.advance(base + (1 if i < rem else 0))
+    run.sync()
+    out = dict(traj=run.trajectory(), acc=run.accept(), logpost=run.logpost(), summary=run.summary(),
+               state=run.state())
+    if method == ffi.METHOD_MLDA2:
+        out["sub_acc"] = run.sub_accept()
+    return out
+
+
+def _same_as_oracle(dev, e, out):
+    assert np.array_equal(dev["acc"], out["acc"])
+    assert np.array_equal(dev["traj"], out["traj"])
+    assert np.array_equal(dev["logpost"], out["logpost"])
+    assert np.array_equal(dev["summary"]["accepted"], e.acc_count)
+    assert np.array_equal(dev["summary"]["wf_mean"], e.wf_mean)
+    assert np.array_equal(dev["summary"]["wf_m2"], e.wf_m2)
+    assert np.array_equal(dev["summary"]["status"], e.status)
+    assert np.array_equal(dev["state"][0], e.x) and np.array_equal(dev["state"][1], e.lp)
+
+
+def _same_as_reference(dev, g, lp_rtol=1e-12):
+    assert np.array_equal(dev["acc"], g["acc"])
+    if "traj" in g:
+        assert np.array_equal(dev["traj"], g["traj"][1:])
+    want = g["logpost"][1:]
+    assert np.abs(dev["logpost"] - want).max() <= lp_rtol * np.abs(want).max()
+
+
+# ---------------------------------------------------------------------------
+# the numeric spec on the device == on the CPU, bit for bit
+# ---------------------------------------------------------------------------
+
+def test_elementary_functions_bit_exact(ctx):
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.integers(1, 2**53, size=400000) * 2.0**-53, np.exp(rng.uniform(-700, 700, 100000))])
+    assert np.array_equal(ctx.numerics(0, x)[0], o.log(x))
+    x = np.concatenate([rng.uniform(-750, 712, 400000), rng.uniform(-40, 2, 200000),
+                        [0.0, -745.3, 709.79, np.inf, -np.inf, -1e-300]])
+    assert np.array_equal(ctx.numerics(1, x)[0], o.exp(x))
+    assert np.isnan(ctx.numerics(1, np.array([np.nan]))[0][0])
+    t = rng.integers(0, 2**53, size=400000) * 2.0**-52
+    s, c = ctx.numerics(2, t)
+    so, co = o.sincospi(t)
+    assert np.array_equal(s, so) and np.array_equal(c, co)
+
+
+def test_sqrt_and_division_correctly_rounded_on_device(ctx):
+    rng = np.random.default_rng(6)
+    x = np.concatenate([rng.uniform(0, 80, 300000), np.exp(rng.uniform(-700, 700, 100000)), [0.0, 5e-324, 2.0]])
+    assert np.array_equal(ctx.numerics(3, x)[0], np.sqrt(x))
+    a = rng.normal(size=400000) * np.exp(rng.uniform(-30, 30, 400000))
+    b = rng.integers(1, 10**7, size=400000).astype(np.float64)
+    assert np.array_equal(ctx.numerics(4, a, divisor=b)[0], a / b)
+    b2 = rng.normal(size=400000) * np.exp(rng.uniform(-300, 300, 400000))
+    assert np.array_equal(ctx.numerics(4, a, divisor=b2)[0], a / b2)
+
+
+def test_draw_stream_bit_exact(ctx):
+    for d, K, nt, t0, chain0 in [(2, 200, 300, 0, 0), (1, 64, 100, 7, 1000), (5, 33, 50, 2**33 + 1, 2**31),
+                                 (128, 8, 20, 3, 17)]:
+        xi, u = ctx.rng_fill(20250103, chain0, K, t0, nt, d)
+        xo, uo = o.rng_fill(20250103, chain0, K, t0, nt, d)
+        assert np.array_equal(xi, xo) and np.array_equal(u, uo)
+
+
+# ---------------------------------------------------------------------------
+# golden fixtures
+# ---------------------------------------------------------------------------
+
+def test_f1_scalar_1d(ffi, ctx, golden):
+    from yagremcmc_amd import lowering
+    g = golden("f1_mrw_1d.npz")
+    n = int(g["n_states"])
+    low = lowering.Lowered(ffi.GAUSS_ISO1D, 1)
+    low.set_array("mean", np.array([float(g["mean"])]))
+    low.desc.variance = float(g["variance"])
+    dev = _device_run(ffi, ctx, low, g["sigma"], g["x0"], int(g["seed"]), n - 1, eq=ffi.EQ_ISCLOSE)
+    e = o.Ensemble(o.gauss_iso1d(float(g["mean"]), float(g["variance"])), g["sigma"], g["x0"], int(g["seed"]),
+                   eq_mode=o.EQ_ISCLOSE)
+    _same_as_oracle(dev, e, e.advance(n - 1))
+    _same_as_reference(dev, g)
+    assert np.array_equal(dev["summary"]["wf_mean"][0], g["wf_mean"].reshape(-1))
+    assert np.array_equal(dev["summary"]["wf_m2"][0] / (n - 2.0), g["wf_var"].reshape(-1))
+
+
+@pytest.mark.parametrize("name,splits", [("f2_mrw_2d.npz", 1), ("f2_mrw_2d.npz", 7), ("f2b_mrw_2d_indep.npz", 2)])
+def test_f2_mrw_2d(ffi, ctx, golden, name, splits):
+    g = golden(name)
+    n = int(g["n_states"])
+    low = _gauss_low(ffi, g["mean"], g["whiten"], g["log_norm"])
+    dev = _device_run(ffi, ctx, low, g["sigma"], g["x0"], int(g["seed"]), n - 1, splits=splits)
+    e = o.Ensemble(o.gauss_whitened(g["mean"], g["whiten"], float(g["log_norm"])), g["sigma"], g["x0"],
+                   int(g["seed"]))
+    _same_as_oracle(dev, e, e.advance(n - 1))
+    _same_as_reference(dev, g)
+    assert np.array_equal(dev["summary"]["accepted"] / (n - 1), g["acc_rate"])
+    assert np.array_equal(dev["summary"]["wf_mean"], g["wf_mean"])
+    assert np.array_equal(dev["summary"]["wf_m2"] / (n - 2.0), g["wf_var"])
+
+
+def test_f3b_linear_2x2(ffi, ctx, golden):
+    g = golden("f3b_linear_2x2.npz")
+    n = int(g["n_states"])
+    low = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, 2, g, fwd_matrix=np.asarray(g["A"]), fwd_shift=np.asarray(g["b"]))
+    dev = _device_run(ffi, ctx, low, g["sigma"], g["x0"], int(g["seed"]), n - 1)
+    p = o.posterior_linear(g["A"], g["b"], g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+    e = o.Ensemble(p, g["sigma"], g["x0"], int(g["seed"]))
+    _same_as_oracle(dev, e, e.advance(n - 1))
+    _same_as_reference(dev, g)
+    from yagremcmc_amd import lowering
+    prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, g["sigma"])
+    lp, st = prob.logdensity(g["grid"])
+    assert np.array_equal(lp, o.logdensity(p, g["grid"])[0]) and (st == 0).all()
+    assert np.abs(lp - g["grid_logpost"]).max() <= 1e-12 * np.abs(g["grid_logpost"]).max()
+    assert np.array_equal(prob.forward(g["grid"]), o.forward(p, g["grid"]))
+
+
+def test_f4_lotka_volterra(ffi, ctx, golden):
+    g = golden("f4_lotka_volterra.npz")
+    n = int(g["n_states"])
+    low = _posterior_low(ffi, ffi.POSTERIOR_LV, 2, g, design=np.asarray(g["design"]), t_final=float(g["t_final"]),
+                         alpha=float(g["alpha"]), gamma=float(g["gamma"]), rk4_steps=int(g["rk4_steps"]))
+    dev = _device_run(ffi, ctx, low, g["sigma"], g["x0"], int(g["seed"]), n - 1)
+    p = o.posterior_lv(g["design"], float(g["t_final"]), float(g["alpha"]), float(g["gamma"]), int(g["rk4_steps"]),
+                       g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+    e = o.Ensemble(p, g["sigma"], g["x0"], int(g["seed"]))
+    _same_as_oracle(dev, e, e.advance(n - 1))
+    _same_as_reference(dev, g)
+    from yagremcmc_amd import lowering
+    prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, g["sigma"])
+    f = prob.forward(g["thetas"])
+    assert np.array_equal(f, o.forward(p, g["thetas"]))
+    assert np.allclose(f.reshape(-1, 5, 2), g["forward_lsoda_rtol1e4"], rtol=1e-3, atol=5e-3)
+    # stiff start of the example script (example_inference_lotkaVolterra_singleLevel.py:106):
+    # same value and same failure flag as the oracle
+    lp, st = prob.logdensity(np.array([[-7.0, 2.8], [-0.6, -0.3]]))
+    lpo, sto = o.logdensity(p, np.array([[-7.0, 2.8], [-0.6, -0.3]]))
+    assert np.array_equal(lp, lpo) and np.array_equal(st, sto)
+
+
+def test_f5_two_level(ffi, ctx, golden):
+    g = golden("f5_mlda2_2d.npz")
+    n, S = int(g["n_states"]), int(g["S"])
+    fine = _gauss_low(ffi, g["fine_mean"], g["fine_whiten"], g["fine_log_norm"])
+    coarse = _gauss_low(ffi, g["coarse_mean"], g["coarse_whiten"], g["coarse_log_norm"])
+    dev = _device_run(ffi, ctx, fine, g["sigma"], g["x0"], int(g["seed"]), n - 1, method=ffi.METHOD_MLDA2,
+                      sur=coarse, S=S, splits=3)
+    of = o.gauss_whitened(g["fine_mean"], g["fine_whiten"], float(g["fine_log_norm"]))
+    oc = o.gauss_whitened(g["coarse_mean"], g["coarse_whiten"], float(g["coarse_log_norm"]))
+    e = o.Ensemble(of, g["sigma"], g["x0"], int(g["seed"]), surrogate=oc, sub_chain_length=S)
+    out = e.advance(n - 1, want_sub=True)
+    _same_as_oracle(dev, e, out)
+    assert np.array_equal(dev["sub_acc"], out["sub_acc"])
+    _same_as_reference(dev, g)
+    assert np.array_equal(dev["sub_acc"], g["sub_acc"])
+
+
+def test_perfect_surrogate_accepts_every_move(ffi, ctx, golden):
+    """test_mlda.py:94-130"""
+    g = golden("f5_mlda2_2d.npz")
+    fine = _gauss_low(ffi, g["fine_mean"], g["fine_whiten"], g["fine_log_norm"])
+    x0 = np.tile([-8.0, -7.0], (4096, 1))
+    dev = _device_run(ffi, ctx, fine, g["sigma"], x0, 99, 300, method=ffi.METHOD_MLDA2, sur=fine, S=4)
+    moved = dev["sub_acc"].any(axis=1)
+    assert np.array_equal(dev["acc"].astype(bool), moved)
+
+
+# ---------------------------------------------------------------------------
+# other dimensions of the lane-per-chain kernels vs the oracle
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("d", [1, 3, 4, 5, 8])
+def test_gauss_target_other_dimensions(ffi, ctx, d):
+    rng = np.random.default_rng(100 + d)
+    a = rng.normal(size=(d, d))
+    cov = a @ a.T + d * np.eye(d)
+    mean = rng.normal(size=d)
+    p = o.gauss_from_cov(mean, cov)
+    low = _gauss_low(ffi, p["mean"], p["whiten"], p["log_norm"])
+    sigma = rng.uniform(0.5, 1.5, size=d)
+    x0 = rng.normal(size=(300, d))
+    dev = _device_run(ffi, ctx, low, sigma, x0, 777, 150, chain0=12345)
+    e = o.Ensemble(p, sigma, x0, 777, chain0=12345)
+    _same_as_oracle(dev, e, e.advance(150))
+
+
+@pytest.mark.parametrize("d,m,nd", [(1, 1, 1), (3, 5, 4), (8, 8, 6), (5, 2, 9)])
+def test_linear_posterior_other_shapes(ffi, ctx, d, m, nd):
+    rng = np.random.default_rng(200 + d)
+    g = dict(A=rng.normal(size=(m, d)), b=rng.normal(size=m), data=rng.normal(size=(nd, m)),
+             noise_precision=rng.uniform(0.5, 3, size=m), prior_mean=rng.normal(size=d),
+             prior_precision=rng.uniform(0.1, 2, size=d))
+    low = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, g, fwd_matrix=g["A"], fwd_shift=g["b"])
+    p = o.posterior_linear(g["A"], g["b"], g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+    sigma = np.full(d, 0.3)
+    x0 = rng.normal(size=(257, d))
+    dev = _device_run(ffi, ctx, low, sigma, x0, 31337, 120)
+    e = o.Ensemble(p, sigma, x0, 31337)
+    _same_as_oracle(dev, e, e.advance(120))
+
+
+# ---------------------------------------------------------------------------
+# BASELINE sizes: size-independent properties + oracle on slices of the ensemble
+# ---------------------------------------------------------------------------
+
+def test_c2_full_size_properties(ffi, ctx, golden):
+    """65 536 chains on the 2-D Gaussian target (BASELINE configs[1])."""
+    from yagremcmc_amd import lowering
+    g = golden("f2_mrw_2d.npz")
+    K, T = 65536, 400
+    low = _gauss_low(ffi, g["mean"], g["whiten"], g["log_norm"])
+    x0 = np.tile([-8.0, -7.0], (1, 1))
+    prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, g["sigma"])
+    run = ffi.Run(prob, 20250103, K, x0, T, _flags(ffi))
+    run.advance(T)
+    traj, acc = run.trajectory(), run.accept()
+    # (i) slices of the big ensemble equal the oracle run on those global chain ids
+    p = o.gauss_whitened(g["mean"], g["whiten"], float(g["log_norm"]))
+    for c0 in (0, 32768 - 32, 65536 - 64):
+        e = o.Ensemble(p, g["sigma"], np.tile([-8.0, -7.0], (64, 1)), 20250103, chain0=c0)
+        out = e.advance(T)
+        assert np.array_equal(traj[:, c0:c0 + 64], out["traj"]) and np.array_equal(acc[:, c0:c0 + 64], out["acc"])
+    # (ii) sharding invariance: the upper half as its own run with a chain offset
+    half = ffi.Run(prob, 20250103, K // 2, x0, T, _flags(ffi), K // 2)
+    half.advance(T)
+    assert np.array_equal(half.trajectory(), traj[:, K // 2:]) and np.array_equal(half.accept(), acc[:, K // 2:])
+    # (iii) a rejected transition repeats the state, an accepted one moves it
+    prev = np.concatenate([np.broadcast_to(x0, (1, K, 2)), traj[:-1]])
+    same = (traj == prev).all(axis=2)
+    assert np.array_equal(same, acc == 0)
+    # (iv) accept counters == column sums of the mask; Welford mean == mean of pre-transition states
+    s = run.summary()
+    assert np.array_equal(s["accepted"], acc.sum(axis=0).astype(np.uint64))
+    assert np.allclose(s["wf_mean"], prev.mean(axis=0), rtol=0, atol=1e-12)
+    # (v) the ensemble has reached the target: moments over chains at the last step
+    last = traj[-1]
+    assert np.abs(last.mean(axis=0) - g["mean"]).max() < 0.03
+    assert np.abs(np.cov(last.T) - g["cov"]).max() < 0.06
+    assert (s["status"] == 0).all()
+
+
+def test_record_capacity_and_rewind(ffi, ctx, golden):
+    from yagremcmc_amd import lowering
+    g = golden("f2_mrw_2d.npz")
+    low = _gauss_low(ffi, g["mean"], g["whiten"], g["log_norm"])
+    prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, g["sigma"])
+    run = ffi.Run(prob, 1, 128, g["x0"][:1], 50, _flags(ffi))
+    run.advance(50)
+    first = run.trajectory()
+    with pytest.raises(ffi.YmcError) as err:
+        run.advance(1)
+    assert err.value.code == ffi.ERR_CAPACITY
+    run.rewind_record()
+    run.advance(50)
+    both = np.concatenate([first, run.trajectory()])
+    e = o.Ensemble(o.gauss_whitened(g["mean"], g["whiten"], float(g["log_norm"])), g["sigma"],
+                   np.tile(g["x0"][:1], (128, 1)), 1)
+    assert np.array_equal(both, e.advance(100)["traj"])
+    assert run.steps_done() == (100, 50)
+    avg_ms, launches = run.kernel_time_ms()
+    assert launches == 2 and avg_ms > 0

@@ -1,0 +1,18 @@
+"""yagremcmc on MI355X: ensembles of Metropolis-Hastings chains as HIP kernels.
+
+Import it as `yagremcmc_amd` (the directory name `yagre-mcmc_amd` is not a
+Python identifier; the sibling package `yagremcmc_amd/` aliases it).  The
+module layout mirrors the reference's (`chain.method.mrw`, `statistics.*`,
+`parameter.*`, `model.*`, `test.testSetup`), so an example script switches by
+replacing `yagremcmc` with `yagremcmc_amd` in its imports.
+"""
+from . import _ffi
+from ._ffi import YmcError, device_count
+from .builders import ChainBuilder, MLDABuilder, MRWBuilder
+from .diagnostics import AcceptanceRateDiagnostics, DummyDiagnostics, FullDiagnostics
+from .ensemble import MLDA, MetropolisedRandomWalk
+from .lowering import UnsupportedPlugin
+
+__all__ = ["ChainBuilder", "MRWBuilder", "MLDABuilder", "MetropolisedRandomWalk", "MLDA",
+           "AcceptanceRateDiagnostics", "FullDiagnostics", "DummyDiagnostics", "UnsupportedPlugin",
+           "YmcError", "device_count"]

@@ -1,0 +1,205 @@
+"""Builders: the drop-in boundary of the chain-ensemble path.
+
+Same property names, validation and error messages as the reference's
+`ChainBuilder` (yagremcmc/chain/builder.py:7-83), `MRWBuilder`
+(chain/method/mrw.py:60-91) and `MLDABuilder` (chain/method/mlda.py:157-344);
+`build_method()` returns an ensemble sampler with the reference's
+`run / chain / diagnostics / target / clear` surface.  Ensemble extensions are
+extra properties with defaults that reproduce the single-chain behaviour.
+"""
+from . import diagnostics as dg
+from .ensemble import MLDA, MetropolisedRandomWalk
+from .lowering import UnsupportedPlugin
+from .plugins import UnnormalisedPosterior
+
+
+class ChainBuilder:
+    """chain/builder.py:7-83"""
+
+    def __init__(self):
+        self._bayesModel = None
+        self._explicitTarget = None
+        self._diagnostics = dg.AcceptanceRateDiagnostics()
+        # ensemble extensions
+        self.nChains = 1
+        self.seed = 0
+        self.device = 0
+        self.chainOffset = 0
+        self.recordTrajectory = True
+        self.recordLogPosterior = False
+        self.rk4Steps = None
+
+    @property
+    def bayesModel(self):
+        return self._bayesModel
+
+    @bayesModel.setter
+    def bayesModel(self, model):
+        self._bayesModel = model
+
+    @property
+    def explicitTarget(self):
+        return self._explicitTarget
+
+    @explicitTarget.setter
+    def explicitTarget(self, density):
+        self._explicitTarget = density
+
+    @property
+    def diagnostics(self):
+        return self._diagnostics
+
+    @diagnostics.setter
+    def diagnostics(self, diagnostics):
+        self._diagnostics = diagnostics
+
+    def _ensemble_options(self):
+        return dict(nChains=self.nChains, seed=self.seed, device=self.device, chainOffset=self.chainOffset,
+                    recordTrajectory=self.recordTrajectory, recordLogPosterior=self.recordLogPosterior,
+                    rk4Steps=self.rk4Steps)
+
+    def validate_target_measure(self):
+        if self._bayesModel is None and self._explicitTarget is None:
+            raise ValueError("Either bayesian model or explicit target density must be provided for chain setup")
+        if self._bayesModel is not None and self._explicitTarget is not None:
+            raise ValueError("Only one of bayes model or explicit target density should be provided.")
+
+    def target_is_posterior(self):
+        return self._bayesModel is not None
+
+    def target_is_explicit(self):
+        return self._explicitTarget is not None
+
+    def _validate_parameters(self):
+        raise NotImplementedError
+
+    def build_from_model(self):
+        raise NotImplementedError
+
+    def build_from_target(self):
+        raise NotImplementedError
+
+    def build_method(self):
+        self._validate_parameters()
+        self.validate_target_measure()
+        if self.target_is_posterior():
+            return self.build_from_model()
+        if self.target_is_explicit():
+            return self.build_from_target()
+        raise ValueError("Invalid target distribution")
+
+
+class MRWBuilder(ChainBuilder):
+    """chain/method/mrw.py:60-91"""
+
+    def __init__(self):
+        super().__init__()
+        self._proposalCov = None
+
+    @property
+    def proposalCovariance(self):
+        return self._proposalCov
+
+    @proposalCovariance.setter
+    def proposalCovariance(self, covariance):
+        self._proposalCov = covariance
+
+    def build_from_model(self):
+        target = UnnormalisedPosterior(self._bayesModel.likelihood, self._bayesModel.prior)
+        return MetropolisedRandomWalk(target, self._proposalCov, self._diagnostics, **self._ensemble_options())
+
+    def build_from_target(self):
+        return MetropolisedRandomWalk(self._explicitTarget, self._proposalCov, self._diagnostics,
+                                      **self._ensemble_options())
+
+    def _validate_parameters(self):
+        if self._proposalCov is None:
+            raise ValueError("Proposal Covariance not set for MRW")
+
+
+class MLDABuilder(ChainBuilder):
+    """chain/method/mlda.py:157-344, explicit targets with one surrogate."""
+
+    def __init__(self):
+        super().__init__()
+        self._basePropCov = None
+        self._nSteps = None
+        self._surrTgts = None
+        self._surrDgnstList = None
+        self._tgtDgnst = None
+        self._biasCorrection = None
+        self.recordSubChain = False
+
+    @property
+    def baseProposalCovariance(self):
+        return self._basePropCov
+
+    @baseProposalCovariance.setter
+    def baseProposalCovariance(self, cov):
+        self._basePropCov = cov
+
+    @property
+    def subChainLengths(self):
+        return self._nSteps
+
+    @subChainLengths.setter
+    def subChainLengths(self, nSteps):
+        self._nSteps = nSteps
+
+    @property
+    def surrogateTargets(self):
+        return self._surrTgts
+
+    @surrogateTargets.setter
+    def surrogateTargets(self, tgts):
+        self._surrTgts = tgts
+
+    @property
+    def targetDiagnostics(self):
+        return self._tgtDgnst
+
+    @targetDiagnostics.setter
+    def targetDiagnostics(self, diagnostics):
+        self._tgtDgnst = diagnostics
+
+    @property
+    def surrogateDiagnostics(self):
+        return self._surrDgnstList
+
+    @surrogateDiagnostics.setter
+    def surrogateDiagnostics(self, surrDgnstList):
+        self._surrDgnstList = surrDgnstList
+
+    @property
+    def biasCorrection(self):
+        return self._biasCorrection
+
+    @biasCorrection.setter
+    def biasCorrection(self, bias):
+        self._biasCorrection = bias
+
+    def _validate_parameters(self):
+        if self._basePropCov is None:
+            raise ValueError("Coarse proposal covariance not set for MLDA")
+        if self._nSteps is None:
+            raise ValueError("Subchain lengths not set for MLDA")
+        if self._bayesModel is not None:
+            raise UnsupportedPlugin("MLDA over a hierarchy of Bayesian models is not lowered to the device yet; "
+                                    "use explicit targets")
+        if self._explicitTarget is not None:
+            if self._surrTgts is None:
+                raise ValueError("Surrogate targets not set for MLDA")
+            if not len(self._nSteps) == len(self._surrTgts):
+                raise ValueError("Number of sub-chain lengths does not match number of surrogate targets")
+            if self._surrDgnstList is not None and not len(self._surrDgnstList) == len(self._surrTgts):
+                raise ValueError("Number of diagnostics does not match the size of the model hierarchy")
+            if self._biasCorrection is not None:
+                raise UnsupportedPlugin("bias correction has no device lowering")
+
+    def build_from_model(self):
+        raise UnsupportedPlugin("MLDA over a hierarchy of Bayesian models is not lowered to the device yet")
+
+    def build_from_target(self):
+        tgt_diag = self._tgtDgnst if self._tgtDgnst is not None else dg.AcceptanceRateDiagnostics()
+        return MLDA(self._explicitTarget, list(self._surrTgts), self._basePropCov, list(self._nSteps), tgt_diag,
+                    self._surrDgnstList, recordSubChain=self.recordSubChain, **self._ensemble_options())

@@ -1,0 +1,737 @@
+/*
+ * ymc_api.hip -- the C ABI of include/ymc.h: handles, device memory, launches.
+ * No exceptions cross the boundary; every failure returns a negative
+ * ymc_status and leaves a message for ymc_last_error().
+ */
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "ymc_kernels.h"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+
+#define YMC_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(YMC_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+#define YMC_TRY(call)          \
+    do {                       \
+        int rc_ = (call);      \
+        if (rc_ != YMC_OK) return rc_; \
+    } while (0)
+
+struct DeviceBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    ~DeviceBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    int alloc(size_t n)
+    {
+        release();
+        if (n == 0) return YMC_OK;
+        YMC_HIP(hipMalloc(&p, n));
+        bytes = n;
+        return YMC_OK;
+    }
+    template <class T>
+    T *as() const { return static_cast<T *>(p); }
+};
+
+/* host copy of one lowered density + its device-resident arrays */
+struct DensityHost {
+    ymc_density_desc d{};
+    std::vector<double> mean, whiten, data, noise_prec, prior_mean, prior_prec, A, b, design;
+    DeviceBuf dev;  /* one allocation: data | noise_prec | prior_mean | prior_prec | A | b | design */
+    size_t off_data = 0, off_noise = 0, off_pmean = 0, off_pprec = 0, off_A = 0, off_b = 0, off_design = 0;
+};
+
+}  // namespace
+
+struct ymc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop{};
+};
+
+struct ymc_problem {
+    ymc_ctx *ctx = nullptr;
+    int method = 0, eq_mode = 0, S = 0, D = 0, kind = 0;
+    DensityHost tgt, sur;
+    std::vector<double> sigma;
+};
+
+struct ymc_run {
+    ymc_ctx *ctx = nullptr;
+    const ymc_problem *problem = nullptr;
+    uint64_t seed = 0, chain0 = 0, K = 0;
+    uint32_t flags = 0;
+    uint64_t capacity = 0, recorded = 0, steps_done = 0;
+    DeviceBuf x, lp, lpc, acc_count, wf_mean, wf_m2, status, traj, acc, lp_out, sub_acc, summary;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;  /* launches since the last query */
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+};
+
+namespace {
+
+int copy_array(std::vector<double> &dst, const double *src, size_t n, const char *what)
+{
+    if (n == 0) {
+        dst.clear();
+        return YMC_OK;
+    }
+    if (!src) return fail(YMC_ERR_INVALID, "density description: %s is null", what);
+    dst.assign(src, src + n);
+    for (double v : dst)
+        if (!std::isfinite(v)) return fail(YMC_ERR_INVALID, "density description: %s is not finite", what);
+    return YMC_OK;
+}
+
+int lower_density(ymc_ctx *ctx, const ymc_density_desc &in, DensityHost &out, int expect_dim)
+{
+    (void)ctx;
+    out.d = in;
+    const int d = in.dim;
+    if (d < 1) return fail(YMC_ERR_INVALID, "parameter dimension must be positive, got %d", d);
+    if (expect_dim > 0 && d != expect_dim)
+        return fail(YMC_ERR_INVALID, "surrogate dimension %d differs from target dimension %d", d, expect_dim);
+    if (d > YMC_LANE_DMAX)
+        return fail(YMC_ERR_UNSUPPORTED, "parameter dimension %d exceeds the lane-per-chain limit %d", d,
+                    YMC_LANE_DMAX);
+    switch (in.kind) {
+    case YMC_DENSITY_GAUSS_WHITENED:
+        YMC_TRY(copy_array(out.mean, in.mean, d, "mean"));
+        YMC_TRY(copy_array(out.whiten, in.whiten, (size_t)d * d, "whiten"));
+        if (!std::isfinite(in.log_norm)) return fail(YMC_ERR_INVALID, "log_norm is not finite");
+        break;
+    case YMC_DENSITY_GAUSS_ISO1D:
+        if (d != 1) return fail(YMC_ERR_INVALID, "GAUSS_ISO1D needs dim 1, got %d", d);
+        YMC_TRY(copy_array(out.mean, in.mean, 1, "mean"));
+        if (!(in.variance > 0.0) || !std::isfinite(in.variance))
+            return fail(YMC_ERR_INVALID, "variance must be positive and finite");
+        break;
+    case YMC_DENSITY_POSTERIOR_LINEAR:
+    case YMC_DENSITY_POSTERIOR_LV: {
+        if (in.n_data < 1 || in.data_dim < 1)
+            return fail(YMC_ERR_INVALID, "data must have at least one row and one column");
+        const size_t nd = in.n_data, m = in.data_dim;
+        YMC_TRY(copy_array(out.data, in.data, nd * m, "data"));
+        YMC_TRY(copy_array(out.noise_prec, in.noise_precision, m, "noise_precision"));
+        YMC_TRY(copy_array(out.prior_mean, in.prior_mean, d, "prior_mean"));
+        YMC_TRY(copy_array(out.prior_prec, in.prior_precision, d, "prior_precision"));
+        if (in.kind == YMC_DENSITY_POSTERIOR_LINEAR) {
+            if (m > YMC_LANE_MMAX)
+                return fail(YMC_ERR_UNSUPPORTED, "forward-map output dimension %zu exceeds the lane-per-chain limit %d",
+                            m, YMC_LANE_MMAX);
+            YMC_TRY(copy_array(out.A, in.fwd_matrix, m * d, "fwd_matrix"));
+            YMC_TRY(copy_array(out.b, in.fwd_shift, m, "fwd_shift"));
+        } else {
+            if (d != 2 || m != 2) return fail(YMC_ERR_INVALID, "Lotka-Volterra needs dim 2 and data_dim 2");
+            if (in.rk4_steps < 1) return fail(YMC_ERR_INVALID, "rk4_steps must be positive");
+            if (!std::isfinite(in.t_final) || !std::isfinite(in.alpha) || !std::isfinite(in.gamma))
+                return fail(YMC_ERR_INVALID, "Lotka-Volterra constants must be finite");
+            YMC_TRY(copy_array(out.design, in.design, nd * 2, "design"));
+        }
+        /* one device block for the arrays the kernels read through scalar loads */
+        std::vector<double> blob;
+        auto put = [&](const std::vector<double> &v, size_t &off) {
+            off = blob.size();
+            blob.insert(blob.end(), v.begin(), v.end());
+        };
+        put(out.data, out.off_data);
+        put(out.noise_prec, out.off_noise);
+        put(out.prior_mean, out.off_pmean);
+        put(out.prior_prec, out.off_pprec);
+        put(out.A, out.off_A);
+        put(out.b, out.off_b);
+        put(out.design, out.off_design);
+        YMC_TRY(out.dev.alloc(blob.size() * sizeof(double)));
+        YMC_HIP(hipMemcpy(out.dev.p, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice));
+        break;
+    }
+    default:
+        return fail(YMC_ERR_UNSUPPORTED, "unknown density kind %d", in.kind);
+    }
+    return YMC_OK;
+}
+
+template <int D>
+DensityDev<D> device_view(const DensityHost &h)
+{
+    DensityDev<D> v;
+    std::memset(&v, 0, sizeof v);
+    for (int j = 0; j < D && j < (int)h.mean.size(); ++j) v.mean[j] = h.mean[j];
+    for (int j = 0; j < D * D && j < (int)h.whiten.size(); ++j) v.whiten[j] = h.whiten[j];
+    v.log_norm = h.d.log_norm;
+    v.variance = h.d.variance;
+    v.n_data = h.d.n_data;
+    v.data_dim = h.d.data_dim;
+    v.rk4_steps = h.d.rk4_steps;
+    const double *base = h.dev.as<double>();
+    if (base) {
+        v.data = base + h.off_data;
+        v.noise_prec = base + h.off_noise;
+        v.prior_mean = base + h.off_pmean;
+        v.prior_prec = base + h.off_pprec;
+        v.A = base + h.off_A;
+        v.b = base + h.off_b;
+        v.design = base + h.off_design;
+    }
+    v.t_final = h.d.t_final;
+    v.alpha = h.d.alpha;
+    v.gamma = h.d.gamma;
+    return v;
+}
+
+template <int D>
+int eval_logdensity_dev(ymc_ctx *ctx, const ymc_problem *p, const DensityHost &h, uint64_t n, const double *x_dev,
+                        double *out_dev, uint32_t *status_dev)
+{
+    YMC_HIP(ymc_launch_logdensity<D>(p->kind, device_view<D>(h), n, x_dev, out_dev, status_dev, ctx->stream));
+    return YMC_OK;
+}
+
+#define YMC_DISPATCH_D(D_, EXPR)                                                         \
+    switch (D_) {                                                                        \
+    case 1: { constexpr int DD = 1; EXPR; } break;                                       \
+    case 2: { constexpr int DD = 2; EXPR; } break;                                       \
+    case 3: { constexpr int DD = 3; EXPR; } break;                                       \
+    case 4: { constexpr int DD = 4; EXPR; } break;                                       \
+    case 5: { constexpr int DD = 5; EXPR; } break;                                       \
+    case 6: { constexpr int DD = 6; EXPR; } break;                                       \
+    case 7: { constexpr int DD = 7; EXPR; } break;                                       \
+    case 8: { constexpr int DD = 8; EXPR; } break;                                       \
+    default: return fail(YMC_ERR_UNSUPPORTED, "parameter dimension %d has no kernel", D_); \
+    }
+
+int eval_logdensity(ymc_ctx *ctx, const ymc_problem *p, const DensityHost &h, uint64_t n, const double *x_dev,
+                    double *out_dev, uint32_t *status_dev)
+{
+    YMC_DISPATCH_D(p->D, return eval_logdensity_dev<DD>(ctx, p, h, n, x_dev, out_dev, status_dev));
+    return YMC_OK;
+}
+
+template <int D>
+int launch_advance(ymc_run *r, uint64_t nsteps)
+{
+    const ymc_problem *p = r->problem;
+    ChainArgs<D> a;
+    std::memset(&a, 0, sizeof a);
+    a.tgt = device_view<D>(p->tgt);
+    if (p->method == YMC_METHOD_MLDA2) a.sur = device_view<D>(p->sur);
+    for (int j = 0; j < D; ++j) a.sigma[j] = p->sigma[j];
+    a.seed = r->seed;
+    a.chain0 = r->chain0;
+    a.K = r->K;
+    a.t0 = r->steps_done;
+    a.wf_n0 = r->steps_done;
+    a.nsteps = (uint32_t)nsteps;
+    a.flags = r->flags;
+    a.eq_mode = p->eq_mode;
+    a.S = p->S;
+    a.x = r->x.as<double>();
+    a.lp = r->lp.as<double>();
+    a.lpc = r->lpc.as<double>();
+    a.acc_count = r->acc_count.as<uint64_t>();
+    a.wf_mean = r->wf_mean.as<double>();
+    a.wf_m2 = r->wf_m2.as<double>();
+    a.status = r->status.as<uint32_t>();
+    const uint64_t row = r->recorded;
+    if (r->flags & YMC_RECORD_TRAJECTORY) a.traj = r->traj.as<double>() + row * r->K * D;
+    if (r->flags & YMC_RECORD_ACCEPT) a.acc = r->acc.as<uint8_t>() + row * r->K;
+    if (r->flags & YMC_RECORD_LOGPOST) a.lp_out = r->lp_out.as<double>() + row * r->K;
+    if ((r->flags & YMC_RECORD_SUB_ACCEPT) && p->method == YMC_METHOD_MLDA2)
+        a.sub_acc = r->sub_acc.as<uint8_t>() + row * (uint64_t)p->S * r->K;
+
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (!r->pool.empty()) {
+        ev = r->pool.back();
+        r->pool.pop_back();
+    } else {
+        YMC_HIP(hipEventCreate(&ev.first));
+        YMC_HIP(hipEventCreate(&ev.second));
+    }
+    YMC_HIP(hipEventRecord(ev.first, r->ctx->stream));
+    hipError_t e = ymc_launch_chain<D>(p->kind, p->method, a, r->ctx->stream);
+    if (e != hipSuccess) {
+        r->pool.push_back(ev);
+        return fail(YMC_ERR_DEVICE, "chain kernel launch failed: %s", hipGetErrorString(e));
+    }
+    YMC_HIP(hipEventRecord(ev.second, r->ctx->stream));
+    r->timed.push_back(ev);
+    return YMC_OK;
+}
+
+bool records_anything(uint32_t flags)
+{
+    return (flags & (YMC_RECORD_TRAJECTORY | YMC_RECORD_ACCEPT | YMC_RECORD_LOGPOST | YMC_RECORD_SUB_ACCEPT)) != 0;
+}
+
+int fetch_rows(ymc_run *r, const DeviceBuf &buf, uint32_t need_flag, const char *what, uint64_t first, uint64_t n,
+               size_t row_bytes, void *dst, size_t dst_bytes)
+{
+    if (!r || !dst) return fail(YMC_ERR_INVALID, "null argument");
+    if (!(r->flags & need_flag)) return fail(YMC_ERR_INVALID, "the run does not record %s", what);
+    if (first + n > r->recorded)
+        return fail(YMC_ERR_INVALID, "rows [%llu, %llu) requested but only %llu recorded", (unsigned long long)first,
+                    (unsigned long long)(first + n), (unsigned long long)r->recorded);
+    if (dst_bytes < n * row_bytes) return fail(YMC_ERR_INVALID, "destination too small for %s", what);
+    YMC_HIP(hipSetDevice(r->ctx->device));
+    YMC_HIP(hipStreamSynchronize(r->ctx->stream));
+    if (n) YMC_HIP(hipMemcpy(dst, static_cast<const char *>(buf.p) + first * row_bytes, n * row_bytes, hipMemcpyDeviceToHost));
+    return YMC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ymc_abi_version(void) { return YMC_ABI_VERSION; }
+
+const char *ymc_last_error(void) { return g_error.c_str(); }
+
+int ymc_device_count(int *count)
+{
+    if (!count) return fail(YMC_ERR_INVALID, "null argument");
+    YMC_HIP(hipGetDeviceCount(count));
+    return YMC_OK;
+}
+
+int ymc_ctx_create(int device, ymc_ctx **out)
+{
+    if (!out) return fail(YMC_ERR_INVALID, "null argument");
+    *out = nullptr;
+    int n = 0;
+    YMC_HIP(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(YMC_ERR_INVALID, "device %d out of range (%d visible)", device, n);
+    ymc_ctx *c = new (std::nothrow) ymc_ctx;
+    if (!c) return fail(YMC_ERR_DEVICE, "out of host memory");
+    c->device = device;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&c->prop, device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(YMC_ERR_DEVICE, "context creation failed: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return YMC_OK;
+}
+
+int ymc_ctx_destroy(ymc_ctx *ctx)
+{
+    if (!ctx) return YMC_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return YMC_OK;
+}
+
+int ymc_ctx_device_info(const ymc_ctx *ctx, ymc_device_info *out)
+{
+    if (!ctx || !out) return fail(YMC_ERR_INVALID, "null argument");
+    std::memset(out, 0, sizeof *out);
+    std::snprintf(out->name, sizeof out->name, "%s", ctx->prop.name);
+    std::snprintf(out->arch, sizeof out->arch, "%s", ctx->prop.gcnArchName);
+    out->compute_units = ctx->prop.multiProcessorCount;
+    out->clock_mhz = ctx->prop.clockRate / 1000;
+    out->hbm_bytes = ctx->prop.totalGlobalMem;
+    return YMC_OK;
+}
+
+int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem **out)
+{
+    if (!ctx || !desc || !out) return fail(YMC_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (desc->method != YMC_METHOD_MRW && desc->method != YMC_METHOD_MLDA2)
+        return fail(YMC_ERR_UNSUPPORTED, "unknown method %d", desc->method);
+    if (desc->state_eq != YMC_EQ_EXACT && desc->state_eq != YMC_EQ_ISCLOSE)
+        return fail(YMC_ERR_INVALID, "unknown state equality rule %d", desc->state_eq);
+    YMC_HIP(hipSetDevice(ctx->device));
+    ymc_problem *p = new (std::nothrow) ymc_problem;
+    if (!p) return fail(YMC_ERR_DEVICE, "out of host memory");
+    p->ctx = ctx;
+    p->method = desc->method;
+    p->eq_mode = desc->state_eq;
+    int rc = lower_density(ctx, desc->target, p->tgt, 0);
+    if (rc == YMC_OK) {
+        p->D = desc->target.dim;
+        p->kind = desc->target.kind;
+        if (p->eq_mode == YMC_EQ_ISCLOSE && p->D != 1)
+            rc = fail(YMC_ERR_INVALID, "the isclose equality rule is the scalar parameter's; dim is %d", p->D);
+    }
+    if (rc == YMC_OK && desc->method == YMC_METHOD_MLDA2) {
+        /* MLDABuilder._validate_parameters, mlda.py:218-269 */
+        if (desc->sub_chain_length < 1) rc = fail(YMC_ERR_INVALID, "Subchain lengths not set for MLDA");
+        if (rc == YMC_OK && desc->surrogate.kind != desc->target.kind)
+            rc = fail(YMC_ERR_UNSUPPORTED, "surrogate density kind %d differs from target kind %d",
+                      desc->surrogate.kind, desc->target.kind);
+        if (rc == YMC_OK) rc = lower_density(ctx, desc->surrogate, p->sur, p->D);
+        p->S = desc->sub_chain_length;
+    }
+    if (rc == YMC_OK) {
+        /* MRWBuilder._validate_parameters, mrw.py:88-91 */
+        if (!desc->proposal_sigma) rc = fail(YMC_ERR_INVALID, "Proposal Covariance not set");
+        if (rc == YMC_OK) rc = copy_array(p->sigma, desc->proposal_sigma, p->D, "proposal_sigma");
+    }
+    if (rc != YMC_OK) {
+        delete p;
+        return rc;
+    }
+    *out = p;
+    return YMC_OK;
+}
+
+int ymc_problem_destroy(ymc_problem *problem)
+{
+    if (problem) {
+        (void)hipSetDevice(problem->ctx->device);
+        delete problem;
+    }
+    return YMC_OK;
+}
+
+int ymc_run_create(ymc_ctx *ctx, const ymc_problem *problem, const ymc_run_desc *desc, ymc_run **out)
+{
+    if (!ctx || !problem || !desc || !out) return fail(YMC_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (problem->ctx != ctx) return fail(YMC_ERR_INVALID, "problem belongs to another context");
+    if (desc->n_chains == 0) return fail(YMC_ERR_INVALID, "n_chains must be positive");
+    if (desc->chain_offset + desc->n_chains > (1ull << 32))
+        return fail(YMC_ERR_INVALID, "global chain ids must stay below 2^32");
+    if (!desc->initial_state) return fail(YMC_ERR_INVALID, "initial_state is null");
+    if (desc->x0_rows != 1 && desc->x0_rows != desc->n_chains)
+        return fail(YMC_ERR_INVALID, "initial_state must have 1 or n_chains rows");
+    if (records_anything(desc->record_flags) && desc->record_capacity == 0)
+        return fail(YMC_ERR_INVALID, "record_capacity must be positive when something is recorded");
+    YMC_HIP(hipSetDevice(ctx->device));
+    ymc_run *r = new (std::nothrow) ymc_run;
+    if (!r) return fail(YMC_ERR_DEVICE, "out of host memory");
+    r->ctx = ctx;
+    r->problem = problem;
+    r->seed = desc->seed;
+    r->chain0 = desc->chain_offset;
+    r->K = desc->n_chains;
+    r->flags = desc->record_flags;
+    r->capacity = records_anything(r->flags) ? desc->record_capacity : 0;
+    const uint64_t K = r->K;
+    const int D = problem->D;
+    const int S = problem->S;
+    auto body = [&]() -> int {
+        std::vector<double> x0((size_t)K * D);
+        for (uint64_t k = 0; k < K; ++k) {
+            const double *src = desc->initial_state + (desc->x0_rows == 1 ? 0 : k * D);
+            for (int j = 0; j < D; ++j) {
+                if (!std::isfinite(src[j])) return fail(YMC_ERR_INVALID, "initial_state is not finite");
+                x0[k * D + j] = src[j];
+            }
+        }
+        YMC_TRY(r->x.alloc(K * D * sizeof(double)));
+        YMC_TRY(r->lp.alloc(K * sizeof(double)));
+        YMC_TRY(r->lpc.alloc(K * sizeof(double)));
+        YMC_TRY(r->acc_count.alloc(K * sizeof(uint64_t)));
+        YMC_TRY(r->wf_mean.alloc(K * D * sizeof(double)));
+        YMC_TRY(r->wf_m2.alloc(K * D * sizeof(double)));
+        YMC_TRY(r->status.alloc(K * sizeof(uint32_t)));
+        YMC_HIP(hipMemcpy(r->x.p, x0.data(), x0.size() * sizeof(double), hipMemcpyHostToDevice));
+        YMC_HIP(hipMemsetAsync(r->lpc.p, 0, r->lpc.bytes, ctx->stream));
+        YMC_HIP(hipMemsetAsync(r->acc_count.p, 0, r->acc_count.bytes, ctx->stream));
+        YMC_HIP(hipMemsetAsync(r->wf_mean.p, 0, r->wf_mean.bytes, ctx->stream));
+        YMC_HIP(hipMemsetAsync(r->wf_m2.p, 0, r->wf_m2.bytes, ctx->stream));
+        YMC_HIP(hipMemsetAsync(r->status.p, 0, r->status.bytes, ctx->stream));
+        if (r->flags & YMC_RECORD_TRAJECTORY) YMC_TRY(r->traj.alloc(r->capacity * K * D * sizeof(double)));
+        if (r->flags & YMC_RECORD_ACCEPT) YMC_TRY(r->acc.alloc(r->capacity * K));
+        if (r->flags & YMC_RECORD_LOGPOST) YMC_TRY(r->lp_out.alloc(r->capacity * K * sizeof(double)));
+        if ((r->flags & YMC_RECORD_SUB_ACCEPT) && problem->method == YMC_METHOD_MLDA2)
+            YMC_TRY(r->sub_acc.alloc(r->capacity * (uint64_t)S * K));
+        /* logpi of the initial states (metropolisHastings.py:110 + first evaluate_log of mrw.py:54) */
+        YMC_TRY(eval_logdensity(ctx, problem, problem->tgt, K, r->x.as<double>(), r->lp.as<double>(), nullptr));
+        if (problem->method == YMC_METHOD_MLDA2)
+            YMC_TRY(eval_logdensity(ctx, problem, problem->sur, K, r->x.as<double>(), r->lpc.as<double>(), nullptr));
+        YMC_HIP(hipStreamSynchronize(ctx->stream));
+        return YMC_OK;
+    };
+    int rc = body();
+    if (rc != YMC_OK) {
+        delete r;
+        return rc;
+    }
+    *out = r;
+    return YMC_OK;
+}
+
+int ymc_run_destroy(ymc_run *run)
+{
+    if (!run) return YMC_OK;
+    (void)hipSetDevice(run->ctx->device);
+    (void)hipStreamSynchronize(run->ctx->stream);
+    for (auto &v : {run->timed, run->pool})
+        for (auto &ev : v) {
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
+    delete run;
+    return YMC_OK;
+}
+
+int ymc_run_advance(ymc_run *run, uint64_t nsteps)
+{
+    if (!run) return fail(YMC_ERR_INVALID, "null argument");
+    if (nsteps == 0) return YMC_OK;
+    if (records_anything(run->flags) && run->recorded + nsteps > run->capacity)
+        return fail(YMC_ERR_CAPACITY, "record holds %llu of %llu rows; %llu more do not fit",
+                    (unsigned long long)run->recorded, (unsigned long long)run->capacity,
+                    (unsigned long long)nsteps);
+    YMC_HIP(hipSetDevice(run->ctx->device));
+    const uint64_t chunk_max = 1u << 24;
+    while (nsteps) {
+        const uint64_t chunk = nsteps < chunk_max ? nsteps : chunk_max;
+        YMC_DISPATCH_D(run->problem->D, YMC_TRY(launch_advance<DD>(run, chunk)));
+        run->steps_done += chunk;
+        if (records_anything(run->flags)) run->recorded += chunk;
+        nsteps -= chunk;
+    }
+    return YMC_OK;
+}
+
+int ymc_run_sync(ymc_run *run)
+{
+    if (!run) return fail(YMC_ERR_INVALID, "null argument");
+    YMC_HIP(hipSetDevice(run->ctx->device));
+    YMC_HIP(hipStreamSynchronize(run->ctx->stream));
+    return YMC_OK;
+}
+
+int ymc_run_kernel_time_ms(ymc_run *run, double *avg_ms, uint64_t *launches)
+{
+    if (!run || !avg_ms) return fail(YMC_ERR_INVALID, "null argument");
+    YMC_HIP(hipSetDevice(run->ctx->device));
+    YMC_HIP(hipStreamSynchronize(run->ctx->stream));
+    double total = 0.0;
+    for (auto &ev : run->timed) {
+        float ms = 0.f;
+        YMC_HIP(hipEventElapsedTime(&ms, ev.first, ev.second));
+        total += ms;
+    }
+    const uint64_t n = run->timed.size();
+    *avg_ms = n ? total / (double)n : 0.0;
+    if (launches) *launches = n;
+    run->pool.insert(run->pool.end(), run->timed.begin(), run->timed.end());
+    run->timed.clear();
+    return YMC_OK;
+}
+
+int ymc_run_rewind_record(ymc_run *run)
+{
+    if (!run) return fail(YMC_ERR_INVALID, "null argument");
+    run->recorded = 0;
+    return YMC_OK;
+}
+
+int ymc_run_steps_done(const ymc_run *run, uint64_t *total, uint64_t *recorded)
+{
+    if (!run) return fail(YMC_ERR_INVALID, "null argument");
+    if (total) *total = run->steps_done;
+    if (recorded) *recorded = run->recorded;
+    return YMC_OK;
+}
+
+int ymc_run_fetch_trajectory(ymc_run *run, uint64_t first, uint64_t n, double *dst, size_t dst_bytes)
+{
+    if (!run) return fail(YMC_ERR_INVALID, "null argument");
+    return fetch_rows(run, run->traj, YMC_RECORD_TRAJECTORY, "the trajectory", first, n,
+                      run->K * run->problem->D * sizeof(double), dst, dst_bytes);
+}
+
+int ymc_run_fetch_accept(ymc_run *run, uint64_t first, uint64_t n, uint8_t *dst, size_t dst_bytes)
+{
+    if (!run) return fail(YMC_ERR_INVALID, "null argument");
+    return fetch_rows(run, run->acc, YMC_RECORD_ACCEPT, "accept decisions", first, n, run->K, dst, dst_bytes);
+}
+
+int ymc_run_fetch_logpost(ymc_run *run, uint64_t first, uint64_t n, double *dst, size_t dst_bytes)
+{
+    if (!run) return fail(YMC_ERR_INVALID, "null argument");
+    return fetch_rows(run, run->lp_out, YMC_RECORD_LOGPOST, "log-densities", first, n, run->K * sizeof(double), dst,
+                      dst_bytes);
+}
+
+int ymc_run_fetch_sub_accept(ymc_run *run, uint64_t first, uint64_t n, uint8_t *dst, size_t dst_bytes)
+{
+    if (!run) return fail(YMC_ERR_INVALID, "null argument");
+    if (run->problem->method != YMC_METHOD_MLDA2) return fail(YMC_ERR_INVALID, "not a two-level run");
+    return fetch_rows(run, run->sub_acc, YMC_RECORD_SUB_ACCEPT, "sub-chain decisions", first, n,
+                      (uint64_t)run->problem->S * run->K, dst, dst_bytes);
+}
+
+int ymc_run_fetch_state(ymc_run *run, double *state, double *logpost)
+{
+    if (!run) return fail(YMC_ERR_INVALID, "null argument");
+    YMC_HIP(hipSetDevice(run->ctx->device));
+    YMC_HIP(hipStreamSynchronize(run->ctx->stream));
+    if (state) YMC_HIP(hipMemcpy(state, run->x.p, run->x.bytes, hipMemcpyDeviceToHost));
+    if (logpost) YMC_HIP(hipMemcpy(logpost, run->lp.p, run->lp.bytes, hipMemcpyDeviceToHost));
+    return YMC_OK;
+}
+
+int ymc_run_fetch_summary(ymc_run *run, uint64_t *accepted, uint64_t *wf_n, double *wf_mean, double *wf_m2,
+                          uint32_t *status)
+{
+    if (!run) return fail(YMC_ERR_INVALID, "null argument");
+    YMC_HIP(hipSetDevice(run->ctx->device));
+    YMC_HIP(hipStreamSynchronize(run->ctx->stream));
+    if (accepted) YMC_HIP(hipMemcpy(accepted, run->acc_count.p, run->acc_count.bytes, hipMemcpyDeviceToHost));
+    if (wf_n) {
+        const uint64_t n = (run->flags & YMC_RECORD_MOMENTS) ? run->steps_done : 0;
+        for (uint64_t k = 0; k < run->K; ++k) wf_n[k] = n;
+    }
+    if (wf_mean) YMC_HIP(hipMemcpy(wf_mean, run->wf_mean.p, run->wf_mean.bytes, hipMemcpyDeviceToHost));
+    if (wf_m2) YMC_HIP(hipMemcpy(wf_m2, run->wf_m2.p, run->wf_m2.bytes, hipMemcpyDeviceToHost));
+    if (status) YMC_HIP(hipMemcpy(status, run->status.p, run->status.bytes, hipMemcpyDeviceToHost));
+    return YMC_OK;
+}
+
+int ymc_logdensity_eval(ymc_ctx *ctx, const ymc_problem *problem, int which, uint64_t n, const double *x,
+                        double *out, uint32_t *status)
+{
+    if (!ctx || !problem || !x || !out) return fail(YMC_ERR_INVALID, "null argument");
+    if (which != 0 && !(which == 1 && problem->method == YMC_METHOD_MLDA2))
+        return fail(YMC_ERR_INVALID, "density %d does not exist in this problem", which);
+    if (n == 0) return YMC_OK;
+    YMC_HIP(hipSetDevice(ctx->device));
+    const int D = problem->D;
+    DeviceBuf xd, od, sd;
+    YMC_TRY(xd.alloc(n * D * sizeof(double)));
+    YMC_TRY(od.alloc(n * sizeof(double)));
+    YMC_TRY(sd.alloc(n * sizeof(uint32_t)));
+    YMC_HIP(hipMemcpyAsync(xd.p, x, xd.bytes, hipMemcpyHostToDevice, ctx->stream));
+    YMC_TRY(eval_logdensity(ctx, problem, which ? problem->sur : problem->tgt, n, xd.as<double>(), od.as<double>(),
+                            sd.as<uint32_t>()));
+    YMC_HIP(hipMemcpyAsync(out, od.p, od.bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (status) YMC_HIP(hipMemcpyAsync(status, sd.p, sd.bytes, hipMemcpyDeviceToHost, ctx->stream));
+    YMC_HIP(hipStreamSynchronize(ctx->stream));
+    return YMC_OK;
+}
+
+int ymc_forward_eval(ymc_ctx *ctx, const ymc_problem *problem, int which, uint64_t n, const double *x, double *out)
+{
+    if (!ctx || !problem || !x || !out) return fail(YMC_ERR_INVALID, "null argument");
+    if (which != 0 && !(which == 1 && problem->method == YMC_METHOD_MLDA2))
+        return fail(YMC_ERR_INVALID, "density %d does not exist in this problem", which);
+    const DensityHost &h = which ? problem->sur : problem->tgt;
+    uint64_t m = 0;
+    if (problem->kind == YMC_DENSITY_POSTERIOR_LINEAR) m = h.d.data_dim;
+    else if (problem->kind == YMC_DENSITY_POSTERIOR_LV) m = 2ull * h.d.n_data;
+    else return fail(YMC_ERR_INVALID, "this density has no forward model");
+    if (n == 0) return YMC_OK;
+    YMC_HIP(hipSetDevice(ctx->device));
+    const int D = problem->D;
+    DeviceBuf xd, od;
+    YMC_TRY(xd.alloc(n * D * sizeof(double)));
+    YMC_TRY(od.alloc(n * m * sizeof(double)));
+    YMC_HIP(hipMemcpyAsync(xd.p, x, xd.bytes, hipMemcpyHostToDevice, ctx->stream));
+    YMC_DISPATCH_D(D, YMC_HIP(ymc_launch_forward<DD>(problem->kind, device_view<DD>(h), n, xd.as<double>(),
+                                                      od.as<double>(), ctx->stream)));
+    YMC_HIP(hipMemcpyAsync(out, od.p, od.bytes, hipMemcpyDeviceToHost, ctx->stream));
+    YMC_HIP(hipStreamSynchronize(ctx->stream));
+    return YMC_OK;
+}
+
+int ymc_rng_fill(ymc_ctx *ctx, uint64_t seed, uint64_t chain0, uint64_t K, uint64_t t0, uint64_t nt, int32_t d,
+                 double *xi, double *u)
+{
+    if (!ctx) return fail(YMC_ERR_INVALID, "null argument");
+    if (d < 1) return fail(YMC_ERR_INVALID, "dimension must be positive");
+    if (K == 0 || nt == 0) return YMC_OK;
+    YMC_HIP(hipSetDevice(ctx->device));
+    DeviceBuf xd, ud;
+    if (xi) YMC_TRY(xd.alloc(K * nt * (uint64_t)d * sizeof(double)));
+    if (u) YMC_TRY(ud.alloc(K * nt * sizeof(double)));
+    YMC_HIP(ymc_launch_rng_fill(seed, chain0, K, t0, nt, d, xd.as<double>(), ud.as<double>(), ctx->stream));
+    if (xi) YMC_HIP(hipMemcpyAsync(xi, xd.p, xd.bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (u) YMC_HIP(hipMemcpyAsync(u, ud.p, ud.bytes, hipMemcpyDeviceToHost, ctx->stream));
+    YMC_HIP(hipStreamSynchronize(ctx->stream));
+    return YMC_OK;
+}
+
+int ymc_numerics_eval(ymc_ctx *ctx, int fn, uint64_t n, const double *x, double *y0, double *y1)
+{
+    if (!ctx || !x || !y0) return fail(YMC_ERR_INVALID, "null argument");
+    if (fn < 0 || fn > 4) return fail(YMC_ERR_INVALID, "unknown function %d", fn);
+    if ((fn == 2 || fn == 4) && !y1) return fail(YMC_ERR_INVALID, "y1 is required for this function");
+    if (n == 0) return YMC_OK;
+    YMC_HIP(hipSetDevice(ctx->device));
+    DeviceBuf xd, ad, bd;
+    YMC_TRY(xd.alloc(n * sizeof(double)));
+    YMC_TRY(ad.alloc(n * sizeof(double)));
+    YMC_TRY(bd.alloc(n * sizeof(double)));
+    YMC_HIP(hipMemcpyAsync(xd.p, x, xd.bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (fn == 4) YMC_HIP(hipMemcpyAsync(bd.p, y1, bd.bytes, hipMemcpyHostToDevice, ctx->stream));
+    YMC_HIP(ymc_launch_numerics(fn, n, xd.as<double>(), ad.as<double>(), bd.as<double>(), ctx->stream));
+    YMC_HIP(hipMemcpyAsync(y0, ad.p, ad.bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (fn == 2) YMC_HIP(hipMemcpyAsync(y1, bd.p, bd.bytes, hipMemcpyDeviceToHost, ctx->stream));
+    YMC_HIP(hipStreamSynchronize(ctx->stream));
+    return YMC_OK;
+}
+
+int ymc_summary_words(const ymc_run *run, uint64_t *words)
+{
+    if (!run || !words) return fail(YMC_ERR_INVALID, "null argument");
+    *words = 3ull * run->problem->D + 5ull;
+    return YMC_OK;
+}
+
+}  // extern "C"
+
+/* used by ymc_comm.hip: pack the per-chain summaries into run->summary */
+int ymc_internal_pack_summary(ymc_run *run, uint64_t **dev_out, uint64_t *words, hipStream_t *stream, int *device)
+{
+    const int D = run->problem->D;
+    const uint64_t w = 3ull * D + 5ull;
+    YMC_HIP(hipSetDevice(run->ctx->device));
+    if (run->summary.bytes < run->K * w * sizeof(uint64_t)) YMC_TRY(run->summary.alloc(run->K * w * sizeof(uint64_t)));
+    const uint64_t wf_n = (run->flags & YMC_RECORD_MOMENTS) ? run->steps_done : 0;
+    YMC_HIP(ymc_launch_pack_summary(run->K, D, wf_n, run->x.as<double>(), run->lp.as<double>(),
+                                    run->acc_count.as<uint64_t>(), run->wf_mean.as<double>(),
+                                    run->wf_m2.as<double>(), run->status.as<uint32_t>(),
+                                    run->summary.as<uint64_t>(), run->ctx->stream));
+    *dev_out = run->summary.as<uint64_t>();
+    *words = w;
+    *stream = run->ctx->stream;
+    *device = run->ctx->device;
+    return YMC_OK;
+}
+
+int ymc_internal_fail(int code, const char *msg) { return fail(code, "%s", msg); }
+int ymc_internal_ctx_device(const ymc_ctx *ctx, hipStream_t *stream)
+{
+    *stream = ctx->stream;
+    return ctx->device;
+}
+uint64_t ymc_internal_run_chains(const ymc_run *run) { return run->K; }

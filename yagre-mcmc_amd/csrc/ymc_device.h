@@ -1,0 +1,290 @@
+/*
+ * ymc_device.h -- device-side building blocks of the chain-ensemble kernels:
+ * the lowered densities, the proposal, the accept/reject rule and the
+ * per-chain diagnostics.  One lane owns one chain; its state, log-density and
+ * counters live in registers for the whole launch.
+ *
+ * The arithmetic (operation order, where an fma is used) is the normative
+ * order of the ensemble and is mirrored operation by operation by the CPU
+ * checker, so results are compared bit-for-bit.  Built with
+ * -ffp-contract=off: a*b+c below is a separate multiply and add, as in the
+ * reference's NumPy expressions.
+ */
+#ifndef YMC_DEVICE_H
+#define YMC_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ymc.h"
+#include "ymc_numerics.h"
+
+#define YMC_LANE_DMAX 8 /* largest parameter dimension of the lane-per-chain kernels */
+#define YMC_LANE_MMAX 8 /* largest forward-map output dimension they hold in registers */
+#define YMC_DBL_MAX 1.79769313486231570815e308
+
+/* A lowered density, passed by value as a kernel argument: the small blocks
+ * (mean, whitening matrix, constants) arrive in SGPRs; the posterior's
+ * arrays are read through uniform (scalar) loads. */
+template <int D>
+struct DensityDev {
+    double mean[D];
+    double whiten[D * D];
+    double log_norm;
+    double variance;
+    int32_t n_data, data_dim, rk4_steps, pad_;
+    const double *data, *noise_prec, *prior_mean, *prior_prec, *A, *b, *design;
+    double t_final, alpha, gamma;
+};
+
+__device__ __forceinline__ bool ymc_finite(double v) { return __builtin_fabs(v) <= YMC_DBL_MAX; }
+
+/* covariance.py:19-22,54-55: dot(x, precision * x), sequential */
+template <int N>
+__device__ __forceinline__ double ymc_diag_norm_sq(const double (&x)[N], const double *__restrict__ prec, int n)
+{
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        if (j < n) {
+            double px = prec[j] * x[j];
+            acc = acc + x[j] * px;
+        }
+    }
+    return acc;
+}
+
+/* gaussian.py:19-24 */
+template <int D>
+__device__ __forceinline__ double ymc_prior_log(const DensityDev<D> &p, const double (&theta)[D])
+{
+    double x[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) x[j] = theta[j] - p.prior_mean[j];
+    return -0.5 * ymc_diag_norm_sq<D>(x, p.prior_prec, D);
+}
+
+/* testSetup.py:96-99 */
+__device__ __forceinline__ void ymc_lv_flow(double x, double y, double alpha, double beta, double gamma,
+                                            double delta, double &dx, double &dy)
+{
+    dx = alpha * x - beta * x * y;
+    dy = delta * x * y - gamma * y;
+}
+
+template <int KIND, int D>
+struct Density;
+
+/* GaussianTargetDensity2d.evaluate_log (testSetup.py:38-40 -> scipy logpdf) */
+template <int D>
+struct Density<YMC_DENSITY_GAUSS_WHITENED, D> {
+    static __device__ __forceinline__ double eval(const DensityDev<D> &p, const double (&x)[D], uint32_t &st)
+    {
+        (void)st;
+        double dev[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) dev[i] = x[i] - p.mean[i];
+        double maha = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            double w = dev[0] * p.whiten[j];
+#pragma unroll
+            for (int i = 1; i < D; ++i) w = w + dev[i] * p.whiten[i * D + j];
+            maha = (j == 0) ? w * w : maha + w * w;
+        }
+        return -0.5 * (p.log_norm + maha);
+    }
+};
+
+/* GaussianTargetDensity1d.evaluate_log (testSetup.py:22-25) */
+template <int D>
+struct Density<YMC_DENSITY_GAUSS_ISO1D, D> {
+    static __device__ __forceinline__ double eval(const DensityDev<D> &p, const double (&x)[D], uint32_t &st)
+    {
+        (void)st;
+        double t = p.mean[0] - x[0];
+        return (-0.5 * (t * t)) / p.variance;
+    }
+};
+
+/* UnnormalisedPosterior.evaluate_log (target.py:19-22) with the linear forward
+ * map (exampleSetup.py:42-47) held per lane: data_dim <= YMC_LANE_MMAX */
+template <int D>
+struct Density<YMC_DENSITY_POSTERIOR_LINEAR, D> {
+    static __device__ __forceinline__ void forward(const DensityDev<D> &p, const double (&x)[D],
+                                                   double (&F)[YMC_LANE_MMAX])
+    {
+#pragma unroll
+        for (int m = 0; m < YMC_LANE_MMAX; ++m) {
+            F[m] = 0.0;
+            if (m < p.data_dim) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < D; ++j) acc = ymc_fma(p.A[m * D + j], x[j], acc);
+                F[m] = acc + p.b[m];
+            }
+        }
+    }
+    static __device__ __forceinline__ double eval(const DensityDev<D> &p, const double (&x)[D], uint32_t &st)
+    {
+        (void)st;
+        double F[YMC_LANE_MMAX];
+        forward(p, x, F);
+        /* likelihood.py:74-84, :33-39 */
+        double total = 0.0;
+        for (int i = 0; i < p.n_data; ++i) {
+            double r[YMC_LANE_MMAX];
+#pragma unroll
+            for (int j = 0; j < YMC_LANE_MMAX; ++j)
+                r[j] = (j < p.data_dim) ? F[j] - p.data[i * p.data_dim + j] : 0.0;
+            total = total + ymc_diag_norm_sq<YMC_LANE_MMAX>(r, p.noise_prec, p.data_dim);
+        }
+        double logl = -0.5 * total;
+        return logl + ymc_prior_log<D>(p, x);
+    }
+};
+
+/* the same with the Lotka-Volterra forward map (testSetup.py:101-141),
+ * integrated by rk4_steps steps of classical RK4 per design row */
+template <int D>
+struct Density<YMC_DENSITY_POSTERIOR_LV, D> {
+    static __device__ __forceinline__ double eval(const DensityDev<D> &p, const double (&th)[D], uint32_t &st)
+    {
+        static_assert(D == 2, "Lotka-Volterra has two parameters");
+        const double beta = ymc_exp(th[0]);
+        const double delta = ymc_exp(th[1]);
+        const double alpha = p.alpha, gamma = p.gamma;
+        const double h = p.t_final / (double)p.rk4_steps;
+        const double h2 = 0.5 * h;
+        const double h6 = h / 6.0;
+        double total = 0.0;
+        bool bad = false;
+        for (int n = 0; n < p.n_data; ++n) {
+            double x = p.design[2 * n], y = p.design[2 * n + 1];
+            for (int s = 0; s < p.rk4_steps; ++s) {
+                double k1x, k1y, k2x, k2y, k3x, k3y, k4x, k4y;
+                ymc_lv_flow(x, y, alpha, beta, gamma, delta, k1x, k1y);
+                ymc_lv_flow(x + h2 * k1x, y + h2 * k1y, alpha, beta, gamma, delta, k2x, k2y);
+                ymc_lv_flow(x + h2 * k2x, y + h2 * k2y, alpha, beta, gamma, delta, k3x, k3y);
+                ymc_lv_flow(x + h * k3x, y + h * k3y, alpha, beta, gamma, delta, k4x, k4y);
+                x = x + h6 * ((k1x + 2.0 * k2x) + (2.0 * k3x + k4x));
+                y = y + h6 * ((k1y + 2.0 * k2y) + (2.0 * k3y + k4y));
+            }
+            bad = bad || !ymc_finite(x) || !ymc_finite(y);
+            double r[2] = {x - p.data[2 * n], y - p.data[2 * n + 1]};
+            total = total + ymc_diag_norm_sq<2>(r, p.noise_prec, 2);
+        }
+        double lp = -0.5 * total + ymc_prior_log<D>(p, th);
+        if (bad) {
+            /* forwardModel.py:15-19 raises; per chain: flag it, reject the proposal */
+            st |= YMC_CHAIN_NONFINITE;
+            lp = -__builtin_inf();
+        }
+        return lp;
+    }
+};
+
+/* vector.py:37-45 (array_equal) / scalar.py:39-44 (math.isclose, rel_tol 1e-9) */
+template <int D>
+__device__ __forceinline__ bool ymc_states_equal(const double (&a)[D], const double (&b)[D], int eq_mode)
+{
+    if (eq_mode == YMC_EQ_ISCLOSE) {
+        double x = a[0], y = b[0];
+        double diff = __builtin_fabs(y - x);
+        bool close = (diff <= __builtin_fabs(1e-9 * y)) || (diff <= __builtin_fabs(1e-9 * x));
+        bool anyinf = __builtin_isinf(x) || __builtin_isinf(y);
+        return (x == y) || (!anyinf && close);
+    }
+    bool eq = true;
+#pragma unroll
+    for (int j = 0; j < D; ++j) eq = eq && (a[j] == b[j]);
+    return eq;
+}
+
+/* mrw.py:32-38 -> gaussian.py:61-66 -> covariance.py:51-52: y = x + sigma * xi */
+template <int D>
+__device__ __forceinline__ void ymc_propose(const double (&x)[D], const double (&sigma)[D], uint64_t seed,
+                                            uint32_t chain, uint64_t t, double (&y)[D])
+{
+#pragma unroll
+    for (int j = 0; 2 * j < D; ++j) {
+        double z0, z1;
+        ymc_draw_normal_pair(seed, chain, t, (uint32_t)j, &z0, &z1);
+        y[2 * j] = x[2 * j] + sigma[2 * j] * z0;
+        if (2 * j + 1 < D) y[2 * j + 1] = x[2 * j + 1] + sigma[2 * j + 1] * z1;
+    }
+}
+
+/* the uniforms of transitions 2p and 2p+1 share one Philox block */
+struct UniformCache {
+    ymc_u32x4 block;
+    uint64_t pair;
+    bool valid;
+};
+
+__device__ __forceinline__ double ymc_uniform_cached(UniformCache &c, uint64_t seed, uint32_t chain, uint64_t t)
+{
+    uint64_t p = t >> 1;
+    if (!c.valid || c.pair != p) { /* wave-uniform: t is the same in every lane */
+        c.block = ymc_uniform_block(seed, chain, t);
+        c.pair = p;
+        c.valid = true;
+    }
+    return ymc_uniform_from_block(c.block, t);
+}
+
+/* metropolisHastings.py:55-73 given the log acceptance ratio; a non-finite
+ * proposal density is rejected and flagged (the reference's NaN -> accept
+ * hole, mrw.py:57, is not reproduced) */
+__device__ __forceinline__ bool ymc_accept(double log_ratio, bool moved, bool finite, double u, uint32_t &st)
+{
+    double a = ymc_exp(log_ratio);
+    a = (a < 1.0) ? a : 1.0;
+    if (moved && !finite) st |= YMC_CHAIN_NONFINITE;
+    return moved && finite && (u <= a);
+}
+
+/* estimation.py:36-53 with n already incremented */
+template <int D>
+__device__ __forceinline__ void ymc_welford(const double (&x)[D], double dn, double (&mean)[D], double (&m2)[D])
+{
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        double delta = x[j] - mean[j];
+        mean[j] = mean[j] + delta / dn;
+        double delta2 = x[j] - mean[j];
+        m2[j] = m2[j] + delta * delta2;
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void ymc_load_row(const double *__restrict__ base, uint64_t k, double (&v)[D])
+{
+    if constexpr (D % 2 == 0) {
+        const double2 *p = reinterpret_cast<const double2 *>(base + k * D);
+#pragma unroll
+        for (int j = 0; j < D / 2; ++j) {
+            double2 q = p[j];
+            v[2 * j] = q.x;
+            v[2 * j + 1] = q.y;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < D; ++j) v[j] = base[k * D + j];
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void ymc_store_row(double *__restrict__ base, uint64_t k, const double (&v)[D])
+{
+    if constexpr (D % 2 == 0) {
+        double2 *p = reinterpret_cast<double2 *>(base + k * D);
+#pragma unroll
+        for (int j = 0; j < D / 2; ++j) p[j] = make_double2(v[2 * j], v[2 * j + 1]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < D; ++j) base[k * D + j] = v[j];
+    }
+}
+
+#endif /* YMC_DEVICE_H */

@@ -1,0 +1,46 @@
+/* ymc_kernels.h -- launch interface between the C ABI (ymc_api.hip) and the
+ * gfx950 kernels (ymc_kernels.hip). */
+#ifndef YMC_KERNELS_H
+#define YMC_KERNELS_H
+
+#include "ymc_device.h"
+
+/* Everything one launch of a lane-per-chain kernel needs, by value. */
+template <int D>
+struct ChainArgs {
+    DensityDev<D> tgt;   /* the (fine) target */
+    DensityDev<D> sur;   /* MLDA2: the coarse density */
+    double sigma[D];     /* proposal standard deviations */
+    uint64_t seed, chain0, K;
+    uint64_t t0;         /* first transition (MLDA2: first fine step) of this launch */
+    uint64_t wf_n0;      /* Welford count before this launch */
+    uint32_t nsteps, flags;
+    int32_t eq_mode, S;
+    /* carried per-chain state */
+    double *x, *lp, *lpc;
+    uint64_t *acc_count;
+    double *wf_mean, *wf_m2;
+    uint32_t *status;
+    /* record rows of this launch (already offset to the write position), or null */
+    double *traj;
+    uint8_t *acc;
+    double *lp_out;
+    uint8_t *sub_acc;
+};
+
+template <int D>
+hipError_t ymc_launch_chain(int kind, int method, const ChainArgs<D> &a, hipStream_t s);
+template <int D>
+hipError_t ymc_launch_logdensity(int kind, const DensityDev<D> &p, uint64_t n, const double *x, double *out,
+                                 uint32_t *status, hipStream_t s);
+template <int D>
+hipError_t ymc_launch_forward(int kind, const DensityDev<D> &p, uint64_t n, const double *x, double *out,
+                              hipStream_t s);
+hipError_t ymc_launch_rng_fill(uint64_t seed, uint64_t chain0, uint64_t K, uint64_t t0, uint64_t nt, int d,
+                               double *xi, double *u, hipStream_t s);
+hipError_t ymc_launch_numerics(int fn, uint64_t n, const double *x, double *y0, double *y1, hipStream_t s);
+hipError_t ymc_launch_pack_summary(uint64_t K, int d, uint64_t wf_n, const double *x, const double *lp,
+                                   const uint64_t *accepted, const double *wmean, const double *wm2,
+                                   const uint32_t *status, uint64_t *out, hipStream_t s);
+
+#endif /* YMC_KERNELS_H */

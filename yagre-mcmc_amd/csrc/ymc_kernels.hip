@@ -1,0 +1,379 @@
+/*
+ * ymc_kernels.hip -- gfx950 kernels of the chain-ensemble hot path.
+ *
+ * mrw_kernel   : MetropolisHastings.run's loop (metropolisHastings.py:112-120)
+ *                for the Metropolised random walk (mrw.py:41-57); one lane =
+ *                one chain, fused propose / evaluate / accept / record.
+ * mlda2_kernel : the same loop for two-level delayed acceptance
+ *                (mlda.py:100-110, :146-154).
+ * Data layout in HBM (all row-major):
+ *   state      x[K][d]           carried between launches
+ *   logpost    lp[K] (, lpc[K])  log-density of the carried state
+ *   record     traj[T][K][d], acc[T][K] (u8), lp_out[T][K], sub_acc[T][S][K]
+ * so one wave writes 64*d*8 contiguous bytes per recorded state (16 B per lane
+ * at d = 2) and 64 contiguous accept bytes.  Nothing is read inside the loop.
+ */
+#include "ymc_kernels.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+template <int KIND, int D>
+__global__ __launch_bounds__(kBlock) void mrw_kernel(const ChainArgs<D> a)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= a.K) return;
+    const uint32_t chain = (uint32_t)(a.chain0 + k);
+
+    double x[D], wmean[D], wm2[D], sigma[D];
+    ymc_load_row<D>(a.x, k, x);
+#pragma unroll
+    for (int j = 0; j < D; ++j) sigma[j] = a.sigma[j];
+    double lp = a.lp[k];
+    uint64_t accepted = a.acc_count[k];
+    uint32_t st = a.status[k];
+    const bool moments = (a.flags & YMC_RECORD_MOMENTS) != 0;
+    if (moments) {
+        ymc_load_row<D>(a.wf_mean, k, wmean);
+        ymc_load_row<D>(a.wf_m2, k, wm2);
+    }
+    UniformCache uc;
+    uc.valid = false;
+    uc.pair = 0;
+
+#pragma unroll 1
+    for (uint32_t n = 0; n < a.nsteps; ++n) {
+        const uint64_t t = a.t0 + n;
+        double y[D];
+        ymc_propose<D>(x, sigma, a.seed, chain, t, y);              /* :116-117 */
+        const double u = ymc_uniform_cached(uc, a.seed, chain, t);  /* :68 */
+        const bool moved = !ymc_states_equal<D>(y, x, a.eq_mode);   /* :60-61 */
+        const double lpy = Density<KIND, D>::eval(a.tgt, y, st);
+        const bool acc = ymc_accept(lpy - lp, moved, ymc_finite(lpy), u, st); /* mrw.py:51-57 */
+        if (moments) ymc_welford<D>(x, (double)(a.wf_n0 + n + 1), wmean, wm2); /* diagnostics.py:91-94 */
+#pragma unroll
+        for (int j = 0; j < D; ++j) x[j] = acc ? y[j] : x[j];       /* :79-92 */
+        lp = acc ? lpy : lp;
+        accepted += acc ? 1u : 0u;
+        if (a.traj) ymc_store_row<D>(a.traj + (uint64_t)n * a.K * D, k, x); /* :75-76 */
+        if (a.acc) a.acc[(uint64_t)n * a.K + k] = acc ? 1 : 0;      /* diagnostics.py:48-54 */
+        if (a.lp_out) a.lp_out[(uint64_t)n * a.K + k] = lp;
+    }
+
+    ymc_store_row<D>(a.x, k, x);
+    a.lp[k] = lp;
+    a.acc_count[k] = accepted;
+    a.status[k] = st;
+    if (moments) {
+        ymc_store_row<D>(a.wf_mean, k, wmean);
+        ymc_store_row<D>(a.wf_m2, k, wm2);
+    }
+}
+
+template <int KIND, int D>
+__global__ __launch_bounds__(kBlock) void mlda2_kernel(const ChainArgs<D> a)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= a.K) return;
+    const uint32_t chain = (uint32_t)(a.chain0 + k);
+    const int S = a.S;
+
+    double x[D], wmean[D], wm2[D], sigma[D];
+    ymc_load_row<D>(a.x, k, x);
+#pragma unroll
+    for (int j = 0; j < D; ++j) sigma[j] = a.sigma[j];
+    double lpf = a.lp[k];
+    double lpc = a.lpc[k];
+    uint64_t accepted = a.acc_count[k];
+    uint32_t st = a.status[k];
+    const bool moments = (a.flags & YMC_RECORD_MOMENTS) != 0;
+    if (moments) {
+        ymc_load_row<D>(a.wf_mean, k, wmean);
+        ymc_load_row<D>(a.wf_m2, k, wm2);
+    }
+    UniformCache uc;
+    uc.valid = false;
+    uc.pair = 0;
+
+#pragma unroll 1
+    for (uint32_t n = 0; n < a.nsteps; ++n) {
+        const uint64_t tbase = (a.t0 + n) * (uint64_t)(S + 1);
+        /* surrogate.run(S + 1, state): an S-step random walk on the coarse density */
+        double z[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) z[j] = x[j];
+        double lpcz = lpc;
+#pragma unroll 1
+        for (int s = 0; s < S; ++s) {
+            const uint64_t t = tbase + (uint64_t)s;
+            double y[D];
+            ymc_propose<D>(z, sigma, a.seed, chain, t, y);
+            const double u = ymc_uniform_cached(uc, a.seed, chain, t);
+            const bool moved = !ymc_states_equal<D>(y, z, a.eq_mode);
+            const double lpcy = Density<KIND, D>::eval(a.sur, y, st);
+            const bool acc = ymc_accept(lpcy - lpcz, moved, ymc_finite(lpcy), u, st);
+#pragma unroll
+            for (int j = 0; j < D; ++j) z[j] = acc ? y[j] : z[j];
+            lpcz = acc ? lpcy : lpcz;
+            if (a.sub_acc) a.sub_acc[((uint64_t)n * S + s) * a.K + k] = acc ? 1 : 0;
+        }
+        /* fine accept/reject, mlda.py:146-154 */
+        const uint64_t tf = tbase + (uint64_t)S;
+        const double u = ymc_uniform_cached(uc, a.seed, chain, tf);
+        const bool moved = !ymc_states_equal<D>(z, x, a.eq_mode);
+        const double lpfy = Density<KIND, D>::eval(a.tgt, z, st);
+        const double log_ratio = ((lpfy + lpc) - lpcz) - lpf;
+        const bool acc = ymc_accept(log_ratio, moved, ymc_finite(lpfy) && ymc_finite(lpcz), u, st);
+        if (moments) ymc_welford<D>(x, (double)(a.wf_n0 + n + 1), wmean, wm2);
+#pragma unroll
+        for (int j = 0; j < D; ++j) x[j] = acc ? z[j] : x[j];
+        lpf = acc ? lpfy : lpf;
+        lpc = acc ? lpcz : lpc;
+        accepted += acc ? 1u : 0u;
+        if (a.traj) ymc_store_row<D>(a.traj + (uint64_t)n * a.K * D, k, x);
+        if (a.acc) a.acc[(uint64_t)n * a.K + k] = acc ? 1 : 0;
+        if (a.lp_out) a.lp_out[(uint64_t)n * a.K + k] = lpf;
+    }
+
+    ymc_store_row<D>(a.x, k, x);
+    a.lp[k] = lpf;
+    a.lpc[k] = lpc;
+    a.acc_count[k] = accepted;
+    a.status[k] = st;
+    if (moments) {
+        ymc_store_row<D>(a.wf_mean, k, wmean);
+        ymc_store_row<D>(a.wf_m2, k, wm2);
+    }
+}
+
+/* DensityInterface.evaluate_log for a batch of parameters */
+template <int KIND, int D>
+__global__ __launch_bounds__(kBlock) void logdensity_kernel(const DensityDev<D> p, uint64_t n,
+                                                            const double *__restrict__ xin,
+                                                            double *__restrict__ out,
+                                                            uint32_t *__restrict__ status)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    double x[D];
+    ymc_load_row<D>(xin, i, x);
+    uint32_t st = 0;
+    out[i] = Density<KIND, D>::eval(p, x, st);
+    if (status) status[i] = st;
+}
+
+/* ForwardModel.evaluate for a batch (linear map held per lane) */
+template <int D>
+__global__ __launch_bounds__(kBlock) void forward_linear_kernel(const DensityDev<D> p, uint64_t n,
+                                                                const double *__restrict__ xin,
+                                                                double *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    double x[D], F[YMC_LANE_MMAX];
+    ymc_load_row<D>(xin, i, x);
+    Density<YMC_DENSITY_POSTERIOR_LINEAR, D>::forward(p, x, F);
+#pragma unroll
+    for (int m = 0; m < YMC_LANE_MMAX; ++m)
+        if (m < p.data_dim) out[i * p.data_dim + m] = F[m];
+}
+
+__global__ __launch_bounds__(kBlock) void forward_lv_kernel(const DensityDev<2> p, uint64_t n,
+                                                            const double *__restrict__ xin,
+                                                            double *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const double beta = ymc_exp(xin[2 * i]), delta = ymc_exp(xin[2 * i + 1]);
+    const double h = p.t_final / (double)p.rk4_steps, h2 = 0.5 * h, h6 = h / 6.0;
+    for (int r = 0; r < p.n_data; ++r) {
+        double x = p.design[2 * r], y = p.design[2 * r + 1];
+        for (int s = 0; s < p.rk4_steps; ++s) {
+            double k1x, k1y, k2x, k2y, k3x, k3y, k4x, k4y;
+            ymc_lv_flow(x, y, p.alpha, beta, p.gamma, delta, k1x, k1y);
+            ymc_lv_flow(x + h2 * k1x, y + h2 * k1y, p.alpha, beta, p.gamma, delta, k2x, k2y);
+            ymc_lv_flow(x + h2 * k2x, y + h2 * k2y, p.alpha, beta, p.gamma, delta, k3x, k3y);
+            ymc_lv_flow(x + h * k3x, y + h * k3y, p.alpha, beta, p.gamma, delta, k4x, k4y);
+            x = x + h6 * ((k1x + 2.0 * k2x) + (2.0 * k3x + k4x));
+            y = y + h6 * ((k1y + 2.0 * k2y) + (2.0 * k3y + k4y));
+        }
+        out[(i * p.n_data + r) * 2] = x;
+        out[(i * p.n_data + r) * 2 + 1] = y;
+    }
+}
+
+/* the draws of chains chain0..chain0+K-1 in transitions t0..t0+nt-1 */
+__global__ __launch_bounds__(kBlock) void rng_fill_kernel(uint64_t seed, uint64_t chain0, uint64_t K,
+                                                          uint64_t t0, uint64_t nt, int d,
+                                                          double *__restrict__ xi, double *__restrict__ u)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= K * nt) return;
+    const uint64_t t = i / K, k = i % K;
+    const uint32_t chain = (uint32_t)(chain0 + k);
+    if (u) u[i] = ymc_draw_uniform(seed, chain, t0 + t);
+    if (xi) {
+        for (int j = 0; 2 * j < d; ++j) {
+            double z0, z1;
+            ymc_draw_normal_pair(seed, chain, t0 + t, (uint32_t)j, &z0, &z1);
+            xi[i * d + 2 * j] = z0;
+            if (2 * j + 1 < d) xi[i * d + 2 * j + 1] = z1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void numerics_kernel(int fn, uint64_t n, const double *__restrict__ x,
+                                                          double *__restrict__ y0, double *__restrict__ y1)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    switch (fn) {
+    case 0: y0[i] = ymc_log(x[i]); break;
+    case 1: y0[i] = ymc_exp(x[i]); break;
+    case 2: {
+        double s, c;
+        ymc_sincospi(x[i], &s, &c);
+        y0[i] = s;
+        y1[i] = c;
+        break;
+    }
+    case 3: y0[i] = __builtin_sqrt(x[i]); break;
+    case 4: y0[i] = x[i] / y1[i]; break;
+    default: break;
+    }
+}
+
+/* per-chain summary record, 3d+5 eight-byte words:
+ * state[d], logpost, accepted, wf_n, wf_mean[d], wf_m2[d], status */
+__global__ __launch_bounds__(kBlock) void pack_summary_kernel(uint64_t K, int d, uint64_t wf_n,
+                                                              const double *__restrict__ x,
+                                                              const double *__restrict__ lp,
+                                                              const uint64_t *__restrict__ accepted,
+                                                              const double *__restrict__ wmean,
+                                                              const double *__restrict__ wm2,
+                                                              const uint32_t *__restrict__ status,
+                                                              uint64_t *__restrict__ out)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (k >= K) return;
+    uint64_t *o = out + k * (uint64_t)(3 * d + 5);
+    for (int j = 0; j < d; ++j) o[j] = ymc_bits(x[k * d + j]);
+    o[d] = ymc_bits(lp[k]);
+    o[d + 1] = accepted[k];
+    o[d + 2] = wf_n;
+    for (int j = 0; j < d; ++j) o[d + 3 + j] = ymc_bits(wmean[k * d + j]);
+    for (int j = 0; j < d; ++j) o[2 * d + 3 + j] = ymc_bits(wm2[k * d + j]);
+    o[3 * d + 3] = status[k];
+    o[3 * d + 4] = 0;
+}
+
+inline unsigned grid_for(uint64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+template <int KIND, int D>
+hipError_t launch_chain(int method, const ChainArgs<D> &a, hipStream_t s)
+{
+    if (method == YMC_METHOD_MRW)
+        hipLaunchKernelGGL((mrw_kernel<KIND, D>), dim3(grid_for(a.K)), dim3(kBlock), 0, s, a);
+    else
+        hipLaunchKernelGGL((mlda2_kernel<KIND, D>), dim3(grid_for(a.K)), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+#define YMC_FOR_EACH_D(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
+
+template <int D>
+hipError_t ymc_launch_chain(int kind, int method, const ChainArgs<D> &a, hipStream_t s)
+{
+    switch (kind) {
+    case YMC_DENSITY_GAUSS_WHITENED: return launch_chain<YMC_DENSITY_GAUSS_WHITENED, D>(method, a, s);
+    case YMC_DENSITY_GAUSS_ISO1D:
+        if constexpr (D == 1) return launch_chain<YMC_DENSITY_GAUSS_ISO1D, 1>(method, a, s);
+        return hipErrorInvalidValue;
+    case YMC_DENSITY_POSTERIOR_LINEAR: return launch_chain<YMC_DENSITY_POSTERIOR_LINEAR, D>(method, a, s);
+    case YMC_DENSITY_POSTERIOR_LV:
+        if constexpr (D == 2) return launch_chain<YMC_DENSITY_POSTERIOR_LV, 2>(method, a, s);
+        return hipErrorInvalidValue;
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <int D>
+hipError_t ymc_launch_logdensity(int kind, const DensityDev<D> &p, uint64_t n, const double *x, double *out,
+                                 uint32_t *status, hipStream_t s)
+{
+    dim3 g(grid_for(n)), b(kBlock);
+    switch (kind) {
+    case YMC_DENSITY_GAUSS_WHITENED:
+        hipLaunchKernelGGL((logdensity_kernel<YMC_DENSITY_GAUSS_WHITENED, D>), g, b, 0, s, p, n, x, out, status);
+        break;
+    case YMC_DENSITY_GAUSS_ISO1D:
+        if constexpr (D == 1)
+            hipLaunchKernelGGL((logdensity_kernel<YMC_DENSITY_GAUSS_ISO1D, 1>), g, b, 0, s, p, n, x, out, status);
+        else
+            return hipErrorInvalidValue;
+        break;
+    case YMC_DENSITY_POSTERIOR_LINEAR:
+        hipLaunchKernelGGL((logdensity_kernel<YMC_DENSITY_POSTERIOR_LINEAR, D>), g, b, 0, s, p, n, x, out, status);
+        break;
+    case YMC_DENSITY_POSTERIOR_LV:
+        if constexpr (D == 2)
+            hipLaunchKernelGGL((logdensity_kernel<YMC_DENSITY_POSTERIOR_LV, 2>), g, b, 0, s, p, n, x, out, status);
+        else
+            return hipErrorInvalidValue;
+        break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+template <int D>
+hipError_t ymc_launch_forward(int kind, const DensityDev<D> &p, uint64_t n, const double *x, double *out,
+                              hipStream_t s)
+{
+    dim3 g(grid_for(n)), b(kBlock);
+    if (kind == YMC_DENSITY_POSTERIOR_LINEAR) {
+        hipLaunchKernelGGL((forward_linear_kernel<D>), g, b, 0, s, p, n, x, out);
+    } else if (kind == YMC_DENSITY_POSTERIOR_LV) {
+        if constexpr (D == 2)
+            hipLaunchKernelGGL(forward_lv_kernel, g, b, 0, s, p, n, x, out);
+        else
+            return hipErrorInvalidValue;
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+#define YMC_INSTANTIATE(D)                                                                             \
+    template hipError_t ymc_launch_chain<D>(int, int, const ChainArgs<D> &, hipStream_t);              \
+    template hipError_t ymc_launch_logdensity<D>(int, const DensityDev<D> &, uint64_t, const double *, \
+                                                 double *, uint32_t *, hipStream_t);                   \
+    template hipError_t ymc_launch_forward<D>(int, const DensityDev<D> &, uint64_t, const double *,    \
+                                              double *, hipStream_t);
+YMC_FOR_EACH_D(YMC_INSTANTIATE)
+
+hipError_t ymc_launch_rng_fill(uint64_t seed, uint64_t chain0, uint64_t K, uint64_t t0, uint64_t nt, int d,
+                               double *xi, double *u, hipStream_t s)
+{
+    hipLaunchKernelGGL(rng_fill_kernel, dim3(grid_for(K * nt)), dim3(kBlock), 0, s, seed, chain0, K, t0, nt, d,
+                       xi, u);
+    return hipGetLastError();
+}
+
+hipError_t ymc_launch_numerics(int fn, uint64_t n, const double *x, double *y0, double *y1, hipStream_t s)
+{
+    hipLaunchKernelGGL(numerics_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, fn, n, x, y0, y1);
+    return hipGetLastError();
+}
+
+hipError_t ymc_launch_pack_summary(uint64_t K, int d, uint64_t wf_n, const double *x, const double *lp,
+                                   const uint64_t *accepted, const double *wmean, const double *wm2,
+                                   const uint32_t *status, uint64_t *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(pack_summary_kernel, dim3(grid_for(K)), dim3(kBlock), 0, s, K, d, wf_n, x, lp, accepted,
+                       wmean, wm2, status, out);
+    return hipGetLastError();
+}

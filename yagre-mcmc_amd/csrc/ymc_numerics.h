@@ -194,13 +194,12 @@ YMC_FN double ymc_exp(double x)
     const double ln2_hi = 0x1.62e42fee00000p-1;
     const double ln2_lo = 0x1.a39ef35793c76p-33;
 
-    if (!(x == x)) return x;                          /* NaN */
-    if (x > 0x1.62e42fefa39efp+9) return __builtin_inf();
-    if (x < -745.2) return 0.0;
-
-    double kd = __builtin_rint(x * inv_ln2);
+    /* clamp so that k stays in int range; the special cases are selected at  */
+    /* the end (straight-line code: no divergent branches on the GPU)          */
+    double xc = (x > 710.0) ? 710.0 : ((x < -746.0) ? -746.0 : x);
+    double kd = __builtin_rint(xc * inv_ln2);
     int32_t k = (int32_t)kd;
-    double r = ymc_fma(-kd, ln2_hi, x);
+    double r = ymc_fma(-kd, ln2_hi, xc);
     r = ymc_fma(-kd, ln2_lo, r);
 
     double p = 0x1.6124613a86d09p-33;                 /* 1/13! */
@@ -218,9 +217,14 @@ YMC_FN double ymc_exp(double x)
     p = ymc_fma(p, r, 1.0);
     p = ymc_fma(p, r, 1.0);                           /* p in [0.70, 1.42] */
 
-    if (k < -1021) return ymc_scale2(p, k + 1000) * 0x1p-1000;
-    if (k > 1022) return ymc_scale2(p, k - 2) * 4.0;
-    return ymc_scale2(p, k);
+    /* 2^k in one or two exactly representable factors */
+    int32_t k1 = (k < -1021) ? k + 1000 : ((k > 1022) ? k - 2 : k);
+    double f2 = (k < -1021) ? 0x1p-1000 : ((k > 1022) ? 4.0 : 1.0);
+    double y = ymc_scale2(p, k1) * f2;
+
+    y = (x > 0x1.62e42fefa39efp+9) ? __builtin_inf() : y;
+    y = (x < -745.2) ? 0.0 : y;
+    return (x == x) ? y : x;                          /* NaN propagates */
 }
 
 /* ------------------------------------------------------------------------ */

@@ -1,0 +1,204 @@
+"""Lowering of plug-in objects to the C ABI's parameter blocks.
+
+The builders accept the plug-in objects of `plugins.py` AND the reference's own
+instances (matched by class name and attributes, never imported).  A recognised
+object becomes a `ymc_density_desc`; anything else raises -- there is no hidden
+CPU path for an unknown `DensityInterface` or `SolverInterface`
+(SURVEY.md 8b).
+"""
+import numpy as np
+
+from . import _ffi
+
+
+class UnsupportedPlugin(NotImplementedError):
+    pass
+
+
+def _name(obj):
+    return type(obj).__name__
+
+
+def _has(obj, *attrs):
+    return all(hasattr(obj, a) for a in attrs)
+
+
+def proposal_sigma(cov, dim):
+    """sqrt(reciprocal(precision)) exactly as DiagonalCovarianceMatrix.apply_chol_factor
+    forms it (statistics/covariance.py:51-52) -- not sqrt(variance)."""
+    if cov is None:
+        raise ValueError("Proposal Covariance not set")
+    if not hasattr(cov, "_precision"):
+        raise UnsupportedPlugin(
+            f"proposal covariance {_name(cov)}: only Diagonal/IID covariances have a device lowering")
+    prec = np.asarray(cov._precision, dtype=np.float64).reshape(-1)
+    if prec.size != dim:
+        raise ValueError(f"proposal covariance has dimension {prec.size}, the state has {dim}")
+    return np.sqrt(np.reciprocal(prec))
+
+
+def _diag_precision(cov, n, what):
+    if not hasattr(cov, "_precision"):
+        raise UnsupportedPlugin(f"{what} covariance {_name(cov)}: only Diagonal/IID covariances are lowered")
+    prec = np.asarray(cov._precision, dtype=np.float64).reshape(-1)
+    if prec.size != n:
+        raise ValueError(f"{what} covariance has dimension {prec.size}, expected {n}")
+    return prec
+
+
+class Lowered:
+    """A ymc_density_desc plus the arrays it points into."""
+
+    def __init__(self, kind, dim):
+        self.desc = _ffi.DensityDesc()
+        self.desc.kind, self.desc.dim = kind, dim
+        self.keep = []
+
+    def set_array(self, field, arr):
+        arr = _ffi.f64(arr)
+        self.keep.append(arr)
+        setattr(self.desc, field, _ffi.dptr(arr))
+        return arr
+
+
+def _whitening_of(target):
+    """(mean, U, log_norm) of a GaussianTargetDensity2d: ours, or the reference's
+    (test/testSetup.py:32-40, scipy frozen multivariate_normal in `dist_`)."""
+    if _has(target, "mean_", "whiten_", "log_norm_"):
+        return target.mean_, target.whiten_, float(target.log_norm_)
+    dist = target.dist_
+    mean = np.asarray(dist.mean, dtype=np.float64)
+    co = getattr(dist, "cov_object", None)
+    if co is not None and _has(co, "_LP", "_log_pdet", "rank"):
+        return mean, np.asarray(co._LP, dtype=np.float64), float(co.rank * np.log(2.0 * np.pi) + co._log_pdet)
+    cov = np.asarray(dist.cov, dtype=np.float64)
+    w, v = np.linalg.eigh(cov)
+    return mean, v * np.sqrt(1.0 / w), float(mean.size * np.log(2.0 * np.pi) + np.sum(np.log(w)))
+
+
+def lower_solver(solver, low, rk4_steps=None):
+    """SolverInterface -> forward-map fields of the descriptor."""
+    n = _name(solver)
+    if n == "ExampleLinearModelSolver" and _has(solver, "_A", "_b"):
+        A = np.asarray(solver._A, dtype=np.float64)
+        if A.ndim != 2:
+            raise ValueError("linear forward map: A must be a matrix")
+        low.desc.kind = _ffi.POSTERIOR_LINEAR
+        low.set_array("fwd_matrix", A)
+        low.set_array("fwd_shift", np.asarray(solver._b, dtype=np.float64).reshape(-1))
+        return A.shape[1], A.shape[0]
+    if n == "LotkaVolterraSolver" and _has(solver, "x_", "tBoundary_", "fixedParam_", "dataShape_"):
+        design = np.asarray(solver.x_, dtype=np.float64)
+        low.desc.kind = _ffi.POSTERIOR_LV
+        low.set_array("design", design)
+        low.desc.t_final = float(solver.tBoundary_[1])
+        low.desc.alpha = float(solver.fixedParam_[0])
+        low.desc.gamma = float(solver.fixedParam_[1])
+        low.desc.rk4_steps = int(rk4_steps or getattr(solver, "rk4Steps_", 50))
+        return 2, 2
+    raise UnsupportedPlugin(
+        f"solver {n} has no device lowering (known: ExampleLinearModelSolver, LotkaVolterraSolver); "
+        "there is no CPU fallback")
+
+
+def lower_posterior(likelihood, prior, rk4_steps=None):
+    """UnnormalisedPosterior(likelihood, prior) (chain/target.py:4-22) with an
+    AdditiveGaussianNoiseLikelihood (statistics/likelihood.py:49-87) and a Gaussian prior."""
+    if _name(likelihood) != "AdditiveGaussianNoiseLikelihood" or not _has(likelihood, "_data", "_fwdModel", "_noiseModel"):
+        raise UnsupportedPlugin(f"likelihood {_name(likelihood)} has no device lowering")
+    if not _has(prior, "mean", "covariance"):
+        raise UnsupportedPlugin(f"prior {_name(prior)} has no device lowering (a Gaussian law is needed)")
+    low = Lowered(0, 0)
+    dim, data_dim = lower_solver(likelihood._fwdModel.solver_, low, rk4_steps)
+    data = np.asarray(likelihood._data.array, dtype=np.float64)
+    if data.ndim != 2 or data.shape[1] != data_dim:
+        raise ValueError(f"data has shape {data.shape}; the forward map has {data_dim} outputs")
+    if low.desc.kind == _ffi.POSTERIOR_LV and data.shape[0] != np.asarray(likelihood._fwdModel.solver_.x_).shape[0]:
+        raise ValueError("Lotka-Volterra: one data row per design row is required")
+    low.desc.dim = dim
+    low.desc.n_data, low.desc.data_dim = data.shape
+    low.set_array("data", data)
+    low.set_array("noise_precision", _diag_precision(likelihood._noiseModel.covariance, data_dim, "noise"))
+    pm = np.asarray(prior.mean.coefficient, dtype=np.float64).reshape(-1)
+    if pm.size != dim:
+        raise ValueError(f"prior mean has dimension {pm.size}, the forward map takes {dim}")
+    low.set_array("prior_mean", pm)
+    low.set_array("prior_precision", _diag_precision(prior.covariance, dim, "prior"))
+    return low
+
+
+def lower_density(density, rk4_steps=None):
+    """DensityInterface -> Lowered."""
+    n = _name(density)
+    if n == "GaussianTargetDensity2d" and (_has(density, "dist_") or _has(density, "whiten_")):
+        mean, U, log_norm = _whitening_of(density)
+        low = Lowered(_ffi.GAUSS_WHITENED, int(np.size(mean)))
+        low.set_array("mean", np.asarray(mean).reshape(-1))
+        low.set_array("whiten", U)
+        low.desc.log_norm = log_norm
+        return low
+    if n == "GaussianTargetDensity1d" and _has(density, "mean_", "var_"):
+        low = Lowered(_ffi.GAUSS_ISO1D, 1)
+        low.set_array("mean", np.asarray(density.mean_.coefficient, dtype=np.float64).reshape(-1)[:1])
+        low.desc.variance = float(density.var_)
+        return low
+    if n == "UnnormalisedPosterior" and _has(density, "likelihood", "prior"):
+        return lower_posterior(density.likelihood, density.prior, rk4_steps)
+    raise UnsupportedPlugin(
+        f"density {n} has no device lowering (known: GaussianTargetDensity1d/2d, UnnormalisedPosterior over "
+        "AdditiveGaussianNoiseLikelihood + Gaussian prior); there is no CPU fallback")
+
+
+def state_eq_of(state):
+    """ScalarParameter compares with math.isclose (parameter/scalar.py:39-44),
+    ParameterVector exactly (parameter/vector.py:37-45)."""
+    return _ffi.EQ_ISCLOSE if _name(state) == "ScalarParameter" else _ffi.EQ_EXACT
+
+
+def make_problem(ctx, method, target, sigma, state_eq=_ffi.EQ_EXACT, surrogate=None, sub_chain_length=0,
+                 rk4_steps=None):
+    tgt = lower_density(target, rk4_steps) if not isinstance(target, Lowered) else target
+    desc = _ffi.ProblemDesc()
+    desc.method, desc.state_eq = method, state_eq
+    desc.target = tgt.desc
+    keep = [tgt]
+    if method == _ffi.METHOD_MLDA2:
+        sur = lower_density(surrogate, rk4_steps) if not isinstance(surrogate, Lowered) else surrogate
+        desc.surrogate = sur.desc
+        desc.sub_chain_length = int(sub_chain_length)
+        keep.append(sur)
+    sigma = _ffi.f64(sigma).reshape(-1)
+    if sigma.size != tgt.desc.dim:
+        raise ValueError(f"proposal covariance has dimension {sigma.size}, the target has {tgt.desc.dim}")
+    desc.proposal_sigma = _ffi.dptr(sigma)
+    keep.append(sigma)
+    return _ffi.Problem(ctx, desc, keep)
+
+
+def density_only_problem(density, device=0):
+    """A problem used only for ymc_logdensity_eval (DensityInterface.evaluate_log)."""
+    n = _name(density)
+    if n == "GaussianDensity":
+        raise UnsupportedPlugin("a bare GaussianDensity is evaluated as part of a posterior only")
+    if n == "AdditiveGaussianNoiseLikelihood":
+        raise UnsupportedPlugin("the likelihood is evaluated as part of a posterior only")
+    low = lower_density(density)
+    return make_problem(_ffi.default_context(device), _ffi.METHOD_MRW, low, np.ones(low.desc.dim))
+
+
+def forward_only_problem(solver, device=0):
+    """A problem used only for ymc_forward_eval (ForwardModel.evaluate)."""
+    prob = getattr(solver, "_ymc_forward_problem", None)
+    if prob is None:
+        low = Lowered(0, 0)
+        dim, data_dim = lower_solver(solver, low)
+        low.desc.dim = dim
+        rows = np.asarray(solver.x_).shape[0] if low.desc.kind == _ffi.POSTERIOR_LV else 1
+        low.desc.n_data, low.desc.data_dim = rows, data_dim
+        low.set_array("data", np.zeros((rows, data_dim)))
+        low.set_array("noise_precision", np.ones(data_dim))
+        low.set_array("prior_mean", np.zeros(dim))
+        low.set_array("prior_precision", np.ones(dim))
+        prob = solver._ymc_forward_problem = make_problem(
+            _ffi.default_context(device), _ffi.METHOD_MRW, low, np.ones(dim))
+    return prob

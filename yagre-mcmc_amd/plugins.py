@@ -1,0 +1,446 @@
+"""Host-side plug-in objects of the chain-ensemble path.
+
+These are the value objects a user hands to the builders: parameters,
+covariances, the Gaussian law, noise, data, likelihood, Bayesian model,
+forward model + solvers, and the explicit test targets.  They carry the same
+names, constructor arguments, properties and error behaviour as the reference's
+(file:line cited per class) so its example scripts keep working after an
+import change -- but they are *descriptions*: evaluating a density goes to the
+device through the C ABI (`lowering.py`), never through a NumPy restatement.
+The builders also accept the reference's own instances (duck-typed in
+`lowering.py`), so a user who has yagremcmc installed need not switch types.
+"""
+import math
+from enum import Enum, unique
+
+import numpy as np
+
+
+# --------------------------------------------------------------------------
+# parameters (yagremcmc/parameter/{interface,scalar,vector}.py)
+# --------------------------------------------------------------------------
+
+class _Parameter:
+    """ParameterInterface, parameter/interface.py:4-37: an immutable coefficient."""
+
+    def __init__(self, coefficient):
+        self.coefficient_ = coefficient
+        self._ctype = type(coefficient)
+
+    @classmethod
+    def from_coefficient(cls, coefficient):
+        return cls(coefficient)
+
+    @classmethod
+    def from_value(cls, value):
+        return cls(value)
+
+    @property
+    def coefficient(self):
+        return self.coefficient_
+
+    def evaluate(self):
+        return self.coefficient_
+
+    def clone_with(self, newCoefficient):
+        if not isinstance(newCoefficient, self._ctype):
+            raise ValueError("Trying to change coefficient type in cloning.")
+        return type(self)(newCoefficient)
+
+    __hash__ = None
+
+
+class ScalarParameter(_Parameter):
+    """parameter/scalar.py:5-51.  Equality is math.isclose (rel_tol 1e-9),
+    which the device reproduces as YMC_EQ_ISCLOSE."""
+
+    def __init__(self, coefficient):
+        if isinstance(coefficient, float):
+            raise Exception("scalar parameters must be 1-dimensional array types")
+        super().__init__(coefficient)
+
+    @property
+    def dimension(self):
+        return 1
+
+    def __eq__(self, other):
+        if isinstance(other, ScalarParameter):
+            return math.isclose(self.coefficient_[0], other.coefficient[0])
+        return NotImplemented
+
+
+class ParameterVector(_Parameter):
+    """parameter/vector.py:5-52.  Equality is exact (numpy.array_equal)."""
+
+    @property
+    def dimension(self):
+        return self.coefficient_.size
+
+    def __eq__(self, other):
+        if isinstance(other, type(self)):
+            return bool(np.array_equal(self.coefficient_, other.coefficient))
+        return NotImplemented
+
+
+class LotkaVolterraParameter(ParameterVector):
+    """test/testSetup.py:47-58: coefficient = log of (beta, delta)."""
+
+    @classmethod
+    def from_interpolation(cls, value):
+        return cls(np.log(value))
+
+    def evaluate(self):
+        return np.exp(self.coefficient_)
+
+
+# --------------------------------------------------------------------------
+# covariance operators (yagremcmc/statistics/covariance.py)
+# --------------------------------------------------------------------------
+
+class CovarianceMatrix:
+    """covariance.py:8-22"""
+
+    def induced_norm_squared(self, x):
+        return np.dot(x, self.apply_inverse(x))
+
+
+class DiagonalCovarianceMatrix(CovarianceMatrix):
+    """covariance.py:25-55: stores the reciprocals of the marginal variances;
+    the proposal's standard deviations are sqrt(reciprocal(precision)) -- formed
+    exactly like that in lowering.proposal_sigma so that x + sigma*xi rounds as
+    in the reference."""
+
+    def __init__(self, marginalVariances):
+        self._precision = np.reciprocal(np.asarray(marginalVariances, dtype=float))
+
+    @property
+    def marginalVariance(self):
+        return np.reciprocal(self._precision)
+
+    @marginalVariance.setter
+    def marginalVariance(self, mVar):
+        self._precision = np.reciprocal(np.asarray(mVar, dtype=float))
+
+    @property
+    def dimension(self):
+        return self._precision.size
+
+    def apply_chol_factor(self, x):
+        return np.sqrt(np.reciprocal(self._precision)) * x
+
+    def apply_inverse(self, x):
+        return self._precision * x
+
+
+class IIDCovarianceMatrix(DiagonalCovarianceMatrix):
+    """covariance.py:58-66"""
+
+    def __init__(self, dimension, variance):
+        super().__init__(np.full(dimension, variance, dtype=float))
+
+
+# --------------------------------------------------------------------------
+# Gaussian law, noise, data (statistics/{gaussian,noise,data}.py)
+# --------------------------------------------------------------------------
+
+class _DeviceDensity:
+    """DensityInterface (statistics/interface.py:6-10) whose evaluate_log runs
+    on the device: the object lowers itself to a ymc_density_desc and calls
+    ymc_logdensity_eval."""
+
+    def _device_problem(self):
+        from . import lowering
+        prob = getattr(self, "_ymc_problem", None)
+        if prob is None:
+            prob = self._ymc_problem = lowering.density_only_problem(self)
+        return prob
+
+    def evaluate_log(self, parameter):
+        x = np.asarray(parameter.coefficient, dtype=float).reshape(1, -1)
+        return float(self._device_problem().logdensity(x)[0][0])
+
+    def evaluate_log_batch(self, coefficients):
+        return self._device_problem().logdensity(coefficients)[0]
+
+
+class GaussianDensity(_DeviceDensity):
+    """gaussian.py:8-24: -0.5 |x - mean|^2 in the precision norm, no constant."""
+
+    def __init__(self, meanVector, covariance):
+        self._mean = meanVector
+        self._cov = covariance
+
+    @property
+    def covariance(self):
+        return self._cov
+
+
+class Gaussian:
+    """gaussian.py:27-66 (the prior law / the proposal law)."""
+
+    def __init__(self, mean, covariance):
+        self._mean = mean
+        self._cov = covariance
+        self._density = GaussianDensity(self._mean.coefficient, self._cov)
+
+    @property
+    def mean(self):
+        return self._mean
+
+    @property
+    def covariance(self):
+        return self._cov
+
+    @property
+    def density(self):
+        return self._density
+
+
+class CentredGaussianNoise:
+    """noise.py:8-22"""
+
+    def __init__(self, covariance):
+        if not (isinstance(covariance, CovarianceMatrix) or hasattr(covariance, "induced_norm_squared")):
+            raise ValueError("CentredGaussianNoise need to be instantiated "
+                             f"with CovarianceMatrix. Got: {type(covariance)}")
+        self._cov = covariance
+
+    @property
+    def covariance(self):
+        return self._cov
+
+    def induced_norm_squared(self, vector):
+        return self._cov.induced_norm_squared(vector)
+
+
+class Data:
+    """data.py:4-23: array of shape (nData, dataDim)."""
+
+    def __init__(self, dataArray):
+        self.array_ = np.array(dataArray)
+        self.size_, self.dim_ = dataArray.shape[0], dataArray.shape[1]
+
+    @property
+    def size(self):
+        return self.size_
+
+    @property
+    def dim(self):
+        return self.dim_
+
+    @property
+    def array(self):
+        return self.array_
+
+
+# --------------------------------------------------------------------------
+# forward models (yagremcmc/model/*, exampleSetup.py, test/testSetup.py)
+# --------------------------------------------------------------------------
+
+@unique
+class EvaluationStatus(Enum):
+    """model/evaluation.py:4-9"""
+    NONE = -1
+    SUCCESS = 0
+    FAILURE = 1
+
+
+class SolverInterface:
+    """model/interface.py:7-67.  Only solvers with a device lowering can drive
+    an ensemble (lowering.lower_solver); a custom Python solver raises there."""
+
+    @property
+    def status(self):
+        raise NotImplementedError
+
+    @property
+    def evaluation(self):
+        raise NotImplementedError
+
+    def interpolate(self, parameter):
+        raise NotImplementedError
+
+    def invoke(self):
+        raise NotImplementedError
+
+
+class _DeviceSolver(SolverInterface):
+    def __init__(self):
+        self._theta = None
+        self._evaluation = None
+        self._status = EvaluationStatus.NONE
+
+    @property
+    def status(self):
+        return self._status
+
+    @property
+    def evaluation(self):
+        if self._status == EvaluationStatus.FAILURE:
+            raise RuntimeError("Trying to retrieve failed evaluation.")
+        if self._status == EvaluationStatus.NONE:
+            raise RuntimeError("Trying to retrieve evaluation before it was performed.")
+        return self._evaluation
+
+    def interpolate(self, parameter):
+        self._theta = np.asarray(parameter.coefficient, dtype=float)
+
+    def invoke(self):
+        from . import lowering
+        out = lowering.forward_only_problem(self).forward(self._theta.reshape(1, -1))[0]
+        self._evaluation = self._shape_evaluation(out)
+        self._status = (EvaluationStatus.SUCCESS if np.all(np.isfinite(out))
+                        else EvaluationStatus.FAILURE)
+
+    def _shape_evaluation(self, flat):
+        return flat
+
+
+class ExampleLinearModelSolver(_DeviceSolver):
+    """exampleSetup.py:8-52: G(theta) = A theta + b."""
+
+    def __init__(self, A, b):
+        super().__init__()
+        self._A = np.asarray(A, dtype=float)
+        self._b = np.asarray(b, dtype=float)
+
+
+class LotkaVolterraSolver(_DeviceSolver):
+    """test/testSetup.py:61-141.  `config` takes the reference's keys (T, alpha,
+    gamma, nData, dataDim; solver/rtol are accepted and ignored) plus the
+    optional 'rk4Steps' (default 50): the ensemble integrates with fixed-step
+    classical RK4 instead of scipy's adaptive solve_ivp."""
+
+    def __init__(self, design, config):
+        super().__init__()
+        self.x_ = np.asarray(design, dtype=float)
+        self.tBoundary_ = (0.0, float(config['T']))
+        self.fixedParam_ = [float(config['alpha']), float(config['gamma'])]
+        self.dataShape_ = (int(config['nData']), int(config['dataDim']))
+        self.rk4Steps_ = int(config.get('rk4Steps', 50))
+        if self.x_.shape != (self.dataShape_[0], 2) or self.dataShape_[1] != 2:
+            raise ValueError("design must have shape (nData, 2) and dataDim must be 2")
+
+    @property
+    def dataShape(self):
+        return self.dataShape_
+
+    @property
+    def nData(self):
+        return self.dataShape_[0]
+
+    @property
+    def dataDim(self):
+        return self.dataShape_[1]
+
+    def _shape_evaluation(self, flat):
+        return flat.reshape(self.dataShape_)
+
+
+class ForwardModel:
+    """model/forwardModel.py:4-19"""
+
+    def __init__(self, solver):
+        self.solver_ = solver
+
+    def evaluate(self, parameter):
+        self.solver_.interpolate(parameter)
+        self.solver_.invoke()
+        if self.solver_.status == EvaluationStatus.SUCCESS:
+            return self.solver_.evaluation
+        raise Exception("Evaluation request failed.")
+
+
+def generate_synthetic_data(parameter, solver, noiseVar):
+    """test/testSetup.py:165-174 (host-side helper; draws from NumPy's global generator)."""
+    solver.interpolate(parameter)
+    solver.invoke()
+    return Data(solver.evaluation + np.sqrt(noiseVar) * np.random.standard_normal(solver.dataShape))
+
+
+# --------------------------------------------------------------------------
+# likelihood, Bayesian model, posterior
+# --------------------------------------------------------------------------
+
+class AdditiveGaussianNoiseLikelihood(_DeviceDensity):
+    """likelihood.py:49-87.  The reference's FIFO evaluation cache (:51,61-72)
+    has no counterpart: on the device logpi(state) stays in a register."""
+
+    def __init__(self, data, forwardModel, noiseModel):
+        if not (isinstance(noiseModel, CentredGaussianNoise)
+                or type(noiseModel).__name__ == "CentredGaussianNoise"):
+            raise ValueError("AdditiveGaussianNoiseLikelihood requires centred Gaussian noise.")
+        self._data = data
+        self._fwdModel = forwardModel
+        self._noiseModel = noiseModel
+
+
+class BayesianRegressionModel:
+    """bayesModel.py:5-29 (non-hierarchical components only)."""
+
+    def __init__(self, likelihood, prior):
+        self._likelihood = likelihood
+        self._prior = prior
+
+    @property
+    def prior(self):
+        return self._prior
+
+    @property
+    def likelihood(self):
+        return self._likelihood
+
+
+class UnnormalisedPosterior(_DeviceDensity):
+    """chain/target.py:4-22: log-likelihood + log prior density."""
+
+    def __init__(self, likelihood, prior):
+        self._likelihood = likelihood
+        self._prior = prior
+
+    @property
+    def likelihood(self):
+        return self._likelihood
+
+    @property
+    def prior(self):
+        return self._prior
+
+
+# --------------------------------------------------------------------------
+# explicit targets (yagremcmc/test/testSetup.py)
+# --------------------------------------------------------------------------
+
+class GaussianTargetDensity1d(_DeviceDensity):
+    """test/testSetup.py:15-29: -0.5 (mean - x)^2 / var."""
+
+    def __init__(self, mean, var):
+        self.mean_ = mean
+        self.var_ = var
+
+    def evaluate_on_mesh(self, mesh):
+        # plotting helper of the examples (:27-29), not part of the chain
+        return np.exp(-0.5 * np.square((self.mean_.coefficient - mesh) / self.var_))
+
+
+class GaussianTargetDensity2d(_DeviceDensity):
+    """test/testSetup.py:32-44: scipy.stats.multivariate_normal(mean, cov).logpdf.
+    The whitening matrix and log pseudo-determinant are formed the way scipy's
+    covariance object does (symmetric eigendecomposition, U = V / sqrt(w))."""
+
+    def __init__(self, mean, cov):
+        self.mean_ = np.array(mean.coefficient, dtype=float)
+        self.cov_ = np.array(cov, dtype=float)
+        d = self.mean_.size
+        if self.cov_.shape != (d, d):
+            raise ValueError("covariance shape does not match the mean")
+        w, v = np.linalg.eigh(self.cov_)
+        if np.min(w) <= 0.0:
+            raise ValueError("the input matrix must be symmetric positive definite")
+        self.whiten_ = v * np.sqrt(1.0 / w)
+        self.log_norm_ = d * np.log(2.0 * np.pi) + np.sum(np.log(w))
+
+    def evaluate_on_mesh(self, mesh):
+        mesh = np.asarray(mesh, dtype=float)
+        flat = mesh.reshape(-1, self.mean_.size)
+        return np.exp(self.evaluate_log_batch(flat)).reshape(mesh.shape[:-1])
