@@ -143,7 +143,8 @@ def cpu_baseline(wl, d):
     bounded sample of the same workload: same target, same recording, fewer
     chains and transitions (~10-20 s of CPU work)."""
     from oracle import oracle
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(visible, 16)     # one GPU's share of the host (the box exposes all 256 hardware threads)
 
     x0 = wl.get("x0")
 
@@ -170,7 +171,7 @@ def cpu_baseline(wl, d):
     return {"value": rate, "unit": "steps/s", "cores": cores, "kind": "port",
             "sample": f"{K} chains x {T} transitions x {reps} passes of the same workload (trajectory, mask, log-density and "
                       f"moments recorded, record buffers resident), {cores} OpenMP threads, {dt:.1f} s",
-            "single_thread_steps_per_s": rate1,
+            "host_threads_visible": visible, "single_thread_steps_per_s": rate1,
             "reference_single_core_steps_per_s_survey_container": 2.2e4}
 
 
