@@ -110,34 +110,6 @@ def make_workload(name, ffi, ctx, lowering):
             "C4: Lotka-Volterra posterior, nData=10, T=10, RK4 x 50", 2, dict(target=o_prob, sigma=sigma))
 
 
-# ---------------------------------------------------------------------------
-# rendezvous of the RCCL unique id without PyTorch: rank 0 publishes it in a
-# file keyed by the launcher's pid and MASTER_PORT, the other ranks poll for it
-# ---------------------------------------------------------------------------
-
-def exchange_unique_id(ffi, rank):
-    key = f"{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}"
-    path = os.path.join("/tmp", f"ymc_rdzv_{key}")
-    if rank == 0:
-        uid = ffi.Communicator.unique_id()
-        tmp = path + f".{os.getpid()}"
-        with open(tmp, "wb") as f:
-            f.write(uid)
-        os.replace(tmp, path)
-        return uid, path
-    deadline = time.time() + 300
-    while time.time() < deadline:
-        try:
-            with open(path, "rb") as f:
-                uid = f.read()
-            if len(uid) == ffi.UNIQUE_ID_BYTES:
-                return uid, path
-        except FileNotFoundError:
-            pass
-        time.sleep(0.05)
-    raise RuntimeError("rank 0 never published the RCCL unique id")
-
-
 def cpu_baseline(wl, d):
     """The oracle (CPU restatement, kind "port") timed on the host cores on a
     bounded sample of the same workload: same target, same recording, fewer
@@ -185,8 +157,7 @@ def main():
             sys.exit("bench.py --gpus N > 1 must be launched as N processes (torch.distributed.run / torchrun)")
         args.gpus = world
 
-    from yagremcmc_amd import _ffi as ffi, lowering
-    from yagremcmc_amd.diagnostics import merge_welford
+    from yagremcmc_amd import _ffi as ffi, distributed, lowering
     ctx = ffi.Context(local_rank if world > 1 else 0)
     info = ctx.info()
     prob, x0, def_chains, def_T, desc, d, wl = make_workload(args.workload, ffi, ctx, lowering)
@@ -196,10 +167,7 @@ def main():
     flags = ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT | (0 if args.no_moments else ffi.RECORD_MOMENTS)
     run = ffi.Run(prob, 20250103, K, x0, T, flags, chain_offset=rank * K)
 
-    comm = None
-    if world > 1:
-        uid, path = exchange_unique_id(ffi, rank)
-        comm = ffi.Communicator(ctx, uid, world, rank)
+    comm = distributed.make_communicator(ctx, rank, world) if world > 1 else None
 
     def barrier():
         run.sync()
@@ -229,31 +197,13 @@ def main():
         tg = time.perf_counter()
         packed = comm.allgather_summary(run)  # (world, K, 3d+5) u64
         gather_ms = (time.perf_counter() - tg) * 1e3
-        flat = packed.reshape(world * K, -1)
-        if rank == 0:
-            try:
-                os.remove(path)
-            except OSError:
-                pass
+        summary = distributed.unpack_summaries(packed, d)
     else:
-        s = run.summary()
-        x, lp = run.state()
-        flat = None
-
+        summary = run.summary()
     if rank != 0:
         return
-
     total_steps = run.steps_done()[0]
-    if flat is not None:
-        accepted = flat[:, d + 1].astype(np.float64)
-        wf_n = flat[:, d + 2]
-        wf_mean = flat[:, d + 3:2 * d + 3].view(np.float64)
-        wf_m2 = flat[:, 2 * d + 3:3 * d + 3].view(np.float64)
-        status = flat[:, 3 * d + 3]
-    else:
-        accepted, wf_n, wf_mean, wf_m2, status = (s["accepted"].astype(np.float64), s["wf_n"], s["wf_mean"],
-                                                  s["wf_m2"], s["status"])
-    pooled = merge_welford(wf_n, wf_mean, wf_m2) if not args.no_moments else (0, None, None)
+    pooled = distributed.pooled_diagnostics(summary, total_steps)
 
     transitions = float(world) * K * T * args.steps
     value = transitions / elapsed
@@ -285,9 +235,9 @@ def main():
                              "bound (Philox + Box-Muller + exp per transition), see DESIGN.md"},
         "hbm_gb_per_s_whole_node": world * achieved,
         "kernel_steps_per_s_per_gpu": K * T / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0,
-        "acceptance_rate": float(accepted.sum() / (len(accepted) * total_steps)),
-        "pooled_mean": None if pooled[1] is None else [float(v) for v in pooled[1]],
-        "chains_flagged_nonfinite": int((status != 0).sum()),
+        "acceptance_rate": pooled["acceptance_rate"],
+        "pooled_mean": None if args.no_moments else [float(v) for v in pooled["mean"]],
+        "chains_flagged_nonfinite": pooled["flagged"],
         "gather_ms": gather_ms,
         "device": info,
     }

@@ -1,0 +1,198 @@
+"""The drop-in surface on the GPU: the reference's own tests, restated for the
+ensemble builders (test_mcmc_1d.py, test_mcmc_2d.py, test_mlda.py,
+test_inference_mcmc_singleLevel.py), plus single-chain shape compatibility."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as o  # noqa: E402
+
+
+def _imports():
+    from yagremcmc_amd.chain.diagnostics import AcceptanceRateDiagnostics, DummyDiagnostics, FullDiagnostics
+    from yagremcmc_amd.chain.method.mlda import MLDABuilder
+    from yagremcmc_amd.chain.method.mrw import MetropolisedRandomWalk, MRWBuilder
+    from yagremcmc_amd.parameter.scalar import ScalarParameter
+    from yagremcmc_amd.parameter.vector import ParameterVector
+    from yagremcmc_amd.statistics.covariance import DiagonalCovarianceMatrix, IIDCovarianceMatrix
+    from yagremcmc_amd.test.testSetup import GaussianTargetDensity1d, GaussianTargetDensity2d
+    return locals()
+
+
+@pytest.mark.parametrize("diag", ["DummyDiagnostics", "AcceptanceRateDiagnostics", "FullDiagnostics"])
+def test_mcmc_1d_single_chain_like_the_reference(diag):
+    """test_mcmc_1d.py:58-116 (seeded statistical test) on ONE chain: trajectory is
+    a list of chainLength coefficient arrays; mean/var within 1e-1."""
+    m = _imports()
+    tgt = m["GaussianTargetDensity1d"](m["ScalarParameter"](np.array([1.0])), 1.0)
+    mc = m["MetropolisedRandomWalk"](tgt, m["IIDCovarianceMatrix"](1, 1.0), m[diag](), seed=18)
+    n = 15000
+    mc.run(n, m["ScalarParameter"](np.array([-3.0])), verbose=False)
+    traj = mc.chain.trajectory
+    assert isinstance(traj, list) and len(traj) == n and traj[0].shape == (1,)
+    states = np.array(traj)
+    samples = states[200::3]
+    assert abs(samples.mean() - 1.0) < 1e-1 and abs(samples.var() - 1.0) < 1e-1
+    # and it is the oracle's chain, bit for bit
+    e = o.Ensemble(o.gauss_iso1d(1.0, 1.0), np.ones(1), np.array([[-3.0]]), 18, eq_mode=o.EQ_ISCLOSE)
+    assert np.array_equal(states[1:, 0], e.advance(n - 1)["traj"][:, 0, 0])
+    if diag != "DummyDiagnostics":
+        assert mc.diagnostics.global_acceptance_rate() == e.acc_count[0] / (n - 1)
+        assert isinstance(mc.diagnostics._decisions if diag == "AcceptanceRateDiagnostics"
+                          else mc.diagnostics._diagnostics._decisions, list)
+    if diag == "FullDiagnostics":
+        assert np.array_equal(mc.diagnostics.mean(), e.wf_mean[0])
+        assert np.array_equal(mc.diagnostics.marginal_variance(), e.wf_m2[0] / (n - 2.0))
+
+
+@pytest.mark.parametrize("proposal", ["iid", "indep"])
+def test_mcmc_2d_moments_ensemble(proposal):
+    """test_mcmc_2d.py:18-81 with 2048 chains: ensemble moments are far tighter
+    than the reference's single-chain tolerances (5e-2 / 1e-1)."""
+    m = _imports()
+    mean = np.array([1.0, 1.5])
+    cov = np.array([[1.2, -0.2], [-0.2, 0.4]])
+    b = m["MRWBuilder"]()
+    b.explicitTarget = m["GaussianTargetDensity2d"](m["ParameterVector"](mean), cov)
+    b.proposalCovariance = (m["IIDCovarianceMatrix"](2, 0.25) if proposal == "iid"
+                            else m["DiagonalCovarianceMatrix"](np.array([cov[0, 0], cov[1, 1]])))
+    b.diagnostics = m["FullDiagnostics"]()
+    b.nChains, b.seed = 2048, 116
+    mc = b.build_method()
+    mc.run(2000, m["ParameterVector"](np.array([-2.0, 0.0])), verbose=True)
+    states = mc.chain.trajectory
+    assert states.shape == (2000, 2048, 2)
+    samples = states[200::5].reshape(-1, 2)
+    assert np.allclose(samples.mean(axis=0), mean, atol=2e-2)
+    assert np.allclose(np.cov(samples.T), cov, atol=3e-2)
+    rate = mc.diagnostics.global_acceptance_rate()
+    assert 0.1 < rate < 0.9
+    assert np.allclose(mc.diagnostics.per_chain_acceptance_rate().mean(), rate)
+    assert mc.diagnostics.marginal_variance().shape == (2,)
+
+
+def test_two_level_builder_and_perfect_surrogate():
+    """test_mlda.py:94-186"""
+    m = _imports()
+    mean = np.array([1.0, 1.5])
+    cov = np.array([[2.4, -0.5], [-0.5, 0.7]])
+    fine = m["GaussianTargetDensity2d"](m["ParameterVector"](mean), cov)
+    coarse = m["GaussianTargetDensity2d"](m["ParameterVector"](mean + np.array([0.15, -0.2])),
+                                          2.0 * cov + np.array([[0.1, 1.2], [1.2, 0.05]]))
+    b = m["MLDABuilder"]()
+    b.explicitTarget, b.surrogateTargets = fine, [coarse]
+    b.baseProposalCovariance = m["IIDCovarianceMatrix"](2, 1.0)
+    b.subChainLengths = [10]
+    b.nChains, b.seed = 1024, 42
+    mc = b.build_method()
+    mc.run(1500, m["ParameterVector"](np.array([-8.0, -7.0])), verbose=False)
+    rate = mc.diagnostics.global_acceptance_rate()
+    assert 0.1 < rate < 0.9
+    samples = mc.chain.trajectory[100:].reshape(-1, 2)
+    assert np.allclose(samples.mean(axis=0), mean, atol=0.05)
+    # perfect surrogate => acceptance rate 1 up to the (never occurring) all-rejected sub-chains
+    b2 = m["MLDABuilder"]()
+    b2.explicitTarget, b2.surrogateTargets = fine, [fine]
+    b2.baseProposalCovariance = m["IIDCovarianceMatrix"](2, 1.0)
+    b2.subChainLengths = [10]
+    b2.nChains = 512
+    mc2 = b2.build_method()
+    mc2.run(500, m["ParameterVector"](np.array([1.0, 1.5])), verbose=False)
+    assert abs(mc2.diagnostics.global_acceptance_rate() - 1.0) < 1e-3
+    with pytest.raises(NotImplementedError):
+        b3 = m["MLDABuilder"]()
+        b3.explicitTarget, b3.surrogateTargets = fine, [coarse, coarse]
+        b3.baseProposalCovariance = m["IIDCovarianceMatrix"](2, 1.0)
+        b3.subChainLengths = [4, 4]
+        b3.build_method()
+
+
+@pytest.mark.parametrize("proposal", ["iid", "indep"])
+def test_lotka_volterra_inference_through_the_builder(proposal):
+    """test_inference_mcmc_singleLevel.py:28-118 wiring; posterior mean near the truth."""
+    import yagremcmc_amd.test.testSetup as setup
+    from yagremcmc_amd.chain.method.mrw import MRWBuilder
+    from yagremcmc_amd.model.forwardModel import ForwardModel
+    from yagremcmc_amd.statistics.bayesModel import BayesianRegressionModel
+    from yagremcmc_amd.statistics.covariance import DiagonalCovarianceMatrix, IIDCovarianceMatrix
+    from yagremcmc_amd.statistics.gaussian import Gaussian
+    from yagremcmc_amd.statistics.likelihood import AdditiveGaussianNoiseLikelihood
+    from yagremcmc_amd.statistics.noise import CentredGaussianNoise
+    np.random.seed(16)
+    config = {'T': 6., 'alpha': 0.8, 'gamma': 0.4, 'nData': 5, 'dataDim': 2, 'solver': 'LSODA', 'rtol': 1e-4}
+    design = np.array([[0.1, 0.9], [0.5, 0.5], [1., 0.5], [0.5, 1.], [2.5, 1.5]])
+    solver = setup.LotkaVolterraSolver(design, config)
+    truth = setup.LotkaVolterraParameter.from_interpolation(np.array([0.4, 0.6]))
+    data = setup.generate_synthetic_data(truth, solver, 0.05)
+    assert data.array.shape == (5, 2)
+    # ForwardModel.evaluate goes through the device and agrees with the oracle's RK4
+    f = ForwardModel(solver).evaluate(truth)
+    p = o.posterior_lv(design, 6.0, 0.8, 0.4, 50, data.array, np.full(2, 20.0), np.zeros(2), np.full(2, 50.0))
+    assert np.array_equal(f, o.forward(p, truth.coefficient).reshape(5, 2))
+    prior = Gaussian(setup.LotkaVolterraParameter.from_coefficient(np.zeros(2)), IIDCovarianceMatrix(2, 0.02))
+    like = AdditiveGaussianNoiseLikelihood(data, ForwardModel(solver), CentredGaussianNoise(IIDCovarianceMatrix(2, 0.05)))
+    b = MRWBuilder()
+    b.proposalCovariance = (IIDCovarianceMatrix(2, 0.02) if proposal == "iid"
+                            else DiagonalCovarianceMatrix(np.array([0.02, 0.01])))
+    b.bayesModel = BayesianRegressionModel(like, prior)
+    b.nChains, b.recordLogPosterior = 256, True
+    mc = b.build_method()
+    init = setup.LotkaVolterraParameter.from_coefficient(np.array([-0.6, -0.3]))
+    mc.run(1000, init, verbose=False)
+    states = mc.chain.trajectory
+    post = states[200::5].reshape(-1, 2).mean(axis=0)
+    # the prior N(0, 0.02 I) dominates 5 noisy rows: the posterior mean sits between 0 and the truth
+    assert np.all(np.abs(post) <= np.abs(truth.coefficient) + 0.1)
+    assert (mc.chain_status == 0).all()
+    # target.evaluate_log on the device == recorded log-posterior of that state
+    lp = mc.log_posterior
+    k, n = 3, 500
+    got = mc.target.evaluate_log(setup.LotkaVolterraParameter.from_coefficient(states[n, k].copy()))
+    assert got == lp[n, k]
+    e = o.Ensemble(p | dict(noise_precision=np.reciprocal(np.full(2, 0.05)), prior_precision=np.reciprocal(np.full(2, 0.02))),
+                   np.sqrt(np.reciprocal(b.proposalCovariance._precision)), np.tile(init.coefficient, (256, 1)), 0)
+    assert np.array_equal(states[1:], e.advance(999)["traj"])
+
+
+def test_reference_style_objects_are_accepted_by_duck_typing():
+    """A user who keeps the reference's own plug-in instances: recognised by class
+    name + attributes (here: stand-ins with the reference's attribute names)."""
+    from types import SimpleNamespace
+    from yagremcmc_amd.chain.method.mrw import MRWBuilder
+    from yagremcmc_amd.parameter.vector import ParameterVector
+    mean, cov = np.array([1.0, 1.5]), np.array([[2.4, -0.5], [-0.5, 0.7]])
+    w, v = np.linalg.eigh(cov)
+    cov_object = SimpleNamespace(_LP=v * np.sqrt(1.0 / w), _log_pdet=float(np.sum(np.log(w))), rank=2)
+    RefTarget = type("GaussianTargetDensity2d", (), {})
+    t = RefTarget()
+    t.dist_ = SimpleNamespace(mean=mean, cov=cov, cov_object=cov_object)
+    RefCov = type("IIDCovarianceMatrix", (), {})
+    c = RefCov()
+    c._precision = np.reciprocal(np.full(2, 1.0))
+    RefDiag = type("FullDiagnostics", (), {})
+    b = MRWBuilder()
+    b.explicitTarget, b.proposalCovariance, b.diagnostics = t, c, RefDiag()
+    b.nChains, b.seed = 64, 5
+    mc = b.build_method()
+    mc.run(300, ParameterVector(np.array([-8.0, -7.0])), verbose=False)
+    e = o.Ensemble(o.gauss_whitened(mean, cov_object._LP, 2 * np.log(2 * np.pi) + cov_object._log_pdet),
+                   np.ones(2), np.tile([-8.0, -7.0], (64, 1)), 5)
+    assert np.array_equal(mc.chain.trajectory[1:], e.advance(299)["traj"])
+    assert np.array_equal(mc.diagnostics.per_chain_mean(), e.wf_mean)
+
+
+def test_unsupported_plugins_raise():
+    from yagremcmc_amd import UnsupportedPlugin
+    from yagremcmc_amd.chain.method.mrw import MRWBuilder
+    from yagremcmc_amd.parameter.vector import ParameterVector
+    from yagremcmc_amd.statistics.covariance import IIDCovarianceMatrix
+
+    class MyDensity:
+        def evaluate_log(self, p):
+            return 0.0
+
+    b = MRWBuilder()
+    b.explicitTarget, b.proposalCovariance = MyDensity(), IIDCovarianceMatrix(2, 1.0)
+    with pytest.raises(UnsupportedPlugin):
+        b.build_method().run(10, ParameterVector(np.zeros(2)), verbose=False)

@@ -1,0 +1,108 @@
+"""Sharding of an ensemble over GPUs (one process per GPU) and the host side of
+the single collective: the gather of per-chain summaries.
+
+Nothing is exchanged while sampling: rank r of W owns the contiguous block of
+global chain ids [r*K, (r+1)*K) and every chain draws from the stream of its
+GLOBAL id, so per-chain results do not depend on W.  After sampling each rank
+contributes its packed summaries (3d+5 eight-byte words per chain, written by
+pack_summary_kernel) to one RCCL all-gather (`_ffi.Communicator`).
+"""
+import os
+import time
+
+import numpy as np
+
+from .diagnostics import merge_welford
+
+
+def launch_env():
+    """(rank, local_rank, world) from the torchrun-style environment."""
+    rank = int(os.environ.get("RANK", "0"))
+    return rank, int(os.environ.get("LOCAL_RANK", str(rank))), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def shard(total_chains, rank, world):
+    """Contiguous equal blocks of global chain ids; -> (chain_offset, n_chains)."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError("bad rank / world size")
+    if total_chains % world:
+        raise ValueError(f"{total_chains} chains do not split evenly over {world} ranks")
+    k = total_chains // world
+    return rank * k, k
+
+
+def summary_words(d):
+    return 3 * d + 5
+
+
+def unpack_summaries(packed, d):
+    """(W, K, 3d+5) u64 -> dict of arrays over all W*K chains in global id order."""
+    flat = np.ascontiguousarray(packed, dtype=np.uint64).reshape(-1, summary_words(d))
+    return dict(
+        state=flat[:, 0:d].view(np.float64),
+        logpost=flat[:, d].view(np.float64),
+        accepted=flat[:, d + 1].copy(),
+        wf_n=flat[:, d + 2].copy(),
+        wf_mean=flat[:, d + 3:2 * d + 3].view(np.float64),
+        wf_m2=flat[:, 2 * d + 3:3 * d + 3].view(np.float64),
+        status=flat[:, 3 * d + 3].astype(np.uint32),
+    )
+
+
+def pooled_diagnostics(summary, steps):
+    """Ensemble-wide acceptance rate and Welford moments from per-chain summaries."""
+    n_chains = summary["accepted"].size
+    rate = float(summary["accepted"].astype(np.float64).sum() / (n_chains * steps)) if steps else 0.0
+    n, mean, m2 = merge_welford(summary["wf_n"], summary["wf_mean"], summary["wf_m2"])
+    var = m2 / (n - 1) if n > 1 else None
+    return dict(acceptance_rate=rate, n=n, mean=mean, marginal_variance=var,
+                flagged=int((summary["status"] != 0).sum()))
+
+
+class FileRendezvous:
+    """Exchange of the RCCL unique id without PyTorch: rank 0 publishes the id in
+    a file keyed by the launcher's pid, MASTER_PORT and run id; the others poll."""
+
+    def __init__(self, directory="/tmp"):
+        key = f"{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}"
+        self.path = os.path.join(directory, f"ymc_rdzv_{key}")
+
+    def publish(self, payload):
+        tmp = f"{self.path}.{os.getpid()}"
+        with open(tmp, "wb") as f:
+            f.write(payload)
+        os.replace(tmp, self.path)
+
+    def wait(self, nbytes, timeout=300.0):
+        deadline = time.time() + timeout
+        while time.time() < deadline:
+            try:
+                with open(self.path, "rb") as f:
+                    payload = f.read()
+                if len(payload) == nbytes:
+                    return payload
+            except FileNotFoundError:
+                pass
+            time.sleep(0.05)
+        raise RuntimeError("rank 0 never published the RCCL unique id")
+
+    def cleanup(self):
+        try:
+            os.remove(self.path)
+        except OSError:
+            pass
+
+
+def make_communicator(ctx, rank, world):
+    from . import _ffi
+    rdzv = FileRendezvous()
+    if rank == 0:
+        uid = _ffi.Communicator.unique_id()
+        rdzv.publish(uid)
+    else:
+        uid = rdzv.wait(_ffi.UNIQUE_ID_BYTES)
+    comm = _ffi.Communicator(ctx, uid, world, rank)
+    comm.barrier()
+    if rank == 0:
+        rdzv.cleanup()
+    return comm
