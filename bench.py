@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c5", "c4"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "c4"])
     ap.add_argument("--chains", type=int, default=0, help="chains per GPU (default: the workload's)")
     ap.add_argument("--transitions", type=int, default=0, help="MH transitions per chain per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -90,6 +90,25 @@ def make_workload(name, ffi, ctx, lowering):
         prob = lowering.make_problem(ctx, ffi.METHOD_MLDA2, fine, sigma, surrogate=coarse, sub_chain_length=6)
         return (prob, x0, 131072, 200, "C5: two-level delayed acceptance (example_mcmc_2d_twoLevel.py), S=6",
                 2, dict(target=o_fine, sigma=sigma, surrogate=oracle.gauss_whitened(cm, Uc, c_c), S=6))
+    if name == "c3":
+        # linear forward model, d = m = 128, nData = 5
+        d = 128
+        rng = np.random.default_rng(7)
+        A = rng.standard_normal((d, d)) / np.sqrt(d)
+        b = rng.standard_normal(d)
+        theta = rng.standard_normal(d)
+        data = np.array([A @ theta + b + np.sqrt(0.3) * rng.standard_normal(d) for _ in range(5)])
+        noise_prec, prior_mean, prior_prec = np.reciprocal(np.full(d, 0.3)), np.zeros(d), np.reciprocal(np.full(d, 5.0))
+        low = lowering.Lowered(ffi.POSTERIOR_LINEAR, d)
+        low.desc.n_data, low.desc.data_dim = 5, d
+        for k, v in (("data", data), ("noise_precision", noise_prec), ("prior_mean", prior_mean),
+                     ("prior_precision", prior_prec), ("fwd_matrix", A), ("fwd_shift", b)):
+            low.set_array(k, v)
+        sigma = np.sqrt(np.reciprocal(np.reciprocal(np.full(d, 1.1e-3))))
+        prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, sigma)
+        o_prob = oracle.posterior_linear(A, b, data, noise_prec, prior_mean, prior_prec)
+        return (prob, np.zeros((1, d)), 262144, 20, "C3: linear forward model posterior d = m = 128, nData = 5 "
+                "(fp64 MFMA tile kernel)", d, dict(target=o_prob, sigma=sigma))
     # c4: Lotka-Volterra, nData=10, T=10, RK4 x 50
     design = lv_problem_arrays()
     truth = np.log(np.array([0.4, 0.6]))
@@ -164,6 +183,8 @@ def main():
     wl["x0"] = x0
     K = args.chains or def_chains
     T = args.transitions or def_T
+    if args.workload == "c3":
+        args.no_moments = True   # the reference's default diagnostics; the tile kernel keeps no Welford state
     flags = ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT | (0 if args.no_moments else ffi.RECORD_MOMENTS)
     run = ffi.Run(prob, 20250103, K, x0, T, flags, chain_offset=rank * K)
 

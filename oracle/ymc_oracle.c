@@ -129,15 +129,19 @@ void ymo_rng_fill(uint64_t seed, uint64_t chain0, int64_t K, uint64_t t0, int64_
 /* ---------------------------------------------------------------------- */
 
 /* CovarianceMatrix.induced_norm_squared with a diagonal precision:
- * covariance.py:19-22 (np.dot(x, Px)) and :54-55 (Px = precision * x). */
+ * covariance.py:19-22 (np.dot(x, Px)) and :54-55 (Px = precision * x).
+ * np.dot's summation order is BLAS' business; the ensemble fixes it as FOUR
+ * INTERLEAVED partial sums (index j feeds partial j mod 4, each in increasing
+ * j) combined as (S0 + S1) + (S2 + S3) -- the order in which the d = 128 tile
+ * kernel finds the terms in the fp64 MFMA accumulator layout. */
 static double ymo_diag_norm_sq(const double *x, const double *prec, int32_t n)
 {
-    double acc = 0.0;
+    double S[4] = {0.0, 0.0, 0.0, 0.0};
     for (int32_t j = 0; j < n; ++j) {
         double px = prec[j] * x[j];
-        acc = acc + x[j] * px;
+        S[j & 3] = S[j & 3] + x[j] * px;
     }
-    return acc;
+    return (S[0] + S[1]) + (S[2] + S[3]);
 }
 
 /* GaussianDensity.evaluate_log, gaussian.py:19-24: -0.5 |x - mean|^2_{Sigma^-1},

@@ -332,3 +332,72 @@ def test_record_capacity_and_rewind(ffi, ctx, golden):
     assert run.steps_done() == (100, 50)
     avg_ms, launches = run.kernel_time_ms()
     assert launches == 2 and avg_ms > 0
+
+
+# ---------------------------------------------------------------------------
+# large dimension: the fp64-MFMA tile kernel (BASELINE configs[2] shapes)
+# ---------------------------------------------------------------------------
+
+def test_f3_linear_d128_matrix_cores(ffi, ctx, golden):
+    import hashlib
+    g = golden("f3_linear_d128.npz")
+    n = int(g["n_states"])
+    low = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, 128, g, fwd_matrix=np.asarray(g["A"]), fwd_shift=np.asarray(g["b"]))
+    dev = _device_run(ffi, ctx, low, g["sigma"], g["x0"], int(g["seed"]), n - 1, moments=False, splits=2)
+    p = o.posterior_linear(g["A"], g["b"], g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+    e = o.Ensemble(p, g["sigma"], g["x0"], int(g["seed"]))
+    out = e.advance(n - 1)
+    # bit-exact against the oracle: the f64 MFMA is a k-ordered fma chain
+    assert np.array_equal(dev["acc"], out["acc"])
+    assert np.array_equal(dev["traj"], out["traj"])
+    assert np.array_equal(dev["logpost"], out["logpost"])
+    assert np.array_equal(dev["summary"]["accepted"], e.acc_count)
+    assert np.array_equal(dev["state"][0], e.x) and np.array_equal(dev["state"][1], e.lp)
+    # and against the live reference's outputs
+    _same_as_reference(dev, g)
+    assert np.array_equal(dev["traj"][:, :2, :], g["traj_head"][1:])
+    full = np.concatenate([g["x0"][None], dev["traj"]])
+    assert hashlib.sha256(np.ascontiguousarray(full).tobytes()).hexdigest() == str(g["traj_sha256"])
+    # batched evaluate_log / forward at d = 128
+    from yagremcmc_amd import lowering
+    prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, g["sigma"])
+    xs = dev["traj"][-1]
+    assert np.array_equal(prob.logdensity(xs)[0], o.logdensity(p, xs)[0])
+    assert np.array_equal(prob.forward(xs), o.forward(p, xs))
+
+
+@pytest.mark.parametrize("d,m,nd,K", [(128, 128, 5, 100), (9, 3, 2, 33), (16, 16, 1, 64), (40, 70, 8, 50),
+                                      (64, 200, 3, 17), (100, 20, 4, 129), (7, 30, 5, 40)])
+def test_tile_kernel_other_shapes(ffi, ctx, d, m, nd, K):
+    rng = np.random.default_rng(300 + d + m)
+    g = dict(A=rng.normal(size=(m, d)) / np.sqrt(d), b=rng.normal(size=m), data=rng.normal(size=(nd, m)),
+             noise_precision=rng.uniform(0.5, 3, size=m), prior_mean=rng.normal(size=d),
+             prior_precision=rng.uniform(0.1, 2, size=d))
+    low = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, g, fwd_matrix=g["A"], fwd_shift=g["b"])
+    p = o.posterior_linear(g["A"], g["b"], g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+    sigma = rng.uniform(0.02, 0.08, size=d)
+    x0 = rng.normal(size=(K, d))
+    dev = _device_run(ffi, ctx, low, sigma, x0, 4711, 60, chain0=1000, moments=False)
+    e = o.Ensemble(p, sigma, x0, 4711, chain0=1000)
+    out = e.advance(60)
+    assert np.array_equal(dev["acc"], out["acc"]) and 0.02 < out["acc"].mean() < 0.98
+    assert np.array_equal(dev["traj"], out["traj"])
+    assert np.array_equal(dev["logpost"], out["logpost"])
+    assert np.array_equal(dev["state"][0], e.x)
+
+
+def test_tile_kernel_limits(ffi, ctx):
+    from yagremcmc_amd import lowering
+    rng = np.random.default_rng(1)
+    g = dict(data=rng.normal(size=(9, 16)), noise_precision=np.ones(16), prior_mean=np.zeros(16),
+             prior_precision=np.ones(16))
+    low = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, 16, g, fwd_matrix=rng.normal(size=(16, 16)), fwd_shift=np.zeros(16))
+    with pytest.raises(ffi.YmcError) as err:   # more data rows than the epilogue unrolls
+        lowering.make_problem(ctx, ffi.METHOD_MRW, low, np.ones(16))
+    assert err.value.code == ffi.ERR_UNSUPPORTED
+    g = dict(data=rng.normal(size=(2, 4)), noise_precision=np.ones(4), prior_mean=np.zeros(200),
+             prior_precision=np.ones(200))
+    low = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, 200, g, fwd_matrix=rng.normal(size=(4, 200)), fwd_shift=np.zeros(4))
+    with pytest.raises(ffi.YmcError) as err:   # d > 128
+        lowering.make_problem(ctx, ffi.METHOD_MRW, low, np.ones(200))
+    assert err.value.code == ffi.ERR_UNSUPPORTED

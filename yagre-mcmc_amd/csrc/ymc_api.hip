@@ -6,12 +6,14 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "ymc_kernels.h"
+#include "ymc_tile.h"
 
 namespace {
 
@@ -70,6 +72,10 @@ struct DensityHost {
     std::vector<double> mean, whiten, data, noise_prec, prior_mean, prior_prec, A, b, design;
     DeviceBuf dev;  /* one allocation: data | noise_prec | prior_mean | prior_prec | A | b | design */
     size_t off_data = 0, off_noise = 0, off_pmean = 0, off_pprec = 0, off_A = 0, off_b = 0, off_design = 0;
+    /* large-dimension linear posterior (ymc_tile.hip): KS k-steps of 4, MT output tiles of 16 */
+    bool tile = false;
+    int KS = 0, MT = 0;
+    DeviceBuf tile_blob;
 };
 
 }  // namespace
@@ -83,6 +89,7 @@ struct ymc_ctx {
 struct ymc_problem {
     ymc_ctx *ctx = nullptr;
     int method = 0, eq_mode = 0, S = 0, D = 0, kind = 0;
+    bool tile = false;
     DensityHost tgt, sur;
     std::vector<double> sigma;
 };
@@ -121,7 +128,8 @@ int lower_density(ymc_ctx *ctx, const ymc_density_desc &in, DensityHost &out, in
     if (d < 1) return fail(YMC_ERR_INVALID, "parameter dimension must be positive, got %d", d);
     if (expect_dim > 0 && d != expect_dim)
         return fail(YMC_ERR_INVALID, "surrogate dimension %d differs from target dimension %d", d, expect_dim);
-    if (d > YMC_LANE_DMAX)
+    const bool big = in.kind == YMC_DENSITY_POSTERIOR_LINEAR && (d > YMC_LANE_DMAX || in.data_dim > YMC_LANE_MMAX);
+    if (d > YMC_LANE_DMAX && !big)
         return fail(YMC_ERR_UNSUPPORTED, "parameter dimension %d exceeds the lane-per-chain limit %d", d,
                     YMC_LANE_DMAX);
     switch (in.kind) {
@@ -146,9 +154,19 @@ int lower_density(ymc_ctx *ctx, const ymc_density_desc &in, DensityHost &out, in
         YMC_TRY(copy_array(out.prior_mean, in.prior_mean, d, "prior_mean"));
         YMC_TRY(copy_array(out.prior_prec, in.prior_precision, d, "prior_precision"));
         if (in.kind == YMC_DENSITY_POSTERIOR_LINEAR) {
-            if (m > YMC_LANE_MMAX)
-                return fail(YMC_ERR_UNSUPPORTED, "forward-map output dimension %zu exceeds the lane-per-chain limit %d",
-                            m, YMC_LANE_MMAX);
+            if (big) {
+                /* the matrix-core tile kernel: A staged in LDS, d <= 128 */
+                if (d > 128) return fail(YMC_ERR_UNSUPPORTED, "parameter dimension %d exceeds the tile kernel's 128", d);
+                if (in.n_data > kTileNDMax)
+                    return fail(YMC_ERR_UNSUPPORTED, "%d data rows exceed the tile kernel's %d", in.n_data, kTileNDMax);
+                const int ks_need = (d + 3) / 4;
+                out.KS = ks_need <= 4 ? 4 : ks_need <= 8 ? 8 : ks_need <= 16 ? 16 : 32;
+                out.MT = (int)((m + 15) / 16);
+                out.MT += out.MT & 1;
+                if (ymc_tile_lds_bytes(out.KS, out.MT, in.n_data) > kTileLdsLimit)
+                    return fail(YMC_ERR_UNSUPPORTED, "forward map %zu x %d does not fit the 160 KB LDS", m, d);
+                out.tile = true;
+            }
             YMC_TRY(copy_array(out.A, in.fwd_matrix, m * d, "fwd_matrix"));
             YMC_TRY(copy_array(out.b, in.fwd_shift, m, "fwd_shift"));
         } else {
@@ -230,9 +248,30 @@ int eval_logdensity_dev(ymc_ctx *ctx, const ymc_problem *p, const DensityHost &h
     default: return fail(YMC_ERR_UNSUPPORTED, "parameter dimension %d has no kernel", D_); \
     }
 
+BigLinearArgs big_view(const DensityHost &h)
+{
+    BigLinearArgs b{};
+    const double *base = h.dev.as<double>();
+    b.A = base + h.off_A;
+    b.b = base + h.off_b;
+    b.data = base + h.off_data;
+    b.noise_prec = base + h.off_noise;
+    b.prior_mean = base + h.off_pmean;
+    b.prior_prec = base + h.off_pprec;
+    b.d = h.d.dim;
+    b.m = h.d.data_dim;
+    b.n_data = h.d.n_data;
+    return b;
+}
+
 int eval_logdensity(ymc_ctx *ctx, const ymc_problem *p, const DensityHost &h, uint64_t n, const double *x_dev,
                     double *out_dev, uint32_t *status_dev)
 {
+    if (h.tile) {
+        if (status_dev) YMC_HIP(hipMemsetAsync(status_dev, 0, n * sizeof(uint32_t), ctx->stream));
+        YMC_HIP(ymc_launch_linear_big_eval(big_view(h), n, x_dev, out_dev, nullptr, ctx->stream));
+        return YMC_OK;
+    }
     YMC_DISPATCH_D(p->D, return eval_logdensity_dev<DD>(ctx, p, h, n, x_dev, out_dev, status_dev));
     return YMC_OK;
 }
@@ -282,6 +321,85 @@ int launch_advance(ymc_run *r, uint64_t nsteps)
     if (e != hipSuccess) {
         r->pool.push_back(ev);
         return fail(YMC_ERR_DEVICE, "chain kernel launch failed: %s", hipGetErrorString(e));
+    }
+    YMC_HIP(hipEventRecord(ev.second, r->ctx->stream));
+    r->timed.push_back(ev);
+    return YMC_OK;
+}
+
+/* A in MFMA A-operand fragment order + the padded constant arrays, one block */
+int build_tile_blob(ymc_problem *p)
+{
+    DensityHost &h = p->tgt;
+    const int KS = h.KS, MT = h.MT, d = h.d.dim, m = h.d.data_dim, nd = h.d.n_data;
+    const size_t m_pad = 16 * (size_t)MT, d_pad = 4 * (size_t)KS;
+    std::vector<double> blob((size_t)MT * KS * 64 + m_pad * (2 + (size_t)nd) + 3 * d_pad, 0.0);
+    for (int mt = 0; mt < MT; ++mt)
+        for (int s = 0; s < KS; ++s)
+            for (int l = 0; l < 64; ++l) {
+                const int row = 16 * mt + (l & 15), col = 4 * s + (l >> 4);
+                if (row < m && col < d) blob[((size_t)mt * KS + s) * 64 + l] = h.A[(size_t)row * d + col];
+            }
+    double *bias = blob.data() + (size_t)MT * KS * 64;
+    double *nprec = bias + m_pad, *data = nprec + m_pad;
+    double *pmean = data + (size_t)nd * m_pad, *pprec = pmean + d_pad, *sigma = pprec + d_pad;
+    for (int j = 0; j < m; ++j) {
+        bias[j] = h.b[j];
+        nprec[j] = h.noise_prec[j];
+        for (int i = 0; i < nd; ++i) data[(size_t)i * m_pad + j] = h.data[(size_t)i * m + j];
+    }
+    for (int j = 0; j < d; ++j) {
+        pmean[j] = h.prior_mean[j];
+        pprec[j] = h.prior_prec[j];
+        sigma[j] = p->sigma[j];
+    }
+    YMC_TRY(h.tile_blob.alloc(blob.size() * sizeof(double)));
+    YMC_HIP(hipMemcpy(h.tile_blob.p, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice));
+    return YMC_OK;
+}
+
+uint64_t tiled_row_doubles(const ymc_run *r)
+{
+    return ((r->K + 15) / 16) * (uint64_t)r->problem->tgt.KS * 64;
+}
+
+int launch_advance_tile(ymc_run *r, uint64_t nsteps)
+{
+    const ymc_problem *p = r->problem;
+    const DensityHost &h = p->tgt;
+    TileArgs a{};
+    a.blob = h.tile_blob.as<double>();
+    a.d = p->D;
+    a.m = h.d.data_dim;
+    a.n_data = h.d.n_data;
+    a.MT = h.MT;
+    a.seed = r->seed;
+    a.chain0 = r->chain0;
+    a.K = r->K;
+    a.t0 = r->steps_done;
+    a.nsteps = (uint32_t)nsteps;
+    a.flags = r->flags;
+    a.x = r->x.as<double>();
+    a.lp = r->lp.as<double>();
+    a.acc_count = r->acc_count.as<uint64_t>();
+    a.status = r->status.as<uint32_t>();
+    const uint64_t row = r->recorded;
+    if (r->flags & YMC_RECORD_TRAJECTORY) a.traj = r->traj.as<double>() + row * tiled_row_doubles(r);
+    if (r->flags & YMC_RECORD_ACCEPT) a.acc = r->acc.as<uint8_t>() + row * r->K;
+    if (r->flags & YMC_RECORD_LOGPOST) a.lp_out = r->lp_out.as<double>() + row * r->K;
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (!r->pool.empty()) {
+        ev = r->pool.back();
+        r->pool.pop_back();
+    } else {
+        YMC_HIP(hipEventCreate(&ev.first));
+        YMC_HIP(hipEventCreate(&ev.second));
+    }
+    YMC_HIP(hipEventRecord(ev.first, r->ctx->stream));
+    hipError_t e = ymc_launch_linear_tile(h.KS, a, r->ctx->stream);
+    if (e != hipSuccess) {
+        r->pool.push_back(ev);
+        return fail(YMC_ERR_DEVICE, "tile kernel launch failed: %s", hipGetErrorString(e));
     }
     YMC_HIP(hipEventRecord(ev.second, r->ctx->stream));
     r->timed.push_back(ev);
@@ -400,6 +518,12 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
         if (!desc->proposal_sigma) rc = fail(YMC_ERR_INVALID, "Proposal Covariance not set");
         if (rc == YMC_OK) rc = copy_array(p->sigma, desc->proposal_sigma, p->D, "proposal_sigma");
     }
+    if (rc == YMC_OK && p->tgt.tile) {
+        if (p->method != YMC_METHOD_MRW)
+            rc = fail(YMC_ERR_UNSUPPORTED, "two-level delayed acceptance is not available at this dimension");
+        if (rc == YMC_OK) rc = build_tile_blob(p);
+        p->tile = true;
+    }
     if (rc != YMC_OK) {
         delete p;
         return rc;
@@ -430,6 +554,8 @@ int ymc_run_create(ymc_ctx *ctx, const ymc_problem *problem, const ymc_run_desc 
         return fail(YMC_ERR_INVALID, "initial_state must have 1 or n_chains rows");
     if (records_anything(desc->record_flags) && desc->record_capacity == 0)
         return fail(YMC_ERR_INVALID, "record_capacity must be positive when something is recorded");
+    if (problem->tile && (desc->record_flags & YMC_RECORD_MOMENTS))
+        return fail(YMC_ERR_UNSUPPORTED, "Welford moments are not accumulated by the large-dimension kernel");
     YMC_HIP(hipSetDevice(ctx->device));
     ymc_run *r = new (std::nothrow) ymc_run;
     if (!r) return fail(YMC_ERR_DEVICE, "out of host memory");
@@ -465,7 +591,8 @@ int ymc_run_create(ymc_ctx *ctx, const ymc_problem *problem, const ymc_run_desc 
         YMC_HIP(hipMemsetAsync(r->wf_mean.p, 0, r->wf_mean.bytes, ctx->stream));
         YMC_HIP(hipMemsetAsync(r->wf_m2.p, 0, r->wf_m2.bytes, ctx->stream));
         YMC_HIP(hipMemsetAsync(r->status.p, 0, r->status.bytes, ctx->stream));
-        if (r->flags & YMC_RECORD_TRAJECTORY) YMC_TRY(r->traj.alloc(r->capacity * K * D * sizeof(double)));
+        if (r->flags & YMC_RECORD_TRAJECTORY)
+            YMC_TRY(r->traj.alloc(r->capacity * (problem->tile ? tiled_row_doubles(r) : K * D) * sizeof(double)));
         if (r->flags & YMC_RECORD_ACCEPT) YMC_TRY(r->acc.alloc(r->capacity * K));
         if (r->flags & YMC_RECORD_LOGPOST) YMC_TRY(r->lp_out.alloc(r->capacity * K * sizeof(double)));
         if ((r->flags & YMC_RECORD_SUB_ACCEPT) && problem->method == YMC_METHOD_MLDA2)
@@ -512,7 +639,11 @@ int ymc_run_advance(ymc_run *run, uint64_t nsteps)
     const uint64_t chunk_max = 1u << 24;
     while (nsteps) {
         const uint64_t chunk = nsteps < chunk_max ? nsteps : chunk_max;
-        YMC_DISPATCH_D(run->problem->D, YMC_TRY(launch_advance<DD>(run, chunk)));
+        if (run->problem->tile) {
+            YMC_TRY(launch_advance_tile(run, chunk));
+        } else {
+            YMC_DISPATCH_D(run->problem->D, YMC_TRY(launch_advance<DD>(run, chunk)));
+        }
         run->steps_done += chunk;
         if (records_anything(run->flags)) run->recorded += chunk;
         nsteps -= chunk;
@@ -565,6 +696,27 @@ int ymc_run_steps_done(const ymc_run *run, uint64_t *total, uint64_t *recorded)
 int ymc_run_fetch_trajectory(ymc_run *run, uint64_t first, uint64_t n, double *dst, size_t dst_bytes)
 {
     if (!run) return fail(YMC_ERR_INVALID, "null argument");
+    if (run->problem->tile) {
+        /* the record is in the kernel's tiled layout: untile on the device, chunk by chunk */
+        if (!dst) return fail(YMC_ERR_INVALID, "null argument");
+        if (!(run->flags & YMC_RECORD_TRAJECTORY)) return fail(YMC_ERR_INVALID, "the run does not record the trajectory");
+        if (first + n > run->recorded) return fail(YMC_ERR_INVALID, "rows beyond the record requested");
+        const uint64_t row_doubles = run->K * (uint64_t)run->problem->D;
+        if (dst_bytes < n * row_doubles * sizeof(double)) return fail(YMC_ERR_INVALID, "destination too small");
+        YMC_HIP(hipSetDevice(run->ctx->device));
+        const uint64_t chunk_rows = std::max<uint64_t>(1, (256ull << 20) / (row_doubles * sizeof(double)));
+        DeviceBuf stage;
+        YMC_TRY(stage.alloc(std::min(chunk_rows, std::max<uint64_t>(n, 1)) * row_doubles * sizeof(double)));
+        for (uint64_t r0 = 0; r0 < n; r0 += chunk_rows) {
+            const uint64_t rows = std::min(chunk_rows, n - r0);
+            YMC_HIP(ymc_launch_untile(run->traj.as<double>(), first + r0, rows, run->K, run->problem->D,
+                                      run->problem->tgt.KS, stage.as<double>(), run->ctx->stream));
+            YMC_HIP(hipMemcpyAsync(dst + r0 * row_doubles, stage.p, rows * row_doubles * sizeof(double),
+                                   hipMemcpyDeviceToHost, run->ctx->stream));
+            YMC_HIP(hipStreamSynchronize(run->ctx->stream));
+        }
+        return YMC_OK;
+    }
     return fetch_rows(run, run->traj, YMC_RECORD_TRAJECTORY, "the trajectory", first, n,
                       run->K * run->problem->D * sizeof(double), dst, dst_bytes);
 }
@@ -656,8 +808,12 @@ int ymc_forward_eval(ymc_ctx *ctx, const ymc_problem *problem, int which, uint64
     YMC_TRY(xd.alloc(n * D * sizeof(double)));
     YMC_TRY(od.alloc(n * m * sizeof(double)));
     YMC_HIP(hipMemcpyAsync(xd.p, x, xd.bytes, hipMemcpyHostToDevice, ctx->stream));
-    YMC_DISPATCH_D(D, YMC_HIP(ymc_launch_forward<DD>(problem->kind, device_view<DD>(h), n, xd.as<double>(),
-                                                      od.as<double>(), ctx->stream)));
+    if (h.tile) {
+        YMC_HIP(ymc_launch_linear_big_eval(big_view(h), n, xd.as<double>(), nullptr, od.as<double>(), ctx->stream));
+    } else {
+        YMC_DISPATCH_D(D, YMC_HIP(ymc_launch_forward<DD>(problem->kind, device_view<DD>(h), n, xd.as<double>(),
+                                                          od.as<double>(), ctx->stream)));
+    }
     YMC_HIP(hipMemcpyAsync(out, od.p, od.bytes, hipMemcpyDeviceToHost, ctx->stream));
     YMC_HIP(hipStreamSynchronize(ctx->stream));
     return YMC_OK;

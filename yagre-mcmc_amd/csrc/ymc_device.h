@@ -39,19 +39,20 @@ struct DensityDev {
 
 __device__ __forceinline__ bool ymc_finite(double v) { return __builtin_fabs(v) <= YMC_DBL_MAX; }
 
-/* covariance.py:19-22,54-55: dot(x, precision * x), sequential */
+/* covariance.py:19-22,54-55: dot(x, precision * x) as four interleaved partial
+ * sums (j mod 4), combined (S0 + S1) + (S2 + S3): the ensemble's canonical order */
 template <int N>
 __device__ __forceinline__ double ymc_diag_norm_sq(const double (&x)[N], const double *__restrict__ prec, int n)
 {
-    double acc = 0.0;
+    double S[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         if (j < n) {
             double px = prec[j] * x[j];
-            acc = acc + x[j] * px;
+            S[j & 3] = S[j & 3] + x[j] * px;
         }
     }
-    return acc;
+    return (S[0] + S[1]) + (S[2] + S[3]);
 }
 
 /* gaussian.py:19-24 */

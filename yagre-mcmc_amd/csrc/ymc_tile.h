@@ -1,0 +1,43 @@
+/* ymc_tile.h -- launch interface of the large-dimension linear-posterior
+ * kernels (ymc_tile.hip). */
+#ifndef YMC_TILE_H
+#define YMC_TILE_H
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+constexpr int kTileWaves = 4;                 /* waves per workgroup (one per SIMD), 16 chains each */
+constexpr int kTileThreads = 64 * kTileWaves;
+constexpr int kTileNDMax = 8;                 /* data rows the likelihood epilogue unrolls over */
+constexpr size_t kTileLdsLimit = 160 * 1024;  /* LDS per CU on gfx950 */
+
+struct TileArgs {
+    /* one device block, staged into LDS by every workgroup:
+     * A fragments [MT][KS][64] | bias[m_pad] | noise_prec[m_pad] | data[n_data][m_pad] |
+     * prior_mean[d_pad] | prior_prec[d_pad] | sigma[d_pad]   (padding = zeros) */
+    const double *blob;
+    int32_t d, m, n_data, MT;
+    uint64_t seed, chain0, K, t0;
+    uint32_t nsteps, flags;
+    double *x, *lp;
+    uint64_t *acc_count;
+    uint32_t *status;
+    double *traj; /* tiled layout [rows][ceil(K/16)][KS][64] */
+    uint8_t *acc;
+    double *lp_out;
+};
+
+struct BigLinearArgs {
+    const double *A, *b, *data, *noise_prec, *prior_mean, *prior_prec; /* unpadded, row-major */
+    int32_t d, m, n_data, pad_;
+};
+
+size_t ymc_tile_lds_bytes(int KS, int MT, int n_data);
+hipError_t ymc_launch_linear_tile(int KS, const TileArgs &a, hipStream_t s);
+hipError_t ymc_launch_untile(const double *tiled, uint64_t row0, uint64_t rows, uint64_t K, int d, int KS,
+                             double *out, hipStream_t s);
+hipError_t ymc_launch_linear_big_eval(const BigLinearArgs &p, uint64_t n, const double *x, double *lp, double *fwd,
+                                      hipStream_t s);
+
+#endif /* YMC_TILE_H */

@@ -1,0 +1,315 @@
+/*
+ * ymc_tile.hip -- the linear-forward-model posterior at large dimension
+ * (BASELINE configs[2]: d = data_dim = 128, 262 144 chains): random-walk
+ * Metropolis with the forward map G(theta) = A theta + b
+ * (exampleSetup.py:42-47) evaluated on the fp64 matrix cores.
+ *
+ * Mapping (one wave = 16 chains, one workgroup = 4 waves = 64 chains):
+ *   lane l = 16 g + c owns chain c of the wave's tile and the parameter
+ *   components j = 4 s + g, s = 0..KS-1 -- exactly the B-operand layout of
+ *   v_mfma_f64_16x16x4_f64 (B[k = l>>4][col = l&15]).  The state x and the
+ *   proposal y therefore never leave registers; the forward map is
+ *       D[output][chain] = sum_k A[output][k] * y[chain][k]
+ *   with A's 16x4 fragments read from LDS (the whole matrix, 128 KB at
+ *   d = m = 128, is staged once per workgroup) and one accumulator tile
+ *   (16 outputs x 16 chains) per MFMA chain.  On gfx950 the f64 MFMA is
+ *   bit-for-bit a k-ordered fma chain (tools/probe_mfma_f64.hip), so F equals
+ *   the CPU checker's  acc = fma(A[m][j], theta[j], acc)  loop exactly.
+ *   The accumulator layout puts output m = 16 tile + 4 r + g of chain c in
+ *   lane (g, c): each lane sums the likelihood terms of the outputs
+ *   m = g (mod 4) in increasing m -- the ensemble's canonical "four
+ *   interleaved partial sums" -- and two cross-lane adds finish
+ *   (S0 + S1) + (S2 + S3).  The prior is summed the same way over j = g (mod 4).
+ *   Normals: lane (g, c) runs Box-Muller on pair 4 q + {0,2,1,3}[g], keeps
+ *   the output that belongs to its own component set and swaps the other with
+ *   lane l ^ 16 (one 64-bit exchange per pair).
+ * Record layout (coalesced 512-B stores): traj[row][chain tile][s][lane],
+ * i.e. logical (row, chain = 16 tile + c, component = 4 s + g); untiled by
+ * untile_kernel when the host fetches it.
+ */
+#include "ymc_kernels.h"
+#include "ymc_tile.h"
+
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask)
+{
+    uint64_t b = ymc_bits(v);
+    uint32_t lo = (uint32_t)b, hi = (uint32_t)(b >> 32);
+    lo = (uint32_t)__shfl_xor((int)lo, mask, 64);
+    hi = (uint32_t)__shfl_xor((int)hi, mask, 64);
+    return ymc_from_bits(((uint64_t)hi << 32) | lo);
+}
+
+/* (S0 + S1) + (S2 + S3) over the four lanes (g = 0..3) that share a chain */
+__device__ __forceinline__ double combine4(double s)
+{
+    double v = s + shfl_xor_f64(s, 16);
+    return v + shfl_xor_f64(v, 32);
+}
+
+template <int KS>
+__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void linear_tile_kernel(const TileArgs a)
+{
+    extern __shared__ double lds[];
+    const int MT = a.MT, m_pad = 16 * MT, d_pad = 4 * KS, n_data = a.n_data;
+    double *Alds = lds;
+    double *bias = Alds + (size_t)MT * KS * 64;
+    double *nprec = bias + m_pad;
+    double *data = nprec + m_pad;
+    double *pmean = data + (size_t)n_data * m_pad;
+    double *pprec = pmean + d_pad;
+    double *sigma = pprec + d_pad;
+    const size_t blob_doubles = (size_t)MT * KS * 64 + (size_t)m_pad * (2 + n_data) + 3 * (size_t)d_pad;
+
+    const int tid = threadIdx.x;
+    for (size_t i = tid; i < blob_doubles / 2; i += kTileThreads)
+        reinterpret_cast<double2 *>(lds)[i] = reinterpret_cast<const double2 *>(a.blob)[i];
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+    const uint64_t nct = (a.K + 15) / 16;
+    const uint64_t tile = (uint64_t)blockIdx.x * kTileWaves + wave;
+    if (tile >= nct) return;
+    const uint64_t k = tile * 16 + c;
+    const bool live = k < a.K;
+    const uint32_t chain = (uint32_t)(a.chain0 + k);
+    const int d = a.d;
+    const bool odd = (g & 1) != 0;
+    const uint32_t pair_of_g = (g == 0) ? 0u : (g == 1) ? 2u : (g == 2) ? 1u : 3u;
+
+    double x[KS], y[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int j = 4 * s + g;
+        x[s] = (live && j < d) ? a.x[k * d + j] : 0.0;
+    }
+    double lp = live ? a.lp[k] : 0.0;
+    uint64_t accepted = live ? a.acc_count[k] : 0;
+    uint32_t st = live ? a.status[k] : 0;
+    UniformCache uc;
+    uc.valid = false;
+    uc.pair = 0;
+
+#pragma unroll 1
+    for (uint32_t n = 0; n < a.nsteps; ++n) {
+        const uint64_t t = a.t0 + n;
+        /* proposal y = x + sigma * xi (mrw.py:32-38) in the MFMA operand layout */
+        bool moved_l = false;
+#pragma unroll
+        for (int q = 0; q < KS / 2; ++q) {
+            double z0, z1;
+            ymc_draw_normal_pair(a.seed, chain, t, 4u * (uint32_t)q + pair_of_g, &z0, &z1);
+            const double keep = odd ? z1 : z0;
+            const double give = odd ? z0 : z1;
+            const double recv = shfl_xor_f64(give, 16);
+            const double xi0 = odd ? recv : keep; /* component 8 q + g     (s = 2 q)     */
+            const double xi1 = odd ? keep : recv; /* component 8 q + 4 + g (s = 2 q + 1) */
+            y[2 * q] = x[2 * q] + sigma[8 * q + g] * xi0;
+            y[2 * q + 1] = x[2 * q + 1] + sigma[8 * q + 4 + g] * xi1;
+            moved_l = moved_l || !(y[2 * q] == x[2 * q]) || !(y[2 * q + 1] == x[2 * q + 1]);
+        }
+        int mv = moved_l ? 1 : 0;
+        mv |= __shfl_xor(mv, 16, 64);
+        mv |= __shfl_xor(mv, 32, 64);
+        const bool moved = mv != 0;
+
+        /* forward map on the matrix cores + Gaussian-noise likelihood (likelihood.py:74-84) */
+        double S[kTileNDMax];
+#pragma unroll
+        for (int i = 0; i < kTileNDMax; ++i) S[i] = 0.0;
+#pragma unroll 1
+        for (int mt = 0; mt < MT; mt += 2) {
+            d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+            const double *Af0 = Alds + (size_t)mt * KS * 64 + lane;
+            const double *Af1 = Af0 + (size_t)KS * 64;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Af0[s * 64], y[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Af1[s * 64], y[s], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 16 * (mt + h) + 4 * r + g;
+                    const double F = (h ? acc1[r] : acc0[r]) + bias[m];
+                    const double pr = nprec[m];
+#pragma unroll
+                    for (int i = 0; i < kTileNDMax; ++i) {
+                        if (i < n_data) {
+                            const double res = F - data[(size_t)i * m_pad + m];
+                            const double px = pr * res;
+                            S[i] = S[i] + res * px;
+                        }
+                    }
+                }
+            }
+        }
+        double total = 0.0;
+#pragma unroll
+        for (int i = 0; i < kTileNDMax; ++i)
+            if (i < n_data) total = total + combine4(S[i]);
+        const double logl = -0.5 * total;
+
+        /* Gaussian prior (gaussian.py:19-24) */
+        double P = 0.0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int j = 4 * s + g;
+            const double dx = y[s] - pmean[j];
+            const double px = pprec[j] * dx;
+            P = P + dx * px;
+        }
+        const double lpy = logl + (-0.5 * combine4(P));
+
+        /* accept / reject (metropolisHastings.py:55-73, mrw.py:51-57) */
+        const double u = ymc_uniform_cached(uc, a.seed, chain, t);
+        const bool acc = ymc_accept(lpy - lp, moved, ymc_finite(lpy), u, st);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) x[s] = acc ? y[s] : x[s];
+        lp = acc ? lpy : lp;
+        accepted += acc ? 1u : 0u;
+
+        if (a.traj) {
+            double *row = a.traj + (((uint64_t)n * nct + tile) * KS) * 64 + lane;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) row[s * 64] = x[s];
+        }
+        if (live && g == 0) {
+            if (a.acc) a.acc[(uint64_t)n * a.K + k] = acc ? 1 : 0;
+            if (a.lp_out) a.lp_out[(uint64_t)n * a.K + k] = lp;
+        }
+    }
+
+    if (live) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int j = 4 * s + g;
+            if (j < d) a.x[k * d + j] = x[s];
+        }
+        if (g == 0) {
+            a.lp[k] = lp;
+            a.acc_count[k] = accepted;
+            a.status[k] = st;
+        }
+    }
+}
+
+/* record in tiled layout -> out[rows][K][d] */
+__global__ __launch_bounds__(256) void untile_kernel(const double *__restrict__ tiled, uint64_t row0, uint64_t rows,
+                                                     uint64_t K, int d, int KS, double *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * K * (uint64_t)d) return;
+    const uint64_t j = i % d, k = (i / d) % K, r = i / ((uint64_t)d * K);
+    const uint64_t nct = (K + 15) / 16;
+    out[i] = tiled[((((row0 + r) * nct + k / 16) * KS + j / 4) * 64) + (j % 4) * 16 + (k % 16)];
+}
+
+/* DensityInterface.evaluate_log / ForwardModel.evaluate for a batch at large
+ * dimension: one lane per parameter vector, plain loops in the canonical
+ * order (used for the initial states and for host-side evaluate_log calls) */
+__global__ __launch_bounds__(256) void linear_big_eval_kernel(const BigLinearArgs p, uint64_t n,
+                                                              const double *__restrict__ xin,
+                                                              double *__restrict__ lp_out,
+                                                              double *__restrict__ fwd_out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double *x = xin + i * p.d;
+    double S[kTileNDMax][4];
+#pragma unroll
+    for (int r = 0; r < kTileNDMax; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) S[r][q] = 0.0;
+    for (int m4 = 0; m4 < p.m; m4 += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = m4 + q;
+            if (m < p.m) {
+                double acc = 0.0;
+                for (int j = 0; j < p.d; ++j) acc = ymc_fma(p.A[(size_t)m * p.d + j], x[j], acc);
+                const double F = acc + p.b[m];
+                if (fwd_out) fwd_out[i * p.m + m] = F;
+                const double pr = p.noise_prec[m];
+#pragma unroll
+                for (int r = 0; r < kTileNDMax; ++r) {
+                    if (r < p.n_data) {
+                        const double res = F - p.data[(size_t)r * p.m + m];
+                        const double px = pr * res;
+                        S[r][q] = S[r][q] + res * px;
+                    }
+                }
+            }
+        }
+    }
+    if (!lp_out) return;
+    double total = 0.0;
+#pragma unroll
+    for (int r = 0; r < kTileNDMax; ++r)
+        if (r < p.n_data) total = total + ((S[r][0] + S[r][1]) + (S[r][2] + S[r][3]));
+    double P[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int j4 = 0; j4 < p.d; j4 += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = j4 + q;
+            if (j < p.d) {
+                const double dx = x[j] - p.prior_mean[j];
+                const double px = p.prior_prec[j] * dx;
+                P[q] = P[q] + dx * px;
+            }
+        }
+    }
+    lp_out[i] = -0.5 * total + (-0.5 * ((P[0] + P[1]) + (P[2] + P[3])));
+}
+
+}  // namespace
+
+size_t ymc_tile_lds_bytes(int KS, int MT, int n_data)
+{
+    const size_t m_pad = 16 * (size_t)MT, d_pad = 4 * (size_t)KS;
+    return ((size_t)MT * KS * 64 + m_pad * (2 + (size_t)n_data) + 3 * d_pad) * sizeof(double);
+}
+
+template <int KS>
+static hipError_t launch_tile(const TileArgs &a, hipStream_t s)
+{
+    const size_t lds = ymc_tile_lds_bytes(KS, a.MT, a.n_data);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_tile_kernel<KS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const uint64_t nct = (a.K + 15) / 16;
+    const unsigned grid = (unsigned)((nct + kTileWaves - 1) / kTileWaves);
+    hipLaunchKernelGGL((linear_tile_kernel<KS>), dim3(grid), dim3(kTileThreads), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t ymc_launch_linear_tile(int KS, const TileArgs &a, hipStream_t s)
+{
+    switch (KS) {
+    case 4: return launch_tile<4>(a, s);
+    case 8: return launch_tile<8>(a, s);
+    case 16: return launch_tile<16>(a, s);
+    case 32: return launch_tile<32>(a, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t ymc_launch_untile(const double *tiled, uint64_t row0, uint64_t rows, uint64_t K, int d, int KS,
+                             double *out, hipStream_t s)
+{
+    const uint64_t n = rows * K * (uint64_t)d;
+    hipLaunchKernelGGL(untile_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tiled, row0, rows, K, d, KS,
+                       out);
+    return hipGetLastError();
+}
+
+hipError_t ymc_launch_linear_big_eval(const BigLinearArgs &p, uint64_t n, const double *x, double *lp, double *fwd,
+                                      hipStream_t s)
+{
+    hipLaunchKernelGGL(linear_big_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, x, lp, fwd);
+    return hipGetLastError();
+}
