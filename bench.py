@@ -188,7 +188,9 @@ def main():
     flags = ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT | (0 if args.no_moments else ffi.RECORD_MOMENTS)
     run = ffi.Run(prob, 20250103, K, x0, T, flags, chain_offset=rank * K)
 
-    comm = distributed.make_communicator(ctx, rank, world) if world > 1 else None
+    # YMC_BENCH_FORCE_COMM=1 exercises the RCCL path with a single rank (1-GPU rehearsal of the N > 1 flow)
+    use_comm = world > 1 or os.environ.get("YMC_BENCH_FORCE_COMM") == "1"
+    comm = distributed.make_communicator(ctx, rank, world) if use_comm else None
 
     def barrier():
         run.sync()

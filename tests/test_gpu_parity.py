@@ -401,3 +401,30 @@ def test_tile_kernel_limits(ffi, ctx):
     with pytest.raises(ffi.YmcError) as err:   # d > 128
         lowering.make_problem(ctx, ffi.METHOD_MRW, low, np.ones(200))
     assert err.value.code == ffi.ERR_UNSUPPORTED
+
+
+# ---------------------------------------------------------------------------
+# the collective: RCCL communicator with one rank (all a 1-GPU box can host)
+# ---------------------------------------------------------------------------
+
+def test_rccl_summary_gather_single_rank(ffi, ctx, golden):
+    from yagremcmc_amd import distributed, lowering
+    g = golden("f2_mrw_2d.npz")
+    low = _gauss_low(ffi, g["mean"], g["whiten"], g["log_norm"])
+    prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, g["sigma"])
+    run = ffi.Run(prob, 77, 1000, g["x0"][:1], 1, ffi.RECORD_MOMENTS)
+    run.advance(250)
+    comm = ffi.Communicator(ctx, ffi.Communicator.unique_id(), 1, 0)
+    comm.barrier()
+    assert comm.allreduce_max(3.25) == 3.25
+    packed = comm.allgather_summary(run)
+    assert packed.shape == (1, 1000, run.summary_words())
+    s = distributed.unpack_summaries(packed, 2)
+    loc, (x, lp) = run.summary(), run.state()
+    assert np.array_equal(s["state"], x) and np.array_equal(s["logpost"], lp)
+    assert np.array_equal(s["accepted"], loc["accepted"]) and np.array_equal(s["wf_n"], loc["wf_n"])
+    assert np.array_equal(s["wf_mean"], loc["wf_mean"]) and np.array_equal(s["wf_m2"], loc["wf_m2"])
+    assert np.array_equal(s["status"], loc["status"])
+    pooled = distributed.pooled_diagnostics(s, 250)
+    assert 0.3 < pooled["acceptance_rate"] < 0.8 and pooled["n"] == 250 * 1000
+    comm.close()

@@ -93,16 +93,37 @@ class FileRendezvous:
             pass
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on the C stdout while a communicator is
+    initialised; a benchmark that promises ONE line on stdout routes it to
+    stderr (fd level, flushing the C buffer before switching back)."""
+
+    def __enter__(self):
+        import ctypes
+        import sys
+        sys.stdout.flush()
+        self._libc = ctypes.CDLL(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        self._libc.fflush(None)
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def make_communicator(ctx, rank, world):
     from . import _ffi
     rdzv = FileRendezvous()
-    if rank == 0:
-        uid = _ffi.Communicator.unique_id()
-        rdzv.publish(uid)
-    else:
-        uid = rdzv.wait(_ffi.UNIQUE_ID_BYTES)
-    comm = _ffi.Communicator(ctx, uid, world, rank)
-    comm.barrier()
+    with _StdoutToStderr():
+        if rank == 0:
+            uid = _ffi.Communicator.unique_id()
+            rdzv.publish(uid)
+        else:
+            uid = rdzv.wait(_ffi.UNIQUE_ID_BYTES)
+        comm = _ffi.Communicator(ctx, uid, world, rank)
+        comm.barrier()
     if rank == 0:
         rdzv.cleanup()
     return comm
