@@ -38,6 +38,21 @@
 
 YMC_FN double ymc_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+/* fma whose ADDEND is a polynomial coefficient (a Horner step).  Same value as
+ * ymc_fma; on the device it is pinned to the three-address v_fma_f64, because
+ * hipcc (ROCm 7.2) otherwise selects the two-address v_fmac_f64 and pays a
+ * v_mov_b64 of the coefficient per step. */
+YMC_FN double ymc_fma_c(double a, double b, double c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double d;
+    __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+#else
+    return __builtin_fma(a, b, c);
+#endif
+}
+
 YMC_FN uint64_t ymc_bits(double x)
 {
     uint64_t u;
@@ -171,8 +186,8 @@ YMC_FN double ymc_log(double x)
     double s = f / (2.0 + f);
     double z = s * s;
     double w = z * z;
-    double t1 = w * ymc_fma(w, ymc_fma(w, Lg6, Lg4), Lg2);
-    double t2 = z * ymc_fma(w, ymc_fma(w, ymc_fma(w, Lg7, Lg5), Lg3), Lg1);
+    double t1 = w * ymc_fma_c(w, ymc_fma_c(w, Lg6, Lg4), Lg2);
+    double t2 = z * ymc_fma_c(w, ymc_fma_c(w, ymc_fma_c(w, Lg7, Lg5), Lg3), Lg1);
     double R = t2 + t1;
     double hfsq = 0.5 * f * f;
     return dk * ln2_hi - ((hfsq - ymc_fma(s, hfsq + R, dk * ln2_lo)) - f);
@@ -203,19 +218,19 @@ YMC_FN double ymc_exp(double x)
     r = ymc_fma(-kd, ln2_lo, r);
 
     double p = 0x1.6124613a86d09p-33;                 /* 1/13! */
-    p = ymc_fma(p, r, 0x1.1eed8eff8d898p-29);         /* 1/12! */
-    p = ymc_fma(p, r, 0x1.ae64567f544e4p-26);         /* 1/11! */
-    p = ymc_fma(p, r, 0x1.27e4fb7789f5cp-22);         /* 1/10! */
-    p = ymc_fma(p, r, 0x1.71de3a556c734p-19);         /* 1/9!  */
-    p = ymc_fma(p, r, 0x1.a01a01a01a01ap-16);         /* 1/8!  */
-    p = ymc_fma(p, r, 0x1.a01a01a01a01ap-13);         /* 1/7!  */
-    p = ymc_fma(p, r, 0x1.6c16c16c16c17p-10);         /* 1/6!  */
-    p = ymc_fma(p, r, 0x1.1111111111111p-7);          /* 1/5!  */
-    p = ymc_fma(p, r, 0x1.5555555555555p-5);          /* 1/4!  */
-    p = ymc_fma(p, r, 0x1.5555555555555p-3);          /* 1/3!  */
-    p = ymc_fma(p, r, 0.5);
-    p = ymc_fma(p, r, 1.0);
-    p = ymc_fma(p, r, 1.0);                           /* p in [0.70, 1.42] */
+    p = ymc_fma_c(p, r, 0x1.1eed8eff8d898p-29);         /* 1/12! */
+    p = ymc_fma_c(p, r, 0x1.ae64567f544e4p-26);         /* 1/11! */
+    p = ymc_fma_c(p, r, 0x1.27e4fb7789f5cp-22);         /* 1/10! */
+    p = ymc_fma_c(p, r, 0x1.71de3a556c734p-19);         /* 1/9!  */
+    p = ymc_fma_c(p, r, 0x1.a01a01a01a01ap-16);         /* 1/8!  */
+    p = ymc_fma_c(p, r, 0x1.a01a01a01a01ap-13);         /* 1/7!  */
+    p = ymc_fma_c(p, r, 0x1.6c16c16c16c17p-10);         /* 1/6!  */
+    p = ymc_fma_c(p, r, 0x1.1111111111111p-7);          /* 1/5!  */
+    p = ymc_fma_c(p, r, 0x1.5555555555555p-5);          /* 1/4!  */
+    p = ymc_fma_c(p, r, 0x1.5555555555555p-3);          /* 1/3!  */
+    p = ymc_fma_c(p, r, 0.5);
+    p = ymc_fma_c(p, r, 1.0);
+    p = ymc_fma_c(p, r, 1.0);                           /* p in [0.70, 1.42] */
 
     /* 2^k in one or two exactly representable factors */
     int32_t k1 = (k < -1021) ? k + 1000 : ((k > 1022) ? k - 2 : k);
@@ -240,25 +255,25 @@ YMC_FN void ymc_sincospi(double t, double *sn, double *cs)
     double r2 = r * r;
 
     double ps = 0x1.aaec32af93359p-21;                /* +pi^17/17! */
-    ps = ymc_fma(ps, r2, -0x1.6fadb9f155744p-16);
-    ps = ymc_fma(ps, r2, 0x1.e8f434d018d63p-12);
-    ps = ymc_fma(ps, r2, -0x1.e3074fde8871fp-8);
-    ps = ymc_fma(ps, r2, 0x1.50783487ee782p-4);
-    ps = ymc_fma(ps, r2, -0x1.32d2cce62bd86p-1);
-    ps = ymc_fma(ps, r2, 0x1.466bc6775aae2p+1);
-    ps = ymc_fma(ps, r2, -0x1.4abbce625be53p+2);
-    ps = ymc_fma(ps, r2, 0x1.921fb54442d18p+1);       /* pi */
+    ps = ymc_fma_c(ps, r2, -0x1.6fadb9f155744p-16);
+    ps = ymc_fma_c(ps, r2, 0x1.e8f434d018d63p-12);
+    ps = ymc_fma_c(ps, r2, -0x1.e3074fde8871fp-8);
+    ps = ymc_fma_c(ps, r2, 0x1.50783487ee782p-4);
+    ps = ymc_fma_c(ps, r2, -0x1.32d2cce62bd86p-1);
+    ps = ymc_fma_c(ps, r2, 0x1.466bc6775aae2p+1);
+    ps = ymc_fma_c(ps, r2, -0x1.4abbce625be53p+2);
+    ps = ymc_fma_c(ps, r2, 0x1.921fb54442d18p+1);       /* pi */
     double s = ps * r;
 
     double pc = 0x1.20c62c2f2d7f5p-18;                /* +pi^16/16! */
-    pc = ymc_fma(pc, r2, -0x1.b6e24f44b128fp-14);
-    pc = ymc_fma(pc, r2, 0x1.f9d38a3763cc3p-10);
-    pc = ymc_fma(pc, r2, -0x1.a6d1f2a204a8cp-6);
-    pc = ymc_fma(pc, r2, 0x1.e1f506891babbp-3);
-    pc = ymc_fma(pc, r2, -0x1.55d3c7e3cbffap+0);
-    pc = ymc_fma(pc, r2, 0x1.03c1f081b5ac4p+2);
-    pc = ymc_fma(pc, r2, -0x1.3bd3cc9be45dep+2);
-    double c = ymc_fma(pc, r2, 1.0);
+    pc = ymc_fma_c(pc, r2, -0x1.b6e24f44b128fp-14);
+    pc = ymc_fma_c(pc, r2, 0x1.f9d38a3763cc3p-10);
+    pc = ymc_fma_c(pc, r2, -0x1.a6d1f2a204a8cp-6);
+    pc = ymc_fma_c(pc, r2, 0x1.e1f506891babbp-3);
+    pc = ymc_fma_c(pc, r2, -0x1.55d3c7e3cbffap+0);
+    pc = ymc_fma_c(pc, r2, 0x1.03c1f081b5ac4p+2);
+    pc = ymc_fma_c(pc, r2, -0x1.3bd3cc9be45dep+2);
+    double c = ymc_fma_c(pc, r2, 1.0);
 
     /* quadrant q mod 4: 0 -> (s,c); 1 -> (c,-s); 2 -> (-s,-c); 3 -> (-c,s) */
     double so = (q & 1) ? c : s;
