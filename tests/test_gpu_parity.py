@@ -428,41 +428,3 @@ def test_rccl_summary_gather_single_rank(ffi, ctx, golden):
     pooled = distributed.pooled_diagnostics(s, 250)
     assert 0.3 < pooled["acceptance_rate"] < 0.8 and pooled["n"] == 250 * 1000
     comm.close()
-
-
-# ---------------------------------------------------------------------------
-# kernel variants are a speed choice only: both give the oracle's bits
-# ---------------------------------------------------------------------------
-
-@pytest.mark.parametrize("variant", ["fused", "split"])
-@pytest.mark.parametrize("d,K,T", [(2, 1000, 203), (1, 130, 64), (3, 64, 17), (5, 257, 40), (8, 100, 33)])
-def test_kernel_variants_agree_with_oracle(ffi, ctx, monkeypatch, variant, d, K, T):
-    monkeypatch.setenv("YMC_KERNEL_VARIANT", variant)
-    rng = np.random.default_rng(900 + d)
-    a = rng.normal(size=(d, d))
-    p = o.gauss_from_cov(rng.normal(size=d), a @ a.T + d * np.eye(d))
-    low = _gauss_low(ffi, p["mean"], p["whiten"], p["log_norm"])
-    sigma = rng.uniform(0.5, 1.5, size=d)
-    x0 = rng.normal(size=(K, d))
-    dev = _device_run(ffi, ctx, low, sigma, x0, 31, T, chain0=7, splits=3)
-    e = o.Ensemble(p, sigma, x0, 31, chain0=7)
-    _same_as_oracle(dev, e, e.advance(T))
-
-
-@pytest.mark.parametrize("variant", ["fused", "split"])
-def test_kernel_variants_on_posteriors(ffi, ctx, golden, monkeypatch, variant):
-    monkeypatch.setenv("YMC_KERNEL_VARIANT", variant)
-    g = golden("f4_lotka_volterra.npz")
-    n = int(g["n_states"])
-    low = _posterior_low(ffi, ffi.POSTERIOR_LV, 2, g, design=np.asarray(g["design"]), t_final=float(g["t_final"]),
-                         alpha=float(g["alpha"]), gamma=float(g["gamma"]), rk4_steps=int(g["rk4_steps"]))
-    dev = _device_run(ffi, ctx, low, g["sigma"], g["x0"], int(g["seed"]), n - 1)
-    _same_as_reference(dev, g)
-    g = golden("f1_mrw_1d.npz")
-    n = int(g["n_states"])
-    from yagremcmc_amd import lowering
-    low = lowering.Lowered(ffi.GAUSS_ISO1D, 1)
-    low.set_array("mean", np.array([float(g["mean"])]))
-    low.desc.variance = float(g["variance"])
-    dev = _device_run(ffi, ctx, low, g["sigma"], g["x0"], int(g["seed"]), n - 1, eq=ffi.EQ_ISCLOSE)
-    _same_as_reference(dev, g)

@@ -277,21 +277,6 @@ int eval_logdensity(ymc_ctx *ctx, const ymc_problem *p, const DensityHost &h, ui
     return YMC_OK;
 }
 
-/* Which single-level kernel: one lane per chain ("fused") needs >= ~3 waves per
- * SIMD to use the VALU fully; below that the three-wave split kernel is
- * faster.  YMC_KERNEL_VARIANT=fused|split overrides (tests run both). */
-int choose_variant(const ymc_run *r)
-{
-    if (r->problem->method != YMC_METHOD_MRW) return YMC_VARIANT_FUSED;
-    if (const char *env = std::getenv("YMC_KERNEL_VARIANT")) {
-        if (!std::strcmp(env, "split")) return YMC_VARIANT_SPLIT;
-        if (!std::strcmp(env, "fused")) return YMC_VARIANT_FUSED;
-    }
-    const uint64_t simds = 4ull * (uint64_t)r->ctx->prop.multiProcessorCount;
-    const uint64_t waves = (r->K + 63) / 64;
-    return waves < 2 * simds ? YMC_VARIANT_SPLIT : YMC_VARIANT_FUSED;
-}
-
 template <int D>
 int launch_advance(ymc_run *r, uint64_t nsteps)
 {
@@ -310,7 +295,6 @@ int launch_advance(ymc_run *r, uint64_t nsteps)
     a.flags = r->flags;
     a.eq_mode = p->eq_mode;
     a.S = p->S;
-    a.variant = choose_variant(r);
     a.x = r->x.as<double>();
     a.lp = r->lp.as<double>();
     a.lpc = r->lpc.as<double>();

@@ -5,8 +5,6 @@
 
 #include "ymc_device.h"
 
-enum { YMC_VARIANT_FUSED = 0, YMC_VARIANT_SPLIT = 1 };
-
 /* Everything one launch of a lane-per-chain kernel needs, by value. */
 template <int D>
 struct ChainArgs {
@@ -18,7 +16,6 @@ struct ChainArgs {
     uint64_t wf_n0;      /* Welford count before this launch */
     uint32_t nsteps, flags;
     int32_t eq_mode, S;
-    int32_t variant, pad_; /* YMC_VARIANT_*: a speed choice only, results are identical */
     /* carried per-chain state */
     double *x, *lp, *lpc;
     uint64_t *acc_count;

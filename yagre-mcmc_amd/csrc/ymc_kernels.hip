@@ -71,125 +71,6 @@ __global__ __launch_bounds__(kBlock) void mrw_kernel(const ChainArgs<D> a)
     }
 }
 
-/*
- * The same loop for SMALL ensembles (fewer than ~3 waves per SIMD with one lane
- * per chain, e.g. BASELINE configs[1]: 65 536 chains = 1 wave/SIMD, where every
- * instruction costs a 4-cycle issue slot).  The work of a chain is split over
- * three waves of a 192-thread workgroup so that the SIMDs see three times the
- * waves: waves 1 and 2 ("producers") turn the counter-based stream into
- * proposal increments sigma*xi and uniforms -- which do not depend on the
- * chain's state -- and hand them through a double-buffered LDS ring to wave 0
- * ("consumer"), which runs the sequential part: density, acceptance ratio,
- * accept/reject, diagnostics, record.  Same draws, same arithmetic, same
- * results as mrw_kernel, bit for bit.
- */
-constexpr int kSplitBatch = 12;
-
-template <int KIND, int D, int NP>
-__global__ __launch_bounds__(64 * (NP + 1)) void mrw_split_kernel(const ChainArgs<D> a)
-{
-    static_assert(kSplitBatch % (2 * NP) == 0, "a batch is dealt to the producers in even/odd pairs");
-    __shared__ double ring[2][kSplitBatch][D + 1][64];
-    const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
-    const uint64_t k = (uint64_t)blockIdx.x * 64 + lane;
-    const bool live = k < a.K;
-    const uint32_t chain = (uint32_t)(a.chain0 + k);
-    const uint32_t nb = (a.nsteps + kSplitBatch - 1) / kSplitBatch;
-
-    if (role != 0) {
-        /* ---- producers: steps {2p, 2p+1} + 2 NP i of every batch ---- */
-        const int p = role - 1;
-        __builtin_amdgcn_s_setprio(0);
-        double sigma[D];
-#pragma unroll
-        for (int j = 0; j < D; ++j) sigma[j] = a.sigma[j];
-        UniformCache uc;
-        uc.valid = false;
-        uc.pair = 0;
-        auto fill = [&](uint32_t b) {
-#pragma unroll
-            for (int i = 0; i < kSplitBatch / NP; ++i) {
-                const int s = 2 * p + 2 * NP * (i >> 1) + (i & 1);
-                const uint32_t n = b * kSplitBatch + s;
-                if (n < a.nsteps) {
-                    const uint64_t t = a.t0 + n;
-#pragma unroll
-                    for (int j = 0; 2 * j < D; ++j) {
-                        double z0, z1;
-                        ymc_draw_normal_pair(a.seed, chain, t, (uint32_t)j, &z0, &z1);
-                        ring[b & 1][s][2 * j][lane] = sigma[2 * j] * z0;
-                        if (2 * j + 1 < D) ring[b & 1][s][2 * j + 1][lane] = sigma[2 * j + 1] * z1;
-                    }
-                    ring[b & 1][s][D][lane] = ymc_uniform_cached(uc, a.seed, chain, t);
-                }
-            }
-        };
-        fill(0);
-        __syncthreads();
-        for (uint32_t b = 0; b < nb; ++b) {
-            if (b + 1 < nb) fill(b + 1);
-            __syncthreads();
-        }
-        return;
-    }
-
-    /* ---- consumer: the sequential part is the critical path, it issues first ---- */
-    __builtin_amdgcn_s_setprio(3);
-    double x[D], wmean[D], wm2[D];
-    double lp = 0.0;
-    uint64_t accepted = 0;
-    uint32_t st = 0;
-    const bool moments = (a.flags & YMC_RECORD_MOMENTS) != 0;
-#pragma unroll
-    for (int j = 0; j < D; ++j) x[j] = wmean[j] = wm2[j] = 0.0;
-    if (live) {
-        ymc_load_row<D>(a.x, k, x);
-        lp = a.lp[k];
-        accepted = a.acc_count[k];
-        st = a.status[k];
-        if (moments) {
-            ymc_load_row<D>(a.wf_mean, k, wmean);
-            ymc_load_row<D>(a.wf_m2, k, wm2);
-        }
-    }
-    __syncthreads();
-    for (uint32_t b = 0; b < nb; ++b) {
-#pragma unroll 1
-        for (int s = 0; s < kSplitBatch; ++s) {
-            const uint32_t n = b * kSplitBatch + s;
-            if (n >= a.nsteps) break;
-            double y[D];
-#pragma unroll
-            for (int j = 0; j < D; ++j) y[j] = x[j] + ring[b & 1][s][j][lane];
-            const double u = ring[b & 1][s][D][lane];
-            const bool moved = !ymc_states_equal<D>(y, x, a.eq_mode);
-            const double lpy = Density<KIND, D>::eval(a.tgt, y, st);
-            const bool acc = ymc_accept(lpy - lp, moved, ymc_finite(lpy), u, st);
-            if (moments) ymc_welford<D>(x, (double)(a.wf_n0 + n + 1), wmean, wm2);
-#pragma unroll
-            for (int j = 0; j < D; ++j) x[j] = acc ? y[j] : x[j];
-            lp = acc ? lpy : lp;
-            accepted += acc ? 1u : 0u;
-            if (live) {
-                if (a.traj) ymc_store_row<D>(a.traj + (uint64_t)n * a.K * D, k, x);
-                if (a.acc) a.acc[(uint64_t)n * a.K + k] = acc ? 1 : 0;
-                if (a.lp_out) a.lp_out[(uint64_t)n * a.K + k] = lp;
-            }
-        }
-        __syncthreads();
-    }
-    if (live) {
-        ymc_store_row<D>(a.x, k, x);
-        a.lp[k] = lp;
-        a.acc_count[k] = accepted;
-        a.status[k] = st;
-        if (moments) {
-            ymc_store_row<D>(a.wf_mean, k, wmean);
-            ymc_store_row<D>(a.wf_m2, k, wm2);
-        }
-    }
-}
-
 template <int KIND, int D>
 __global__ __launch_bounds__(kBlock) void mlda2_kernel(const ChainArgs<D> a)
 {
@@ -392,9 +273,7 @@ inline unsigned grid_for(uint64_t n) { return (unsigned)((n + kBlock - 1) / kBlo
 template <int KIND, int D>
 hipError_t launch_chain(int method, const ChainArgs<D> &a, hipStream_t s)
 {
-    if (method == YMC_METHOD_MRW && a.variant == YMC_VARIANT_SPLIT)
-        hipLaunchKernelGGL((mrw_split_kernel<KIND, D, 2>), dim3((unsigned)((a.K + 63) / 64)), dim3(192), 0, s, a);
-    else if (method == YMC_METHOD_MRW)
+    if (method == YMC_METHOD_MRW)
         hipLaunchKernelGGL((mrw_kernel<KIND, D>), dim3(grid_for(a.K)), dim3(kBlock), 0, s, a);
     else
         hipLaunchKernelGGL((mlda2_kernel<KIND, D>), dim3(grid_for(a.K)), dim3(kBlock), 0, s, a);

@@ -41,10 +41,16 @@ YMC_FN double ymc_fma(double a, double b, double c) { return __builtin_fma(a, b,
 /* fma whose ADDEND is a polynomial coefficient (a Horner step).  Same value as
  * ymc_fma; on the device it is pinned to the three-address v_fma_f64, because
  * hipcc (ROCm 7.2) otherwise selects the two-address v_fmac_f64 and pays a
- * v_mov_b64 of the coefficient per step. */
+ * v_mov_b64 of the coefficient per step.  The coefficient sits in a VGPR pair
+ * by default (cheapest at low occupancy); a translation unit that is short of
+ * VGPRs defines YMC_COEFF_IN_SGPR and gets it from an SGPR pair instead. */
 YMC_FN double ymc_fma_c(double a, double b, double c)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(YMC_COEFF_IN_SGPR)
+    double d;
+    __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+#elif defined(__HIP_DEVICE_COMPILE__)
     double d;
     __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;

@@ -7,7 +7,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
-constexpr int kTileWaves = 4;                 /* waves per workgroup (one per SIMD), 16 chains each */
+constexpr int kTileWaves = 8;                 /* waves per workgroup (one per SIMD), 16 chains each */
 constexpr int kTileThreads = 64 * kTileWaves;
 constexpr int kTileNDMax = 8;                 /* data rows the likelihood epilogue unrolls over */
 constexpr size_t kTileLdsLimit = 160 * 1024;  /* LDS per CU on gfx950 */

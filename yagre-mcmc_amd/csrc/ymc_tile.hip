@@ -4,7 +4,7 @@
  * Metropolis with the forward map G(theta) = A theta + b
  * (exampleSetup.py:42-47) evaluated on the fp64 matrix cores.
  *
- * Mapping (one wave = 16 chains, one workgroup = 4 waves = 64 chains):
+ * Mapping (one wave = 16 chains, one workgroup = 8 waves = 128 chains, two waves per SIMD):
  *   lane l = 16 g + c owns chain c of the wave's tile and the parameter
  *   components j = 4 s + g, s = 0..KS-1 -- exactly the B-operand layout of
  *   v_mfma_f64_16x16x4_f64 (B[k = l>>4][col = l&15]).  The state x and the
@@ -27,6 +27,9 @@
  * i.e. logical (row, chain = 16 tile + c, component = 4 s + g); untiled by
  * untile_kernel when the host fetches it.
  */
+/* x and y take 128 of the 256 VGPRs a wave may use at two waves per SIMD: keep the
+ * polynomial coefficients of the draw transform in SGPRs */
+#define YMC_COEFF_IN_SGPR 1
 #include "ymc_kernels.h"
 #include "ymc_tile.h"
 
@@ -51,7 +54,7 @@ __device__ __forceinline__ double combine4(double s)
 }
 
 template <int KS>
-__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void linear_tile_kernel(const TileArgs a)
+__global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArgs a)
 {
     extern __shared__ double lds[];
     const int MT = a.MT, m_pad = 16 * MT, d_pad = 4 * KS, n_data = a.n_data;
