@@ -377,13 +377,11 @@ def test_tile_kernel_other_shapes(ffi, ctx, d, m, nd, K):
     p = o.posterior_linear(g["A"], g["b"], g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
     sigma = rng.uniform(0.02, 0.08, size=d)
     x0 = rng.normal(size=(K, d))
-    dev = _device_run(ffi, ctx, low, sigma, x0, 4711, 60, chain0=1000, moments=False)
+    dev = _device_run(ffi, ctx, low, sigma, x0, 4711, 60, chain0=1000, moments=True, splits=3)
     e = o.Ensemble(p, sigma, x0, 4711, chain0=1000)
     out = e.advance(60)
-    assert np.array_equal(dev["acc"], out["acc"]) and 0.02 < out["acc"].mean() < 0.98
-    assert np.array_equal(dev["traj"], out["traj"])
-    assert np.array_equal(dev["logpost"], out["logpost"])
-    assert np.array_equal(dev["state"][0], e.x)
+    assert 0.02 < out["acc"].mean() < 0.98
+    _same_as_oracle(dev, e, out)   # incl. the Welford moments replayed from the record
 
 
 def test_tile_kernel_limits(ffi, ctx):

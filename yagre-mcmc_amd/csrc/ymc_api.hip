@@ -101,7 +101,7 @@ struct ymc_run {
     uint64_t seed = 0, chain0 = 0, K = 0;
     uint32_t flags = 0;
     uint64_t capacity = 0, recorded = 0, steps_done = 0;
-    DeviceBuf x, lp, lpc, acc_count, wf_mean, wf_m2, status, traj, acc, lp_out, sub_acc, summary;
+    DeviceBuf x, lp, lpc, acc_count, wf_mean, wf_m2, status, traj, acc, lp_out, sub_acc, summary, x_before;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;  /* launches since the last query */
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
 };
@@ -388,6 +388,11 @@ int launch_advance_tile(ymc_run *r, uint64_t nsteps)
     if (r->flags & YMC_RECORD_TRAJECTORY) a.traj = r->traj.as<double>() + row * tiled_row_doubles(r);
     if (r->flags & YMC_RECORD_ACCEPT) a.acc = r->acc.as<uint8_t>() + row * r->K;
     if (r->flags & YMC_RECORD_LOGPOST) a.lp_out = r->lp_out.as<double>() + row * r->K;
+    const bool moments = (r->flags & YMC_RECORD_MOMENTS) != 0;
+    if (moments) {
+        if (!r->x_before.p) YMC_TRY(r->x_before.alloc(r->x.bytes));
+        YMC_HIP(hipMemcpyAsync(r->x_before.p, r->x.p, r->x.bytes, hipMemcpyDeviceToDevice, r->ctx->stream));
+    }
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (!r->pool.empty()) {
         ev = r->pool.back();
@@ -398,6 +403,9 @@ int launch_advance_tile(ymc_run *r, uint64_t nsteps)
     }
     YMC_HIP(hipEventRecord(ev.first, r->ctx->stream));
     hipError_t e = ymc_launch_linear_tile(h.KS, a, r->ctx->stream);
+    if (e == hipSuccess && moments)
+        e = ymc_launch_welford_replay(a.traj, r->x_before.as<double>(), nsteps, r->K, p->D, h.KS, r->steps_done,
+                                      r->wf_mean.as<double>(), r->wf_m2.as<double>(), r->ctx->stream);
     if (e != hipSuccess) {
         r->pool.push_back(ev);
         return fail(YMC_ERR_DEVICE, "tile kernel launch failed: %s", hipGetErrorString(e));
@@ -555,8 +563,9 @@ int ymc_run_create(ymc_ctx *ctx, const ymc_problem *problem, const ymc_run_desc 
         return fail(YMC_ERR_INVALID, "initial_state must have 1 or n_chains rows");
     if (records_anything(desc->record_flags) && desc->record_capacity == 0)
         return fail(YMC_ERR_INVALID, "record_capacity must be positive when something is recorded");
-    if (problem->tile && (desc->record_flags & YMC_RECORD_MOMENTS))
-        return fail(YMC_ERR_UNSUPPORTED, "Welford moments are not accumulated by the large-dimension kernel");
+    if (problem->tile && (desc->record_flags & YMC_RECORD_MOMENTS) && !(desc->record_flags & YMC_RECORD_TRAJECTORY))
+        return fail(YMC_ERR_UNSUPPORTED,
+                    "at this dimension the Welford moments are replayed from the record: record the trajectory too");
     YMC_HIP(hipSetDevice(ctx->device));
     ymc_run *r = new (std::nothrow) ymc_run;
     if (!r) return fail(YMC_ERR_DEVICE, "out of host memory");

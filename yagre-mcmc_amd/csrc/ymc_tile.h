@@ -37,6 +37,8 @@ size_t ymc_tile_lds_bytes(int KS, int MT, int n_data);
 hipError_t ymc_launch_linear_tile(int KS, const TileArgs &a, hipStream_t s);
 hipError_t ymc_launch_untile(const double *tiled, uint64_t row0, uint64_t rows, uint64_t K, int d, int KS,
                              double *out, hipStream_t s);
+hipError_t ymc_launch_welford_replay(const double *tiled, const double *x_before, uint64_t rows, uint64_t K, int d,
+                                     int KS, uint64_t wf_n0, double *wf_mean, double *wf_m2, hipStream_t s);
 hipError_t ymc_launch_linear_big_eval(const BigLinearArgs &p, uint64_t n, const double *x, double *lp, double *fwd,
                                       hipStream_t s);
 

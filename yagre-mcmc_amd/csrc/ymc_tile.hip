@@ -212,6 +212,40 @@ __global__ __launch_bounds__(256) void untile_kernel(const double *__restrict__ 
     out[i] = tiled[((((row0 + r) * nct + k / 16) * KS + j / 4) * 64) + (j % 4) * 16 + (k % 16)];
 }
 
+/* FullDiagnostics' Welford accumulator (diagnostics.py:91-94, estimation.py:36-53)
+ * for the tile kernel, which has no registers left for 2 x 128 running moments:
+ * replayed from the record after each launch.  Thread i owns one (chain,
+ * component) in the record's tiled order, so every row is read as coalesced
+ * 512-B segments; the update sequence per component is the online one, hence
+ * the same bits.  The pre-transition state of the launch's first transition is
+ * the carried state saved before the launch (`x_before`). */
+__global__ __launch_bounds__(256) void welford_replay_kernel(const double *__restrict__ tiled,
+                                                             const double *__restrict__ x_before, uint64_t rows,
+                                                             uint64_t K, int d, int KS, uint64_t wf_n0,
+                                                             double *__restrict__ wf_mean, double *__restrict__ wf_m2)
+{
+    const uint64_t nct = (K + 15) / 16;
+    const uint64_t per_row = nct * (uint64_t)KS * 64;
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= per_row) return;
+    const uint64_t lane = i & 63, s = (i >> 6) % KS, ct = (i >> 6) / KS;
+    const uint64_t k = ct * 16 + (lane & 15);
+    const int j = (int)(4 * s + (lane >> 4));
+    if (k >= K || j >= d) return;
+    double mean = wf_mean[k * d + j], m2 = wf_m2[k * d + j];
+    double v = x_before[k * d + j];
+    for (uint64_t n = 0; n < rows; ++n) {
+        const double dn = (double)(wf_n0 + n + 1);
+        const double delta = v - mean;
+        mean = mean + delta / dn;
+        const double delta2 = v - mean;
+        m2 = m2 + delta * delta2;
+        v = tiled[n * per_row + i];
+    }
+    wf_mean[k * d + j] = mean;
+    wf_m2[k * d + j] = m2;
+}
+
 /* DensityInterface.evaluate_log / ForwardModel.evaluate for a batch at large
  * dimension: one lane per parameter vector, plain loops in the canonical
  * order (used for the initial states and for host-side evaluate_log calls) */
@@ -307,6 +341,15 @@ hipError_t ymc_launch_untile(const double *tiled, uint64_t row0, uint64_t rows, 
     const uint64_t n = rows * K * (uint64_t)d;
     hipLaunchKernelGGL(untile_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tiled, row0, rows, K, d, KS,
                        out);
+    return hipGetLastError();
+}
+
+hipError_t ymc_launch_welford_replay(const double *tiled, const double *x_before, uint64_t rows, uint64_t K, int d,
+                                     int KS, uint64_t wf_n0, double *wf_mean, double *wf_m2, hipStream_t s)
+{
+    const uint64_t per_row = ((K + 15) / 16) * (uint64_t)KS * 64;
+    hipLaunchKernelGGL(welford_replay_kernel, dim3((unsigned)((per_row + 255) / 256)), dim3(256), 0, s, tiled, x_before,
+                       rows, K, d, KS, wf_n0, wf_mean, wf_m2);
     return hipGetLastError();
 }
 
