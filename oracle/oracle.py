@@ -170,6 +170,17 @@ def exp(x):
     return _vec1(lib().ymo_exp_v, x)
 
 
+def accept_prob(x):
+    return _vec1(lib().ymo_accept_prob_v, x)
+
+
+def div_by_recip(a, b):
+    a, b = _f64(a).reshape(-1), _f64(b).reshape(-1)
+    q = np.empty_like(a)
+    lib().ymo_div_by_recip_v(C.c_int64(a.size), _ptr(a), _ptr(b), _ptr(q))
+    return q
+
+
 def sincospi(x):
     x = _f64(x).reshape(-1)
     s, c = np.empty_like(x), np.empty_like(x)

@@ -89,9 +89,20 @@ void ymo_log_v(int64_t n, const double *x, double *y)
     for (int64_t i = 0; i < n; ++i) y[i] = ymc_log(x[i]);
 }
 
+void ymo_accept_prob_v(int64_t n, const double *x, double *y)
+{
+    for (int64_t i = 0; i < n; ++i) y[i] = ymc_accept_prob(x[i]);
+}
+
 void ymo_exp_v(int64_t n, const double *x, double *y)
 {
     for (int64_t i = 0; i < n; ++i) y[i] = ymc_exp(x[i]);
+}
+
+/* a[i] / b[i] through ymc_div_by_recip with y = 1/b[i] by the hardware division */
+void ymo_div_by_recip_v(int64_t n, const double *a, const double *b, double *q)
+{
+    for (int64_t i = 0; i < n; ++i) q[i] = ymc_div_by_recip(a[i], b[i], 1.0 / b[i]);
 }
 
 void ymo_sincospi_v(int64_t n, const double *x, double *s, double *c)
@@ -355,8 +366,7 @@ static int ymo_accept(double log_ratio, int proposal_finite, uint64_t seed, uint
         if (margin) *margin = INFINITY;
         return 0;
     }
-    double a = ymc_exp(log_ratio);
-    a = (a < 1.0) ? a : 1.0;
+    double a = ymc_accept_prob(log_ratio); /* = exp(log_ratio) clipped at 1, see ymc_numerics.h */
     double u = ymc_draw_uniform(seed, chain, t);
     if (margin) *margin = fabs(u - a);
     return u <= a;

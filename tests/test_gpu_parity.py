@@ -426,3 +426,102 @@ def test_rccl_summary_gather_single_rank(ffi, ctx, golden):
     pooled = distributed.pooled_diagnostics(s, 250)
     assert 0.3 < pooled["acceptance_rate"] < 0.8 and pooled["n"] == 250 * 1000
     comm.close()
+
+
+# ---------------------------------------------------------------------------
+# the other BASELINE configurations at full per-GPU size: properties + oracle slices
+# ---------------------------------------------------------------------------
+
+def _slices_match_oracle(ffi, traj, acc, make_oracle, K, T, width=32):
+    for c0 in (0, K // 2 - width // 2, K - width):
+        out = make_oracle(c0, width).advance(T)
+        assert np.array_equal(traj[:, c0:c0 + width], out["traj"])
+        assert np.array_equal(acc[:, c0:c0 + width], out["acc"])
+
+
+def test_c3_full_size_linear_d128(ffi, ctx):
+    """262 144 chains, d = m = 128, nData = 5 (BASELINE configs[2]); 6 transitions."""
+    from yagremcmc_amd import lowering
+    d, K, T = 128, 262144, 6
+    rng = np.random.default_rng(7)
+    A = rng.standard_normal((d, d)) / np.sqrt(d)
+    g = dict(A=A, b=rng.standard_normal(d), noise_precision=np.reciprocal(np.full(d, 0.3)), prior_mean=np.zeros(d),
+             prior_precision=np.reciprocal(np.full(d, 5.0)))
+    theta = rng.standard_normal(d)
+    g["data"] = np.array([A @ theta + g["b"] + np.sqrt(0.3) * rng.standard_normal(d) for _ in range(5)])
+    low = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, g, fwd_matrix=A, fwd_shift=g["b"])
+    sigma = np.sqrt(np.reciprocal(np.reciprocal(np.full(d, 1.1e-3))))
+    prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, sigma)
+    x0 = np.zeros((1, d))
+    run = ffi.Run(prob, 20250103, K, x0, T, ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT)
+    run.advance(T)
+    traj, acc = run.trajectory(), run.accept()
+    p = o.posterior_linear(A, g["b"], g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+    _slices_match_oracle(ffi, traj, acc, lambda c0, w: o.Ensemble(p, sigma, np.zeros((w, d)), 20250103, chain0=c0), K, T)
+    prev = np.concatenate([np.broadcast_to(x0, (1, K, d)), traj[:-1]])
+    assert np.array_equal((traj == prev).all(axis=2), acc == 0)
+    assert np.array_equal(run.summary()["accepted"], acc.sum(axis=0).astype(np.uint64))
+    assert 0.2 < acc.mean() < 0.8
+    # sharding invariance on a quarter of the ensemble
+    part = ffi.Run(prob, 20250103, K // 4, x0, T, ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT, 3 * K // 4)
+    part.advance(T)
+    assert np.array_equal(part.trajectory(), traj[:, 3 * K // 4:])
+
+
+def test_c5_full_size_two_level(ffi, ctx, golden):
+    """131 072 chains per GPU of the two-level sampler, S = 6 (BASELINE configs[4] per-GPU share)."""
+    from yagremcmc_amd import lowering
+    g = golden("f5_mlda2_2d.npz")
+    K, T, S = 131072, 60, 6
+    fine = _gauss_low(ffi, g["fine_mean"], g["fine_whiten"], g["fine_log_norm"])
+    coarse = _gauss_low(ffi, g["coarse_mean"], g["coarse_whiten"], g["coarse_log_norm"])
+    prob = lowering.make_problem(ctx, ffi.METHOD_MLDA2, fine, g["sigma"], surrogate=coarse, sub_chain_length=S)
+    x0 = np.array([[-8.0, -7.0]])
+    flags = ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT | ffi.RECORD_SUB_ACCEPT | ffi.RECORD_MOMENTS
+    run = ffi.Run(prob, 5, K, x0, T, flags)
+    run.advance(T)
+    traj, acc, sub = run.trajectory(), run.accept(), run.sub_accept()
+    of = o.gauss_whitened(g["fine_mean"], g["fine_whiten"], float(g["fine_log_norm"]))
+    oc = o.gauss_whitened(g["coarse_mean"], g["coarse_whiten"], float(g["coarse_log_norm"]))
+    _slices_match_oracle(ffi, traj, acc, lambda c0, w: o.Ensemble(of, g["sigma"], np.tile(x0, (w, 1)), 5, chain0=c0,
+                                                                  surrogate=oc, sub_chain_length=S), K, T)
+    # a fine step can only be accepted if some coarse sub-step moved
+    assert not (acc.astype(bool) & ~sub.any(axis=1)).any()
+    prev = np.concatenate([np.broadcast_to(x0, (1, K, 2)), traj[:-1]])
+    assert np.array_equal((traj == prev).all(axis=2), acc == 0)
+    s = run.summary()
+    assert np.array_equal(s["accepted"], acc.sum(axis=0).astype(np.uint64))
+    assert np.allclose(s["wf_mean"], prev.mean(axis=0), rtol=0, atol=1e-12)
+
+
+def test_c4_full_size_lotka_volterra(ffi, ctx, golden):
+    """16 384 chains per GPU, nData = 10, T = 10, RK4 x 50 (BASELINE configs[3] per-GPU share)."""
+    from yagremcmc_amd import lowering
+    K, T = 16384, 12
+    rng = np.random.default_rng(1111)
+    design = rng.uniform(0.5, 1.5, size=(10, 2))
+    base = dict(noise_precision=np.reciprocal(np.full(2, 0.04)), prior_mean=np.zeros(2),
+                prior_precision=np.reciprocal(np.full(2, 1.4)))
+    p0 = o.posterior_lv(design, 10.0, 0.8, 0.4, 50, np.zeros((10, 2)), **base)
+    data = o.forward(p0, np.log([0.4, 0.6])).reshape(10, 2) + 0.2 * rng.standard_normal((10, 2))
+    p = o.posterior_lv(design, 10.0, 0.8, 0.4, 50, data, **base)
+    low = _posterior_low(ffi, ffi.POSTERIOR_LV, 2, dict(base, data=data), design=design, t_final=10.0, alpha=0.8,
+                         gamma=0.4, rk4_steps=50)
+    sigma = np.sqrt(np.reciprocal(np.reciprocal(np.full(2, 0.15))))
+    prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, sigma)
+    x0 = np.array([[-0.6, -0.3]])
+    run = ffi.Run(prob, 9, K, x0, T, _flags(ffi))
+    run.advance(T)
+    traj, acc = run.trajectory(), run.accept()
+    _slices_match_oracle(ffi, traj, acc, lambda c0, w: o.Ensemble(p, sigma, np.tile(x0, (w, 1)), 9, chain0=c0), K, T)
+    lp = run.logpost()
+    assert np.array_equal(lp[-1], prob.logdensity(traj[-1])[0])      # recorded logpi == batch evaluate_log
+    assert (run.summary()["status"] == 0).all()
+    # a wide proposal from the stiff corner: non-finite solves are flagged and never accepted
+    stiff = ffi.Run(prob, 9, 4096, np.array([[-7.0, 2.8]]), 4, _flags(ffi))
+    stiff.advance(4)
+    st = stiff.summary()["status"]
+    assert np.isfinite(stiff.trajectory()).all()
+    e = o.Ensemble(p, sigma, np.tile([[-7.0, 2.8]], (64, 1)), 9)
+    out = e.advance(4)
+    assert np.array_equal(stiff.trajectory()[:, :64], out["traj"]) and np.array_equal(st[:64], e.status)

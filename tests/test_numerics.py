@@ -50,6 +50,30 @@ def test_exp_against_libm():
     assert (np.abs(o.exp(xs) - np.exp(xs)) <= 2 * 4.94065645841246544e-324 + 2 * np.spacing(np.exp(xs))).all()
 
 
+def test_accept_probability_is_clipped_exp():
+    """ymc_accept_prob(d) == min(1, ymc_exp(d)) with NaN -> 1 (mrw.py:54-57), for every kind of input"""
+    rng = np.random.default_rng(21)
+    d = np.concatenate([rng.uniform(-760, 5, size=300000), rng.normal(size=100000) * 1e-8,
+                        [0.0, -0.0, np.inf, -np.inf, np.nan, 800.0, -745.19, -745.21, -708.39, -708.4, 1e-320, -1e-320]])
+    e = o.exp(d)
+    want = np.where(e < 1.0, e, 1.0)
+    assert np.array_equal(o.accept_prob(d), want)
+
+
+def test_division_by_reciprocal_is_the_ieee_quotient():
+    """Markstein's correction with y = RN(1/b): random and near-midpoint quotients"""
+    rng = np.random.default_rng(22)
+    for rep in range(8):
+        n = 500000
+        b = rng.integers(1, 2**31 if rep % 2 else 5000, size=n).astype(np.float64)
+        a = rng.normal(size=n) * np.exp(rng.uniform(-20, 20, size=n))
+        if rep >= 4:
+            m = rng.integers(2**52, 2**53, size=n).astype(np.float64)
+            a = b * (m + 0.5) * 2.0**rng.integers(-60, -40, size=n)
+            a = np.nextafter(a, a * rng.choice([0.5, 2.0], size=n))
+        assert np.array_equal(o.div_by_recip(a, b), a / b)
+
+
 def test_sincospi_against_libm_and_exact_points():
     rng = np.random.default_rng(13)
     t = rng.integers(0, 2**53, size=300000) * 2.0**-52  # the Box-Muller argument grid, [0,2)

@@ -1,0 +1,208 @@
+// Experiment harness: producer/consumer variants of the single-level random-walk kernel for the
+// 2-D Gaussian target at K = 65 536 chains (1 wave per SIMD when one lane owns one chain).
+// All variants must give the fused kernel's bits; they are timed in interleaved rounds in ONE process.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I../yagre-mcmc_amd/csrc exp_split.hip -o exp_split
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "ymc_device.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+
+constexpr int D = 2;
+using Dens = Density<YMC_DENSITY_GAUSS_WHITENED, D>;
+
+struct Args {
+    DensityDev<D> tgt;
+    double sigma[D];
+    uint64_t seed, K, t0;
+    uint32_t nsteps;
+    double *x, *lp, *wmean, *wm2, *traj;
+    uint64_t* acc_count;
+    uint8_t* acc;
+};
+
+__device__ __forceinline__ void tail(const Args& a, uint64_t k, uint32_t n, double (&x)[D], double& lp, uint64_t& accepted,
+                                     double (&wmean)[D], double (&wm2)[D], const double (&delta)[D], double u)
+{
+    double y[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) y[j] = x[j] + delta[j];
+    uint32_t st = 0;
+    const bool moved = !ymc_states_equal<D>(y, x, 0);
+    const double lpy = Dens::eval(a.tgt, y, st);
+    const bool acc = ymc_accept(lpy - lp, moved, ymc_finite(lpy), u, st);
+    ymc_welford<D>(x, (double)(a.t0 + n + 1), wmean, wm2);
+#pragma unroll
+    for (int j = 0; j < D; ++j) x[j] = acc ? y[j] : x[j];
+    lp = acc ? lpy : lp;
+    accepted += acc ? 1u : 0u;
+    ymc_store_row<D>(a.traj + (uint64_t)n * a.K * D, k, x);
+    a.acc[(uint64_t)n * a.K + k] = acc ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void fused(const Args a)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t chain = (uint32_t)k;
+    double x[D], wmean[D], wm2[D], sigma[D] = {a.sigma[0], a.sigma[1]};
+    ymc_load_row<D>(a.x, k, x);
+    ymc_load_row<D>(a.wmean, k, wmean);
+    ymc_load_row<D>(a.wm2, k, wm2);
+    double lp = a.lp[k];
+    uint64_t accepted = a.acc_count[k];
+    UniformCache uc;
+    uc.valid = false;
+    uc.pair = 0;
+#pragma unroll 1
+    for (uint32_t n = 0; n < a.nsteps; ++n) {
+        const uint64_t t = a.t0 + n;
+        double z0, z1;
+        ymc_draw_normal_pair(a.seed, chain, t, 0, &z0, &z1);
+        const double delta[D] = {sigma[0] * z0, sigma[1] * z1};
+        const double u = ymc_uniform_cached(uc, a.seed, chain, t);
+        tail(a, k, n, x, lp, accepted, wmean, wm2, delta, u);
+    }
+    ymc_store_row<D>(a.x, k, x);
+    ymc_store_row<D>(a.wmean, k, wmean);
+    ymc_store_row<D>(a.wm2, k, wm2);
+    a.lp[k] = lp;
+    a.acc_count[k] = accepted;
+}
+
+// NP producer waves + 1 consumer wave per 64 chains. Ring buffer of B = 2*NP*R transitions, double-buffered.
+// The consumer reads a whole buffer into registers right after the barrier (one LDS latency per buffer).
+template <int NP, int R, int PRIO>
+__global__ __launch_bounds__(64 * (NP + 1)) void split(const Args a)
+{
+    constexpr int B = 2 * NP * R;
+    __shared__ double ring[2][B][D + 1][64];
+    const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+    const uint64_t k = (uint64_t)blockIdx.x * 64 + lane;
+    const uint32_t chain = (uint32_t)k;
+    const uint32_t nb = a.nsteps / B;  // harness: nsteps is a multiple of B, t0 even
+    if (role != 0) {
+        const int p = role - 1;
+        const double s0 = a.sigma[0], s1 = a.sigma[1];
+        auto fill = [&](uint32_t b) {
+#pragma unroll 1
+            for (int r = 0; r < R; ++r) {
+                const int q = 2 * (NP * r + p);
+                const uint64_t t = a.t0 + b * B + q;
+                const ymc_u32x4 ub = ymc_uniform_block(a.seed, chain, t);
+                ring[b & 1][q][D][lane] = ymc_u01_co(ub.v[0], ub.v[1]);
+                ring[b & 1][q + 1][D][lane] = ymc_u01_co(ub.v[2], ub.v[3]);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    double z0, z1;
+                    ymc_draw_normal_pair(a.seed, chain, t + h, 0, &z0, &z1);
+                    ring[b & 1][q + h][0][lane] = s0 * z0;
+                    ring[b & 1][q + h][1][lane] = s1 * z1;
+                }
+            }
+        };
+        fill(0);
+        __syncthreads();
+        for (uint32_t b = 0; b < nb; ++b) {
+            if (b + 1 < nb) fill(b + 1);
+            __syncthreads();
+        }
+        return;
+    }
+    if (PRIO) __builtin_amdgcn_s_setprio(3);
+    double x[D], wmean[D], wm2[D];
+    ymc_load_row<D>(a.x, k, x);
+    ymc_load_row<D>(a.wmean, k, wmean);
+    ymc_load_row<D>(a.wm2, k, wm2);
+    double lp = a.lp[k];
+    uint64_t accepted = a.acc_count[k];
+    __syncthreads();
+    for (uint32_t b = 0; b < nb; ++b) {
+        double dl[B][D], u[B];
+#pragma unroll
+        for (int s = 0; s < B; ++s) {
+            dl[s][0] = ring[b & 1][s][0][lane];
+            dl[s][1] = ring[b & 1][s][1][lane];
+            u[s] = ring[b & 1][s][D][lane];
+        }
+#pragma unroll
+        for (int s = 0; s < B; ++s) tail(a, k, b * B + s, x, lp, accepted, wmean, wm2, dl[s], u[s]);
+        __syncthreads();
+    }
+    ymc_store_row<D>(a.x, k, x);
+    ymc_store_row<D>(a.wmean, k, wmean);
+    ymc_store_row<D>(a.wm2, k, wm2);
+    a.lp[k] = lp;
+    a.acc_count[k] = accepted;
+}
+
+struct Bufs {
+    double *x, *lp, *wmean, *wm2, *traj;
+    uint64_t* acc_count;
+    uint8_t* acc;
+};
+
+int main(int argc, char** argv)
+{
+    const uint64_t K = argc > 1 ? atoll(argv[1]) : 65536;
+    const uint32_t T = 960;
+    Args a;
+    memset(&a, 0, sizeof a);
+    a.tgt.mean[0] = 1.0; a.tgt.mean[1] = 1.5;
+    a.tgt.whiten[0] = -0.34990314; a.tgt.whiten[1] = -0.60586986; a.tgt.whiten[2] = -1.2849522; a.tgt.whiten[3] = 0.16498339;
+    a.tgt.log_norm = 4.0;
+    a.sigma[0] = a.sigma[1] = 1.0;
+    a.seed = 20250103; a.K = K; a.t0 = 0; a.nsteps = T;
+    auto alloc = [&](Bufs& b) {
+        CK(hipMalloc(&b.x, K * D * 8)); CK(hipMalloc(&b.lp, K * 8)); CK(hipMalloc(&b.wmean, K * D * 8)); CK(hipMalloc(&b.wm2, K * D * 8));
+        CK(hipMalloc(&b.traj, (size_t)T * K * D * 8)); CK(hipMalloc(&b.acc_count, K * 8)); CK(hipMalloc(&b.acc, (size_t)T * K));
+    };
+    auto reset = [&](Bufs& b) {
+        std::vector<double> x0(K * D); for (uint64_t i = 0; i < K; ++i) { x0[2 * i] = -8; x0[2 * i + 1] = -7; }
+        std::vector<double> lp0(K, -50.0);
+        CK(hipMemcpy(b.x, x0.data(), K * D * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(b.lp, lp0.data(), K * 8, hipMemcpyHostToDevice));
+        CK(hipMemset(b.wmean, 0, K * D * 8)); CK(hipMemset(b.wm2, 0, K * D * 8)); CK(hipMemset(b.acc_count, 0, K * 8));
+    };
+    Bufs ref, alt;
+    alloc(ref); alloc(alt);
+    auto bind = [&](Bufs& b) { a.x = b.x; a.lp = b.lp; a.wmean = b.wmean; a.wm2 = b.wm2; a.traj = b.traj; a.acc_count = b.acc_count; a.acc = b.acc; };
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    struct Variant { const char* name; void (*launch)(const Args&, uint64_t); };
+    Variant vars[] = {
+        {"fused", [](const Args& a, uint64_t K) { hipLaunchKernelGGL(fused, dim3(K / 256), dim3(256), 0, 0, a); }},
+        {"split NP2 R2", [](const Args& a, uint64_t K) { hipLaunchKernelGGL((split<2, 2, 0>), dim3(K / 64), dim3(192), 0, 0, a); }},
+        {"split NP2 R2 prio", [](const Args& a, uint64_t K) { hipLaunchKernelGGL((split<2, 2, 1>), dim3(K / 64), dim3(192), 0, 0, a); }},
+        {"split NP3 R2 prio", [](const Args& a, uint64_t K) { hipLaunchKernelGGL((split<3, 2, 1>), dim3(K / 64), dim3(256), 0, 0, a); }},
+        {"split NP3 R1 prio", [](const Args& a, uint64_t K) { hipLaunchKernelGGL((split<3, 1, 1>), dim3(K / 64), dim3(256), 0, 0, a); }},
+        {"split NP4 R1 prio", [](const Args& a, uint64_t K) { hipLaunchKernelGGL((split<4, 1, 1>), dim3(K / 64), dim3(320), 0, 0, a); }},
+        {"split NP5 R1 prio", [](const Args& a, uint64_t K) { hipLaunchKernelGGL((split<5, 1, 1>), dim3(K / 64), dim3(384), 0, 0, a); }},
+        {"split NP4 R1", [](const Args& a, uint64_t K) { hipLaunchKernelGGL((split<4, 1, 0>), dim3(K / 64), dim3(320), 0, 0, a); }},
+    };
+    const int nv = sizeof vars / sizeof vars[0];
+    // reference output
+    reset(ref); bind(ref); vars[0].launch(a, K); CK(hipDeviceSynchronize());
+    std::vector<double> tref((size_t)T * K * D), talt((size_t)T * K * D);
+    CK(hipMemcpy(tref.data(), ref.traj, tref.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<std::vector<float>> times(nv);
+    for (int round = 0; round < 7; ++round)
+        for (int v = 0; v < nv; ++v) {
+            reset(alt); bind(alt);
+            CK(hipEventRecord(e0)); vars[v].launch(a, K); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            CK(hipGetLastError());
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            times[v].push_back(ms);
+            if (round == 0) {
+                CK(hipMemcpy(talt.data(), alt.traj, talt.size() * 8, hipMemcpyDeviceToHost));
+                if (memcmp(talt.data(), tref.data(), talt.size() * 8) != 0) printf("!! %s differs from fused\n", vars[v].name);
+            }
+        }
+    for (int v = 0; v < nv; ++v) {
+        std::sort(times[v].begin(), times[v].end());
+        float med = times[v][times[v].size() / 2];
+        printf("%-22s median %.3f ms  min %.3f ms  -> %.3e steps/s\n", vars[v].name, med, times[v][0], (double)K * T / (med * 1e-3));
+    }
+    return 0;
+}

@@ -101,7 +101,7 @@ struct ymc_run {
     uint64_t seed = 0, chain0 = 0, K = 0;
     uint32_t flags = 0;
     uint64_t capacity = 0, recorded = 0, steps_done = 0;
-    DeviceBuf x, lp, lpc, acc_count, wf_mean, wf_m2, status, traj, acc, lp_out, sub_acc, summary, x_before;
+    DeviceBuf x, lp, lpc, acc_count, wf_mean, wf_m2, status, traj, acc, lp_out, sub_acc, summary, x_before, recip;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;  /* launches since the last query */
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
 };
@@ -302,6 +302,11 @@ int launch_advance(ymc_run *r, uint64_t nsteps)
     a.wf_mean = r->wf_mean.as<double>();
     a.wf_m2 = r->wf_m2.as<double>();
     a.status = r->status.as<uint32_t>();
+    if (r->flags & YMC_RECORD_MOMENTS) {
+        if (r->recip.bytes < nsteps * sizeof(double)) YMC_TRY(r->recip.alloc(nsteps * sizeof(double)));
+        YMC_HIP(ymc_launch_recip(r->steps_done, nsteps, r->recip.as<double>(), r->ctx->stream));
+        a.recip = r->recip.as<double>();
+    }
     const uint64_t row = r->recorded;
     if (r->flags & YMC_RECORD_TRAJECTORY) a.traj = r->traj.as<double>() + row * r->K * D;
     if (r->flags & YMC_RECORD_ACCEPT) a.acc = r->acc.as<uint8_t>() + row * r->K;

@@ -239,20 +239,24 @@ __device__ __forceinline__ double ymc_uniform_cached(UniformCache &c, uint64_t s
  * hole, mrw.py:57, is not reproduced) */
 __device__ __forceinline__ bool ymc_accept(double log_ratio, bool moved, bool finite, double u, uint32_t &st)
 {
-    double a = ymc_exp(log_ratio);
-    a = (a < 1.0) ? a : 1.0;
+    const double a = ymc_accept_prob(log_ratio);
     if (moved && !finite) st |= YMC_CHAIN_NONFINITE;
     return moved && finite && (u <= a);
 }
 
-/* estimation.py:36-53 with n already incremented */
+/* estimation.py:36-53 with n already incremented.  Every lane divides by the
+ * same sample count dn, so delta / dn is formed from rdn = RN(1 / dn) (one IEEE
+ * division per transition for the whole ensemble, recip_kernel) by Markstein's
+ * correction -- the correctly rounded quotient, bit for bit the `/` of the
+ * reference and of the CPU checker. */
 template <int D>
-__device__ __forceinline__ void ymc_welford(const double (&x)[D], double dn, double (&mean)[D], double (&m2)[D])
+__device__ __forceinline__ void ymc_welford(const double (&x)[D], double dn, double rdn, double (&mean)[D],
+                                            double (&m2)[D])
 {
 #pragma unroll
     for (int j = 0; j < D; ++j) {
         double delta = x[j] - mean[j];
-        mean[j] = mean[j] + delta / dn;
+        mean[j] = mean[j] + ymc_div_by_recip(delta, dn, rdn);
         double delta2 = x[j] - mean[j];
         m2[j] = m2[j] + delta * delta2;
     }

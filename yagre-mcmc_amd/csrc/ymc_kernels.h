@@ -20,6 +20,7 @@ struct ChainArgs {
     double *x, *lp, *lpc;
     uint64_t *acc_count;
     double *wf_mean, *wf_m2;
+    const double *recip; /* recip[n] = RN(1 / (wf_n0 + n + 1)) for the transitions of this launch (moments only) */
     uint32_t *status;
     /* record rows of this launch (already offset to the write position), or null */
     double *traj;
@@ -36,6 +37,7 @@ hipError_t ymc_launch_logdensity(int kind, const DensityDev<D> &p, uint64_t n, c
 template <int D>
 hipError_t ymc_launch_forward(int kind, const DensityDev<D> &p, uint64_t n, const double *x, double *out,
                               hipStream_t s);
+hipError_t ymc_launch_recip(uint64_t n0, uint64_t count, double *out, hipStream_t s);
 hipError_t ymc_launch_rng_fill(uint64_t seed, uint64_t chain0, uint64_t K, uint64_t t0, uint64_t nt, int d,
                                double *xi, double *u, hipStream_t s);
 hipError_t ymc_launch_numerics(int fn, uint64_t n, const double *x, double *y0, double *y1, hipStream_t s);

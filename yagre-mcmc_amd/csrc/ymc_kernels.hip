@@ -19,12 +19,46 @@ namespace {
 
 constexpr int kBlock = 256;
 
-template <int KIND, int D>
+inline unsigned grid_for(uint64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+/* Record masks and the state-equality rule are COMPILE-TIME parameters of the
+ * chain kernels: with one wave per SIMD (BASELINE configs[1]) every uniform
+ * branch in the loop costs an instruction-buffer bubble, and the loop body of
+ * the common configurations is a single basic block (measured +30 % at 65 536
+ * chains against the same kernel with run-time flags).  kRuntimeRec selects
+ * the run-time form that serves every other flag combination. */
+constexpr unsigned kRuntimeRec = ~0u;
+constexpr unsigned kTA = YMC_RECORD_TRAJECTORY | YMC_RECORD_ACCEPT;
+
+template <unsigned REC>
+struct Rec {
+    static constexpr bool rt = REC == kRuntimeRec;
+    template <int D>
+    static __device__ __forceinline__ bool traj(const ChainArgs<D> &a) { return rt ? a.traj != nullptr : (REC & YMC_RECORD_TRAJECTORY) != 0; }
+    template <int D>
+    static __device__ __forceinline__ bool acc(const ChainArgs<D> &a) { return rt ? a.acc != nullptr : (REC & YMC_RECORD_ACCEPT) != 0; }
+    template <int D>
+    static __device__ __forceinline__ bool lp(const ChainArgs<D> &a) { return rt ? a.lp_out != nullptr : (REC & YMC_RECORD_LOGPOST) != 0; }
+    template <int D>
+    static __device__ __forceinline__ bool sub(const ChainArgs<D> &a) { return rt ? a.sub_acc != nullptr : (REC & YMC_RECORD_SUB_ACCEPT) != 0; }
+    template <int D>
+    static __device__ __forceinline__ bool moments(const ChainArgs<D> &a) { return rt ? (a.flags & YMC_RECORD_MOMENTS) != 0 : (REC & YMC_RECORD_MOMENTS) != 0; }
+};
+
+/* EQ < 0: rule taken from the arguments at run time */
+template <int D, int EQ>
+__device__ __forceinline__ bool states_equal(const double (&p)[D], const double (&q)[D], int runtime_eq)
+{
+    return ymc_states_equal<D>(p, q, EQ < 0 ? runtime_eq : EQ);
+}
+
+template <int KIND, int D, unsigned REC, int EQ>
 __global__ __launch_bounds__(kBlock) void mrw_kernel(const ChainArgs<D> a)
 {
     const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (k >= a.K) return;
     const uint32_t chain = (uint32_t)(a.chain0 + k);
+    using R = Rec<REC>;
 
     double x[D], wmean[D], wm2[D], sigma[D];
     ymc_load_row<D>(a.x, k, x);
@@ -33,33 +67,44 @@ __global__ __launch_bounds__(kBlock) void mrw_kernel(const ChainArgs<D> a)
     double lp = a.lp[k];
     uint64_t accepted = a.acc_count[k];
     uint32_t st = a.status[k];
-    const bool moments = (a.flags & YMC_RECORD_MOMENTS) != 0;
+    const bool moments = R::moments(a);
     if (moments) {
         ymc_load_row<D>(a.wf_mean, k, wmean);
         ymc_load_row<D>(a.wf_m2, k, wm2);
     }
-    UniformCache uc;
-    uc.valid = false;
-    uc.pair = 0;
 
-#pragma unroll 1
-    for (uint32_t n = 0; n < a.nsteps; ++n) {
+    /* one transition (metropolisHastings.py:114-120) given its accept uniform */
+    auto transition = [&](uint32_t n, double u) {
         const uint64_t t = a.t0 + n;
         double y[D];
-        ymc_propose<D>(x, sigma, a.seed, chain, t, y);              /* :116-117 */
-        const double u = ymc_uniform_cached(uc, a.seed, chain, t);  /* :68 */
-        const bool moved = !ymc_states_equal<D>(y, x, a.eq_mode);   /* :60-61 */
+        ymc_propose<D>(x, sigma, a.seed, chain, t, y);                          /* :116-117 */
+        const bool moved = !states_equal<D, EQ>(y, x, a.eq_mode);               /* :60-61 */
         const double lpy = Density<KIND, D>::eval(a.tgt, y, st);
-        const bool acc = ymc_accept(lpy - lp, moved, ymc_finite(lpy), u, st); /* mrw.py:51-57 */
-        if (moments) ymc_welford<D>(x, (double)(a.wf_n0 + n + 1), wmean, wm2); /* diagnostics.py:91-94 */
+        const bool acc = ymc_accept(lpy - lp, moved, ymc_finite(lpy), u, st);   /* mrw.py:51-57, :68-70 */
+        if (moments) ymc_welford<D>(x, (double)(a.wf_n0 + n + 1), a.recip[n], wmean, wm2); /* diagnostics.py:91-94 */
 #pragma unroll
-        for (int j = 0; j < D; ++j) x[j] = acc ? y[j] : x[j];       /* :79-92 */
+        for (int j = 0; j < D; ++j) x[j] = acc ? y[j] : x[j];                   /* :79-92 */
         lp = acc ? lpy : lp;
         accepted += acc ? 1u : 0u;
-        if (a.traj) ymc_store_row<D>(a.traj + (uint64_t)n * a.K * D, k, x); /* :75-76 */
-        if (a.acc) a.acc[(uint64_t)n * a.K + k] = acc ? 1 : 0;      /* diagnostics.py:48-54 */
-        if (a.lp_out) a.lp_out[(uint64_t)n * a.K + k] = lp;
+        if (R::traj(a)) ymc_store_row<D>(a.traj + (uint64_t)n * a.K * D, k, x); /* :75-76 */
+        if (R::acc(a)) a.acc[(uint64_t)n * a.K + k] = acc ? 1 : 0;              /* diagnostics.py:48-54 */
+        if (R::lp(a)) a.lp_out[(uint64_t)n * a.K + k] = lp;
+    };
+
+    /* transitions 2p and 2p+1 share one Philox block of uniforms: walk in aligned pairs */
+    uint32_t n = 0;
+    if (a.nsteps > 0 && (a.t0 & 1u)) {
+        transition(0, ymc_draw_uniform(a.seed, chain, a.t0));
+        n = 1;
     }
+    const uint32_t npairs = (a.nsteps - n) / 2;
+#pragma unroll 1
+    for (uint32_t i = 0; i < npairs; ++i, n += 2) {
+        const ymc_u32x4 ub = ymc_uniform_block(a.seed, chain, a.t0 + n);
+        transition(n, ymc_u01_co(ub.v[0], ub.v[1]));
+        transition(n + 1, ymc_u01_co(ub.v[2], ub.v[3]));
+    }
+    if (n < a.nsteps) transition(n, ymc_draw_uniform(a.seed, chain, a.t0 + n));
 
     ymc_store_row<D>(a.x, k, x);
     a.lp[k] = lp;
@@ -71,13 +116,14 @@ __global__ __launch_bounds__(kBlock) void mrw_kernel(const ChainArgs<D> a)
     }
 }
 
-template <int KIND, int D>
+template <int KIND, int D, unsigned REC, int EQ>
 __global__ __launch_bounds__(kBlock) void mlda2_kernel(const ChainArgs<D> a)
 {
     const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (k >= a.K) return;
     const uint32_t chain = (uint32_t)(a.chain0 + k);
     const int S = a.S;
+    using R = Rec<REC>;
 
     double x[D], wmean[D], wm2[D], sigma[D];
     ymc_load_row<D>(a.x, k, x);
@@ -87,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void mlda2_kernel(const ChainArgs<D> a)
     double lpc = a.lpc[k];
     uint64_t accepted = a.acc_count[k];
     uint32_t st = a.status[k];
-    const bool moments = (a.flags & YMC_RECORD_MOMENTS) != 0;
+    const bool moments = R::moments(a);
     if (moments) {
         ymc_load_row<D>(a.wf_mean, k, wmean);
         ymc_load_row<D>(a.wf_m2, k, wm2);
@@ -110,30 +156,30 @@ __global__ __launch_bounds__(kBlock) void mlda2_kernel(const ChainArgs<D> a)
             double y[D];
             ymc_propose<D>(z, sigma, a.seed, chain, t, y);
             const double u = ymc_uniform_cached(uc, a.seed, chain, t);
-            const bool moved = !ymc_states_equal<D>(y, z, a.eq_mode);
+            const bool moved = !states_equal<D, EQ>(y, z, a.eq_mode);
             const double lpcy = Density<KIND, D>::eval(a.sur, y, st);
             const bool acc = ymc_accept(lpcy - lpcz, moved, ymc_finite(lpcy), u, st);
 #pragma unroll
             for (int j = 0; j < D; ++j) z[j] = acc ? y[j] : z[j];
             lpcz = acc ? lpcy : lpcz;
-            if (a.sub_acc) a.sub_acc[((uint64_t)n * S + s) * a.K + k] = acc ? 1 : 0;
+            if (R::sub(a)) a.sub_acc[((uint64_t)n * S + s) * a.K + k] = acc ? 1 : 0;
         }
         /* fine accept/reject, mlda.py:146-154 */
         const uint64_t tf = tbase + (uint64_t)S;
         const double u = ymc_uniform_cached(uc, a.seed, chain, tf);
-        const bool moved = !ymc_states_equal<D>(z, x, a.eq_mode);
+        const bool moved = !states_equal<D, EQ>(z, x, a.eq_mode);
         const double lpfy = Density<KIND, D>::eval(a.tgt, z, st);
         const double log_ratio = ((lpfy + lpc) - lpcz) - lpf;
         const bool acc = ymc_accept(log_ratio, moved, ymc_finite(lpfy) && ymc_finite(lpcz), u, st);
-        if (moments) ymc_welford<D>(x, (double)(a.wf_n0 + n + 1), wmean, wm2);
+        if (moments) ymc_welford<D>(x, (double)(a.wf_n0 + n + 1), a.recip[n], wmean, wm2);
 #pragma unroll
         for (int j = 0; j < D; ++j) x[j] = acc ? z[j] : x[j];
         lpf = acc ? lpfy : lpf;
         lpc = acc ? lpcz : lpc;
         accepted += acc ? 1u : 0u;
-        if (a.traj) ymc_store_row<D>(a.traj + (uint64_t)n * a.K * D, k, x);
-        if (a.acc) a.acc[(uint64_t)n * a.K + k] = acc ? 1 : 0;
-        if (a.lp_out) a.lp_out[(uint64_t)n * a.K + k] = lpf;
+        if (R::traj(a)) ymc_store_row<D>(a.traj + (uint64_t)n * a.K * D, k, x);
+        if (R::acc(a)) a.acc[(uint64_t)n * a.K + k] = acc ? 1 : 0;
+        if (R::lp(a)) a.lp_out[(uint64_t)n * a.K + k] = lpf;
     }
 
     ymc_store_row<D>(a.x, k, x);
@@ -223,6 +269,13 @@ __global__ __launch_bounds__(kBlock) void rng_fill_kernel(uint64_t seed, uint64_
     }
 }
 
+/* out[i] = RN(1 / (n0 + i + 1)): the Welford divisors' reciprocals of one launch */
+__global__ __launch_bounds__(kBlock) void recip_kernel(uint64_t n0, uint64_t count, double *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < count) out[i] = 1.0 / (double)(n0 + i + 1);
+}
+
 __global__ __launch_bounds__(kBlock) void numerics_kernel(int fn, uint64_t n, const double *__restrict__ x,
                                                           double *__restrict__ y0, double *__restrict__ y1)
 {
@@ -268,15 +321,31 @@ __global__ __launch_bounds__(kBlock) void pack_summary_kernel(uint64_t K, int d,
     o[3 * d + 4] = 0;
 }
 
-inline unsigned grid_for(uint64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
+template <int KIND, int D, unsigned REC, int EQ>
+void launch_one(int method, const ChainArgs<D> &a, hipStream_t s)
+{
+    if (method == YMC_METHOD_MRW)
+        hipLaunchKernelGGL((mrw_kernel<KIND, D, REC, EQ>), dim3(grid_for(a.K)), dim3(kBlock), 0, s, a);
+    else
+        hipLaunchKernelGGL((mlda2_kernel<KIND, D, REC, EQ>), dim3(grid_for(a.K)), dim3(kBlock), 0, s, a);
+}
+
+/* the specialised kernels cover what the builders produce by default (trajectory
+ * + decisions, with or without FullDiagnostics' moments, exact state equality);
+ * every other combination runs the run-time-flag form */
 template <int KIND, int D>
 hipError_t launch_chain(int method, const ChainArgs<D> &a, hipStream_t s)
 {
-    if (method == YMC_METHOD_MRW)
-        hipLaunchKernelGGL((mrw_kernel<KIND, D>), dim3(grid_for(a.K)), dim3(kBlock), 0, s, a);
+    const unsigned rec = (a.traj ? YMC_RECORD_TRAJECTORY : 0u) | (a.acc ? YMC_RECORD_ACCEPT : 0u) |
+                         (a.lp_out ? YMC_RECORD_LOGPOST : 0u) | (a.sub_acc ? YMC_RECORD_SUB_ACCEPT : 0u) |
+                         (a.flags & YMC_RECORD_MOMENTS);
+    if (a.eq_mode == YMC_EQ_EXACT && rec == kTA)
+        launch_one<KIND, D, kTA, YMC_EQ_EXACT>(method, a, s);
+    else if (a.eq_mode == YMC_EQ_EXACT && rec == (kTA | YMC_RECORD_MOMENTS))
+        launch_one<KIND, D, kTA | YMC_RECORD_MOMENTS, YMC_EQ_EXACT>(method, a, s);
     else
-        hipLaunchKernelGGL((mlda2_kernel<KIND, D>), dim3(grid_for(a.K)), dim3(kBlock), 0, s, a);
+        launch_one<KIND, D, kRuntimeRec, -1>(method, a, s);
     return hipGetLastError();
 }
 
@@ -360,6 +429,12 @@ hipError_t ymc_launch_rng_fill(uint64_t seed, uint64_t chain0, uint64_t K, uint6
 {
     hipLaunchKernelGGL(rng_fill_kernel, dim3(grid_for(K * nt)), dim3(kBlock), 0, s, seed, chain0, K, t0, nt, d,
                        xi, u);
+    return hipGetLastError();
+}
+
+hipError_t ymc_launch_recip(uint64_t n0, uint64_t count, double *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(recip_kernel, dim3(grid_for(count)), dim3(kBlock), 0, s, n0, count, out);
     return hipGetLastError();
 }
 

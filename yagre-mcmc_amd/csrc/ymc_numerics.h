@@ -74,6 +74,25 @@ YMC_FN double ymc_from_bits(uint64_t u)
 }
 
 /* ------------------------------------------------------------------------ */
+/* a / b given y = RN(1/b): Markstein's correction, twice.  q0 = RN(a y) is   */
+/* within 1.5 ulp of a/b; the first step makes it faithful; for a faithful q  */
+/* and a correctly rounded reciprocal  RN(q + (a - b q) y)  IS  RN(a/b)       */
+/* (P. Markstein, IBM J. R&D 34(1), 1990; the final step of the IA-64 divide).*/
+/* Used where many lanes divide by the same b (Welford: b = sample count):    */
+/* 5 fma-class operations instead of the ~14 of an IEEE division sequence.    */
+/* Requires a, b, a/b in the normal range; tests/test_numerics.py checks it   */
+/* against the hardware division on random and near-midpoint quotients.       */
+/* ------------------------------------------------------------------------ */
+YMC_FN double ymc_div_by_recip(double a, double b, double y)
+{
+    double q = a * y;
+    double r = ymc_fma(-q, b, a);
+    q = ymc_fma(r, y, q);
+    r = ymc_fma(-q, b, a);
+    return ymc_fma(r, y, q);
+}
+
+/* ------------------------------------------------------------------------ */
 /* Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as   */
 /* easy as 1, 2, 3", SC'11).  Pinned by the Random123 known-answer vectors  */
 /* in tests/test_numerics.py.                                               */
@@ -246,6 +265,46 @@ YMC_FN double ymc_exp(double x)
     y = (x > 0x1.62e42fefa39efp+9) ? __builtin_inf() : y;
     y = (x < -745.2) ? 0.0 : y;
     return (x == x) ? y : x;                          /* NaN propagates */
+}
+
+/* min(1, exp(d)) for any double d -- the Metropolis acceptance probability    */
+/*   a = exp(log_ratio); a = a if a < 1 else 1        (mrw.py:54-57)           */
+/* Same value as that expression on ymc_exp for every input (NaN and +inf      */
+/* give 1, like the reference's comparison), without the overflow and NaN      */
+/* handling the full-range exp needs: the argument is clamped to <= 0 first.   */
+YMC_FN double ymc_accept_prob(double d)
+{
+    const double inv_ln2 = 0x1.71547652b82fep+0;
+    const double ln2_hi = 0x1.62e42fee00000p-1;
+    const double ln2_lo = 0x1.a39ef35793c76p-33;
+
+    double x = (d < 0.0) ? d : 0.0;                   /* NaN, +inf, d >= 0 -> 0 -> exp = 1 */
+    double xc = (x < -746.0) ? -746.0 : x;
+    double kd = __builtin_rint(xc * inv_ln2);
+    int32_t k = (int32_t)kd;
+    double r = ymc_fma(-kd, ln2_hi, xc);
+    r = ymc_fma(-kd, ln2_lo, r);
+
+    double p = 0x1.6124613a86d09p-33;
+    p = ymc_fma_c(p, r, 0x1.1eed8eff8d898p-29);
+    p = ymc_fma_c(p, r, 0x1.ae64567f544e4p-26);
+    p = ymc_fma_c(p, r, 0x1.27e4fb7789f5cp-22);
+    p = ymc_fma_c(p, r, 0x1.71de3a556c734p-19);
+    p = ymc_fma_c(p, r, 0x1.a01a01a01a01ap-16);
+    p = ymc_fma_c(p, r, 0x1.a01a01a01a01ap-13);
+    p = ymc_fma_c(p, r, 0x1.6c16c16c16c17p-10);
+    p = ymc_fma_c(p, r, 0x1.1111111111111p-7);
+    p = ymc_fma_c(p, r, 0x1.5555555555555p-5);
+    p = ymc_fma_c(p, r, 0x1.5555555555555p-3);
+    p = ymc_fma_c(p, r, 0.5);
+    p = ymc_fma_c(p, r, 1.0);
+    p = ymc_fma_c(p, r, 1.0);
+
+    int32_t k1 = (k < -1021) ? k + 1000 : k;
+    double f2 = (k < -1021) ? 0x1p-1000 : 1.0;
+    double y = ymc_scale2(p, k1) * f2;
+    y = (x < -745.2) ? 0.0 : y;
+    return (y < 1.0) ? y : 1.0;
 }
 
 /* ------------------------------------------------------------------------ */
