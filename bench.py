@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD MI355X data sheet, FP64 matrix (the micro-architecture guide lists no f64 MFMA rate)
 
 
 def parse():
@@ -242,6 +243,25 @@ def main():
         except Exception:
             traffic = None
 
+    if args.workload == "c3":
+        # the forward map is a batched 128 x 128 GEMV on the fp64 matrix cores: 2 d m flop per transition
+        flops = 2.0 * d * d * K * T
+        tf = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+        roofline = {"bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tf / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "kernel_ms_avg": kernel_ms,
+                    "launches_timed": launches, "algorithmic_flops_per_launch": flops,
+                    "algorithmic_bytes_per_launch": launch_bytes, "hbm_gb_per_s": achieved,
+                    "note": "per GPU (rank 0); v_mfma_f64_16x16x4_f64 GEMV (2 d m flop per transition); on gfx950 the "
+                            "f64 MFMA shares the SIMD's fp64 datapath with the VALU, so the 128 normal draws per "
+                            "transition (VALU) add to, rather than hide behind, the matrix time -- DESIGN.md"}
+    else:
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel_ms_avg": kernel_ms,
+                    "launches_timed": launches, "algorithmic_bytes_per_launch": launch_bytes,
+                    "note": "per GPU (rank 0); bytes = (8 d + 1) per transition per chain, traffic = PMC WRITE_SIZE + "
+                            "2 x FETCH_SIZE of the same configuration (profiles/); the kernel is VALU-issue bound "
+                            "(Philox + Box-Muller + exp per transition, one wave per SIMD at 65 536 chains), "
+                            "see DESIGN.md"}
     out = {
         "metric": "MH steps/sec (whole node)", "value": value, "unit": "steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -250,12 +270,7 @@ def main():
                    "transitions_per_step": T, "record": "trajectory f64 [T][K][d] + accept u8 [T][K]"
                    + ("" if args.no_moments else " + Welford moments"), "parallelism": f"chains sharded over {world} GPU(s)",
                    "rng": "Philox4x32-10, seed 20250103, keyed by global chain id"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "kernel_ms_avg": kernel_ms, "launches_timed": launches,
-                     "algorithmic_bytes_per_launch": launch_bytes,
-                     "note": "per GPU (rank 0); bytes = (8 d + 1) per transition per chain; the kernel is fp64-VALU "
-                             "bound (Philox + Box-Muller + exp per transition), see DESIGN.md"},
+        "roofline": roofline,
         "hbm_gb_per_s_whole_node": world * achieved,
         "kernel_steps_per_s_per_gpu": K * T / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0,
         "acceptance_rate": pooled["acceptance_rate"],
