@@ -525,3 +525,32 @@ def test_c4_full_size_lotka_volterra(ffi, ctx, golden):
     e = o.Ensemble(p, sigma, np.tile([[-7.0, 2.8]], (64, 1)), 9)
     out = e.advance(4)
     assert np.array_equal(stiff.trajectory()[:, :64], out["traj"]) and np.array_equal(st[:64], e.status)
+
+
+@pytest.mark.parametrize("rows", ["0", "1"])
+def test_lotka_volterra_row_parallel_variant(ffi, ctx, golden, monkeypatch, rows):
+    """One lane per chain vs one lane per (chain, design row): a speed choice, same bits."""
+    monkeypatch.setenv("YMC_LV_ROWS", rows)
+    g = golden("f4_lotka_volterra.npz")
+    n = int(g["n_states"])
+    low = _posterior_low(ffi, ffi.POSTERIOR_LV, 2, g, design=np.asarray(g["design"]), t_final=float(g["t_final"]),
+                         alpha=float(g["alpha"]), gamma=float(g["gamma"]), rk4_steps=int(g["rk4_steps"]))
+    dev = _device_run(ffi, ctx, low, g["sigma"], g["x0"], int(g["seed"]), n - 1, splits=2)
+    p = o.posterior_lv(g["design"], float(g["t_final"]), float(g["alpha"]), float(g["gamma"]), int(g["rk4_steps"]),
+                       g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+    e = o.Ensemble(p, g["sigma"], g["x0"], int(g["seed"]))
+    _same_as_oracle(dev, e, e.advance(n - 1))
+    _same_as_reference(dev, g)
+    # 10 rows, a chain count that leaves idle lanes and a ragged last wave; stiff start => flagged chains
+    rng = np.random.default_rng(8)
+    design = rng.uniform(0.5, 1.5, size=(10, 2))
+    base = dict(noise_precision=np.array([25.0, 20.0]), prior_mean=np.array([0.1, -0.2]), prior_precision=np.array([0.7, 0.9]))
+    data = rng.uniform(0.2, 2.0, size=(10, 2))
+    p = o.posterior_lv(design, 10.0, 0.8, 0.4, 50, data, **base)
+    low = _posterior_low(ffi, ffi.POSTERIOR_LV, 2, dict(base, data=data), design=design, t_final=10.0, alpha=0.8,
+                         gamma=0.4, rk4_steps=50)
+    x0 = np.concatenate([np.tile([[-0.6, -0.3]], (100, 1)), np.tile([[-7.0, 2.8]], (31, 1))])
+    sigma = np.array([0.4, 0.3])
+    dev = _device_run(ffi, ctx, low, sigma, x0, 3, 25, chain0=99)
+    e = o.Ensemble(p, sigma, x0, 3, chain0=99)
+    _same_as_oracle(dev, e, e.advance(25))

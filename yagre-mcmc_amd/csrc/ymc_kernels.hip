@@ -193,6 +193,113 @@ __global__ __launch_bounds__(kBlock) void mlda2_kernel(const ChainArgs<D> a)
     }
 }
 
+/*
+ * Lotka-Volterra posterior for SMALL ensembles (BASELINE configs[3]: 16 384
+ * chains per GPU = a quarter of a wave per SIMD with one lane per chain).  The
+ * likelihood is n_data independent ODE solves (testSetup.py:118-141), so a chain
+ * is spread over G = n_data lanes: lane r integrates design row r, the row
+ * norms are gathered in row order (the canonical sequential sum), and every
+ * lane of the group repeats the cheap rest (draws, prior, accept) so that no
+ * broadcast is needed.  64 / G chains per wave.  Same bits as mrw_kernel.
+ */
+template <unsigned REC>
+__global__ __launch_bounds__(kBlock) void mrw_lv_rows_kernel(const ChainArgs<2> a)
+{
+    constexpr int D = 2;
+    using R = Rec<REC>;
+    const DensityDev<2> &p = a.tgt;
+    const int G = p.n_data;
+    const int cpw = 64 / G;                                  /* chains per wave */
+    const int lane = threadIdx.x & 63;
+    const int slot = lane / G, row = lane - slot * G;
+    const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const uint64_t k = wave * cpw + slot;
+    const bool live = slot < cpw && k < a.K;
+    const uint64_t kk = live ? k : 0;                        /* idle lanes shadow chain 0 and never store */
+    const uint32_t chain = (uint32_t)(a.chain0 + kk);
+    const int base = slot * G;
+
+    double x[D], wmean[D], wm2[D], sigma[D] = {a.sigma[0], a.sigma[1]};
+    ymc_load_row<D>(a.x, kk, x);
+    double lp = a.lp[kk];
+    uint64_t accepted = a.acc_count[kk];
+    uint32_t st = a.status[kk];
+    const bool moments = R::moments(a);
+    wmean[0] = wmean[1] = wm2[0] = wm2[1] = 0.0;
+    if (moments) {
+        ymc_load_row<D>(a.wf_mean, kk, wmean);
+        ymc_load_row<D>(a.wf_m2, kk, wm2);
+    }
+    const double alpha = p.alpha, gamma = p.gamma;
+    const double h = p.t_final / (double)p.rk4_steps, h2 = 0.5 * h, h6 = h / 6.0;
+    const int myrow = (slot < cpw) ? row : 0;
+    const double dx0 = p.design[2 * myrow], dy0 = p.design[2 * myrow + 1];
+    const double obs0 = p.data[2 * myrow], obs1 = p.data[2 * myrow + 1];
+    UniformCache uc;
+    uc.valid = false;
+    uc.pair = 0;
+
+#pragma unroll 1
+    for (uint32_t n = 0; n < a.nsteps; ++n) {
+        const uint64_t t = a.t0 + n;
+        double y[D];
+        ymc_propose<D>(x, sigma, a.seed, chain, t, y);
+        const double u = ymc_uniform_cached(uc, a.seed, chain, t);
+        const bool moved = !ymc_states_equal<D>(y, x, YMC_EQ_EXACT);
+        /* this lane's ODE solve (Density<POSTERIOR_LV>::eval, one design row) */
+        const double beta = ymc_exp(y[0]), delta = ymc_exp(y[1]);
+        double sx = dx0, sy = dy0;
+        for (int s = 0; s < p.rk4_steps; ++s) {
+            double k1x, k1y, k2x, k2y, k3x, k3y, k4x, k4y;
+            ymc_lv_flow(sx, sy, alpha, beta, gamma, delta, k1x, k1y);
+            ymc_lv_flow(sx + h2 * k1x, sy + h2 * k1y, alpha, beta, gamma, delta, k2x, k2y);
+            ymc_lv_flow(sx + h2 * k2x, sy + h2 * k2y, alpha, beta, gamma, delta, k3x, k3y);
+            ymc_lv_flow(sx + h * k3x, sy + h * k3y, alpha, beta, gamma, delta, k4x, k4y);
+            sx = sx + h6 * ((k1x + 2.0 * k2x) + (2.0 * k3x + k4x));
+            sy = sy + h6 * ((k1y + 2.0 * k2y) + (2.0 * k3y + k4y));
+        }
+        const int bad_l = (!ymc_finite(sx) || !ymc_finite(sy)) ? 1 : 0;
+        const double res[2] = {sx - obs0, sy - obs1};
+        const double term = ymc_diag_norm_sq<2>(res, p.noise_prec, 2);
+        /* gather the rows in order: total = ((t_0) + t_1) + ... (likelihood.py:80) */
+        double total = 0.0;
+        int bad = 0;
+        for (int i = 0; i < G; ++i) {
+            const uint64_t b = ymc_bits(term);
+            const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)b, base + i, 64);
+            const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(b >> 32), base + i, 64);
+            total = total + ymc_from_bits(((uint64_t)hi << 32) | lo);
+            bad |= __shfl(bad_l, base + i, 64);
+        }
+        double lpy = -0.5 * total + ymc_prior_log<D>(p, y);
+        if (bad) {
+            st |= YMC_CHAIN_NONFINITE;
+            lpy = -__builtin_inf();
+        }
+        const bool acc = ymc_accept(lpy - lp, moved, ymc_finite(lpy), u, st);
+        if (moments) ymc_welford<D>(x, (double)(a.wf_n0 + n + 1), a.recip[n], wmean, wm2);
+#pragma unroll
+        for (int j = 0; j < D; ++j) x[j] = acc ? y[j] : x[j];
+        lp = acc ? lpy : lp;
+        accepted += acc ? 1u : 0u;
+        if (live && row == 0) {
+            if (R::traj(a)) ymc_store_row<D>(a.traj + (uint64_t)n * a.K * D, k, x);
+            if (R::acc(a)) a.acc[(uint64_t)n * a.K + k] = acc ? 1 : 0;
+            if (R::lp(a)) a.lp_out[(uint64_t)n * a.K + k] = lp;
+        }
+    }
+    if (live && row == 0) {
+        ymc_store_row<D>(a.x, k, x);
+        a.lp[k] = lp;
+        a.acc_count[k] = accepted;
+        a.status[k] = st;
+        if (moments) {
+            ymc_store_row<D>(a.wf_mean, k, wmean);
+            ymc_store_row<D>(a.wf_m2, k, wm2);
+        }
+    }
+}
+
 /* DensityInterface.evaluate_log for a batch of parameters */
 template <int KIND, int D>
 __global__ __launch_bounds__(kBlock) void logdensity_kernel(const DensityDev<D> p, uint64_t n,
@@ -363,7 +470,17 @@ hipError_t ymc_launch_chain(int kind, int method, const ChainArgs<D> &a, hipStre
         return hipErrorInvalidValue;
     case YMC_DENSITY_POSTERIOR_LINEAR: return launch_chain<YMC_DENSITY_POSTERIOR_LINEAR, D>(method, a, s);
     case YMC_DENSITY_POSTERIOR_LV:
-        if constexpr (D == 2) return launch_chain<YMC_DENSITY_POSTERIOR_LV, 2>(method, a, s);
+        if constexpr (D == 2) {
+            if (method == YMC_METHOD_MRW && a.eq_mode == YMC_EQ_EXACT && a.lv_rows) {
+                /* small ensemble: n_data lanes per chain */
+                const int cpw = 64 / a.tgt.n_data;
+                const uint64_t waves = (a.K + cpw - 1) / cpw;
+                hipLaunchKernelGGL((mrw_lv_rows_kernel<kRuntimeRec>), dim3((unsigned)((waves * 64 + kBlock - 1) / kBlock)),
+                                   dim3(kBlock), 0, s, a);
+                return hipGetLastError();
+            }
+            return launch_chain<YMC_DENSITY_POSTERIOR_LV, 2>(method, a, s);
+        }
         return hipErrorInvalidValue;
     default: return hipErrorInvalidValue;
     }
