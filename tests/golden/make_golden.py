@@ -416,8 +416,56 @@ def fixture_f4():
           "LSODA vs DOP853:", np.abs(f_ref - f_tight).max())
 
 
+def fixture_f7():
+    """Two-level delayed acceptance over a model hierarchy: the shipped linear example
+    (example_inference_linearModel_twoLevel.py:24-177, vanilla MLDA, sub-chain length 5)."""
+    from numpy.random import seed as np_seed, standard_normal
+    from yagremcmc.statistics.modelHierarchy import BayesianRegressionModelHierarchy
+    from yagremcmc.utility.hierarchy import Hierarchy, SharedComponent
+    np_seed(2222)
+    A_t, b_t = np.array([[1.4, -0.2], [-0.6, 0.7]]), np.zeros(2)
+    A_s, b_s = A_t + np.array([[-0.6, -0.2], [0.4, 1.1]]), np.array([0.5, -0.9])
+    true = np.array([1.5, 0.5])
+    sd = np.sqrt(0.3)
+    data = np.array([A_t @ true + b_t + sd * standard_normal(2) for _ in range(5)])
+    prior_mean = true + np.array([-0.2, 0.4])
+    prior = Gaussian(ParameterVector(prior_mean.copy()), IIDCovarianceMatrix(2, 5.0))
+    noise = CentredGaussianNoise(IIDCovarianceMatrix(2, sd ** 2))
+    lik_s = AdditiveGaussianNoiseLikelihood(Data(data), ForwardModel(ExampleLinearModelSolver(A_s, b_s)), noise)
+    lik_t = AdditiveGaussianNoiseLikelihood(Data(data), ForwardModel(ExampleLinearModelSolver(A_t, b_t)), noise)
+    model = BayesianRegressionModelHierarchy(Hierarchy([lik_s, lik_t]), SharedComponent(prior, 2))
+    seed, K, n, S = 20250109, 32, 600, 5
+    cov = IIDCovarianceMatrix(2, 0.5)
+    x0 = np.zeros(2)
+    traj = np.empty((n, K, 2))
+    acc = np.empty((n - 1, K), dtype=np.uint8)
+    sub = np.empty((n - 1, S, K), dtype=np.uint8)
+    lp = np.empty((n, K))
+    for k in range(K):
+        b = MLDABuilder()
+        b.baseProposalCovariance = cov
+        b.subChainLengths = [S]
+        b.bayesModel = model
+        b.surrogateDiagnostics = [AcceptanceRateDiagnostics()]
+        mc = b.build_method()
+        rp = Replay(seed, k, 2, (n - 1) * (S + 1), sub_chain_length=S)
+        rp.install()
+        mark_fine_level(mc, rp)
+        mc.run(n, ParameterVector(x0.copy()), verbose=False)
+        traj[:, k, :] = np.array(mc.chain.trajectory)
+        acc[:, k] = mc.diagnostics._decisions
+        sub[:, :, k] = np.array(mc.surrogate(0).diagnostics._decisions, dtype=np.uint8).reshape(n - 1, S)
+        lp[:, k] = eval_log_along(mc.target, traj[:, k, :], lambda s: ParameterVector(np.array(s)))
+    np.savez_compressed(
+        os.path.join(HERE, "f7_mlda2_linear_models.npz"), seed=seed, n_states=n, S=S, A_fine=A_t, b_fine=b_t,
+        A_coarse=A_s, b_coarse=b_s, data=data, noise_precision=np.reciprocal(np.full(2, sd ** 2)),
+        prior_mean=prior_mean, prior_precision=np.reciprocal(np.full(2, 5.0)), sigma=sigma_of(cov),
+        x0=np.zeros((K, 2)), traj=traj, acc=acc, sub_acc=sub, logpost=lp)
+    print("F7", acc.mean(), sub.mean())
+
+
 def main():
-    which = sys.argv[1:] or ["f1", "f2", "f2b", "f3", "f3b", "f4", "f5"]
+    which = sys.argv[1:] or ["f1", "f2", "f2b", "f3", "f3b", "f4", "f5", "f7"]
     if "f1" in which:
         fixture_f1()
     if "f2" in which:
@@ -435,6 +483,8 @@ def main():
         fixture_f4()
     if "f5" in which:
         fixture_f5()
+    if "f7" in which:
+        fixture_f7()
 
 
 if __name__ == "__main__":

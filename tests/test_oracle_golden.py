@@ -146,3 +146,16 @@ def test_sharding_by_global_chain_id(golden):
     lo = o.Ensemble(p, g["sigma"], g["x0"][:40], 5, chain0=0).advance(100)
     hi = o.Ensemble(p, g["sigma"], g["x0"][40:], 5, chain0=40).advance(100)
     assert np.array_equal(np.concatenate([lo["traj"], hi["traj"]], axis=1), whole["traj"])
+
+
+def test_f7_two_level_over_a_model_hierarchy(golden):
+    """example_inference_linearModel_twoLevel.py: vanilla MLDA over [surrogate, target] linear models"""
+    g = golden("f7_mlda2_linear_models.npz")
+    n, S = int(g["n_states"]), int(g["S"])
+    common = (g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+    fine = o.posterior_linear(g["A_fine"], g["b_fine"], *common)
+    coarse = o.posterior_linear(g["A_coarse"], g["b_coarse"], *common)
+    e = o.Ensemble(fine, g["sigma"], g["x0"], int(g["seed"]), surrogate=coarse, sub_chain_length=S)
+    out = e.advance(n - 1, want_sub=True)
+    _check(out, g, n)
+    assert np.array_equal(out["sub_acc"], g["sub_acc"])

@@ -184,8 +184,17 @@ class MLDABuilder(ChainBuilder):
         if self._nSteps is None:
             raise ValueError("Subchain lengths not set for MLDA")
         if self._bayesModel is not None:
-            raise UnsupportedPlugin("MLDA over a hierarchy of Bayesian models is not lowered to the device yet; "
-                                    "use explicit targets")
+            # mlda.py:228-249
+            if not (hasattr(self._bayesModel, "level") and hasattr(self._bayesModel, "size")):
+                raise ValueError("MLDA requires a hierarchy of models.")
+            if self._surrTgts is not None:
+                raise ValueError("Cannot set explicit surrogate targets for a hierarchy of Bayesian models.")
+            if not len(self._nSteps) == self._bayesModel.size - 1:
+                raise ValueError("Number of sub-chain lengths does not match the size of the model hierarchy.")
+            if self._surrDgnstList is not None and not len(self._surrDgnstList) == self._bayesModel.size - 1:
+                raise ValueError("Number of diagnostics does not match the size of the model hierarchy")
+            if self._biasCorrection is not None:
+                raise UnsupportedPlugin("bias correction has no device lowering")
         if self._explicitTarget is not None:
             if self._surrTgts is None:
                 raise ValueError("Surrogate targets not set for MLDA")
@@ -197,7 +206,16 @@ class MLDABuilder(ChainBuilder):
                 raise UnsupportedPlugin("bias correction has no device lowering")
 
     def build_from_model(self):
-        raise UnsupportedPlugin("MLDA over a hierarchy of Bayesian models is not lowered to the device yet")
+        """mlda.py:315-335: the finest level is the target, the coarser ones are the surrogates
+        (one surrogate level on the device)."""
+        self._validate_parameters()
+        model = self._bayesModel
+        target = UnnormalisedPosterior(model.level(-1).likelihood, model.level(-1).prior)
+        surrogates = [UnnormalisedPosterior(model.level(k).likelihood, model.level(k).prior)
+                      for k in range(model.size - 1)]
+        tgt_diag = self._tgtDgnst if self._tgtDgnst is not None else dg.AcceptanceRateDiagnostics()
+        return MLDA(target, surrogates, self._basePropCov, list(self._nSteps), tgt_diag, self._surrDgnstList,
+                    recordSubChain=self.recordSubChain, **self._ensemble_options())
 
     def build_from_target(self):
         tgt_diag = self._tgtDgnst if self._tgtDgnst is not None else dg.AcceptanceRateDiagnostics()

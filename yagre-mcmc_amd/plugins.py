@@ -391,6 +391,63 @@ class BayesianRegressionModel:
         return self._likelihood
 
 
+class HierarchyBase:
+    """utility/hierarchy.py:5-31"""
+
+    def __init__(self, nLevels):
+        if nLevels < 1:
+            raise ValueError(f"Trying to set up hierarchy with {nLevels} levels.")
+        self._nLevels = nLevels
+
+    @property
+    def size(self):
+        return self._nLevels
+
+    def validate_level_index(self, idx):
+        if idx < -1 or self._nLevels <= idx:
+            raise ValueError(f"invalid level index. Trying to access level {idx} in a hierarchy of "
+                             f"{self._nLevels} levels.")
+
+
+class SharedComponent(HierarchyBase):
+    """utility/hierarchy.py:34-46: the same component at every level"""
+
+    def __init__(self, sharedComponent, nLevels):
+        super().__init__(nLevels)
+        self._sharedComponent = sharedComponent
+
+    def level(self, lvlIdx):
+        self.validate_level_index(lvlIdx)
+        return self._sharedComponent
+
+
+class Hierarchy(HierarchyBase):
+    """utility/hierarchy.py:49-63: one component per level, coarsest first"""
+
+    def __init__(self, hierarchy):
+        super().__init__(len(hierarchy))
+        self._hierarchy = list(hierarchy)
+
+    def level(self, lvlIdx):
+        self.validate_level_index(lvlIdx)
+        return self._hierarchy[lvlIdx]
+
+
+class BayesianRegressionModelHierarchy(Hierarchy):
+    """statistics/modelHierarchy.py:6-53"""
+
+    def __init__(self, likelihood, prior):
+        for name, inst in (("prior", prior), ("likelihood", likelihood)):
+            if not (isinstance(inst, HierarchyBase) or (hasattr(inst, "level") and hasattr(inst, "size"))):
+                raise ValueError(f"Argument '{name}' must be derived from the Hierarchy base class. "
+                                 f"Received type: {type(inst).__name__}.")
+        if prior.size != likelihood.size:
+            raise ValueError("Hierarchies have mismatched sizes. The following mismatches were found:\n"
+                             f" - prior: size {prior.size}\n - likelihood: size {likelihood.size}")
+        super().__init__([BayesianRegressionModel(likelihood.level(ell), prior.level(ell))
+                          for ell in range(likelihood.size)])
+
+
 class UnnormalisedPosterior(_DeviceDensity):
     """chain/target.py:4-22: log-likelihood + log prior density."""
 
