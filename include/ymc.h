@@ -74,12 +74,13 @@ typedef struct ymc_density_desc {
     double alpha;
     double gamma;
     int32_t rk4_steps;
-    int32_t reserved_;
+    int32_t likelihood_only;       /* POSTERIOR_*: 1 = the likelihood alone (the target of pCN, pcn.py:77-78) */
 } ymc_density_desc;
 
 typedef enum ymc_method {
     YMC_METHOD_MRW = 1,   /* MetropolisedRandomWalk, chain/method/mrw.py:41-57 */
-    YMC_METHOD_MLDA2 = 2  /* MLDA with one surrogate, chain/method/mlda.py:100-110,146-154 */
+    YMC_METHOD_MLDA2 = 2, /* MLDA with one surrogate, chain/method/mlda.py:100-110,146-154 */
+    YMC_METHOD_PCN = 3    /* PreconditionedCrankNicolson, chain/method/pcn.py:9-57 */
 } ymc_method;
 
 typedef enum ymc_state_eq {
@@ -96,7 +97,10 @@ typedef struct ymc_problem_desc {
     ymc_density_desc surrogate;    /* MLDA2: the coarse density (same kind and dim) */
     int32_t sub_chain_length;      /* MLDA2: subChainLengths[0] */
     int32_t reserved_;
-    const double *proposal_sigma;  /* [d]: sqrt(reciprocal(precision)) of the proposal covariance (covariance.py:51-52) */
+    /* [d]: sqrt(reciprocal(precision)) of the proposal covariance (covariance.py:51-52);
+     * PCN: of the PRIOR covariance (the proposal draws from the prior, pcn.py:29) */
+    const double *proposal_sigma;
+    double pcn_step_size;          /* PCN: stepSize h, 0 < h <= 0.5 (pcn.py:42) */
 } ymc_problem_desc;
 
 /* record_flags */

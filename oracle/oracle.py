@@ -33,7 +33,7 @@ class _Density(C.Structure):
         ("data", _dp), ("noise_precision", _dp), ("prior_mean", _dp), ("prior_precision", _dp),
         ("fwd_matrix", _dp), ("fwd_shift", _dp),
         ("design", _dp), ("t_final", C.c_double), ("alpha", C.c_double), ("gamma", C.c_double),
-        ("rk4_steps", C.c_int32),
+        ("rk4_steps", C.c_int32), ("likelihood_only", C.c_int32),
     ]
 
 
@@ -137,7 +137,7 @@ def _lower(p):
     for name in ("log_norm", "variance", "t_final", "alpha", "gamma"):
         if name in p:
             setattr(d, name, p[name])
-    for name in ("n_data", "data_dim", "rk4_steps"):
+    for name in ("n_data", "data_dim", "rk4_steps", "likelihood_only"):
         if name in p:
             setattr(d, name, p[name])
     return d, keep
@@ -229,7 +229,10 @@ class Ensemble:
     """K chains advanced by the oracle; mirrors the state a device run carries."""
 
     def __init__(self, target, sigma, x0, seed, chain0=0, eq_mode=EQ_EXACT, surrogate=None,
-                 sub_chain_length=0, nthreads=1):
+                 sub_chain_length=0, nthreads=1, pcn_step_size=None):
+        """`pcn_step_size`: run preconditioned Crank-Nicolson instead of the random walk; `target`
+        must then carry likelihood_only=1 and `sigma` is the PRIOR's standard deviation."""
+        self.pcn_step_size = pcn_step_size
         self.target, self.surrogate = target, surrogate
         self.S = int(sub_chain_length)
         self.d = target["dim"]
@@ -266,7 +269,13 @@ class Ensemble:
         margin = np.empty((nsteps, K)) if want_margin else None
         tgt, keep = _lower(self.target)
         out = dict(traj=traj, acc=acc, logpost=lp_out, margin=margin)
-        if self.surrogate is None:
+        if self.pcn_step_size is not None:
+            lib().ymo_pcn_advance(
+                C.byref(tgt), _ptr(self.sigma), C.c_double(self.pcn_step_size), C.c_int32(self.eq_mode),
+                C.c_uint64(self.seed), C.c_uint64(self.chain0), C.c_int64(K), C.c_uint64(self.t), C.c_int64(nsteps),
+                _ptr(self.x), _ptr(self.lp), _vp(self.acc_count), _vp(self.wf_n), _ptr(self.wf_mean),
+                _ptr(self.wf_m2), _vp(self.status), _ptr(traj), _vp(acc), _ptr(lp_out), C.c_int32(self.nthreads))
+        elif self.surrogate is None:
             lib().ymo_mrw_advance(
                 C.byref(tgt), _ptr(self.sigma), C.c_int32(self.eq_mode), C.c_uint64(self.seed),
                 C.c_uint64(self.chain0), C.c_int64(K), C.c_uint64(self.t), C.c_int64(nsteps),

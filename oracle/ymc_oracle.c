@@ -72,6 +72,7 @@ typedef struct ymo_density {
     const double *design;          /* n_data x 2 initial conditions */
     double t_final, alpha, gamma;
     int32_t rk4_steps;
+    int32_t likelihood_only;       /* 1: evaluate the likelihood alone (the target of pCN, pcn.py:77-78) */
 } ymo_density;
 
 /* ---------------------------------------------------------------------- */
@@ -273,6 +274,7 @@ static double ymo_logdensity_one(const ymo_density *p, const double *x, uint32_t
         /* UnnormalisedPosterior.evaluate_log, target.py:19-22: logL + log prior */
         double F[YMO_MMAX];
         ymo_forward_linear(p, x, F);
+        if (p->likelihood_only) return ymo_log_likelihood(p, F, 0);
         return ymo_log_likelihood(p, F, 0) + ymo_gaussian_prior_log(p, x);
     }
     case YMO_POST_LV: {
@@ -283,6 +285,7 @@ static double ymo_logdensity_one(const ymo_density *p, const double *x, uint32_t
             if (status) *status |= YMO_STATUS_NONFINITE;
             return -INFINITY;
         }
+        if (p->likelihood_only) return ymo_log_likelihood(p, F, 1);
         return ymo_log_likelihood(p, F, 1) + ymo_gaussian_prior_log(p, x);
     }
     default:
@@ -452,6 +455,76 @@ void ymo_mrw_advance(const ymo_density *tgt, const double *sigma, int32_t eq_mod
                 if (acc) acc[n * K + k] = (uint8_t)accepted;
                 if (lp_out) lp_out[n * K + k] = lp[k];
                 if (margin) margin[n * K + k] = mg;
+            }
+        }
+    }
+}
+
+/* PCNProposal.generate_proposal, pcn.py:23-36.  The prior's realisation is
+ * mean + sigma_prior * z (Gaussian.generate_realisation, gaussian.py:61-66) and
+ *   y = sqrt(1 - 2h) * x + sqrt(2h) * xi        (pcn.py:32-36)
+ * c1 = sqrt(1 - 2h), c2 = sqrt(2h) are formed by the caller as NumPy does. */
+static void ymo_propose_pcn(const double *x, const double *prior_sigma, const double *prior_mean, double c1,
+                            double c2, uint64_t seed, uint32_t chain, uint64_t t, int32_t d, double *y)
+{
+    for (int32_t j = 0; 2 * j < d; ++j) {
+        double z0, z1;
+        ymc_draw_normal_pair(seed, chain, t, (uint32_t)j, &z0, &z1);
+        double xi0 = prior_mean[2 * j] + prior_sigma[2 * j] * z0;
+        y[2 * j] = c1 * x[2 * j] + c2 * xi0;
+        if (2 * j + 1 < d) {
+            double xi1 = prior_mean[2 * j + 1] + prior_sigma[2 * j + 1] * z1;
+            y[2 * j + 1] = c1 * x[2 * j + 1] + c2 * xi1;
+        }
+    }
+}
+
+/*
+ * PreconditionedCrankNicolson (pcn.py:38-57) for K chains: the loop of
+ * metropolisHastings.py:103-120 with the pCN proposal and the LIKELIHOOD as
+ * target (PCNBuilder.build_from_model, pcn.py:75-78: `tgt` has likelihood_only
+ * set; its prior fields describe the Gaussian prior the proposal draws from).
+ * Arguments as ymo_mrw_advance; prior_sigma = sqrt(reciprocal(prior precision)).
+ */
+void ymo_pcn_advance(const ymo_density *tgt, const double *prior_sigma, double step_size, int32_t eq_mode,
+                     uint64_t seed, uint64_t chain0, int64_t K, uint64_t t0, int64_t nsteps, double *x, double *lp,
+                     uint64_t *acc_count, uint64_t *wf_n, double *wf_mean, double *wf_m2, uint32_t *status,
+                     double *traj, uint8_t *acc, double *lp_out, int32_t nthreads)
+{
+    int32_t d = tgt->dim;
+    const double t2 = 2.0 * step_size;
+    const double c1 = sqrt(1.0 - t2), c2 = sqrt(t2);
+    const int64_t block = ymo_block_size(d);
+    const int64_t nblocks = (K + block - 1) / block;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(dynamic, 1)
+#endif
+    for (int64_t kb = 0; kb < nblocks; ++kb) {
+        const int64_t k_lo = kb * block, k_hi = (k_lo + block < K) ? k_lo + block : K;
+        double y[YMO_DMAX];
+        for (int64_t n = 0; n < nsteps; ++n) {
+            uint64_t t = t0 + (uint64_t)n;
+            for (int64_t k = k_lo; k < k_hi; ++k) {
+                uint32_t chain = (uint32_t)(chain0 + (uint64_t)k);
+                double *xs = x + k * d;
+                uint32_t st = status ? status[k] : 0;
+                ymo_propose_pcn(xs, prior_sigma, tgt->prior_mean, c1, c2, seed, chain, t, d, y);
+                int accepted = 0;
+                double lpy = lp[k];
+                if (!ymo_states_equal(y, xs, d, eq_mode)) {          /* metropolisHastings.py:60-61 */
+                    lpy = ymo_logdensity_one(tgt, y, &st);
+                    accepted = ymo_accept(lpy - lp[k], ymo_is_finite(lpy), seed, chain, t, &st, NULL); /* pcn.py:51-57 */
+                }
+                if (wf_n) ymo_welford(xs, d, &wf_n[k], wf_mean + k * d, wf_m2 + k * d);
+                if (accepted) {
+                    memcpy(xs, y, sizeof(double) * (size_t)d);
+                    lp[k] = lpy;
+                    if (acc_count) acc_count[k] += 1;
+                }
+                if (status) status[k] = st;
+                if (traj) memcpy(traj + (n * K + k) * d, xs, sizeof(double) * (size_t)d);
+                if (acc) acc[n * K + k] = (uint8_t)accepted;
+                if (lp_out) lp_out[n * K + k] = lp[k];
             }
         }
     }

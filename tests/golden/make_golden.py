@@ -464,8 +464,45 @@ def fixture_f7():
     print("F7", acc.mean(), sub.mean())
 
 
+def fixture_f8():
+    """Preconditioned Crank-Nicolson on the Lotka-Volterra model (test_inference_mcmc_singleLevel.py:121-148
+    wiring, the build's RK4 as the solver plug-in, centred prior) and on the 2x2 linear model."""
+    from yagremcmc.chain.method.pcn import PCNBuilder
+    g4 = np.load(os.path.join(HERE, "f4_lotka_volterra.npz"))
+    problem = oracle.posterior_lv(g4["design"], float(g4["t_final"]), float(g4["alpha"]), float(g4["gamma"]), 50,
+                                  g4["data"], g4["noise_precision"], g4["prior_mean"], g4["prior_precision"])
+    like = AdditiveGaussianNoiseLikelihood(
+        Data(g4["data"]), ForwardModel(RK4LotkaVolterraSolver(problem)),
+        CentredGaussianNoise(IIDCovarianceMatrix(2, 0.05)))
+    prior_cov = DiagonalCovarianceMatrix(np.array([0.02, 0.05]))
+    prior = Gaussian(LotkaVolterraParameter.from_coefficient(np.zeros(2)), prior_cov)
+    model = BayesianRegressionModel(like, prior)
+    seed, K, n, h = 20250110, 16, 400, 0.01
+    x0 = np.array([-0.6, -0.3])
+    traj = np.empty((n, K, 2))
+    acc = np.empty((n - 1, K), dtype=np.uint8)
+    lp = np.empty((n, K))
+    for k in range(K):
+        b = PCNBuilder()
+        b.stepSize = h
+        b.bayesModel = model
+        mc = b.build_method()
+        rp = Replay(seed, k, 2, n - 1)
+        rp.install()
+        mc.run(n, LotkaVolterraParameter.from_coefficient(x0.copy()), verbose=False)
+        traj[:, k, :] = np.array(mc.chain.trajectory)
+        acc[:, k] = mc.diagnostics._decisions
+        lp[:, k] = eval_log_along(mc.target, traj[:, k, :], lambda s: LotkaVolterraParameter.from_coefficient(np.array(s)))
+    np.savez_compressed(
+        os.path.join(HERE, "f8_pcn_lotka_volterra.npz"), seed=seed, n_states=n, step_size=h, design=g4["design"],
+        t_final=g4["t_final"], alpha=g4["alpha"], gamma=g4["gamma"], rk4_steps=50, data=g4["data"],
+        noise_precision=np.reciprocal(np.full(2, 0.05)), prior_mean=np.zeros(2), prior_precision=prior_cov._precision,
+        prior_sigma=sigma_of(prior_cov), x0=np.tile(x0, (K, 1)), traj=traj, acc=acc, loglik=lp)
+    print("F8", acc.mean())
+
+
 def main():
-    which = sys.argv[1:] or ["f1", "f2", "f2b", "f3", "f3b", "f4", "f5", "f7"]
+    which = sys.argv[1:] or ["f1", "f2", "f2b", "f3", "f3b", "f4", "f5", "f7", "f8"]
     if "f1" in which:
         fixture_f1()
     if "f2" in which:
@@ -485,6 +522,8 @@ def main():
         fixture_f5()
     if "f7" in which:
         fixture_f7()
+    if "f8" in which:
+        fixture_f8()
 
 
 if __name__ == "__main__":

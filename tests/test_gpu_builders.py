@@ -241,3 +241,57 @@ def test_two_level_over_a_model_hierarchy_f7(golden):
         b2.baseProposalCovariance, b2.subChainLengths = IIDCovarianceMatrix(2, 0.5), [3, 3]
         b2.bayesModel = b.bayesModel
         b2.build_method()
+
+
+def test_pcn_builder_f8(golden):
+    """PCNBuilder (pcn.py:60-88; test_inference_mcmc_singleLevel.py:121-148): device chains == the live
+    reference's; the sampler's target is the likelihood; builder errors as in the reference."""
+    import yagremcmc_amd.test.testSetup as setup
+    from yagremcmc_amd.chain.method.pcn import PCNBuilder
+    from yagremcmc_amd.model.forwardModel import ForwardModel
+    from yagremcmc_amd.statistics.bayesModel import BayesianRegressionModel
+    from yagremcmc_amd.statistics.covariance import DiagonalCovarianceMatrix, IIDCovarianceMatrix
+    from yagremcmc_amd.statistics.data import Data
+    from yagremcmc_amd.statistics.gaussian import Gaussian
+    from yagremcmc_amd.statistics.likelihood import AdditiveGaussianNoiseLikelihood
+    from yagremcmc_amd.statistics.noise import CentredGaussianNoise
+    g = golden("f8_pcn_lotka_volterra.npz")
+    n, K = int(g["n_states"]), g["x0"].shape[0]
+    cfg = {'T': float(g["t_final"]), 'alpha': float(g["alpha"]), 'gamma': float(g["gamma"]), 'nData': 5, 'dataDim': 2}
+    solver = setup.LotkaVolterraSolver(np.asarray(g["design"]), cfg)
+    like = AdditiveGaussianNoiseLikelihood(Data(np.asarray(g["data"])), ForwardModel(solver),
+                                           CentredGaussianNoise(IIDCovarianceMatrix(2, 0.05)))
+    prior = Gaussian(setup.LotkaVolterraParameter.from_coefficient(np.zeros(2)),
+                     DiagonalCovarianceMatrix(np.array([0.02, 0.05])))
+    assert np.array_equal(prior.covariance._precision, g["prior_precision"])
+    b = PCNBuilder()
+    with pytest.raises(ValueError, match="Step size not set in PCN."):
+        b.bayesModel = BayesianRegressionModel(like, prior)
+        b.build_method()
+    b.stepSize = float(g["step_size"])
+    b.nChains, b.seed, b.recordLogPosterior = K, int(g["seed"]), True
+    mc = b.build_method()
+    assert mc.target is like
+    mc.run(n, setup.LotkaVolterraParameter.from_coefficient(np.array([-0.6, -0.3])), verbose=False)
+    assert np.array_equal(mc.chain.trajectory, g["traj"])
+    assert np.array_equal(mc.accept_decisions, g["acc"])
+    assert np.abs(mc.log_posterior - g["loglik"]).max() <= 1e-12 * np.abs(g["loglik"]).max()
+    # and bit-exact against the oracle including diagnostics
+    p = o.posterior_lv(g["design"], cfg['T'], cfg['alpha'], cfg['gamma'], 50, g["data"], g["noise_precision"],
+                       g["prior_mean"], g["prior_precision"])
+    p["likelihood_only"] = 1
+    e = o.Ensemble(p, g["prior_sigma"], g["x0"], int(g["seed"]), pcn_step_size=float(g["step_size"]))
+    out = e.advance(n - 1)
+    assert np.array_equal(mc.log_posterior[1:], out["logpost"])
+    # likelihood.evaluate_log on the device == the recorded value
+    got = like.evaluate_log(setup.LotkaVolterraParameter.from_coefficient(mc.chain.trajectory[100, 3].copy()))
+    assert got == mc.log_posterior[100, 3]
+    b2 = PCNBuilder()
+    b2.stepSize, b2.explicitTarget = 0.01, object()
+    with pytest.raises(RuntimeError):
+        b2.build_method()
+    off = Gaussian(setup.LotkaVolterraParameter.from_coefficient(np.array([0.1, 0.0])), IIDCovarianceMatrix(2, 0.02))
+    b3 = PCNBuilder()
+    b3.stepSize, b3.bayesModel = 0.01, BayesianRegressionModel(like, off)
+    with pytest.raises(ValueError, match="centred prior"):
+        b3.build_method()

@@ -159,3 +159,16 @@ def test_f7_two_level_over_a_model_hierarchy(golden):
     out = e.advance(n - 1, want_sub=True)
     _check(out, g, n)
     assert np.array_equal(out["sub_acc"], g["sub_acc"])
+
+
+def test_f8_preconditioned_crank_nicolson(golden):
+    """pcn.py:9-57 on the Lotka-Volterra likelihood with a centred Gaussian prior"""
+    g = golden("f8_pcn_lotka_volterra.npz")
+    n = int(g["n_states"])
+    p = o.posterior_lv(g["design"], float(g["t_final"]), float(g["alpha"]), float(g["gamma"]), int(g["rk4_steps"]),
+                       g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+    p["likelihood_only"] = 1
+    e = o.Ensemble(p, g["prior_sigma"], g["x0"], int(g["seed"]), pcn_step_size=float(g["step_size"]))
+    out = e.advance(n - 1)
+    assert np.array_equal(out["acc"], g["acc"]) and np.array_equal(out["traj"], g["traj"][1:])
+    assert np.abs(out["logpost"] - g["loglik"][1:]).max() <= LP_RTOL * np.abs(g["loglik"]).max()

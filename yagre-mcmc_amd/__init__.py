@@ -8,11 +8,12 @@ replacing `yagremcmc` with `yagremcmc_amd` in its imports.
 """
 from . import _ffi
 from ._ffi import YmcError, device_count
-from .builders import ChainBuilder, MLDABuilder, MRWBuilder
+from .builders import ChainBuilder, MLDABuilder, MRWBuilder, PCNBuilder
 from .diagnostics import AcceptanceRateDiagnostics, DummyDiagnostics, FullDiagnostics
-from .ensemble import MLDA, MetropolisedRandomWalk
+from .ensemble import MLDA, MetropolisedRandomWalk, PreconditionedCrankNicolson
 from .lowering import UnsupportedPlugin
 
-__all__ = ["ChainBuilder", "MRWBuilder", "MLDABuilder", "MetropolisedRandomWalk", "MLDA",
+__all__ = ["ChainBuilder", "MRWBuilder", "MLDABuilder", "PCNBuilder", "MetropolisedRandomWalk", "MLDA",
+           "PreconditionedCrankNicolson",
            "AcceptanceRateDiagnostics", "FullDiagnostics", "DummyDiagnostics", "UnsupportedPlugin",
            "YmcError", "device_count"]

@@ -19,7 +19,7 @@ OK, ERR_INVALID, ERR_DEVICE, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_COMM = 0, -1, -2
 # ymc_density_kind
 GAUSS_WHITENED, GAUSS_ISO1D, POSTERIOR_LINEAR, POSTERIOR_LV = 1, 2, 3, 4
 # ymc_method / ymc_state_eq
-METHOD_MRW, METHOD_MLDA2 = 1, 2
+METHOD_MRW, METHOD_MLDA2, METHOD_PCN = 1, 2, 3
 EQ_EXACT, EQ_ISCLOSE = 0, 1
 # record flags
 RECORD_TRAJECTORY, RECORD_ACCEPT, RECORD_LOGPOST, RECORD_SUB_ACCEPT, RECORD_MOMENTS = 1, 2, 4, 8, 16
@@ -48,7 +48,7 @@ class DensityDesc(C.Structure):
         ("data", _dp), ("noise_precision", _dp), ("prior_mean", _dp), ("prior_precision", _dp),
         ("fwd_matrix", _dp), ("fwd_shift", _dp), ("design", _dp),
         ("t_final", C.c_double), ("alpha", C.c_double), ("gamma", C.c_double),
-        ("rk4_steps", C.c_int32), ("reserved_", C.c_int32),
+        ("rk4_steps", C.c_int32), ("likelihood_only", C.c_int32),
     ]
 
 
@@ -57,7 +57,7 @@ class ProblemDesc(C.Structure):
         ("method", C.c_int32), ("state_eq", C.c_int32),
         ("target", DensityDesc), ("surrogate", DensityDesc),
         ("sub_chain_length", C.c_int32), ("reserved_", C.c_int32),
-        ("proposal_sigma", _dp),
+        ("proposal_sigma", _dp), ("pcn_step_size", C.c_double),
     ]
 
 

@@ -8,7 +8,7 @@ Same property names, validation and error messages as the reference's
 extra properties with defaults that reproduce the single-chain behaviour.
 """
 from . import diagnostics as dg
-from .ensemble import MLDA, MetropolisedRandomWalk
+from .ensemble import MLDA, MetropolisedRandomWalk, PreconditionedCrankNicolson
 from .lowering import UnsupportedPlugin
 from .plugins import UnnormalisedPosterior
 
@@ -221,3 +221,30 @@ class MLDABuilder(ChainBuilder):
         tgt_diag = self._tgtDgnst if self._tgtDgnst is not None else dg.AcceptanceRateDiagnostics()
         return MLDA(self._explicitTarget, list(self._surrTgts), self._basePropCov, list(self._nSteps), tgt_diag,
                     self._surrDgnstList, recordSubChain=self.recordSubChain, **self._ensemble_options())
+
+
+class PCNBuilder(ChainBuilder):
+    """chain/method/pcn.py:60-88"""
+
+    def __init__(self):
+        super().__init__()
+        self._stepSize = None
+
+    @property
+    def stepSize(self):
+        return self._stepSize
+
+    @stepSize.setter
+    def stepSize(self, h):
+        self._stepSize = h
+
+    def build_from_model(self):
+        return PreconditionedCrankNicolson(self._bayesModel.likelihood, self._bayesModel.prior, self._stepSize,
+                                           self._diagnostics, **self._ensemble_options())
+
+    def build_from_target(self):
+        raise RuntimeError("PCN is only defined in relation to a Bayesian model")
+
+    def _validate_parameters(self):
+        if self._stepSize is None:
+            raise ValueError("Step size not set in PCN.")

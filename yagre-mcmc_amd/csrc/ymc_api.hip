@@ -90,6 +90,7 @@ struct ymc_ctx {
 struct ymc_problem {
     ymc_ctx *ctx = nullptr;
     int method = 0, eq_mode = 0, S = 0, D = 0, kind = 0;
+    double pcn_c1 = 0.0, pcn_c2 = 0.0;
     bool tile = false;
     DensityHost tgt, sur;
     std::vector<double> sigma;
@@ -212,6 +213,7 @@ DensityDev<D> device_view(const DensityHost &h)
     v.n_data = h.d.n_data;
     v.data_dim = h.d.data_dim;
     v.rk4_steps = h.d.rk4_steps;
+    v.likelihood_only = h.d.likelihood_only;
     const double *base = h.dev.as<double>();
     if (base) {
         v.data = base + h.off_data;
@@ -300,6 +302,8 @@ int launch_advance(ymc_run *r, uint64_t nsteps)
     a.tgt = device_view<D>(p->tgt);
     if (p->method == YMC_METHOD_MLDA2) a.sur = device_view<D>(p->sur);
     for (int j = 0; j < D; ++j) a.sigma[j] = p->sigma[j];
+    a.pcn_c1 = p->pcn_c1;
+    a.pcn_c2 = p->pcn_c2;
     a.seed = r->seed;
     a.chain0 = r->chain0;
     a.K = r->K;
@@ -516,7 +520,7 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
 {
     if (!ctx || !desc || !out) return fail(YMC_ERR_INVALID, "null argument");
     *out = nullptr;
-    if (desc->method != YMC_METHOD_MRW && desc->method != YMC_METHOD_MLDA2)
+    if (desc->method != YMC_METHOD_MRW && desc->method != YMC_METHOD_MLDA2 && desc->method != YMC_METHOD_PCN)
         return fail(YMC_ERR_UNSUPPORTED, "unknown method %d", desc->method);
     if (desc->state_eq != YMC_EQ_EXACT && desc->state_eq != YMC_EQ_ISCLOSE)
         return fail(YMC_ERR_INVALID, "unknown state equality rule %d", desc->state_eq);
@@ -547,9 +551,21 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
         if (!desc->proposal_sigma) rc = fail(YMC_ERR_INVALID, "Proposal Covariance not set");
         if (rc == YMC_OK) rc = copy_array(p->sigma, desc->proposal_sigma, p->D, "proposal_sigma");
     }
+    if (rc == YMC_OK && desc->method == YMC_METHOD_PCN) {
+        /* PreconditionedCrankNicolson.__init__, pcn.py:40-49; PCNBuilder, pcn.py:77-83 */
+        if (p->kind != YMC_DENSITY_POSTERIOR_LINEAR && p->kind != YMC_DENSITY_POSTERIOR_LV)
+            rc = fail(YMC_ERR_INVALID, "PCN is only defined in relation to a Bayesian model");
+        else if (!(desc->pcn_step_size > 0.0 && desc->pcn_step_size <= 0.5))
+            rc = fail(YMC_ERR_INVALID, "PCN step size must be in (0, 0.5], got %g", desc->pcn_step_size);
+        else {
+            const double t = 2.0 * desc->pcn_step_size;
+            p->pcn_c1 = std::sqrt(1.0 - t);
+            p->pcn_c2 = std::sqrt(t);
+        }
+    }
     if (rc == YMC_OK && p->tgt.tile) {
         if (p->method != YMC_METHOD_MRW)
-            rc = fail(YMC_ERR_UNSUPPORTED, "two-level delayed acceptance is not available at this dimension");
+            rc = fail(YMC_ERR_UNSUPPORTED, "only the random-walk sampler is available at this dimension");
         if (rc == YMC_OK) rc = build_tile_blob(p);
         p->tile = true;
     }

@@ -32,7 +32,7 @@ struct DensityDev {
     double whiten[D * D];
     double log_norm;
     double variance;
-    int32_t n_data, data_dim, rk4_steps, pad_;
+    int32_t n_data, data_dim, rk4_steps, likelihood_only;
     const double *data, *noise_prec, *prior_mean, *prior_prec, *A, *b, *design;
     double t_final, alpha, gamma;
 };
@@ -141,7 +141,7 @@ struct Density<YMC_DENSITY_POSTERIOR_LINEAR, D> {
             total = total + ymc_diag_norm_sq<YMC_LANE_MMAX>(r, p.noise_prec, p.data_dim);
         }
         double logl = -0.5 * total;
-        return logl + ymc_prior_log<D>(p, x);
+        return p.likelihood_only ? logl : logl + ymc_prior_log<D>(p, x);
     }
 };
 
@@ -175,7 +175,7 @@ struct Density<YMC_DENSITY_POSTERIOR_LV, D> {
             double r[2] = {x - p.data[2 * n], y - p.data[2 * n + 1]};
             total = total + ymc_diag_norm_sq<2>(r, p.noise_prec, 2);
         }
-        double lp = -0.5 * total + ymc_prior_log<D>(p, th);
+        double lp = p.likelihood_only ? -0.5 * total : -0.5 * total + ymc_prior_log<D>(p, th);
         if (bad) {
             /* forwardModel.py:15-19 raises; per chain: flag it, reject the proposal */
             st |= YMC_CHAIN_NONFINITE;
@@ -213,6 +213,26 @@ __device__ __forceinline__ void ymc_propose(const double (&x)[D], const double (
         ymc_draw_normal_pair(seed, chain, t, (uint32_t)j, &z0, &z1);
         y[2 * j] = x[2 * j] + sigma[2 * j] * z0;
         if (2 * j + 1 < D) y[2 * j + 1] = x[2 * j + 1] + sigma[2 * j + 1] * z1;
+    }
+}
+
+/* PCNProposal.generate_proposal, pcn.py:23-36: xi = prior mean + sigma_prior * z (the prior's
+ * realisation, gaussian.py:61-66), y = sqrt(1 - 2h) * x + sqrt(2h) * xi */
+template <int D>
+__device__ __forceinline__ void ymc_propose_pcn(const double (&x)[D], const double (&sigma)[D],
+                                                const double *__restrict__ prior_mean, double c1, double c2,
+                                                uint64_t seed, uint32_t chain, uint64_t t, double (&y)[D])
+{
+#pragma unroll
+    for (int j = 0; 2 * j < D; ++j) {
+        double z0, z1;
+        ymc_draw_normal_pair(seed, chain, t, (uint32_t)j, &z0, &z1);
+        const double xi0 = prior_mean[2 * j] + sigma[2 * j] * z0;
+        y[2 * j] = c1 * x[2 * j] + c2 * xi0;
+        if (2 * j + 1 < D) {
+            const double xi1 = prior_mean[2 * j + 1] + sigma[2 * j + 1] * z1;
+            y[2 * j + 1] = c1 * x[2 * j + 1] + c2 * xi1;
+        }
     }
 }
 

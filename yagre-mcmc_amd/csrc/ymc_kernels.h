@@ -10,7 +10,8 @@ template <int D>
 struct ChainArgs {
     DensityDev<D> tgt;   /* the (fine) target */
     DensityDev<D> sur;   /* MLDA2: the coarse density */
-    double sigma[D];     /* proposal standard deviations */
+    double sigma[D];     /* proposal standard deviations (pCN: of the prior) */
+    double pcn_c1, pcn_c2; /* pCN: sqrt(1 - 2h), sqrt(2h) */
     uint64_t seed, chain0, K;
     uint64_t t0;         /* first transition (MLDA2: first fine step) of this launch */
     uint64_t wf_n0;      /* Welford count before this launch */

@@ -271,3 +271,23 @@ class MLDA(MetropolisHastingsEnsemble):
         return lowering.make_problem(ctx, _ffi.METHOD_MLDA2, self._tgtDensity, sigma, state_eq,
                                      surrogate=self._surrogate, sub_chain_length=self._subChainLength,
                                      rk4_steps=self.rk4Steps)
+
+
+class PreconditionedCrankNicolson(MetropolisHastingsEnsemble):
+    """chain/method/pcn.py:38-57: proposal sqrt(1-2h) x + sqrt(2h) xi with xi drawn from the
+    (centred, Gaussian) prior; the target of the accept/reject step is the likelihood."""
+
+    def __init__(self, targetDensity, prior, stepSize, diagnostics, **ensemble):
+        assert 0 < stepSize and stepSize <= 0.5
+        if not lowering._has(prior, "mean", "covariance"):
+            raise NotImplementedError("PCN only supports Gaussian priors")
+        if np.any(np.asarray(prior.mean.coefficient) != 0.0):
+            raise ValueError("Preconditioned Crank Nicholson requires centred prior")
+        super().__init__(targetDensity, prior.covariance, diagnostics, **ensemble)
+        self._prior = prior
+        self._stepSize = float(stepSize)
+
+    def _make_problem(self, ctx, state_eq):
+        low = lowering.lower_likelihood(self._tgtDensity, self._prior, self.rk4Steps)
+        sigma = lowering.proposal_sigma(self._prior.covariance, low.desc.dim)
+        return lowering.make_problem(ctx, _ffi.METHOD_PCN, low, sigma, state_eq, pcn_step_size=self._stepSize)

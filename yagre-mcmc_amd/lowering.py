@@ -155,8 +155,16 @@ def state_eq_of(state):
     return _ffi.EQ_ISCLOSE if _name(state) == "ScalarParameter" else _ffi.EQ_EXACT
 
 
+def lower_likelihood(likelihood, prior, rk4_steps=None):
+    """The likelihood alone as a density (the target of pCN, pcn.py:75-78): the posterior's
+    descriptor with likelihood_only set; the prior fields still describe the Gaussian prior."""
+    low = lower_posterior(likelihood, prior, rk4_steps)
+    low.desc.likelihood_only = 1
+    return low
+
+
 def make_problem(ctx, method, target, sigma, state_eq=_ffi.EQ_EXACT, surrogate=None, sub_chain_length=0,
-                 rk4_steps=None):
+                 rk4_steps=None, pcn_step_size=0.0):
     tgt = lower_density(target, rk4_steps) if not isinstance(target, Lowered) else target
     desc = _ffi.ProblemDesc()
     desc.method, desc.state_eq = method, state_eq
@@ -171,6 +179,7 @@ def make_problem(ctx, method, target, sigma, state_eq=_ffi.EQ_EXACT, surrogate=N
     if sigma.size != tgt.desc.dim:
         raise ValueError(f"proposal covariance has dimension {sigma.size}, the target has {tgt.desc.dim}")
     desc.proposal_sigma = _ffi.dptr(sigma)
+    desc.pcn_step_size = float(pcn_step_size)
     keep.append(sigma)
     return _ffi.Problem(ctx, desc, keep)
 
@@ -181,7 +190,12 @@ def density_only_problem(density, device=0):
     if n == "GaussianDensity":
         raise UnsupportedPlugin("a bare GaussianDensity is evaluated as part of a posterior only")
     if n == "AdditiveGaussianNoiseLikelihood":
-        raise UnsupportedPlugin("the likelihood is evaluated as part of a posterior only")
+        # the likelihood alone: a flat stand-in prior of the right dimension, never evaluated
+        from .plugins import Gaussian, IIDCovarianceMatrix, ParameterVector
+        probe = Lowered(0, 0)
+        dim, _ = lower_solver(density._fwdModel.solver_, probe)
+        low = lower_likelihood(density, Gaussian(ParameterVector(np.zeros(dim)), IIDCovarianceMatrix(dim, 1.0)))
+        return make_problem(_ffi.default_context(device), _ffi.METHOD_MRW, low, np.ones(dim))
     low = lower_density(density)
     return make_problem(_ffi.default_context(device), _ffi.METHOD_MRW, low, np.ones(low.desc.dim))
 
