@@ -35,11 +35,16 @@ states = mcmc.chain.ensemble_trajectory          # (nSteps, nChains, 2)
 burnin = 1000
 samples = states[burnin:].reshape(-1, 2)
 
+# integrated autocorrelation time of every chain, computed on the device from the record
+meanIAT = mcmc.integrated_autocorrelation('mean', burnin=burnin)
+maxIAT = mcmc.integrated_autocorrelation('max', burnin=burnin)
+
 print("\nAnalytics")
 print("---------")
 print(f"chains: {nChains}, states per chain: {nSteps}")
 print(f"acceptance rate (pooled): {mcmc.diagnostics.global_acceptance_rate():.4f}")
 print(f"kernel time per launch: {mcmc.kernel_time_ms()[0]:.3f} ms")
+print(f"mean IAT (median over chains): {np.median(meanIAT):.0f}   max IAT (median over chains): {np.median(maxIAT):.0f}")
 print("\nInference")
 print("---------")
 print(f"true mean: {tgtMean.coefficient}")

@@ -152,9 +152,9 @@ int ymc_ctx_device_info(const ymc_ctx *ctx, ymc_device_info *out);
 int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem **out);
 int ymc_problem_destroy(ymc_problem *problem);
 
-/* MetropolisHastings.run, entry part (:103-110): stores the initial states as
- * record row 0 is NOT done -- the record holds the state AFTER each
- * transition; the caller keeps x0. */
+/* MetropolisHastings.run, entry part (:103-110).  The record holds the state
+ * AFTER each transition; the initial states (row 0 of the reference's
+ * trajectory) stay with the caller. */
 int ymc_run_create(ymc_ctx *ctx, const ymc_problem *problem, const ymc_run_desc *desc, ymc_run **out);
 int ymc_run_destroy(ymc_run *run);
 
@@ -192,6 +192,22 @@ int ymc_logdensity_eval(ymc_ctx *ctx, const ymc_problem *problem, int which, uin
  * x[n][d] -> out[n][m], m = data_dim (linear) or 2*n_data (Lotka-Volterra) */
 int ymc_forward_eval(ymc_ctx *ctx, const ymc_problem *problem, int which, uint64_t n,
                      const double *x, double *out);
+
+/* ---- post-processing (yagremcmc/postprocessing/autocorrelation.py) --------
+ * integrated_autocorrelation (:92-140) for every chain of a run, from record
+ * rows [first, first + n) (the caller's burn-in is `first`): method 0 = 'mean'
+ * (IAT of the per-state mean over the components), 1 = 'max' (largest IAT over
+ * the components); sokal_const as :92.  iat[n_chains]. */
+int ymc_run_iat(ymc_run *run, uint64_t first, uint64_t n, int method, double sokal_const, int32_t *iat);
+/* the same for states held by the caller: states[n][n_chains][d] (the shape of
+ * ymc_run_fetch_trajectory's output; n_chains = 1 is the reference's (n, d) array) */
+int ymc_iat_states(ymc_ctx *ctx, const double *states, uint64_t n, uint64_t n_chains, int32_t d, int method,
+                   double sokal_const, int32_t *iat);
+/* and for plain sequences: series[n_series][length] (row-major), one IAT per series;
+ * acf (optional) receives the first acf_lags values of
+ * estimate_autocorrelation_function_1d (:5-29) per series, acf[n_series][acf_lags] */
+int ymc_iat_series(ymc_ctx *ctx, const double *series, uint64_t n_series, uint64_t length, double sokal_const,
+                   int32_t *iat, double *acf, uint64_t acf_lags);
 
 /* parity hooks: the device's draws and elementary functions, bit-for-bit
  * comparable with the CPU build of csrc/ymc_numerics.h.

@@ -501,8 +501,28 @@ def fixture_f8():
     print("F8", acc.mean())
 
 
+def fixture_f9():
+    """Post-processing: the reference's IAT / ACF (postprocessing/autocorrelation.py) of the F2 and F1 chains."""
+    import yagremcmc.postprocessing.autocorrelation as ac
+    g2 = np.load(os.path.join(HERE, "f2_mrw_2d.npz"))
+    traj = g2["traj"]                                   # (2000, 64, 2), produced by the reference
+    out = {}
+    for burnin in (0, 200):
+        out[f"iat_mean_b{burnin}"] = np.array([ac.integrated_autocorrelation(traj[burnin:, k, :], 'mean')
+                                               for k in range(traj.shape[1])], dtype=np.int32)
+        out[f"iat_max_b{burnin}"] = np.array([ac.integrated_autocorrelation(traj[burnin:, k, :], 'max')
+                                              for k in range(traj.shape[1])], dtype=np.int32)
+    out["acf_chain0_dim0_b200"] = ac.estimate_autocorrelation_function_1d(traj[200:, 0, 0])
+    g1 = np.load(os.path.join(HERE, "f1_mrw_1d.npz"))
+    s1 = g1["traj"][:, 0, :]                             # (10000, 1) as np.array(mcmc.chain.trajectory)
+    out["f1_iat_mean_b200"] = ac.integrated_autocorrelation(s1[200:], 'mean')
+    out["f1_iat_max_b200"] = ac.integrated_autocorrelation(s1[200:], 'max')
+    np.savez_compressed(os.path.join(HERE, "f9_iat.npz"), **out)
+    print("F9", out["iat_mean_b200"][:8], out["iat_max_b200"][:8], out["f1_iat_mean_b200"])
+
+
 def main():
-    which = sys.argv[1:] or ["f1", "f2", "f2b", "f3", "f3b", "f4", "f5", "f7", "f8"]
+    which = sys.argv[1:] or ["f1", "f2", "f2b", "f3", "f3b", "f4", "f5", "f7", "f8", "f9"]
     if "f1" in which:
         fixture_f1()
     if "f2" in which:
@@ -524,6 +544,8 @@ def main():
         fixture_f7()
     if "f8" in which:
         fixture_f8()
+    if "f9" in which:
+        fixture_f9()
 
 
 if __name__ == "__main__":

@@ -295,3 +295,54 @@ def test_pcn_builder_f8(golden):
     b3.stepSize, b3.bayesModel = 0.01, BayesianRegressionModel(like, off)
     with pytest.raises(ValueError, match="centred prior"):
         b3.build_method()
+
+
+def test_integrated_autocorrelation_on_device_f9(golden):
+    """postprocessing/autocorrelation.py:92-140 on the device == the reference's values for the F2 / F1 chains"""
+    from yagremcmc_amd import _ffi
+    from yagremcmc_amd.postprocessing import autocorrelation as ac
+    g2, g9, g1 = golden("f2_mrw_2d.npz"), golden("f9_iat.npz"), golden("f1_mrw_1d.npz")
+    traj = g2["traj"]
+    for burnin in (0, 200):
+        assert np.array_equal(ac.integrated_autocorrelation(traj[burnin:], 'mean'), g9[f"iat_mean_b{burnin}"])
+        assert np.array_equal(ac.integrated_autocorrelation(traj[burnin:], 'max'), g9[f"iat_max_b{burnin}"])
+    # one chain, (n, d) host array: the reference's call signature and return type
+    one = ac.integrated_autocorrelation(traj[200:, 5, :], 'max')
+    assert isinstance(one, int) and one == int(g9["iat_max_b200"][5])
+    s1 = g1["traj"][:, 0, :]
+    assert ac.integrated_autocorrelation(s1[200:], 'mean') == int(g9["f1_iat_mean_b200"])
+    assert ac.integrated_autocorrelation(s1[200:], 'max') == int(g9["f1_iat_max_b200"])
+    acf = ac.estimate_autocorrelation_function_1d(traj[200:, 0, 0])
+    assert acf.shape == g9["acf_chain0_dim0_b200"].shape and acf[0] == 1.0
+    assert np.abs(acf - g9["acf_chain0_dim0_b200"]).max() < 1e-12
+    with pytest.raises(ValueError, match="Invalid IAT"):
+        ac.integrated_autocorrelation(traj[:, 0, :], 'median')
+    # from the record in HBM, through the sampler (the F2 problem, same seed => same chains)
+    from yagremcmc_amd.chain.method.mrw import MRWBuilder
+    from yagremcmc_amd.parameter.vector import ParameterVector
+    from yagremcmc_amd.statistics.covariance import IIDCovarianceMatrix
+    from yagremcmc_amd.test.testSetup import GaussianTargetDensity2d
+    RefT = type("GaussianTargetDensity2d", (), {})
+    t = RefT()
+    from types import SimpleNamespace
+    w, v = np.linalg.eigh(g2["cov"])
+    t.dist_ = SimpleNamespace(mean=g2["mean"], cov=g2["cov"], cov_object=SimpleNamespace(
+        _LP=g2["whiten"], _log_pdet=float(g2["log_norm"]) - 2 * np.log(2 * np.pi), rank=2))
+    b = MRWBuilder()
+    b.explicitTarget, b.proposalCovariance = t, IIDCovarianceMatrix(2, 1.0)
+    b.nChains, b.seed = 64, int(g2["seed"])
+    mc = b.build_method()
+    mc.run(2000, ParameterVector(np.array([-8.0, -7.0])), verbose=False)
+    assert np.array_equal(mc.chain.trajectory, traj)
+    for burnin in (0, 200):
+        assert np.array_equal(mc.integrated_autocorrelation('mean', burnin=burnin), g9[f"iat_mean_b{burnin}"])
+        assert np.array_equal(mc.integrated_autocorrelation('max', burnin=burnin), g9[f"iat_max_b{burnin}"])
+    # long series (beyond the LDS-resident size) and many series at once
+    rng = np.random.default_rng(3)
+    x = np.zeros((30000, 3, 1))
+    e = rng.normal(size=x.shape)
+    for i in range(1, x.shape[0]):
+        x[i] = 0.9 * x[i - 1] + e[i]
+    iat = ac.integrated_autocorrelation(x, 'mean')
+    assert iat.shape == (3,) and (np.abs(iat - 19) <= 4).all()        # AR(1), phi = 0.9: tau = 19
+    del GaussianTargetDensity2d, _ffi

@@ -100,6 +100,9 @@ _PROTOTYPES = {
     "ymc_run_fetch_summary": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "ymc_logdensity_eval": (C.c_int, [_vp, _vp, C.c_int, _u64, _vp, _vp, _vp]),
     "ymc_forward_eval": (C.c_int, [_vp, _vp, C.c_int, _u64, _vp, _vp]),
+    "ymc_run_iat": (C.c_int, [_vp, _u64, _u64, C.c_int, C.c_double, _vp]),
+    "ymc_iat_states": (C.c_int, [_vp, _vp, _u64, _u64, C.c_int32, C.c_int, C.c_double, _vp]),
+    "ymc_iat_series": (C.c_int, [_vp, _vp, _u64, _u64, C.c_double, _vp, _vp, _u64]),
     "ymc_rng_fill": (C.c_int, [_vp, _u64, _u64, _u64, _u64, _u64, C.c_int32, _vp, _vp]),
     "ymc_numerics_eval": (C.c_int, [_vp, C.c_int, _u64, _vp, _vp, _vp]),
     "ymc_comm_unique_id": (C.c_int, [_vp, C.c_size_t]),
@@ -193,6 +196,23 @@ class Context(Handle):
         u = np.empty((nt, K)) if uniforms else None
         check(lib().ymc_rng_fill(self.raw, seed, chain0, K, t0, nt, d, vptr(xi), vptr(u)))
         return xi, u
+
+    def iat_states(self, states, method=0, sokal_const=5.0):
+        """states (n, K, d) -> IAT per chain"""
+        states = f64(states)
+        n, K, d = states.shape
+        out = np.empty(K, dtype=np.int32)
+        check(lib().ymc_iat_states(self.raw, vptr(states), n, K, d, method, float(sokal_const), vptr(out)))
+        return out
+
+    def iat_series(self, series, sokal_const=5.0, acf_lags=0):
+        """series (S, N) -> (IAT per series, acf (S, acf_lags) or None)"""
+        series = f64(series)
+        S, N = series.shape
+        out = np.empty(S, dtype=np.int32)
+        acf = np.empty((S, acf_lags)) if acf_lags else None
+        check(lib().ymc_iat_series(self.raw, vptr(series), S, N, float(sokal_const), vptr(out), vptr(acf), acf_lags))
+        return out, acf
 
     def numerics(self, fn, x, divisor=None):
         x = f64(x).reshape(-1)
@@ -318,6 +338,14 @@ class Run(Handle):
         st = np.empty(self.K, dtype=np.uint32)
         check(lib().ymc_run_fetch_summary(self.raw, vptr(acc), vptr(n), vptr(mean), vptr(m2), vptr(st)))
         return dict(accepted=acc, wf_n=n, wf_mean=mean, wf_m2=m2, status=st)
+
+    def iat(self, first=0, n=None, method=0, sokal_const=5.0):
+        """Integrated autocorrelation time of every chain from record rows [first, first+n)."""
+        if n is None:
+            n = self.steps_done()[1] - first
+        out = np.empty(self.K, dtype=np.int32)
+        check(lib().ymc_run_iat(self.raw, first, n, method, float(sokal_const), vptr(out)))
+        return out
 
     def summary_words(self):
         w = _u64(0)

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "ymc_kernels.h"
+#include "ymc_post.h"
 #include "ymc_tile.h"
 
 namespace {
@@ -861,6 +862,87 @@ int ymc_forward_eval(ymc_ctx *ctx, const ymc_problem *problem, int which, uint64
                                                           od.as<double>(), ctx->stream)));
     }
     YMC_HIP(hipMemcpyAsync(out, od.p, od.bytes, hipMemcpyDeviceToHost, ctx->stream));
+    YMC_HIP(hipStreamSynchronize(ctx->stream));
+    return YMC_OK;
+}
+
+} /* extern "C" */
+
+namespace {
+
+/* IAT of every chain from device-resident states traj[rows][K][d], rows [first, first + n) */
+int iat_from_device_states(ymc_ctx *ctx, const double *traj, uint64_t first, uint64_t n, uint64_t K, int d, int method,
+                           double sokal_const, int32_t *iat)
+{
+    if (method != 0 && method != 1)
+        return fail(YMC_ERR_INVALID, "Invalid IAT - Type: %d. Options are 'mean' (0) and 'max' (1).", method);
+    if (!(sokal_const > 0.0)) return fail(YMC_ERR_INVALID, "the Sokal constant must be positive");
+    if (n < 2) return fail(YMC_ERR_INVALID, "a series needs at least two entries");
+    const uint64_t per_chain = method == 0 ? 1 : (uint64_t)d, S = K * per_chain;
+    DeviceBuf series, out;
+    YMC_TRY(series.alloc(S * n * sizeof(double)));
+    YMC_TRY(out.alloc(S * sizeof(int32_t)));
+    hipStream_t st = ctx->stream;
+    YMC_HIP(ymc_launch_series_from_record(traj, first, n, K, d, method == 0, series.as<double>(), st));
+    YMC_HIP(ymc_launch_iat(series.as<double>(), S, n, sokal_const, out.as<int32_t>(), nullptr, st));
+    std::vector<int32_t> host(S);
+    YMC_HIP(hipMemcpyAsync(host.data(), out.p, S * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    YMC_HIP(hipStreamSynchronize(st));
+    for (uint64_t k = 0; k < K; ++k) {
+        int32_t best = host[k * per_chain]; /* 'max': autocorrelation.py:131-138 */
+        for (uint64_t j = 1; j < per_chain; ++j) best = std::max(best, host[k * per_chain + j]);
+        iat[k] = best;
+    }
+    return YMC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ymc_run_iat(ymc_run *run, uint64_t first, uint64_t n, int method, double sokal_const, int32_t *iat)
+{
+    if (!run || !iat) return fail(YMC_ERR_INVALID, "null argument");
+    if (!(run->flags & YMC_RECORD_TRAJECTORY)) return fail(YMC_ERR_INVALID, "the run does not record the trajectory");
+    if (run->problem->tile) return fail(YMC_ERR_UNSUPPORTED, "IAT from the tiled record is not available yet");
+    if (first + n > run->recorded) return fail(YMC_ERR_INVALID, "rows beyond the record requested");
+    YMC_HIP(hipSetDevice(run->ctx->device));
+    return iat_from_device_states(run->ctx, run->traj.as<double>(), first, n, run->K, run->problem->D, method,
+                                  sokal_const, iat);
+}
+
+int ymc_iat_states(ymc_ctx *ctx, const double *states, uint64_t n, uint64_t n_chains, int32_t d, int method,
+                   double sokal_const, int32_t *iat)
+{
+    if (!ctx || !states || !iat) return fail(YMC_ERR_INVALID, "null argument");
+    if (n_chains == 0 || d < 1) return fail(YMC_ERR_INVALID, "empty states");
+    YMC_HIP(hipSetDevice(ctx->device));
+    DeviceBuf dev;
+    YMC_TRY(dev.alloc(n * n_chains * (uint64_t)d * sizeof(double)));
+    YMC_HIP(hipMemcpyAsync(dev.p, states, dev.bytes, hipMemcpyHostToDevice, ctx->stream));
+    return iat_from_device_states(ctx, dev.as<double>(), 0, n, n_chains, d, method, sokal_const, iat);
+}
+
+int ymc_iat_series(ymc_ctx *ctx, const double *series, uint64_t n_series, uint64_t length, double sokal_const,
+                   int32_t *iat, double *acf, uint64_t acf_lags)
+{
+    if (!ctx || !series || !iat) return fail(YMC_ERR_INVALID, "null argument");
+    if (!(sokal_const > 0.0)) return fail(YMC_ERR_INVALID, "the Sokal constant must be positive");
+    if (n_series == 0) return YMC_OK;
+    if (length < 2) return fail(YMC_ERR_INVALID, "a series needs at least two entries");
+    YMC_HIP(hipSetDevice(ctx->device));
+    DeviceBuf dev, out, acf_dev;
+    YMC_TRY(dev.alloc(n_series * length * sizeof(double)));
+    YMC_TRY(out.alloc(n_series * sizeof(int32_t)));
+    YMC_HIP(hipMemcpyAsync(dev.p, series, dev.bytes, hipMemcpyHostToDevice, ctx->stream));
+    YMC_HIP(ymc_launch_iat(dev.as<double>(), n_series, length, sokal_const, out.as<int32_t>(), nullptr, ctx->stream));
+    YMC_HIP(hipMemcpyAsync(iat, out.p, out.bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (acf && acf_lags) {
+        YMC_TRY(acf_dev.alloc(n_series * acf_lags * sizeof(double)));
+        YMC_HIP(hipMemsetAsync(acf_dev.p, 0, acf_dev.bytes, ctx->stream));
+        YMC_HIP(ymc_launch_acf(dev.as<double>(), n_series, length, acf_lags, acf_dev.as<double>(), ctx->stream));
+        YMC_HIP(hipMemcpyAsync(acf, acf_dev.p, acf_dev.bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
     YMC_HIP(hipStreamSynchronize(ctx->stream));
     return YMC_OK;
 }

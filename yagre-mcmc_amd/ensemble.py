@@ -155,6 +155,22 @@ class MetropolisHastingsEnsemble:
     def kernel_time_ms(self):
         return self._run.kernel_time_ms()
 
+    def integrated_autocorrelation(self, method='mean', burnin=0, sokalConst=5.):
+        """postprocessing/autocorrelation.py:92-140 for every chain, computed on the device from the
+        record: the equivalent of `ac.integrated_autocorrelation(states[burnin:], method)` per chain.
+        Returns an int for one chain, an array of nChains ints otherwise."""
+        methods = {"mean": 0, "max": 1}
+        if method not in methods:
+            raise ValueError(f"Invalid IAT - Type: {method}. Options are 'mean' and 'max'.")
+        if burnin == 0:
+            # row 0 of the reference's trajectory is the initial state, which the device record
+            # does not hold: go through the fetched states so that it is included
+            states = self._chain.ensemble_trajectory
+            out = _ffi.default_context(self.device).iat_states(states, methods[method], sokalConst)
+        else:
+            out = self._run.iat(burnin - 1, None, methods[method], sokalConst)
+        return int(out[0]) if self.nChains == 1 else out
+
     # -- internals -------------------------------------------------------------
     def _initial_states(self, initialState):
         if hasattr(initialState, "coefficient"):
