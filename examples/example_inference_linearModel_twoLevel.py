@@ -1,0 +1,77 @@
+"""Linear forward model, two-level delayed acceptance over a model hierarchy and
+preconditioned Crank-Nicolson -- the ensemble version of the MRW / vanilla-MLDA
+parts of the reference's example_inference_linearModel_twoLevel.py (same maps,
+prior, noise, proposal; the adaptive-error-model part has no device path)."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from yagremcmc_amd.chain.method.mlda import MLDABuilder
+from yagremcmc_amd.chain.method.mrw import MRWBuilder
+from yagremcmc_amd.chain.method.pcn import PCNBuilder
+from yagremcmc_amd.exampleSetup import ExampleLinearModelSolver
+from yagremcmc_amd.model.forwardModel import ForwardModel
+from yagremcmc_amd.parameter.vector import ParameterVector
+from yagremcmc_amd.statistics.bayesModel import BayesianRegressionModel
+from yagremcmc_amd.statistics.covariance import IIDCovarianceMatrix
+from yagremcmc_amd.statistics.data import Data
+from yagremcmc_amd.statistics.gaussian import Gaussian
+from yagremcmc_amd.statistics.likelihood import AdditiveGaussianNoiseLikelihood
+from yagremcmc_amd.statistics.modelHierarchy import BayesianRegressionModelHierarchy
+from yagremcmc_amd.statistics.noise import CentredGaussianNoise
+from yagremcmc_amd.utility.hierarchy import Hierarchy, SharedComponent
+
+nChains = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+nSteps = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
+np.random.seed(2222)
+DIM = 2
+
+tgtMap = np.array([[1.4, -0.2], [-0.6, 0.7]])
+surMap = tgtMap + np.array([[-0.6, -0.2], [0.4, 1.1]])
+tgtSolver = ExampleLinearModelSolver(tgtMap, np.zeros(DIM))
+surSolver = ExampleLinearModelSolver(surMap, np.array([0.5, -0.9]))
+
+trueParam = ParameterVector(np.array([1.5, 0.5]))
+noiseVar = 0.3
+tgtSolver.interpolate(trueParam)
+tgtSolver.invoke()                                   # forward solve on the device
+data = Data(np.array([tgtSolver.evaluation + np.sqrt(noiseVar) * np.random.standard_normal(DIM) for _ in range(5)]))
+
+prior = Gaussian(ParameterVector(trueParam.coefficient + np.array([-0.2, 0.4])), IIDCovarianceMatrix(DIM, 5.))
+noise = CentredGaussianNoise(IIDCovarianceMatrix(DIM, noiseVar))
+surLikelihood = AdditiveGaussianNoiseLikelihood(data, ForwardModel(surSolver), noise)
+tgtLikelihood = AdditiveGaussianNoiseLikelihood(data, ForwardModel(tgtSolver), noise)
+proposalCov = IIDCovarianceMatrix(DIM, 0.5)
+init = ParameterVector(np.zeros(DIM))
+
+
+def report(name, mc, burnin=500):
+    states = mc.chain.ensemble_trajectory
+    iat = np.atleast_1d(mc.integrated_autocorrelation('mean', burnin=burnin))
+    print(f"{name:28s} acceptance {mc.diagnostics.global_acceptance_rate():.3f}   posterior mean "
+          f"{states[burnin:].reshape(-1, DIM).mean(axis=0)}   median IAT {np.median(iat):.0f}")
+
+
+mrw = MRWBuilder()
+mrw.proposalCovariance, mrw.bayesModel, mrw.nChains = proposalCov, BayesianRegressionModel(tgtLikelihood, prior), nChains
+tgtMRW = mrw.build_method()
+tgtMRW.run(nSteps, init, verbose=False)
+report("target MRW", tgtMRW)
+
+mlda = MLDABuilder()
+mlda.baseProposalCovariance, mlda.subChainLengths, mlda.nChains = proposalCov, [5], nChains
+mlda.bayesModel = BayesianRegressionModelHierarchy(Hierarchy([surLikelihood, tgtLikelihood]), SharedComponent(prior, 2))
+vanillaMLDA = mlda.build_method()
+vanillaMLDA.run(nSteps, init, verbose=False)
+report("vanilla MLDA (sub-chain 5)", vanillaMLDA)
+
+centred = Gaussian(ParameterVector(np.zeros(DIM)), IIDCovarianceMatrix(DIM, 5.))
+pcn = PCNBuilder()
+pcn.stepSize, pcn.bayesModel, pcn.nChains = 0.05, BayesianRegressionModel(tgtLikelihood, centred), nChains
+pcnChain = pcn.build_method()
+pcnChain.run(nSteps, init, verbose=False)
+report("pCN (centred prior, h=0.05)", pcnChain)
+print(f"true parameter: {trueParam.coefficient}")

@@ -127,6 +127,9 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` or `make -C yagre-mcmc_amd/csrc`. The MH path has no CPU fallback.")
+        # the host driver of this pool only supports dmabuf IPC; RCCL / cross-process GPU memory
+        # sharing needs this before the HIP runtime initialises
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOTYPES.items():
             fn = getattr(handle, name)

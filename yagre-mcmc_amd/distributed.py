@@ -115,6 +115,8 @@ class _StdoutToStderr:
 
 def make_communicator(ctx, rank, world):
     from . import _ffi
+    # one node: RCCL's bootstrap sockets go over loopback (the container hostname may not resolve)
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     rdzv = FileRendezvous()
     with _StdoutToStderr():
         if rank == 0:
