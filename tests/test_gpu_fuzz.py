@@ -1,0 +1,113 @@
+"""Seeded fuzz of the HIP path against the oracle: random density kinds, dimensions, ensemble
+sizes (ragged last wave), chain offsets, record-flag combinations, odd/even launch splits and
+samplers.  Everything the device returns must equal the oracle bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as o  # noqa: E402
+
+
+def _lowered(ffi, kind, d, rng):
+    from yagremcmc_amd import lowering
+    if kind == "gauss":
+        a = rng.normal(size=(d, d))
+        p = o.gauss_from_cov(rng.normal(size=d), a @ a.T + d * np.eye(d))
+        low = lowering.Lowered(ffi.GAUSS_WHITENED, d)
+        low.set_array("mean", p["mean"])
+        low.set_array("whiten", p["whiten"])
+        low.desc.log_norm = p["log_norm"]
+        return low, p
+    if kind == "iso1d":
+        p = o.gauss_iso1d(float(rng.normal()), float(rng.uniform(0.5, 2.0)))
+        low = lowering.Lowered(ffi.GAUSS_ISO1D, 1)
+        low.set_array("mean", p["mean"])
+        low.desc.variance = p["variance"]
+        return low, p
+    if kind == "linear":
+        m, nd = int(rng.integers(1, 9)), int(rng.integers(1, 7))
+        g = dict(A=rng.normal(size=(m, d)), b=rng.normal(size=m), data=rng.normal(size=(nd, m)),
+                 noise_precision=rng.uniform(0.5, 3, size=m), prior_mean=rng.normal(size=d) * 0.0,
+                 prior_precision=rng.uniform(0.1, 2, size=d))
+        p = o.posterior_linear(g["A"], g["b"], g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+        low = lowering.Lowered(ffi.POSTERIOR_LINEAR, d)
+        low.desc.n_data, low.desc.data_dim = nd, m
+        for k, v in (("data", g["data"]), ("noise_precision", g["noise_precision"]), ("prior_mean", g["prior_mean"]),
+                     ("prior_precision", g["prior_precision"]), ("fwd_matrix", g["A"]), ("fwd_shift", g["b"])):
+            low.set_array(k, v)
+        return low, p
+    nd = int(rng.integers(2, 12))
+    design = rng.uniform(0.5, 1.5, size=(nd, 2))
+    g = dict(data=rng.uniform(0.2, 2.0, size=(nd, 2)), noise_precision=rng.uniform(5, 30, size=2),
+             prior_mean=np.zeros(2), prior_precision=rng.uniform(0.5, 2, size=2))
+    steps, T = int(rng.integers(10, 40)), float(rng.uniform(2, 8))
+    p = o.posterior_lv(design, T, 0.8, 0.4, steps, g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+    low = lowering.Lowered(ffi.POSTERIOR_LV, 2)
+    low.desc.n_data, low.desc.data_dim = nd, 2
+    for k, v in (("data", g["data"]), ("noise_precision", g["noise_precision"]), ("prior_mean", g["prior_mean"]),
+                 ("prior_precision", g["prior_precision"]), ("design", design)):
+        low.set_array(k, v)
+    low.desc.t_final, low.desc.alpha, low.desc.gamma, low.desc.rk4_steps = T, 0.8, 0.4, steps
+    return low, p
+
+
+@pytest.mark.parametrize("case", range(48))
+def test_random_configuration_matches_oracle(case, monkeypatch):
+    from yagremcmc_amd import _ffi as ffi, lowering
+    ctx = ffi.default_context(0)
+    rng = np.random.default_rng(5000 + case)
+    kind = ["gauss", "gauss", "linear", "lv", "iso1d", "gauss"][case % 6]
+    d = {"iso1d": 1, "lv": 2}.get(kind, int(rng.integers(1, 9)))
+    low, p = _lowered(ffi, kind, d, rng)
+    method = ["mrw", "mrw", "mlda", "pcn"][int(rng.integers(0, 4))]
+    if method == "pcn" and kind not in ("linear", "lv"):
+        method = "mrw"
+    K = int(rng.choice([1, 7, 64, 65, 200, 513]))
+    T = int(rng.integers(1, 60))
+    chain0 = int(rng.choice([0, 3, 2**31, 2**32 - 1000]))
+    seed = int(rng.integers(0, 2**63))
+    flags = ffi.RECORD_ACCEPT | int(rng.choice([0, ffi.RECORD_TRAJECTORY])) | int(rng.choice([0, ffi.RECORD_LOGPOST])) \
+        | int(rng.choice([0, ffi.RECORD_MOMENTS]))
+    sigma = rng.uniform(0.05, 0.6, size=d)
+    x0 = rng.normal(size=(K, d)) * 0.3
+    if kind == "lv":
+        x0 = x0 - np.array([0.6, 0.3])
+        monkeypatch.setenv("YMC_LV_ROWS", str(case % 2))
+    eq = ffi.EQ_ISCLOSE if kind == "iso1d" and case % 2 else ffi.EQ_EXACT
+    kwargs = {}
+    if method == "mlda":
+        S = int(rng.integers(1, 5))
+        low2, p2 = _lowered(ffi, kind, d, np.random.default_rng(9000 + case)) if kind in ("gauss", "iso1d") else (low, p)
+        prob = lowering.make_problem(ctx, ffi.METHOD_MLDA2, low, sigma, eq, surrogate=low2, sub_chain_length=S)
+        e = o.Ensemble(p, sigma, x0, seed, chain0=chain0, eq_mode=eq, surrogate=p2, sub_chain_length=S)
+        flags |= int(rng.choice([0, ffi.RECORD_SUB_ACCEPT]))
+        kwargs["want_sub"] = True
+    elif method == "pcn":
+        low.desc.likelihood_only = 1
+        p = dict(p, likelihood_only=1)
+        h = float(rng.uniform(0.005, 0.3))
+        prob = lowering.make_problem(ctx, ffi.METHOD_PCN, low, sigma, eq, pcn_step_size=h)
+        e = o.Ensemble(p, sigma, x0, seed, chain0=chain0, eq_mode=eq, pcn_step_size=h)
+    else:
+        prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, sigma, eq)
+        e = o.Ensemble(p, sigma, x0, seed, chain0=chain0, eq_mode=eq)
+    run = ffi.Run(prob, seed, K, x0, T, flags, chain0)
+    cut = int(rng.integers(0, T + 1))
+    run.advance(cut)
+    run.advance(T - cut)
+    out = e.advance(T, **kwargs)
+    assert np.array_equal(run.accept(), out["acc"])
+    if flags & ffi.RECORD_TRAJECTORY:
+        assert np.array_equal(run.trajectory(), out["traj"])
+    if flags & ffi.RECORD_LOGPOST:
+        assert np.array_equal(run.logpost(), out["logpost"], equal_nan=True)
+    if flags & ffi.RECORD_SUB_ACCEPT:
+        assert np.array_equal(run.sub_accept(), out["sub_acc"])
+    x, lp = run.state()
+    assert np.array_equal(x, e.x) and np.array_equal(lp, e.lp, equal_nan=True)
+    s = run.summary()
+    assert np.array_equal(s["accepted"], e.acc_count) and np.array_equal(s["status"], e.status)
+    if flags & ffi.RECORD_MOMENTS:
+        assert np.array_equal(s["wf_mean"], e.wf_mean) and np.array_equal(s["wf_m2"], e.wf_m2)
+        assert (s["wf_n"] == T).all()
