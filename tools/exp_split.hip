@@ -21,6 +21,7 @@ struct Args {
     uint64_t seed, K, t0;
     uint32_t nsteps;
     double *x, *lp, *wmean, *wm2, *traj;
+    const double* recip;   // recip[n] = 1 / (t0 + n + 1)
     uint64_t* acc_count;
     uint8_t* acc;
 };
@@ -35,7 +36,7 @@ __device__ __forceinline__ void tail(const Args& a, uint64_t k, uint32_t n, doub
     const bool moved = !ymc_states_equal<D>(y, x, 0);
     const double lpy = Dens::eval(a.tgt, y, st);
     const bool acc = ymc_accept(lpy - lp, moved, ymc_finite(lpy), u, st);
-    ymc_welford<D>(x, (double)(a.t0 + n + 1), wmean, wm2);
+    ymc_welford<D>(x, (double)(a.t0 + n + 1), a.recip[n], wmean, wm2);
 #pragma unroll
     for (int j = 0; j < D; ++j) x[j] = acc ? y[j] : x[j];
     lp = acc ? lpy : lp;
@@ -139,6 +140,77 @@ __global__ __launch_bounds__(64 * (NP + 1)) void split(const Args a)
     a.acc_count[k] = accepted;
 }
 
+// Phase-locked variant: ONE workgroup of NW waves per CU-sized slice of NW/4*... chains.  All NW waves
+// first PRODUCE the draws of B transitions of the workgroup's CW*64 chains into LDS (high occupancy,
+// no serial work), barrier, then the first CW waves CONSUME them (one lane = one chain) while the
+// other waves wait at the next barrier: the serial part never competes for issue slots.
+template <int NW, int CW, int B>
+__global__ __launch_bounds__(64 * NW) void phased(const Args a)
+{
+    extern __shared__ double ring[];   // [B][D+1][CW*64]
+    constexpr int NC = CW * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t kbase = (uint64_t)blockIdx.x * NC;
+    const uint32_t nb = a.nsteps / B;  // harness: multiple of B, t0 even, B even
+    const double s0 = a.sigma[0], s1 = a.sigma[1];
+    // consumer state
+    double x[D] = {0, 0}, wmean[D] = {0, 0}, wm2[D] = {0, 0};
+    double lp = 0;
+    uint64_t accepted = 0;
+    const uint64_t kc = kbase + (uint64_t)wave * 64 + lane;
+    if (wave < CW) {
+        ymc_load_row<D>(a.x, kc, x);
+        ymc_load_row<D>(a.wmean, kc, wmean);
+        ymc_load_row<D>(a.wm2, kc, wm2);
+        lp = a.lp[kc];
+        accepted = a.acc_count[kc];
+    }
+    for (uint32_t b = 0; b < nb; ++b) {
+        // produce: work items = (pair of transitions, chain); NC chains x B/2 pairs over NW*64 threads
+        for (int item = tid; item < NC * (B / 2); item += 64 * NW) {
+            const int c = item % NC, pr = item / NC;
+            const uint32_t chain = (uint32_t)(kbase + c);
+            const uint64_t t = a.t0 + (uint64_t)b * B + 2 * pr;
+            const ymc_u32x4 ub = ymc_uniform_block(a.seed, chain, t);
+            ring[((2 * pr) * (D + 1) + D) * NC + c] = ymc_u01_co(ub.v[0], ub.v[1]);
+            ring[((2 * pr + 1) * (D + 1) + D) * NC + c] = ymc_u01_co(ub.v[2], ub.v[3]);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                double z0, z1;
+                ymc_draw_normal_pair(a.seed, chain, t + h, 0, &z0, &z1);
+                ring[((2 * pr + h) * (D + 1) + 0) * NC + c] = s0 * z0;
+                ring[((2 * pr + h) * (D + 1) + 1) * NC + c] = s1 * z1;
+            }
+        }
+        __syncthreads();
+        if (wave < CW) {
+            const int c = wave * 64 + lane;
+#pragma unroll 2
+            for (int s = 0; s < B; ++s) {
+                const double dl[D] = {ring[(s * (D + 1) + 0) * NC + c], ring[(s * (D + 1) + 1) * NC + c]};
+                const double u = ring[(s * (D + 1) + D) * NC + c];
+                tail(a, kc, b * B + s, x, lp, accepted, wmean, wm2, dl, u);
+            }
+        }
+        __syncthreads();
+    }
+    if (wave < CW) {
+        ymc_store_row<D>(a.x, kc, x);
+        ymc_store_row<D>(a.wmean, kc, wmean);
+        ymc_store_row<D>(a.wm2, kc, wm2);
+        a.lp[kc] = lp;
+        a.acc_count[kc] = accepted;
+    }
+}
+
+template <int NW, int CW, int B>
+void launch_phased(const Args& a, uint64_t K)
+{
+    const size_t lds = (size_t)B * (D + 1) * CW * 64 * sizeof(double);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&phased<NW, CW, B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((phased<NW, CW, B>), dim3(K / (CW * 64)), dim3(64 * NW), lds, 0, a);
+}
+
 struct Bufs {
     double *x, *lp, *wmean, *wm2, *traj;
     uint64_t* acc_count;
@@ -168,6 +240,12 @@ int main(int argc, char** argv)
     };
     Bufs ref, alt;
     alloc(ref); alloc(alt);
+    {
+        std::vector<double> rc(T);
+        for (uint32_t n = 0; n < T; ++n) rc[n] = 1.0 / (double)(n + 1);
+        double* d; CK(hipMalloc(&d, T * 8)); CK(hipMemcpy(d, rc.data(), T * 8, hipMemcpyHostToDevice));
+        a.recip = d;
+    }
     auto bind = [&](Bufs& b) { a.x = b.x; a.lp = b.lp; a.wmean = b.wmean; a.wm2 = b.wm2; a.traj = b.traj; a.acc_count = b.acc_count; a.acc = b.acc; };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     struct Variant { const char* name; void (*launch)(const Args&, uint64_t); };
@@ -180,6 +258,12 @@ int main(int argc, char** argv)
         {"split NP4 R1 prio", [](const Args& a, uint64_t K) { hipLaunchKernelGGL((split<4, 1, 1>), dim3(K / 64), dim3(320), 0, 0, a); }},
         {"split NP5 R1 prio", [](const Args& a, uint64_t K) { hipLaunchKernelGGL((split<5, 1, 1>), dim3(K / 64), dim3(384), 0, 0, a); }},
         {"split NP4 R1", [](const Args& a, uint64_t K) { hipLaunchKernelGGL((split<4, 1, 0>), dim3(K / 64), dim3(320), 0, 0, a); }},
+        {"phased NW16 CW4 B16", [](const Args& a, uint64_t K) { launch_phased<16, 4, 16>(a, K); }},
+        {"phased NW16 CW4 B24", [](const Args& a, uint64_t K) { launch_phased<16, 4, 24>(a, K); }},
+        {"phased NW16 CW4 B8", [](const Args& a, uint64_t K) { launch_phased<16, 4, 8>(a, K); }},
+        {"phased NW8 CW2 B16", [](const Args& a, uint64_t K) { launch_phased<8, 2, 16>(a, K); }},
+        {"phased NW8 CW1 B16", [](const Args& a, uint64_t K) { launch_phased<8, 1, 16>(a, K); }},
+        {"phased NW16 CW2 B32", [](const Args& a, uint64_t K) { launch_phased<16, 2, 32>(a, K); }},
     };
     const int nv = sizeof vars / sizeof vars[0];
     // reference output

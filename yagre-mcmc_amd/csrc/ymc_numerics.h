@@ -42,13 +42,25 @@ YMC_FN double ymc_fma(double a, double b, double c) { return __builtin_fma(a, b,
  * ymc_fma; on the device it is pinned to the three-address v_fma_f64, because
  * hipcc (ROCm 7.2) otherwise selects the two-address v_fmac_f64 and pays a
  * v_mov_b64 of the coefficient per step.  The coefficient sits in a VGPR pair
- * by default (cheapest at low occupancy); a translation unit that is short of
- * VGPRs defines YMC_COEFF_IN_SGPR and gets it from an SGPR pair instead. */
+ * by default; a translation unit whose kernels loop over transitions defines
+ * YMC_COEFF_HOISTED to keep every coefficient in VGPRs across the loop, one
+ * that is short of VGPRs defines YMC_COEFF_IN_SGPR and gets it from an SGPR
+ * pair instead.  All three give the same bits. */
 YMC_FN double ymc_fma_c(double a, double b, double c)
 {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(YMC_COEFF_IN_SGPR)
     double d;
     __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+#elif defined(__HIP_DEVICE_COMPILE__) && defined(YMC_COEFF_HOISTED)
+    /* v_div_fixup_f64(c, +-1, 1) returns c for a finite c (its sign is taken from the "quotient"
+     * of the two other operands, hence the -1 for a negative c): an opaque, speculatable,
+     * non-convergent copy of the coefficient into a VGPR pair, which LICM lifts out of the
+     * transition loop.  (An asm statement is convergent in HIP and stays in the loop; a plain
+     * literal is re-materialised there with two s_mov_b32 and a v_mov_b64 per use.) */
+    const double cv = __builtin_amdgcn_div_fixup(c, c < 0.0 ? -1.0 : 1.0, 1.0);
+    double d;
+    __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(cv));
     return d;
 #elif defined(__HIP_DEVICE_COMPILE__)
     double d;
