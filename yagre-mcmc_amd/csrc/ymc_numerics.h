@@ -71,6 +71,17 @@ YMC_FN double ymc_fma_c(double a, double b, double c)
 #endif
 }
 
+/* A polynomial's LEADING coefficient (the first multiplicand of a Horner chain): the value c;
+ * in a YMC_COEFF_HOISTED unit it is kept in a VGPR pair across the loop like the addends above. */
+YMC_FN double ymc_coeff(double c)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && defined(YMC_COEFF_HOISTED)
+    return __builtin_amdgcn_div_fixup(c, c < 0.0 ? -1.0 : 1.0, 1.0);
+#else
+    return c;
+#endif
+}
+
 YMC_FN uint64_t ymc_bits(double x)
 {
     uint64_t u;
@@ -161,18 +172,27 @@ YMC_FN ymc_u32x4 ymc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32
 /* the ensemble is sharded over GPUs.                                       */
 /* ------------------------------------------------------------------------ */
 
+/* m * 2^-53 for 0 <= m <= 2^53, exactly: both halves convert exactly, both products are exact
+ * and their sum has at most 53 significant bits (one instruction fewer than a u64 conversion). */
+YMC_FN double ymc_u53_to_unit(uint64_t m)
+{
+    double hi = (double)(uint32_t)(m >> 32);
+    double lo = (double)(uint32_t)m;
+    return ymc_fma(hi, 0x1p-21, lo * 0x1p-53);
+}
+
 /* 53-bit mantissa from two words -> [0,1) on the 2^-53 grid */
 YMC_FN double ymc_u01_co(uint32_t lo, uint32_t hi)
 {
     uint64_t m = (((uint64_t)hi << 32) | lo) >> 11;
-    return (double)m * 0x1p-53;
+    return ymc_u53_to_unit(m);
 }
 
 /* 53-bit mantissa from two words -> (0,1] on the 2^-53 grid */
 YMC_FN double ymc_u01_oc(uint32_t lo, uint32_t hi)
 {
     uint64_t m = ((((uint64_t)hi << 32) | lo) >> 11) + 1u;
-    return (double)m * 0x1p-53;
+    return ymc_u53_to_unit(m);
 }
 
 YMC_FN ymc_u32x4 ymc_uniform_block(uint64_t seed, uint32_t chain, uint64_t t)
@@ -223,8 +243,8 @@ YMC_FN double ymc_log(double x)
     double s = f / (2.0 + f);
     double z = s * s;
     double w = z * z;
-    double t1 = w * ymc_fma_c(w, ymc_fma_c(w, Lg6, Lg4), Lg2);
-    double t2 = z * ymc_fma_c(w, ymc_fma_c(w, ymc_fma_c(w, Lg7, Lg5), Lg3), Lg1);
+    double t1 = w * ymc_fma_c(w, ymc_fma_c(w, ymc_coeff(Lg6), Lg4), Lg2);
+    double t2 = z * ymc_fma_c(w, ymc_fma_c(w, ymc_fma_c(w, ymc_coeff(Lg7), Lg5), Lg3), Lg1);
     double R = t2 + t1;
     double hfsq = 0.5 * f * f;
     return dk * ln2_hi - ((hfsq - ymc_fma(s, hfsq + R, dk * ln2_lo)) - f);
@@ -254,7 +274,7 @@ YMC_FN double ymc_exp(double x)
     double r = ymc_fma(-kd, ln2_hi, xc);
     r = ymc_fma(-kd, ln2_lo, r);
 
-    double p = 0x1.6124613a86d09p-33;                 /* 1/13! */
+    double p = ymc_coeff(0x1.6124613a86d09p-33);                 /* 1/13! */
     p = ymc_fma_c(p, r, 0x1.1eed8eff8d898p-29);         /* 1/12! */
     p = ymc_fma_c(p, r, 0x1.ae64567f544e4p-26);         /* 1/11! */
     p = ymc_fma_c(p, r, 0x1.27e4fb7789f5cp-22);         /* 1/10! */
@@ -297,7 +317,7 @@ YMC_FN double ymc_accept_prob(double d)
     double r = ymc_fma(-kd, ln2_hi, xc);
     r = ymc_fma(-kd, ln2_lo, r);
 
-    double p = 0x1.6124613a86d09p-33;
+    double p = ymc_coeff(0x1.6124613a86d09p-33);
     p = ymc_fma_c(p, r, 0x1.1eed8eff8d898p-29);
     p = ymc_fma_c(p, r, 0x1.ae64567f544e4p-26);
     p = ymc_fma_c(p, r, 0x1.27e4fb7789f5cp-22);
@@ -331,7 +351,7 @@ YMC_FN void ymc_sincospi(double t, double *sn, double *cs)
     int32_t q = (int32_t)qd;
     double r2 = r * r;
 
-    double ps = 0x1.aaec32af93359p-21;                /* +pi^17/17! */
+    double ps = ymc_coeff(0x1.aaec32af93359p-21);                /* +pi^17/17! */
     ps = ymc_fma_c(ps, r2, -0x1.6fadb9f155744p-16);
     ps = ymc_fma_c(ps, r2, 0x1.e8f434d018d63p-12);
     ps = ymc_fma_c(ps, r2, -0x1.e3074fde8871fp-8);
@@ -342,7 +362,7 @@ YMC_FN void ymc_sincospi(double t, double *sn, double *cs)
     ps = ymc_fma_c(ps, r2, 0x1.921fb54442d18p+1);       /* pi */
     double s = ps * r;
 
-    double pc = 0x1.20c62c2f2d7f5p-18;                /* +pi^16/16! */
+    double pc = ymc_coeff(0x1.20c62c2f2d7f5p-18);                /* +pi^16/16! */
     pc = ymc_fma_c(pc, r2, -0x1.b6e24f44b128fp-14);
     pc = ymc_fma_c(pc, r2, 0x1.f9d38a3763cc3p-10);
     pc = ymc_fma_c(pc, r2, -0x1.a6d1f2a204a8cp-6);
