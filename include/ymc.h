@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define YMC_ABI_VERSION 1
+#define YMC_ABI_VERSION 2
 
 typedef enum ymc_status {
     YMC_OK = 0,
@@ -80,8 +80,22 @@ typedef struct ymc_density_desc {
 typedef enum ymc_method {
     YMC_METHOD_MRW = 1,   /* MetropolisedRandomWalk, chain/method/mrw.py:41-57 */
     YMC_METHOD_MLDA2 = 2, /* MLDA with one surrogate, chain/method/mlda.py:100-110,146-154 */
-    YMC_METHOD_PCN = 3    /* PreconditionedCrankNicolson, chain/method/pcn.py:9-57 */
+    YMC_METHOD_PCN = 3,   /* PreconditionedCrankNicolson, chain/method/pcn.py:9-57 */
+    /* MLDA with an EVEN number n of surrogates exactly as the reference executes it
+     * (mlda.py:12-73,100-116; n = 2: example_mcmc_2d_hierarchical.py, test_mlda.py:47-60;
+     * n = 4: test_mlda.py:189-256).  MLDAProposal.generate_proposal calls generate_proposal of the
+     * top SurrogateTransition, which calls run() of the level below, which calls generate_proposal
+     * of the one below that, ...: only every second level's accept step is ever executed.  What
+     * runs is a nest of E = n/2 + 1 effective levels:
+     *   level 0      a random walk on surrogateTargets[0], subChainLengths[1] steps
+     *   level e      1 <= e <= E-2: subChainLengths[2e+1] steps, each = one level-(e-1) run accepted
+     *                with exp(P(y) + Q(x) - Q(y) - P(x)), P = surrogateTargets[2e], Q = [2e-1]
+     *   level E-1    the recorded chain: P = the target, Q = surrogateTargets[n-1]
+     * (An odd n >= 3 raises AttributeError in the reference; the Python layer raises the same.) */
+    YMC_METHOD_MLDA_NESTED = 4
 } ymc_method;
+
+#define YMC_MAX_LEVELS 4 /* effective levels E of YMC_METHOD_MLDA_NESTED (n <= 6 surrogates) */
 
 typedef enum ymc_state_eq {
     YMC_EQ_EXACT = 0,   /* ParameterVector.__eq__, parameter/vector.py:37-45 */
@@ -101,6 +115,12 @@ typedef struct ymc_problem_desc {
      * PCN: of the PRIOR covariance (the proposal draws from the prior, pcn.py:29) */
     const double *proposal_sigma;
     double pcn_step_size;          /* PCN: stepSize h, 0 < h <= 0.5 (pcn.py:42) */
+    /* MLDA_NESTED (all densities of the same kind and dim as `target`, which is level E-1's P): */
+    int32_t n_levels;                         /* E, 2 .. YMC_MAX_LEVELS */
+    int32_t reserved2_;
+    const ymc_density_desc *level_target;     /* [E-1]: P of levels 0 .. E-2 */
+    const ymc_density_desc *level_correction; /* [E-1]: Q of levels 1 .. E-1 */
+    const int32_t *level_steps;               /* [E-1]: steps of one run of levels 0 .. E-2 */
 } ymc_problem_desc;
 
 /* record_flags */
@@ -177,6 +197,9 @@ int ymc_run_fetch_accept(ymc_run *run, uint64_t first, uint64_t n, uint8_t *dst,
 int ymc_run_fetch_logpost(ymc_run *run, uint64_t first, uint64_t n, double *dst, size_t dst_bytes);
 /* dst[n][sub_chain_length][n_chains] */
 int ymc_run_fetch_sub_accept(ymc_run *run, uint64_t first, uint64_t n, uint8_t *dst, size_t dst_bytes);
+/* MLDA_NESTED: accepted transitions of the lower levels so far, dst[E-1][n_chains], and the
+ * transitions each of them has made, made[E-1] (either may be NULL) */
+int ymc_run_fetch_level_accept(ymc_run *run, uint64_t *dst, size_t dst_bytes, uint64_t *made);
 /* current state [n_chains][d] and its log-density [n_chains] (either may be NULL) */
 int ymc_run_fetch_state(ymc_run *run, double *state, double *logpost);
 /* per-chain summary: accepted transitions, Welford n / mean / M2

@@ -297,5 +297,74 @@ class Ensemble:
         return out
 
 
+def nested_levels(surrogates, sub_chain_lengths, target):
+    """Effective levels of MLDA with an even number n of surrogates as the reference runs it
+    (mlda.py:12-73,100-116): returns (P, Q, steps) with P[e], Q[e] for e = 0..E-1 (Q[0] None),
+    steps[e] for e < E-1, E = n/2 + 1."""
+    n = len(surrogates)
+    assert n >= 2 and n % 2 == 0 and len(sub_chain_lengths) == n
+    E = n // 2 + 1
+    P = [surrogates[2 * e] for e in range(E - 1)] + [target]
+    Q = [None] + [surrogates[2 * e - 1] for e in range(1, E)]
+    steps = [int(sub_chain_lengths[2 * e + 1]) for e in range(E - 1)]
+    return P, Q, steps
+
+
+class NestedEnsemble:
+    """K chains of the nested delayed-acceptance scheme (ymo_mlda_nested_advance)."""
+
+    def __init__(self, P, Q, steps, sigma, x0, seed, chain0=0, eq_mode=EQ_EXACT, nthreads=1):
+        self.P, self.Q, self.steps = list(P), list(Q), [int(v) for v in steps]
+        self.E = len(self.P)
+        assert len(self.Q) == self.E and len(self.steps) == self.E - 1 and self.E >= 2
+        self.d = self.P[-1]["dim"]
+        x0 = _f64(x0)
+        if x0.ndim == 1:
+            x0 = x0.reshape(1, -1)
+        self.K = x0.shape[0]
+        self.x = x0.copy()
+        self.sigma = _f64(sigma).reshape(-1)
+        self.seed, self.chain0, self.eq_mode, self.nthreads = int(seed), int(chain0), int(eq_mode), int(nthreads)
+        self.t = 0
+        cost = 1
+        for s_ in self.steps:
+            cost = s_ * cost + 1
+        self.cost_top = cost
+        self.lp = logdensity(self.P[-1], self.x)[0]
+        self.lpq = logdensity(self.Q[-1], self.x)[0]
+        self.acc_count = np.zeros(self.K, dtype=np.uint64)
+        self.level_acc = np.zeros((self.E - 1, self.K), dtype=np.uint64)
+        self.wf_n = np.zeros(self.K, dtype=np.uint64)
+        self.wf_mean = np.zeros((self.K, self.d))
+        self.wf_m2 = np.zeros((self.K, self.d))
+        self.status = np.zeros(self.K, dtype=np.uint32)
+
+    def advance(self, nsteps):
+        K, d, E = self.K, self.d, self.E
+        traj = np.empty((nsteps, K, d))
+        acc = np.empty((nsteps, K), dtype=np.uint8)
+        lp_out = np.empty((nsteps, K))
+        keep = []
+        Parr = (C.c_void_p * E)()
+        Qarr = (C.c_void_p * E)()
+        for e in range(E):
+            dp, kp = _lower(self.P[e])
+            keep += [dp, kp]
+            Parr[e] = C.addressof(dp)
+            if self.Q[e] is not None:
+                dq, kq = _lower(self.Q[e])
+                keep += [dq, kq]
+                Qarr[e] = C.addressof(dq)
+        steps = (C.c_int32 * max(E - 1, 1))(*self.steps)
+        lib().ymo_mlda_nested_advance(
+            C.c_int32(E), Parr, Qarr, steps, _ptr(self.sigma), C.c_int32(self.eq_mode), C.c_uint64(self.seed),
+            C.c_uint64(self.chain0), C.c_int64(K), C.c_uint64(self.t), C.c_uint64(self.cost_top), C.c_int64(nsteps),
+            _ptr(self.x), _ptr(self.lp), _ptr(self.lpq), _vp(self.acc_count), _vp(self.level_acc), _vp(self.wf_n),
+            _ptr(self.wf_mean), _ptr(self.wf_m2), _vp(self.status), _ptr(traj), _vp(acc), _ptr(lp_out),
+            C.c_int32(self.nthreads))
+        self.t += nsteps
+        return dict(traj=traj, acc=acc, logpost=lp_out)
+
+
 def max_threads():
     return int(lib().ymo_max_threads())

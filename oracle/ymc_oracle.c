@@ -608,6 +608,126 @@ void ymo_mlda2_advance(const ymo_density *fine, const ymo_density *coarse, const
     }
 }
 
+/* ------------------------------------------------------------------------ */
+/* Nested delayed acceptance: MLDA with an even number of surrogates as the   */
+/* reference executes it (mlda.py:12-73,100-116; YMC_METHOD_MLDA_NESTED in    */
+/* include/ymc.h).  P[e], Q[e]: densities of effective level e (Q[0] unused), */
+/* steps[e]: steps of one run of level e < E-1.  Decisions take consecutive   */
+/* transition indices *t in execution order.                                  */
+/* ------------------------------------------------------------------------ */
+typedef struct ymo_nest {
+    const ymo_density *const *P, *const *Q;
+    const int32_t *steps;
+    const double *sigma;
+    int32_t d, eq_mode;
+    uint64_t seed;
+    uint32_t chain;
+    uint64_t t;
+    uint32_t st;
+    uint64_t *lacc; /* [E-1] accepted transitions of the lower levels of this chain */
+} ymo_nest;
+
+/* MetropolisHastings.run of effective level e from x (metropolisHastings.py:103-120) */
+static void ymo_nest_run(ymo_nest *w, int32_t e, double *x)
+{
+    const int32_t d = w->d, S = w->steps[e];
+    double y[YMO_DMAX];
+    if (e == 0) {
+        double lp = ymo_logdensity_one(w->P[0], x, &w->st);
+        for (int32_t s = 0; s < S; ++s) {
+            ymo_propose(x, w->sigma, w->seed, w->chain, w->t, d, y);
+            if (!ymo_states_equal(y, x, d, w->eq_mode)) {
+                double lpy = ymo_logdensity_one(w->P[0], y, &w->st);
+                if (ymo_accept(lpy - lp, ymo_is_finite(lpy), w->seed, w->chain, w->t, &w->st, NULL)) {
+                    memcpy(x, y, sizeof(double) * (size_t)d);
+                    lp = lpy;
+                    w->lacc[0] += 1;
+                }
+            }
+            w->t += 1;
+        }
+        return;
+    }
+    double lpP = ymo_logdensity_one(w->P[e], x, &w->st);
+    double lpQ = ymo_logdensity_one(w->Q[e], x, &w->st);
+    for (int32_t s = 0; s < S; ++s) {
+        memcpy(y, x, sizeof(double) * (size_t)d);
+        ymo_nest_run(w, e - 1, y);                       /* SurrogateTransition.generate_proposal, mlda.py:23-33 */
+        if (!ymo_states_equal(y, x, d, w->eq_mode)) {
+            double lpPy = ymo_logdensity_one(w->P[e], y, &w->st);
+            double lpQy = ymo_logdensity_one(w->Q[e], y, &w->st);
+            double log_ratio = ((lpPy + lpQ) - lpQy) - lpP; /* mlda.py:35-43 */
+            if (ymo_accept(log_ratio, ymo_is_finite(lpPy) && ymo_is_finite(lpQy), w->seed, w->chain, w->t,
+                           &w->st, NULL)) {
+                memcpy(x, y, sizeof(double) * (size_t)d);
+                lpP = lpPy;
+                lpQ = lpQy;
+                w->lacc[e] += 1;
+            }
+        }
+        w->t += 1;
+    }
+}
+
+/* E effective levels; lp[K] = P[E-1](x), lpq[K] = Q[E-1](x) of the carried states;
+ * level_acc[E-1][K]; cost_top = transitions one top-level step spans */
+void ymo_mlda_nested_advance(int32_t E, const ymo_density *const *P, const ymo_density *const *Q,
+                             const int32_t *steps, const double *sigma, int32_t eq_mode, uint64_t seed,
+                             uint64_t chain0, int64_t K, uint64_t n0, uint64_t cost_top, int64_t nsteps,
+                             double *x, double *lp, double *lpq, uint64_t *acc_count, uint64_t *level_acc,
+                             uint64_t *wf_n, double *wf_mean, double *wf_m2, uint32_t *status, double *traj,
+                             uint8_t *acc, double *lp_out, int32_t nthreads)
+{
+    const int32_t d = P[E - 1]->dim;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(dynamic, 16)
+#endif
+    for (int64_t k = 0; k < K; ++k) {
+        uint64_t lacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        ymo_nest w;
+        w.P = P;
+        w.Q = Q;
+        w.steps = steps;
+        w.sigma = sigma;
+        w.d = d;
+        w.eq_mode = eq_mode;
+        w.seed = seed;
+        w.chain = (uint32_t)(chain0 + (uint64_t)k);
+        w.st = status ? status[k] : 0;
+        w.lacc = lacc;
+        double *xs = x + k * d;
+        double y[YMO_DMAX];
+        for (int64_t n = 0; n < nsteps; ++n) {
+            w.t = (n0 + (uint64_t)n) * cost_top;
+            memcpy(y, xs, sizeof(double) * (size_t)d);
+            ymo_nest_run(&w, E - 2, y);                  /* MLDAProposal.generate_proposal, mlda.py:100-116 */
+            int accepted = 0;
+            if (!ymo_states_equal(y, xs, d, eq_mode)) {
+                double lpPy = ymo_logdensity_one(P[E - 1], y, &w.st);
+                double lpQy = ymo_logdensity_one(Q[E - 1], y, &w.st);
+                double log_ratio = ((lpPy + lpq[k]) - lpQy) - lp[k]; /* mlda.py:146-154 */
+                accepted = ymo_accept(log_ratio, ymo_is_finite(lpPy) && ymo_is_finite(lpQy), seed, w.chain, w.t,
+                                      &w.st, NULL);
+                if (wf_n) ymo_welford(xs, d, &wf_n[k], wf_mean + k * d, wf_m2 + k * d);
+                if (accepted) {
+                    memcpy(xs, y, sizeof(double) * (size_t)d);
+                    lp[k] = lpPy;
+                    lpq[k] = lpQy;
+                }
+            } else if (wf_n) {
+                ymo_welford(xs, d, &wf_n[k], wf_mean + k * d, wf_m2 + k * d);
+            }
+            if (accepted && acc_count) acc_count[k] += 1;
+            if (traj) memcpy(traj + (n * K + k) * d, xs, sizeof(double) * (size_t)d);
+            if (acc) acc[n * K + k] = (uint8_t)accepted;
+            if (lp_out) lp_out[n * K + k] = lp[k];
+        }
+        if (status) status[k] = w.st;
+        if (level_acc)
+            for (int32_t e = 0; e < E - 1; ++e) level_acc[(int64_t)e * K + k] += lacc[e];
+    }
+}
+
 int32_t ymo_max_threads(void)
 {
 #ifdef _OPENMP

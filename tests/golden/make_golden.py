@@ -110,6 +110,40 @@ def mark_fine_level(mc, replay):
     mc._accept_reject = wrapped
 
 
+class SequentialReplay:
+    """Draws by address for the nested scheme: every accept/reject DECISION of any level takes the
+    next transition index in execution order (csrc/ymc_numerics.h, draw addressing).  The index
+    advances when a level's _accept_reject returns (watch()), whether or not it drew a uniform."""
+
+    def __init__(self, seed, chain, dim, n_transitions):
+        self.xi, self.u = oracle.rng_fill(seed, chain, 1, 0, n_transitions, dim)
+        self.xi, self.u = self.xi[:, 0, :], self.u[:, 0]
+        self.t = 0
+
+    def standard_normal(self, size=None):
+        out = self.xi[self.t].copy()
+        assert size is None or int(size) == out.size
+        return out
+
+    def uniform(self, low=0.0, high=1.0, size=None):
+        return np.array([self.u[self.t]])
+
+    def install(self):
+        ref_gaussian.standard_normal = self.standard_normal
+        ref_mh.uniform = self.uniform
+
+    def watch(self, mh):
+        inner = mh._accept_reject
+
+        def wrapped(proposal, state):
+            try:
+                return inner(proposal, state)
+            finally:
+                self.t += 1
+
+        mh._accept_reject = wrapped
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -521,8 +555,82 @@ def fixture_f9():
     print("F9", out["iat_mean_b200"][:8], out["iat_max_b200"][:8], out["f1_iat_mean_b200"])
 
 
+# ---------------------------------------------------------------------------
+# F10 / F11: MLDA with 2 and with 4 surrogates as the reference executes them
+# (example_mcmc_2d_hierarchical.py:13-47; test_mlda.py:189-256)
+# ---------------------------------------------------------------------------
+
+def run_nested(name, seed, K, n, tgt_mean, tgt_cov, sur_means, sur_covs, sub_lengths, x0):
+    target = GaussianTargetDensity2d(ParameterVector(np.array(tgt_mean, dtype=float)), np.array(tgt_cov, dtype=float))
+    surs = [GaussianTargetDensity2d(ParameterVector(np.array(m, dtype=float)), np.array(c, dtype=float))
+            for m, c in zip(sur_means, sur_covs)]
+    ns = len(surs)
+    E = ns // 2 + 1
+    steps = [sub_lengths[2 * e + 1] for e in range(E - 1)]
+    cost = 1
+    for s_ in steps:
+        cost = s_ * cost + 1
+    cov = IIDCovarianceMatrix(2, 1.0)
+    traj = np.empty((n, K, 2))
+    acc = np.empty((n - 1, K), dtype=np.uint8)
+    lp = np.empty((n, K))
+    level_acc = np.zeros((E - 1, K), dtype=np.uint64)
+    for k in range(K):
+        b = MLDABuilder()
+        b.explicitTarget = target
+        b.surrogateTargets = list(surs)
+        b.baseProposalCovariance = cov
+        b.subChainLengths = list(sub_lengths)
+        b.surrogateDiagnostics = [AcceptanceRateDiagnostics() for _ in range(ns)]
+        mc = b.build_method()
+        rp = SequentialReplay(seed, k, 2, (n - 1) * cost)
+        rp.install()
+        rp.watch(mc)
+        for i in range(ns):
+            rp.watch(mc.surrogate(i))
+        mc.run(n, ParameterVector(np.array(x0, dtype=float)), verbose=False)
+        assert rp.t == (n - 1) * cost, (rp.t, (n - 1) * cost)
+        traj[:, k, :] = np.array(mc.chain.trajectory)
+        acc[:, k] = mc.diagnostics._decisions
+        lp[:, k] = eval_log_along(target, traj[:, k, :], lambda s: ParameterVector(np.array(s)))
+        for e in range(E - 1):
+            dec = mc.surrogate(2 * e).diagnostics._decisions
+            level_acc[e, k] = int(np.sum(dec))
+        for i in range(1, ns, 2):   # the levels whose accept step never runs
+            assert len(mc.surrogate(i).diagnostics._decisions) == 0
+    mu_t, U_t, c_t = scipy_whitening(target)
+    sw = [scipy_whitening(s_) for s_ in surs]
+    np.savez_compressed(
+        os.path.join(HERE, name), seed=seed, n_states=n, sub_lengths=np.array(sub_lengths),
+        tgt_mean=mu_t, tgt_whiten=U_t, tgt_log_norm=c_t,
+        sur_mean=np.array([w[0] for w in sw]), sur_whiten=np.array([w[1] for w in sw]),
+        sur_log_norm=np.array([w[2] for w in sw]), sigma=sigma_of(cov),
+        x0=np.tile(np.array(x0, dtype=float), (K, 1)), traj=traj, acc=acc, logpost=lp, level_acc=level_acc,
+        cost_top=cost)
+    print(name, acc.mean(), level_acc.sum(axis=1))
+
+
+def fixture_f10():
+    # example_mcmc_2d_hierarchical.py: two surrogates, subChainLengths [4, 4]
+    tgt_mean, tgt_cov = [1.0, 1.5], [[2.4, -0.5], [-0.5, 0.7]]
+    run_nested("f10_mlda_nested2.npz", 20250110, 32, 400, tgt_mean, tgt_cov,
+               [[1.0 - 0.05, 1.5 + 0.01], [1.0, 1.5 - 0.01]],
+               [3.0 * np.array([[2.8, -0.1], [-0.1, 1.7]]), 1.5 * np.array([[2.4, -0.3], [-0.3, 1.1]])],
+               [4, 4], [-8.0, -7.0])
+
+
+def fixture_f11():
+    # test_mlda.py:189-256: four surrogates, subChainLengths [6, 4, 4, 3]
+    tm = np.array([1.0, 1.5])
+    means = [tm + np.array([0.2, -0.3]), tm + np.array([-0.1, 0.1]), tm + np.array([0.05, -0.05]), tm.copy()]
+    covs = [8. * np.array([[3.0, -0.2], [-0.2, 1.5]]), 6. * np.array([[2.7, -0.25], [-0.25, 1.3]]),
+            4. * np.array([[2.5, -0.3], [-0.3, 1.1]]), 2. * np.array([[2.4, -0.35], [-0.35, 1.0]])]
+    run_nested("f11_mlda_nested4.npz", 20250111, 16, 300, tm, [[2.4, -0.5], [-0.5, 0.7]], means, covs,
+               [6, 4, 4, 3], [2.0, -3.0])
+
+
 def main():
-    which = sys.argv[1:] or ["f1", "f2", "f2b", "f3", "f3b", "f4", "f5", "f7", "f8", "f9"]
+    which = sys.argv[1:] or ["f1", "f2", "f2b", "f3", "f3b", "f4", "f5", "f7", "f8", "f9", "f10", "f11"]
     if "f1" in which:
         fixture_f1()
     if "f2" in which:
@@ -546,6 +654,10 @@ def main():
         fixture_f8()
     if "f9" in which:
         fixture_f9()
+    if "f10" in which:
+        fixture_f10()
+    if "f11" in which:
+        fixture_f11()
 
 
 if __name__ == "__main__":

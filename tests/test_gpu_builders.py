@@ -100,12 +100,92 @@ def test_two_level_builder_and_perfect_surrogate():
     mc2 = b2.build_method()
     mc2.run(500, m["ParameterVector"](np.array([1.0, 1.5])), verbose=False)
     assert abs(mc2.diagnostics.global_acceptance_rate() - 1.0) < 1e-3
-    with pytest.raises(NotImplementedError):
-        b3 = m["MLDABuilder"]()
-        b3.explicitTarget, b3.surrogateTargets = fine, [coarse, coarse]
-        b3.baseProposalCovariance = m["IIDCovarianceMatrix"](2, 1.0)
-        b3.subChainLengths = [4, 4]
-        b3.build_method()
+
+
+def _mlda_test_data(m):
+    """test_mlda.py:14-43"""
+    mean = np.array([1.0, 1.5])
+    cov = np.array([[2.4, -0.5], [-0.5, 0.7]])
+    PV, G = m["ParameterVector"], m["GaussianTargetDensity2d"]
+    return dict(
+        tgtMean=mean, tgt=G(PV(mean), cov),
+        base=G(PV(mean + np.array([-0.05, 0.01])), 3.0 * np.array([[2.8, -0.1], [-0.1, 1.7]])),
+        fine=G(PV(mean + np.array([0.0, -0.01])), 1.5 * np.array([[2.4, -0.3], [-0.3, 1.1]])))
+
+
+def test_mlda_chain_with_two_surrogates_like_the_reference():
+    """test_mlda.py:47-91 (subChainLengths [6, 6]) and example_mcmc_2d_hierarchical.py, on an
+    ensemble; every chain is the oracle's nested chain bit for bit."""
+    m = _imports()
+    d = _mlda_test_data(m)
+    b = m["MLDABuilder"]()
+    b.explicitTarget = d["tgt"]
+    b.surrogateTargets = [d["base"], d["fine"]]
+    b.baseProposalCovariance = m["IIDCovarianceMatrix"](2, 1.0)
+    b.subChainLengths = [6, 6]
+    b.nChains, b.seed = 256, 42
+    mc = b.build_method()
+    assert mc.nSurrogates == 2
+    mc.run(2000, m["ParameterVector"](np.array([-8.0, -7.0])), verbose=False)
+    assert mc.chain.trajectory.shape == (2000, 256, 2)
+    assert 0.1 < mc.diagnostics.global_acceptance_rate() < 0.9
+    est = mc.chain.trajectory[500::5].reshape(-1, 2).mean(axis=0)
+    assert np.allclose(est, d["tgtMean"], atol=0.1)
+    rates = mc.level_acceptance_rates()
+    assert len(rates) == 2 and all(0.05 < r < 0.95 for r in rates)
+    assert mc.surrogate(0).diagnostics.global_acceptance_rate() == rates[0]
+    assert mc.surrogate(1).diagnostics.global_acceptance_rate() == 0.  # its accept step never runs
+    assert mc.surrogate(-1).target is d["fine"]
+    # == the oracle's nest
+    from yagremcmc_amd import lowering
+    w = [lowering._whitening_of(x) for x in (d["tgt"], d["base"], d["fine"])]
+    og = [o.gauss_whitened(*x) for x in w]
+    P, Q, steps = o.nested_levels(og[1:], [6, 6], og[0])
+    e = o.NestedEnsemble(P, Q, steps, np.ones(2), np.tile([-8.0, -7.0], (256, 1)), 42)
+    out = e.advance(300)
+    assert np.array_equal(mc.chain.trajectory[1:301], out["traj"])
+    assert np.array_equal(mc.accept_decisions[:300], out["acc"])
+
+
+def test_mlda_five_level_method_like_the_reference():
+    """test_mlda.py:189-256: four surrogates, subChainLengths [6, 4, 4, 3]."""
+    m = _imports()
+    d = _mlda_test_data(m)
+    PV, G = m["ParameterVector"], m["GaussianTargetDensity2d"]
+    tm = d["tgtMean"]
+    means = [tm + np.array([0.2, -0.3]), tm + np.array([-0.1, 0.1]), tm + np.array([0.05, -0.05]), tm + 0.0]
+    covs = [8. * np.array([[3.0, -0.2], [-0.2, 1.5]]), 6. * np.array([[2.7, -0.25], [-0.25, 1.3]]),
+            4. * np.array([[2.5, -0.3], [-0.3, 1.1]]), 2. * np.array([[2.4, -0.35], [-0.35, 1.0]])]
+    b = m["MLDABuilder"]()
+    b.explicitTarget = d["tgt"]
+    b.surrogateTargets = [G(PV(mu), c) for mu, c in zip(means, covs)]
+    b.baseProposalCovariance = m["IIDCovarianceMatrix"](2, 1.0)
+    b.subChainLengths = [6, 4, 4, 3]
+    b.nChains, b.seed = 512, 789
+    mc = b.build_method()
+    mc.run(1000, PV(np.array([2.0, -3.0])), verbose=False)
+    assert 0.1 < mc.diagnostics.global_acceptance_rate() < 0.9
+    est = mc.chain.trajectory[200::3].reshape(-1, 2).mean(axis=0)
+    assert np.allclose(est, tm, atol=0.2)
+    assert len(mc.level_acceptance_rates()) == 3
+
+
+def test_mlda_three_surrogates_fail_like_the_reference():
+    """With an odd number >= 3 of surrogates the reference's run() raises AttributeError
+    (mlda.py:23-33 calls run() of a level whose proposal method is the base random walk)."""
+    m = _imports()
+    d = _mlda_test_data(m)
+    b = m["MLDABuilder"]()
+    b.explicitTarget = d["tgt"]
+    b.surrogateTargets = [d["base"], d["fine"], d["fine"]]
+    b.baseProposalCovariance = m["IIDCovarianceMatrix"](2, 1.0)
+    b.subChainLengths = [2, 2, 2]
+    mc = b.build_method()
+    with pytest.raises(AttributeError, match="set_state"):
+        mc.run(10, m["ParameterVector"](np.array([0.0, 0.0])), verbose=False)
+    b.subChainLengths = [2, 2]
+    with pytest.raises(ValueError, match="Number of sub-chain lengths"):
+        b.build_method()
 
 
 @pytest.mark.parametrize("proposal", ["iid", "indep"])

@@ -238,6 +238,99 @@ def test_perfect_surrogate_accepts_every_move(ffi, ctx, golden):
     assert np.array_equal(dev["acc"].astype(bool), moved)
 
 
+def _nested_device_run(ffi, ctx, g_tgt, g_surs, sub_lengths, sigma, x0, seed, nsteps, splits=1, chain0=0):
+    """Through the C ABI: problem with YMC_METHOD_MLDA_NESTED built from lowered densities."""
+    from yagremcmc_amd import lowering
+
+    class _Pre:  # a density that is already lowered
+        def __init__(self, low):
+            self.low = low
+
+    real = lowering.lower_density
+
+    def passthrough(d, rk4_steps=None):
+        return d.low if isinstance(d, _Pre) else real(d, rk4_steps)
+
+    lowering.lower_density = passthrough
+    try:
+        prob = lowering.make_nested_problem(ctx, _Pre(g_tgt), [_Pre(s_) for s_ in g_surs], sub_lengths, sigma)
+    finally:
+        lowering.lower_density = real
+    K = x0.shape[0]
+    run = ffi.Run(prob, seed, K, x0, nsteps, _flags(ffi, True), chain0)
+    base, rem = divmod(nsteps, splits)
+    for i in range(splits):
+        run.advance(base + (1 if i < rem else 0))
+    run.sync()
+    acc, made = run.level_accept()
+    return dict(traj=run.trajectory(), acc=run.accept(), logpost=run.logpost(), summary=run.summary(),
+                state=run.state(), level_acc=acc, level_made=made)
+
+
+@pytest.mark.parametrize("name", ["f10_mlda_nested2.npz", "f11_mlda_nested4.npz"])
+def test_f10_f11_even_surrogate_hierarchies(ffi, ctx, golden, name):
+    g = golden(name)
+    n = int(g["n_states"])
+    ns = g["sur_mean"].shape[0]
+    subs = [int(v) for v in g["sub_lengths"]]
+    tgt = _gauss_low(ffi, g["tgt_mean"], g["tgt_whiten"], g["tgt_log_norm"])
+    surs = [_gauss_low(ffi, g["sur_mean"][i], g["sur_whiten"][i], g["sur_log_norm"][i]) for i in range(ns)]
+    dev = _nested_device_run(ffi, ctx, tgt, surs, subs, g["sigma"], g["x0"], int(g["seed"]), n - 1, splits=3)
+    ot = o.gauss_whitened(g["tgt_mean"], g["tgt_whiten"], float(g["tgt_log_norm"]))
+    osur = [o.gauss_whitened(g["sur_mean"][i], g["sur_whiten"][i], float(g["sur_log_norm"][i])) for i in range(ns)]
+    P, Q, steps = o.nested_levels(osur, subs, ot)
+    e = o.NestedEnsemble(P, Q, steps, g["sigma"], g["x0"], int(g["seed"]))
+    out = e.advance(n - 1)
+    _same_as_oracle(dev, e, out)
+    assert np.array_equal(dev["level_acc"], e.level_acc)
+    _same_as_reference(dev, g)
+    assert np.array_equal(dev["level_acc"], g["level_acc"])
+    made = (n - 1)
+    for e_ in range(len(steps) - 1, -1, -1):
+        made *= steps[e_]
+        assert dev["level_made"][e_] == made
+
+
+@pytest.mark.parametrize("d,E", [(1, 2), (3, 3), (5, 4), (8, 4)])
+def test_nested_other_dimensions_and_depths_vs_oracle(ffi, ctx, d, E):
+    rng = np.random.default_rng(100 * d + E)
+    ns = 2 * (E - 1)
+
+    def rand_gauss(scale):
+        A = rng.normal(size=(d, d))
+        cov = scale * (A @ A.T / d + np.eye(d))
+        return o.gauss_from_cov(rng.normal(size=d) * 0.2, cov)
+
+    ot = rand_gauss(1.0)
+    osur = [rand_gauss(1.5 + 0.5 * (ns - i)) for i in range(ns)]
+    subs = [int(v) for v in rng.integers(1, 4, size=ns)]
+    low = lambda p: _gauss_low(ffi, p["mean"], p["whiten"], p["log_norm"])
+    sigma = np.full(d, 0.9)
+    x0 = rng.normal(size=(300, d))
+    dev = _nested_device_run(ffi, ctx, low(ot), [low(s_) for s_ in osur], subs, sigma, x0, 4242, 60, splits=2,
+                             chain0=1000)
+    P, Q, steps = o.nested_levels(osur, subs, ot)
+    e = o.NestedEnsemble(P, Q, steps, sigma, x0, 4242, chain0=1000)
+    out = e.advance(60)
+    _same_as_oracle(dev, e, out)
+    assert np.array_equal(dev["level_acc"], e.level_acc)
+
+
+def test_nested_full_size_perfect_surrogates_accept_every_move(ffi, ctx, golden):
+    """test_mlda.py:94-130 at ensemble size: all densities equal => every top-level proposal that
+    moved is accepted, and so is every decision of the lower levels."""
+    g = golden("f10_mlda_nested2.npz")
+    tgt = _gauss_low(ffi, g["tgt_mean"], g["tgt_whiten"], g["tgt_log_norm"])
+    K, n = 65536, 50
+    x0 = np.tile([-8.0, -7.0], (K, 1))
+    dev = _nested_device_run(ffi, ctx, tgt, [tgt, tgt, tgt, tgt], [6, 4, 4, 3], g["sigma"], x0, 123, n)
+    # level 1 decides on the end point of 4 random-walk steps on the same density: ratio == 1
+    acc1, made1 = dev["level_acc"][1], int(dev["level_made"][1])
+    moved_any = np.any(np.diff(np.concatenate([x0[None], dev["traj"]]), axis=0) != 0.0, axis=2)
+    assert np.array_equal(dev["acc"].astype(bool), moved_any)
+    assert made1 == n * 3 and np.all(acc1 <= made1) and acc1.mean() > 0.9 * made1
+
+
 # ---------------------------------------------------------------------------
 # other dimensions of the lane-per-chain kernels vs the oracle
 # ---------------------------------------------------------------------------

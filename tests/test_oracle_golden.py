@@ -121,6 +121,43 @@ def test_f5_two_level_delayed_acceptance(golden):
     assert np.array_equal(out["sub_acc"], g["sub_acc"])
 
 
+def _nested_from_fixture(g):
+    tgt = o.gauss_whitened(g["tgt_mean"], g["tgt_whiten"], float(g["tgt_log_norm"]))
+    surs = [o.gauss_whitened(g["sur_mean"][i], g["sur_whiten"][i], float(g["sur_log_norm"][i]))
+            for i in range(g["sur_mean"].shape[0])]
+    return o.nested_levels(surs, [int(v) for v in g["sub_lengths"]], tgt)
+
+
+@pytest.mark.parametrize("name", ["f10_mlda_nested2.npz", "f11_mlda_nested4.npz"])
+def test_f10_f11_even_surrogate_hierarchies_as_the_reference_runs_them(golden, name):
+    """example_mcmc_2d_hierarchical.py (2 surrogates) and test_mlda.py:189-256 (4 surrogates): only
+    every second level decides; chains, decisions and per-level accept counts == the reference's."""
+    g = golden(name)
+    n = int(g["n_states"])
+    P, Q, steps = _nested_from_fixture(g)
+    e = o.NestedEnsemble(P, Q, steps, g["sigma"], g["x0"], int(g["seed"]))
+    assert e.cost_top == int(g["cost_top"])
+    out = e.advance(n - 1)
+    _check(out, g, n)
+    assert np.array_equal(e.level_acc, g["level_acc"])
+    # resumable: two halves == one piece
+    e2 = o.NestedEnsemble(P, Q, steps, g["sigma"], g["x0"], int(g["seed"]), nthreads=3)
+    a, b = e2.advance(100), e2.advance(n - 101)
+    assert np.array_equal(np.concatenate([a["traj"], b["traj"]]), out["traj"])
+    assert np.array_equal(e2.level_acc, e.level_acc)
+
+
+def test_nested_with_one_level_pair_equals_two_level_scheme_when_q_is_p0(golden):
+    """E = 2 with Q = P[0] is exactly the one-surrogate scheme (same draws by address)."""
+    g = golden("f5_mlda2_2d.npz")
+    fine = o.gauss_whitened(g["fine_mean"], g["fine_whiten"], float(g["fine_log_norm"]))
+    coarse = o.gauss_whitened(g["coarse_mean"], g["coarse_whiten"], float(g["coarse_log_norm"]))
+    S = int(g["S"])
+    two = o.Ensemble(fine, g["sigma"], g["x0"][:8], 77, surrogate=coarse, sub_chain_length=S).advance(150)
+    nest = o.NestedEnsemble([coarse, fine], [None, coarse], [S], g["sigma"], g["x0"][:8], 77).advance(150)
+    assert np.array_equal(two["traj"], nest["traj"]) and np.array_equal(two["acc"], nest["acc"])
+
+
 def test_perfect_surrogate_accepts_everything(golden):
     """test_mlda.py:94-130: coarse == fine => every fine proposal that moved is accepted."""
     g = golden("f5_mlda2_2d.npz")

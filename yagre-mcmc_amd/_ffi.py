@@ -12,14 +12,15 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libymc.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # ymc_status
 OK, ERR_INVALID, ERR_DEVICE, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_COMM = 0, -1, -2, -3, -4, -5
 # ymc_density_kind
 GAUSS_WHITENED, GAUSS_ISO1D, POSTERIOR_LINEAR, POSTERIOR_LV = 1, 2, 3, 4
 # ymc_method / ymc_state_eq
-METHOD_MRW, METHOD_MLDA2, METHOD_PCN = 1, 2, 3
+METHOD_MRW, METHOD_MLDA2, METHOD_PCN, METHOD_MLDA_NESTED = 1, 2, 3, 4
+MAX_LEVELS = 4
 EQ_EXACT, EQ_ISCLOSE = 0, 1
 # record flags
 RECORD_TRAJECTORY, RECORD_ACCEPT, RECORD_LOGPOST, RECORD_SUB_ACCEPT, RECORD_MOMENTS = 1, 2, 4, 8, 16
@@ -58,6 +59,9 @@ class ProblemDesc(C.Structure):
         ("target", DensityDesc), ("surrogate", DensityDesc),
         ("sub_chain_length", C.c_int32), ("reserved_", C.c_int32),
         ("proposal_sigma", _dp), ("pcn_step_size", C.c_double),
+        ("n_levels", C.c_int32), ("reserved2_", C.c_int32),
+        ("level_target", C.POINTER(DensityDesc)), ("level_correction", C.POINTER(DensityDesc)),
+        ("level_steps", C.POINTER(C.c_int32)),
     ]
 
 
@@ -96,6 +100,7 @@ _PROTOTYPES = {
     "ymc_run_fetch_accept": (C.c_int, [_vp, _u64, _u64, _vp, C.c_size_t]),
     "ymc_run_fetch_logpost": (C.c_int, [_vp, _u64, _u64, _vp, C.c_size_t]),
     "ymc_run_fetch_sub_accept": (C.c_int, [_vp, _u64, _u64, _vp, C.c_size_t]),
+    "ymc_run_fetch_level_accept": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     "ymc_run_fetch_state": (C.c_int, [_vp, _vp, _vp]),
     "ymc_run_fetch_summary": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "ymc_logdensity_eval": (C.c_int, [_vp, _vp, C.c_int, _u64, _vp, _vp, _vp]),
@@ -252,6 +257,7 @@ class Problem(Handle):
         self.dim = desc.target.dim
         self.method = desc.method
         self.S = desc.sub_chain_length if desc.method == METHOD_MLDA2 else 0
+        self.n_levels = desc.n_levels if desc.method == METHOD_MLDA_NESTED else 0
         self.kind = desc.target.kind
         self._n_data = (desc.target.n_data, desc.target.data_dim)
         del keepalive  # the library copied everything
@@ -326,6 +332,14 @@ class Run(Handle):
 
     def sub_accept(self, first=0, n=None):
         return self._fetch("ymc_run_fetch_sub_accept", first, n, (self.S, self.K), np.uint8)
+
+    def level_accept(self):
+        """Nested delayed acceptance: (accepted[E-1][K], made[E-1]) of the lower levels."""
+        E = self.problem.n_levels
+        acc = np.zeros((E - 1, self.K), dtype=np.uint64)
+        made = np.zeros(E - 1, dtype=np.uint64)
+        check(lib().ymc_run_fetch_level_accept(self.raw, vptr(acc), acc.nbytes, vptr(made)))
+        return acc, made
 
     def state(self):
         x = np.empty((self.K, self.d))

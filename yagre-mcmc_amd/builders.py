@@ -118,7 +118,8 @@ class MRWBuilder(ChainBuilder):
 
 
 class MLDABuilder(ChainBuilder):
-    """chain/method/mlda.py:157-344, explicit targets with one surrogate."""
+    """chain/method/mlda.py:157-344: one surrogate (two-level delayed acceptance) or an even number
+    of them (the nest the reference executes, ensemble.MLDA)."""
 
     def __init__(self):
         super().__init__()
@@ -206,8 +207,7 @@ class MLDABuilder(ChainBuilder):
                 raise UnsupportedPlugin("bias correction has no device lowering")
 
     def build_from_model(self):
-        """mlda.py:315-335: the finest level is the target, the coarser ones are the surrogates
-        (one surrogate level on the device)."""
+        """mlda.py:315-335: the finest level is the target, the coarser ones are the surrogates."""
         self._validate_parameters()
         model = self._bayesModel
         target = UnnormalisedPosterior(model.level(-1).likelihood, model.level(-1).prior)

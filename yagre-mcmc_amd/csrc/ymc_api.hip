@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "ymc_kernels.h"
+#include "ymc_nested.h"
 #include "ymc_post.h"
 #include "ymc_tile.h"
 
@@ -95,6 +96,12 @@ struct ymc_problem {
     bool tile = false;
     DensityHost tgt, sur;
     std::vector<double> sigma;
+    /* MLDA_NESTED: P of levels 0..E-2 (level E-1's is tgt), Q of levels 1..E-1 (index 0 unused) */
+    int E = 0;
+    DensityHost lvlP[YMC_MAX_LEVELS], lvlQ[YMC_MAX_LEVELS];
+    int lvl_steps[YMC_MAX_LEVELS] = {0, 0, 0, 0};
+    uint64_t lvl_cost[YMC_MAX_LEVELS] = {0, 0, 0, 0}; /* transitions one step of level e spans */
+    DeviceBuf lvlP_dev, lvlQ_dev;                     /* DensityDev<D>[E] each */
 };
 
 struct ymc_run {
@@ -104,6 +111,7 @@ struct ymc_run {
     uint32_t flags = 0;
     uint64_t capacity = 0, recorded = 0, steps_done = 0;
     DeviceBuf x, lp, lpc, acc_count, wf_mean, wf_m2, status, traj, acc, lp_out, sub_acc, summary, x_before, recip;
+    DeviceBuf level_acc; /* MLDA_NESTED: [E-1][K] */
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;  /* launches since the last query */
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
 };
@@ -353,6 +361,81 @@ int launch_advance(ymc_run *r, uint64_t nsteps)
     return YMC_OK;
 }
 
+/* the nest's lowered densities as two device arrays (they exceed the kernel-argument segment) */
+template <int D>
+int upload_levels(ymc_problem *p)
+{
+    std::vector<DensityDev<D>> P(p->E), Q(p->E);
+    std::memset(P.data(), 0, P.size() * sizeof(DensityDev<D>));
+    std::memset(Q.data(), 0, Q.size() * sizeof(DensityDev<D>));
+    for (int e = 0; e < p->E; ++e) {
+        P[e] = device_view<D>(e == p->E - 1 ? p->tgt : p->lvlP[e]);
+        if (e >= 1) Q[e] = device_view<D>(p->lvlQ[e]);
+    }
+    YMC_TRY(p->lvlP_dev.alloc(P.size() * sizeof(DensityDev<D>)));
+    YMC_TRY(p->lvlQ_dev.alloc(Q.size() * sizeof(DensityDev<D>)));
+    YMC_HIP(hipMemcpy(p->lvlP_dev.p, P.data(), p->lvlP_dev.bytes, hipMemcpyHostToDevice));
+    YMC_HIP(hipMemcpy(p->lvlQ_dev.p, Q.data(), p->lvlQ_dev.bytes, hipMemcpyHostToDevice));
+    return YMC_OK;
+}
+
+template <int D>
+int launch_advance_nested(ymc_run *r, uint64_t nsteps)
+{
+    const ymc_problem *p = r->problem;
+    NestedArgs<D> a;
+    std::memset(&a, 0, sizeof a);
+    a.P = p->lvlP_dev.as<DensityDev<D>>();
+    a.Q = p->lvlQ_dev.as<DensityDev<D>>();
+    for (int e = 0; e < YMC_MAX_LEVELS; ++e) a.steps[e] = p->lvl_steps[e];
+    a.E = p->E;
+    a.eq_mode = p->eq_mode;
+    for (int j = 0; j < D; ++j) a.sigma[j] = p->sigma[j];
+    a.seed = r->seed;
+    a.chain0 = r->chain0;
+    a.K = r->K;
+    a.t0 = r->steps_done;
+    a.cost_top = p->lvl_cost[p->E - 1];
+    a.wf_n0 = r->steps_done;
+    a.nsteps = (uint32_t)nsteps;
+    a.flags = r->flags;
+    a.x = r->x.as<double>();
+    a.lp = r->lp.as<double>();
+    a.lpq = r->lpc.as<double>();
+    a.acc_count = r->acc_count.as<uint64_t>();
+    a.level_acc = r->level_acc.as<uint64_t>();
+    a.wf_mean = r->wf_mean.as<double>();
+    a.wf_m2 = r->wf_m2.as<double>();
+    a.status = r->status.as<uint32_t>();
+    if (r->flags & YMC_RECORD_MOMENTS) {
+        if (r->recip.bytes < nsteps * sizeof(double)) YMC_TRY(r->recip.alloc(nsteps * sizeof(double)));
+        YMC_HIP(ymc_launch_recip(r->steps_done, nsteps, r->recip.as<double>(), r->ctx->stream));
+        a.recip = r->recip.as<double>();
+    }
+    const uint64_t row = r->recorded;
+    if (r->flags & YMC_RECORD_TRAJECTORY) a.traj = r->traj.as<double>() + row * r->K * D;
+    if (r->flags & YMC_RECORD_ACCEPT) a.acc = r->acc.as<uint8_t>() + row * r->K;
+    if (r->flags & YMC_RECORD_LOGPOST) a.lp_out = r->lp_out.as<double>() + row * r->K;
+
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (!r->pool.empty()) {
+        ev = r->pool.back();
+        r->pool.pop_back();
+    } else {
+        YMC_HIP(hipEventCreate(&ev.first));
+        YMC_HIP(hipEventCreate(&ev.second));
+    }
+    YMC_HIP(hipEventRecord(ev.first, r->ctx->stream));
+    hipError_t e = ymc_launch_nested<D>(p->kind, a, r->ctx->stream);
+    if (e != hipSuccess) {
+        r->pool.push_back(ev);
+        return fail(YMC_ERR_DEVICE, "nested chain kernel launch failed: %s", hipGetErrorString(e));
+    }
+    YMC_HIP(hipEventRecord(ev.second, r->ctx->stream));
+    r->timed.push_back(ev);
+    return YMC_OK;
+}
+
 /* A in MFMA A-operand fragment order + the padded constant arrays, one block */
 int build_tile_blob(ymc_problem *p)
 {
@@ -521,7 +604,8 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
 {
     if (!ctx || !desc || !out) return fail(YMC_ERR_INVALID, "null argument");
     *out = nullptr;
-    if (desc->method != YMC_METHOD_MRW && desc->method != YMC_METHOD_MLDA2 && desc->method != YMC_METHOD_PCN)
+    if (desc->method != YMC_METHOD_MRW && desc->method != YMC_METHOD_MLDA2 && desc->method != YMC_METHOD_PCN &&
+        desc->method != YMC_METHOD_MLDA_NESTED)
         return fail(YMC_ERR_UNSUPPORTED, "unknown method %d", desc->method);
     if (desc->state_eq != YMC_EQ_EXACT && desc->state_eq != YMC_EQ_ISCLOSE)
         return fail(YMC_ERR_INVALID, "unknown state equality rule %d", desc->state_eq);
@@ -547,6 +631,29 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
         if (rc == YMC_OK) rc = lower_density(ctx, desc->surrogate, p->sur, p->D);
         p->S = desc->sub_chain_length;
     }
+    if (rc == YMC_OK && desc->method == YMC_METHOD_MLDA_NESTED) {
+        const int E = desc->n_levels;
+        if (E < 2 || E > YMC_MAX_LEVELS)
+            rc = fail(YMC_ERR_UNSUPPORTED, "nested delayed acceptance has 2 to %d effective levels, got %d",
+                      YMC_MAX_LEVELS, E);
+        else if (!desc->level_target || !desc->level_correction || !desc->level_steps)
+            rc = fail(YMC_ERR_INVALID, "Surrogate targets not set for MLDA");
+        p->E = E;
+        for (int e = 0; rc == YMC_OK && e < E - 1; ++e) {
+            const ymc_density_desc &P = desc->level_target[e], &Q = desc->level_correction[e];
+            if (desc->level_steps[e] < 1) rc = fail(YMC_ERR_INVALID, "Subchain lengths not set for MLDA");
+            if (rc == YMC_OK && (P.kind != desc->target.kind || Q.kind != desc->target.kind))
+                rc = fail(YMC_ERR_UNSUPPORTED, "surrogate density kinds %d / %d differ from target kind %d", P.kind,
+                          Q.kind, desc->target.kind);
+            if (rc == YMC_OK) rc = lower_density(ctx, P, p->lvlP[e], p->D);
+            if (rc == YMC_OK) rc = lower_density(ctx, Q, p->lvlQ[e + 1], p->D);
+            if (rc == YMC_OK && (p->lvlP[e].tile || p->lvlQ[e + 1].tile))
+                rc = fail(YMC_ERR_UNSUPPORTED, "only the random-walk sampler is available at this dimension");
+            p->lvl_steps[e] = desc->level_steps[e];
+            p->lvl_cost[e] = e == 0 ? 1 : (uint64_t)p->lvl_steps[e - 1] * p->lvl_cost[e - 1] + 1;
+        }
+        if (rc == YMC_OK) p->lvl_cost[E - 1] = (uint64_t)p->lvl_steps[E - 2] * p->lvl_cost[E - 2] + 1;
+    }
     if (rc == YMC_OK) {
         /* MRWBuilder._validate_parameters, mrw.py:88-91 */
         if (!desc->proposal_sigma) rc = fail(YMC_ERR_INVALID, "Proposal Covariance not set");
@@ -569,6 +676,13 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
             rc = fail(YMC_ERR_UNSUPPORTED, "only the random-walk sampler is available at this dimension");
         if (rc == YMC_OK) rc = build_tile_blob(p);
         p->tile = true;
+    }
+    if (rc == YMC_OK && p->method == YMC_METHOD_MLDA_NESTED) {
+        auto up = [&]() -> int {
+            YMC_DISPATCH_D(p->D, return upload_levels<DD>(p));
+            return YMC_OK;
+        };
+        rc = up();
     }
     if (rc != YMC_OK) {
         delete p;
@@ -648,6 +762,12 @@ int ymc_run_create(ymc_ctx *ctx, const ymc_problem *problem, const ymc_run_desc 
         YMC_TRY(eval_logdensity(ctx, problem, problem->tgt, K, r->x.as<double>(), r->lp.as<double>(), nullptr));
         if (problem->method == YMC_METHOD_MLDA2)
             YMC_TRY(eval_logdensity(ctx, problem, problem->sur, K, r->x.as<double>(), r->lpc.as<double>(), nullptr));
+        if (problem->method == YMC_METHOD_MLDA_NESTED) {
+            YMC_TRY(eval_logdensity(ctx, problem, problem->lvlQ[problem->E - 1], K, r->x.as<double>(),
+                                    r->lpc.as<double>(), nullptr));
+            YMC_TRY(r->level_acc.alloc((uint64_t)(problem->E - 1) * K * sizeof(uint64_t)));
+            YMC_HIP(hipMemsetAsync(r->level_acc.p, 0, r->level_acc.bytes, ctx->stream));
+        }
         YMC_HIP(hipStreamSynchronize(ctx->stream));
         return YMC_OK;
     };
@@ -688,6 +808,8 @@ int ymc_run_advance(ymc_run *run, uint64_t nsteps)
         const uint64_t chunk = nsteps < chunk_max ? nsteps : chunk_max;
         if (run->problem->tile) {
             YMC_TRY(launch_advance_tile(run, chunk));
+        } else if (run->problem->method == YMC_METHOD_MLDA_NESTED) {
+            YMC_DISPATCH_D(run->problem->D, YMC_TRY(launch_advance_nested<DD>(run, chunk)));
         } else {
             YMC_DISPATCH_D(run->problem->D, YMC_TRY(launch_advance<DD>(run, chunk)));
         }
@@ -787,6 +909,29 @@ int ymc_run_fetch_sub_accept(ymc_run *run, uint64_t first, uint64_t n, uint8_t *
     if (run->problem->method != YMC_METHOD_MLDA2) return fail(YMC_ERR_INVALID, "not a two-level run");
     return fetch_rows(run, run->sub_acc, YMC_RECORD_SUB_ACCEPT, "sub-chain decisions", first, n,
                       (uint64_t)run->problem->S * run->K, dst, dst_bytes);
+}
+
+int ymc_run_fetch_level_accept(ymc_run *run, uint64_t *dst, size_t dst_bytes, uint64_t *made)
+{
+    if (!run) return fail(YMC_ERR_INVALID, "null argument");
+    const ymc_problem *p = run->problem;
+    if (p->method != YMC_METHOD_MLDA_NESTED) return fail(YMC_ERR_INVALID, "not a nested run");
+    YMC_HIP(hipSetDevice(run->ctx->device));
+    YMC_HIP(hipStreamSynchronize(run->ctx->stream));
+    if (dst) {
+        if (dst_bytes < run->level_acc.bytes)
+            return fail(YMC_ERR_INVALID, "destination holds %zu bytes, %zu needed", dst_bytes, run->level_acc.bytes);
+        YMC_HIP(hipMemcpy(dst, run->level_acc.p, run->level_acc.bytes, hipMemcpyDeviceToHost));
+    }
+    if (made) {
+        /* level e makes lvl_steps[e] transitions per step of level e+1 */
+        uint64_t above = run->steps_done;
+        for (int e = p->E - 2; e >= 0; --e) {
+            above *= (uint64_t)p->lvl_steps[e];
+            made[e] = above;
+        }
+    }
+    return YMC_OK;
 }
 
 int ymc_run_fetch_state(ymc_run *run, double *state, double *logpost)

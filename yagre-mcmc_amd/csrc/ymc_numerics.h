@@ -159,7 +159,10 @@ YMC_FN ymc_u32x4 ymc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32
 /* are numbered t = 0, 1, 2, ... (for the single-level random walk t is the */
 /* step index; for two-level delayed acceptance with sub-chain length S,    */
 /* fine step n owns t = n*(S+1) + s, s = 0..S-1 the coarse sub-steps and    */
-/* s = S the fine accept/reject).  Every draw is addressed, never           */
+/* s = S the fine accept/reject; for the nested scheme every accept/reject  */
+/* decision of any level takes the next t in execution order, so one step   */
+/* of level e spans c_e = S_{e-1} c_{e-1} + 1 transitions, c_0 = 1, and top */
+/* step n starts at t = n c_{E-1}).  Every draw is addressed, never         */
 /* sequenced, so the reference's "proposal == state => no uniform drawn"    */
 /* rule (metropolisHastings.py:60-61) does not shift any later draw.        */
 /*                                                                          */

@@ -249,31 +249,99 @@ class MetropolisedRandomWalk(MetropolisHastingsEnsemble):
                                      rk4_steps=self.rk4Steps)
 
 
+class SurrogateLevel:
+    """What `mcmc.surrogate(i)` returns (mlda.py:84-89 hands out the reference's per-level
+    MetropolisHastings object): the level's target and its acceptance statistics."""
+
+    def __init__(self, owner, index):
+        self._owner, self._index = owner, index
+
+    @property
+    def target(self):
+        return self._owner._surrogates[self._index]
+
+    @property
+    def diagnostics(self):
+        return self._owner._level_diagnostics(self._index)
+
+
+class LevelAcceptance:
+    """AcceptanceRateDiagnostics surface (diagnostics.py:36-54) of a lower level: counts only."""
+
+    def __init__(self, accepted, made):
+        self.accepted, self.made = accepted, int(made)
+
+    def global_acceptance_rate(self):
+        if self.made == 0:
+            return 0.
+        return float(self.accepted.sum()) / (self.made * self.accepted.size)
+
+    def per_chain_acceptance_rate(self):
+        return self.accepted / max(self.made, 1)
+
+
 class MLDA(MetropolisHastingsEnsemble):
-    """chain/method/mlda.py:120-154 restricted to ONE surrogate level: the
-    proposal is the end point of a subChainLength-step random walk on the
-    surrogate density (mlda.py:102-110); acceptance is mlda.py:146-154."""
+    """chain/method/mlda.py:120-154.
+
+    One surrogate: the proposal is the end point of a subChainLength-step random walk on the
+    surrogate density (mlda.py:102-110), acceptance is mlda.py:146-154 (YMC_METHOD_MLDA2).
+
+    An even number of surrogates: the nest the reference actually executes, in which only every
+    second level applies its accept step (YMC_METHOD_MLDA_NESTED, include/ymc.h).  An odd number
+    >= 3 fails in the reference when `run` reaches the base level (`MetropolisedRandomWalk` is
+    asked for `set_state`); the same AttributeError is raised here."""
 
     def __init__(self, targetDensity, surrogateDensities, baseProposalCov, nSteps, targetDiagnostics,
                  surrogateDiagnosticsList=None, *, recordSubChain=False, **ensemble):
-        if len(surrogateDensities) != 1 or len(nSteps) != 1:
-            raise lowering.UnsupportedPlugin(
-                "the device path implements two-level delayed acceptance (one surrogate); "
-                f"got {len(surrogateDensities)} surrogates")
+        if len(surrogateDensities) < 1:
+            raise ValueError("Surrogate hierarchy must contain at least one surrogate.")
+        if len(nSteps) != len(surrogateDensities):
+            raise ValueError("Number of sub-chain lengths does not match number of surrogate targets")
         super().__init__(targetDensity, baseProposalCov, targetDiagnostics, **ensemble)
-        self._surrogate = surrogateDensities[0]
-        self._subChainLength = int(nSteps[0])
+        self._surrogates = list(surrogateDensities)
+        self._nSteps = [int(v) for v in nSteps]
         self._surrogateDiagnostics = surrogateDiagnosticsList
         self.recordSubChain = bool(recordSubChain)
+        if self.recordSubChain and len(self._surrogates) != 1:
+            raise lowering.UnsupportedPlugin("sub-chain decisions are recorded for one surrogate only")
 
     @property
     def nSurrogates(self):
-        return 1
+        return len(self._surrogates)
+
+    def surrogate(self, sIdx):
+        if sIdx < -1 or sIdx >= self.nSurrogates:
+            raise IndexError(f"invalid surrogate index: {sIdx}")
+        return SurrogateLevel(self, sIdx % self.nSurrogates)
 
     @property
     def sub_chain_decisions(self):
-        """(N-1, S, K) outcomes of the coarse sub-steps (needs recordSubChain)."""
+        """(N-1, S, K) outcomes of the coarse sub-steps (one surrogate, needs recordSubChain)."""
         return self._run.sub_accept()
+
+    def level_acceptance_rates(self):
+        """Acceptance rate of every level that takes decisions, coarsest first, the recorded chain
+        last (pooled over chains)."""
+        top = self._diagnostics.global_acceptance_rate()
+        if self.nSurrogates == 1:
+            return [top]
+        acc, made = self._run.level_accept()
+        return [LevelAcceptance(acc[e], made[e]).global_acceptance_rate() for e in range(acc.shape[0])] + [top]
+
+    def _level_diagnostics(self, index):
+        """Surrogate i of an even hierarchy decides iff i is even (it is level i/2 of the nest)."""
+        n = self.nSurrogates
+        if n == 1 or self._run is None or index % 2 == 1:
+            return LevelAcceptance(np.zeros(self.nChains, dtype=np.uint64), 0)
+        acc, made = self._run.level_accept()
+        return LevelAcceptance(acc[index // 2], made[index // 2])
+
+    def run(self, chainLength, initialState, verbose=True):
+        n = self.nSurrogates
+        if n >= 3 and n % 2 == 1 and int(chainLength) > 1:
+            # mlda.py:23-33 -> metropolisHastings.py:116 on the base level
+            raise AttributeError("'MetropolisedRandomWalk' object has no attribute 'set_state'")
+        super().run(chainLength, initialState, verbose)
 
     def _record_flags(self):
         flags = super()._record_flags()
@@ -284,9 +352,12 @@ class MLDA(MetropolisHastingsEnsemble):
     def _make_problem(self, ctx, state_eq):
         dim = lowering.lower_density(self._tgtDensity, self.rk4Steps).desc.dim
         sigma = lowering.proposal_sigma(self._proposalCov, dim)
-        return lowering.make_problem(ctx, _ffi.METHOD_MLDA2, self._tgtDensity, sigma, state_eq,
-                                     surrogate=self._surrogate, sub_chain_length=self._subChainLength,
-                                     rk4_steps=self.rk4Steps)
+        if self.nSurrogates == 1:
+            return lowering.make_problem(ctx, _ffi.METHOD_MLDA2, self._tgtDensity, sigma, state_eq,
+                                         surrogate=self._surrogates[0], sub_chain_length=self._nSteps[0],
+                                         rk4_steps=self.rk4Steps)
+        return lowering.make_nested_problem(ctx, self._tgtDensity, self._surrogates, self._nSteps, sigma,
+                                            state_eq, rk4_steps=self.rk4Steps)
 
 
 class PreconditionedCrankNicolson(MetropolisHastingsEnsemble):

@@ -163,6 +163,42 @@ def lower_likelihood(likelihood, prior, rk4_steps=None):
     return low
 
 
+def nested_levels(target, surrogates, sub_chain_lengths):
+    """The effective levels of MLDA with an even number n of surrogates as the reference executes it
+    (mlda.py:12-73,100-116; include/ymc.h, YMC_METHOD_MLDA_NESTED): only every second level's accept
+    step runs.  Returns (P, Q, steps): P of levels 0..E-2, Q of levels 1..E-1, steps of levels 0..E-2."""
+    n = len(surrogates)
+    E = n // 2 + 1
+    P = [surrogates[2 * e] for e in range(E - 1)]
+    Q = [surrogates[2 * e - 1] for e in range(1, E)]
+    steps = [int(sub_chain_lengths[2 * e + 1]) for e in range(E - 1)]
+    return P, Q, steps
+
+
+def make_nested_problem(ctx, target, surrogates, sub_chain_lengths, sigma, state_eq=_ffi.EQ_EXACT, rk4_steps=None):
+    tgt = lower_density(target, rk4_steps)
+    P, Q, steps = nested_levels(target, surrogates, sub_chain_lengths)
+    E = len(P) + 1
+    if E > _ffi.MAX_LEVELS:
+        raise UnsupportedPlugin(f"{len(surrogates)} surrogates make {E} nested levels; the device nest holds "
+                                f"{_ffi.MAX_LEVELS}")
+    lowP = [lower_density(p, rk4_steps) for p in P]
+    lowQ = [lower_density(q, rk4_steps) for q in Q]
+    desc = _ffi.ProblemDesc()
+    desc.method, desc.state_eq = _ffi.METHOD_MLDA_NESTED, state_eq
+    desc.target = tgt.desc
+    desc.n_levels = E
+    arrP = (_ffi.DensityDesc * (E - 1))(*[l.desc for l in lowP])
+    arrQ = (_ffi.DensityDesc * (E - 1))(*[l.desc for l in lowQ])
+    arrS = (_ffi.C.c_int32 * (E - 1))(*steps)
+    desc.level_target, desc.level_correction, desc.level_steps = arrP, arrQ, arrS
+    sigma = _ffi.f64(sigma).reshape(-1)
+    if sigma.size != tgt.desc.dim:
+        raise ValueError(f"proposal covariance has dimension {sigma.size}, the target has {tgt.desc.dim}")
+    desc.proposal_sigma = _ffi.dptr(sigma)
+    return _ffi.Problem(ctx, desc, [tgt, lowP, lowQ, arrP, arrQ, arrS, sigma])
+
+
 def make_problem(ctx, method, target, sigma, state_eq=_ffi.EQ_EXACT, surrogate=None, sub_chain_length=0,
                  rk4_steps=None, pcn_step_size=0.0):
     tgt = lower_density(target, rk4_steps) if not isinstance(target, Lowered) else target
