@@ -178,7 +178,10 @@ def main():
         args.gpus = world
 
     from yagremcmc_amd import _ffi as ffi, distributed, lowering
-    ctx = ffi.Context(local_rank if world > 1 else 0)
+    device = local_rank if world > 1 else 0
+    if os.environ.get("YMC_BENCH_ALLOW_SHARED_GPU") == "1":
+        device %= ffi.device_count()  # rehearsal of the N > 1 flow on a box with fewer GPUs than ranks
+    ctx = ffi.Context(device)
     info = ctx.info()
     prob, x0, def_chains, def_T, desc, d, wl = make_workload(args.workload, ffi, ctx, lowering)
     wl["x0"] = x0
@@ -277,6 +280,7 @@ def main():
         "pooled_mean": None if args.no_moments else [float(v) for v in pooled["mean"]],
         "chains_flagged_nonfinite": pooled["flagged"],
         "gather_ms": gather_ms,
+        "collective": None if comm is None else comm.backend,
         "device": info,
     }
     if world == 1 and not args.no_cpu_baseline:

@@ -105,3 +105,66 @@ def test_shard_and_rendezvous(tmp_path, monkeypatch):
     assert b.wait(128, timeout=1.0) == b"x" * 128
     a.cleanup()
     assert not os.path.exists(a.path)
+
+
+class _FakeRun:
+    """summary()/state() of a device run, served by the oracle ensemble"""
+
+    def __init__(self, e):
+        self.e, self.K, self.d = e, e.K, e.d
+
+    def summary(self):
+        e = self.e
+        return dict(accepted=e.acc_count, wf_n=e.wf_n, wf_mean=e.wf_mean, wf_m2=e.wf_m2, status=e.status)
+
+    def state(self):
+        return self.e.x, self.e.lp
+
+
+def _file_comm_worker(rank, world, port, total, steps, q):
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as o
+    from yagremcmc_amd import distributed
+    os.environ.update(MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), YMC_COMM="file")
+    comm = distributed.make_communicator(None, rank, world)
+    assert comm.backend == "file"
+    g = np.load(os.path.join(ROOT, "tests", "golden", "f2_mrw_2d.npz"))
+    p = o.gauss_whitened(g["mean"], g["whiten"], float(g["log_norm"]))
+    off, k = distributed.shard(total, rank, world)
+    e = o.Ensemble(p, g["sigma"], np.tile([-8.0, -7.0], (k, 1)), 4242, chain0=off)
+    e.advance(steps, record=False)
+    comm.barrier()
+    tmax = comm.allreduce_max(float(rank + 1))
+    packed = comm.allgather_summary(_FakeRun(e))
+    for _ in range(3):
+        comm.barrier()  # exercises the clean-up of earlier collectives
+    if rank == 0:
+        q.put((packed, tmax))
+
+
+def test_file_communicator_two_ranks(tmp_path):
+    """The stand-in used when RCCL cannot come up: same gather result as the device layout."""
+    import multiprocessing as mp
+    from oracle import oracle as o
+    from yagremcmc_amd import distributed
+    total, steps, world = 64, 100, 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_file_comm_worker, args=(r, world, port, total, steps, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    packed, tmax = q.get(timeout=120)
+    for p_ in procs:
+        p_.join(timeout=60)
+        assert p_.exitcode == 0
+    assert tmax == 2.0 and packed.shape == (2, 32, 11)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "f2_mrw_2d.npz"))
+    p = o.gauss_whitened(g["mean"], g["whiten"], float(g["log_norm"]))
+    e = o.Ensemble(p, g["sigma"], np.tile([-8.0, -7.0], (total, 1)), 4242)
+    e.advance(steps, record=False)
+    assert np.array_equal(packed.reshape(-1, 11), _pack_like_device(e, 2))
+    summary = distributed.unpack_summaries(packed, 2)
+    assert np.array_equal(summary["state"], e.x) and np.array_equal(summary["accepted"], e.acc_count)

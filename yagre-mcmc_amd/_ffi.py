@@ -374,6 +374,7 @@ class Communicator(Handle):
     """One rank of the RCCL communicator (one process per GPU)."""
 
     _destroy = "ymc_comm_destroy"
+    backend = "rccl"
 
     @staticmethod
     def unique_id():

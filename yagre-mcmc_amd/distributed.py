@@ -8,6 +8,7 @@ contributes its packed summaries (3d+5 eight-byte words per chain, written by
 pack_summary_kernel) to one RCCL all-gather (`_ffi.Communicator`).
 """
 import os
+import sys
 import time
 
 import numpy as np
@@ -113,19 +114,101 @@ class _StdoutToStderr:
         return False
 
 
+def pack_summary_host(run, d):
+    """The word layout of pack_summary_kernel from a host-side summary fetch: (K, 3d+5) u64."""
+    s, (x, lp) = run.summary(), run.state()
+    out = np.zeros((run.K, summary_words(d)), dtype=np.uint64)
+    out[:, 0:d] = np.ascontiguousarray(x).view(np.uint64)
+    out[:, d] = np.ascontiguousarray(lp).view(np.uint64)
+    out[:, d + 1] = s["accepted"]
+    out[:, d + 2] = s["wf_n"]
+    out[:, d + 3:2 * d + 3] = np.ascontiguousarray(s["wf_mean"]).view(np.uint64)
+    out[:, 2 * d + 3:3 * d + 3] = np.ascontiguousarray(s["wf_m2"]).view(np.uint64)
+    out[:, 3 * d + 3] = s["status"]
+    return out
+
+
+class FileCommunicator:
+    """The communicator's interface over files of one node's /tmp: the stand-in when RCCL cannot be
+    brought up (library missing, bootstrap refused).  Nothing on the sampling path uses it; it only
+    keeps the barrier, the max-over-ranks timing and the final gather of summaries working."""
+
+    backend = "file"
+
+    def __init__(self, rank, world, directory="/tmp", timeout=600.0):
+        self.rank, self.nranks, self.timeout = rank, world, timeout
+        self.dir = FileRendezvous(directory).path + "_comm"
+        os.makedirs(self.dir, exist_ok=True)
+        self.seq = 0
+
+    def _path(self, seq, rank):
+        return os.path.join(self.dir, f"op{seq}_r{rank}.npy")
+
+    def _exchange(self, array):
+        seq, self.seq = self.seq, self.seq + 1
+        if seq >= 2:
+            try:
+                os.remove(self._path(seq - 2, self.rank))  # every rank has read it (it wrote op seq-1 since)
+            except OSError:
+                pass
+        tmp = self._path(seq, self.rank) + f".{os.getpid()}.tmp"
+        with open(tmp, "wb") as f:
+            np.save(f, np.ascontiguousarray(array))
+        os.replace(tmp, self._path(seq, self.rank))
+        out, deadline = [], time.time() + self.timeout
+        for r in range(self.nranks):
+            while True:
+                try:
+                    out.append(np.load(self._path(seq, r)))
+                    break
+                except (FileNotFoundError, ValueError, EOFError):
+                    if time.time() > deadline:
+                        raise RuntimeError(f"rank {r} did not reach collective {seq}")
+                    time.sleep(0.002)
+        return out
+
+    def barrier(self):
+        self._exchange(np.zeros(1))
+
+    def allreduce_max(self, value):
+        return float(max(v[0] for v in self._exchange(np.array([float(value)]))))
+
+    def allgather_summary(self, run):
+        return np.stack(self._exchange(pack_summary_host(run, run.d)))
+
+
+_FALLBACK_MARK = b"YMC-NO-RCCL"
+
+
 def make_communicator(ctx, rank, world):
+    """The RCCL communicator of this rank; a FileCommunicator if YMC_COMM=file is set or RCCL fails to
+    come up (rank 0 then tells the others through the rendezvous file, so all ranks agree)."""
     from . import _ffi
+    if os.environ.get("YMC_COMM", "rccl") == "file":
+        return FileCommunicator(rank, world)
     # one node: RCCL's bootstrap sockets go over loopback (the container hostname may not resolve)
     os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     rdzv = FileRendezvous()
+    mark = _FALLBACK_MARK.ljust(_ffi.UNIQUE_ID_BYTES, b"\0")
     with _StdoutToStderr():
         if rank == 0:
-            uid = _ffi.Communicator.unique_id()
+            try:
+                uid = _ffi.Communicator.unique_id()
+            except (OSError, _ffi.YmcError) as e:
+                print(f"ymc: RCCL unavailable ({e}); using the file communicator", file=sys.stderr)
+                uid = mark
             rdzv.publish(uid)
         else:
             uid = rdzv.wait(_ffi.UNIQUE_ID_BYTES)
-        comm = _ffi.Communicator(ctx, uid, world, rank)
-        comm.barrier()
+        if uid == mark:
+            return FileCommunicator(rank, world)
+        try:
+            comm = _ffi.Communicator(ctx, uid, world, rank)
+            comm.barrier()
+        except _ffi.YmcError as e:
+            # ncclCommInitRank fails on every rank or on none (it is itself a collective)
+            print(f"ymc: RCCL communicator failed on rank {rank} ({e}); using the file communicator", file=sys.stderr)
+            return FileCommunicator(rank, world)
     if rank == 0:
         rdzv.cleanup()
     return comm
