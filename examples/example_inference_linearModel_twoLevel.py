@@ -1,7 +1,8 @@
-"""Linear forward model, two-level delayed acceptance over a model hierarchy and
-preconditioned Crank-Nicolson -- the ensemble version of the MRW / vanilla-MLDA
-parts of the reference's example_inference_linearModel_twoLevel.py (same maps,
-prior, noise, proposal; the adaptive-error-model part has no device path)."""
+"""Linear forward model: random walk, two-level delayed acceptance over a model
+hierarchy, the same with the adaptive error model, and preconditioned
+Crank-Nicolson -- the ensemble version of the reference's
+example_inference_linearModel_twoLevel.py (same maps, prior, noise, proposal,
+minDataSize 100 with the noise heuristic)."""
 import os
 import sys
 
@@ -9,6 +10,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
+from yagremcmc_amd.chain.method.aem import AEMBuilder
 from yagremcmc_amd.chain.method.mlda import MLDABuilder
 from yagremcmc_amd.chain.method.mrw import MRWBuilder
 from yagremcmc_amd.chain.method.pcn import PCNBuilder
@@ -19,7 +21,7 @@ from yagremcmc_amd.statistics.bayesModel import BayesianRegressionModel
 from yagremcmc_amd.statistics.covariance import IIDCovarianceMatrix
 from yagremcmc_amd.statistics.data import Data
 from yagremcmc_amd.statistics.gaussian import Gaussian
-from yagremcmc_amd.statistics.likelihood import AdditiveGaussianNoiseLikelihood
+from yagremcmc_amd.statistics.likelihood import AdditiveGaussianNoiseLikelihood, AEMLikelihood
 from yagremcmc_amd.statistics.modelHierarchy import BayesianRegressionModelHierarchy
 from yagremcmc_amd.statistics.noise import CentredGaussianNoise
 from yagremcmc_amd.utility.hierarchy import Hierarchy, SharedComponent
@@ -67,6 +69,18 @@ mlda.bayesModel = BayesianRegressionModelHierarchy(Hierarchy([surLikelihood, tgt
 vanillaMLDA = mlda.build_method()
 vanillaMLDA.run(nSteps, init, verbose=False)
 report("vanilla MLDA (sub-chain 5)", vanillaMLDA)
+
+aemSur = AEMLikelihood(data, ForwardModel(surSolver), noise, 100, True)
+aemTgt = AEMLikelihood(data, ForwardModel(tgtSolver), noise, 100, True)
+aem = AEMBuilder()
+aem.baseProposalCovariance, aem.subChainLengths, aem.nChains = proposalCov, [5], nChains
+aem.bayesModel = BayesianRegressionModelHierarchy(Hierarchy([aemSur, aemTgt]), SharedComponent(prior, 2))
+aemMLDA = aem.build_method()
+aemMLDA.run(nSteps, init, verbose=False)
+report("MLDA + adaptive error model", aemMLDA)
+em = aemMLDA.error_model()
+print(f"{'':28s} chains past minDataSize: {int(em['has_precision'].sum())} of {nChains}; learned error mean "
+      f"(median over chains) {np.median(em['mean'], axis=0)}")
 
 centred = Gaussian(ParameterVector(np.zeros(DIM)), IIDCovarianceMatrix(DIM, 5.))
 pcn = PCNBuilder()

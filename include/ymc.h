@@ -92,7 +92,13 @@ typedef enum ymc_method {
      *                with exp(P(y) + Q(x) - Q(y) - P(x)), P = surrogateTargets[2e], Q = [2e-1]
      *   level E-1    the recorded chain: P = the target, Q = surrogateTargets[n-1]
      * (An odd n >= 3 raises AttributeError in the reference; the Python layer raises the same.) */
-    YMC_METHOD_MLDA_NESTED = 4
+    YMC_METHOD_MLDA_NESTED = 4,
+    /* AdaptiveErrorModel with one surrogate (chain/method/aem.py:6-58): MLDA2 whose coarse
+     * AEMLikelihood (statistics/likelihood.py:90-155, noise.py:25-61) learns the model error
+     * F_fine - F_coarse from the accepted fine proposals, per chain, including the reference's
+     * three-entry AEMCache of log-likelihood values (utility/memoisation.py:76-149).
+     * POSTERIOR_LINEAR only (the reference's error model needs a vector-valued forward map). */
+    YMC_METHOD_AEM2 = 5
 } ymc_method;
 
 #define YMC_MAX_LEVELS 4 /* effective levels E of YMC_METHOD_MLDA_NESTED (n <= 6 surrogates) */
@@ -109,15 +115,15 @@ typedef struct ymc_problem_desc {
     int32_t state_eq;              /* ymc_state_eq */
     ymc_density_desc target;       /* the (fine) target density */
     ymc_density_desc surrogate;    /* MLDA2: the coarse density (same kind and dim) */
-    int32_t sub_chain_length;      /* MLDA2: subChainLengths[0] */
-    int32_t reserved_;
+    int32_t sub_chain_length;      /* MLDA2, AEM2: subChainLengths[0] */
+    int32_t aem_min_data_size;     /* AEM2: AEMLikelihood minDataSize (>= 2, likelihood.py:99-100) */
     /* [d]: sqrt(reciprocal(precision)) of the proposal covariance (covariance.py:51-52);
      * PCN: of the PRIOR covariance (the proposal draws from the prior, pcn.py:29) */
     const double *proposal_sigma;
     double pcn_step_size;          /* PCN: stepSize h, 0 < h <= 0.5 (pcn.py:42) */
     /* MLDA_NESTED (all densities of the same kind and dim as `target`, which is level E-1's P): */
     int32_t n_levels;                         /* E, 2 .. YMC_MAX_LEVELS */
-    int32_t reserved2_;
+    int32_t aem_use_noise_heuristic;          /* AEM2: AEMLikelihood useNoiseHeuristic (noise.py:41-46) */
     const ymc_density_desc *level_target;     /* [E-1]: P of levels 0 .. E-2 */
     const ymc_density_desc *level_correction; /* [E-1]: Q of levels 1 .. E-1 */
     const int32_t *level_steps;               /* [E-1]: steps of one run of levels 0 .. E-2 */
@@ -200,6 +206,12 @@ int ymc_run_fetch_sub_accept(ymc_run *run, uint64_t first, uint64_t n, uint8_t *
 /* MLDA_NESTED: accepted transitions of the lower levels so far, dst[E-1][n_chains], and the
  * transitions each of them has made, made[E-1] (either may be NULL) */
 int ymc_run_fetch_level_accept(ymc_run *run, uint64_t *dst, size_t dst_bytes, uint64_t *made);
+/* AEM2: the coarse likelihood's learned error model per chain (likelihood.py:107-109,142-150):
+ * n[n_chains] accepted fine proposals, mean / m2 [n_chains][data_dim] Welford state (marginal
+ * variance = m2 / (n - 1)), precision[n_chains][data_dim] of the inflated noise (valid where
+ * has_precision[n_chains] != 0); any pointer may be NULL */
+int ymc_run_fetch_error_model(ymc_run *run, uint64_t *n, double *mean, double *m2, double *precision,
+                              int32_t *has_precision);
 /* current state [n_chains][d] and its log-density [n_chains] (either may be NULL) */
 int ymc_run_fetch_state(ymc_run *run, double *state, double *logpost);
 /* per-chain summary: accepted transitions, Welford n / mean / M2

@@ -366,5 +366,55 @@ class NestedEnsemble:
         return dict(traj=traj, acc=acc, logpost=lp_out)
 
 
+class AemEnsemble:
+    """K chains of two-level delayed acceptance with the adaptive error model on the coarse
+    (linear) likelihood (ymo_aem_advance); `fine`, `coarse` are posterior_linear dicts."""
+
+    def __init__(self, fine, coarse, sigma, x0, seed, sub_chain_length, min_data_size, use_noise_heuristic,
+                 chain0=0, eq_mode=EQ_EXACT, nthreads=1):
+        self.fine, self.coarse = fine, coarse
+        self.S, self.min_data, self.heur = int(sub_chain_length), int(min_data_size), int(bool(use_noise_heuristic))
+        self.d, self.m = fine["dim"], coarse["data_dim"]
+        x0 = _f64(x0)
+        if x0.ndim == 1:
+            x0 = x0.reshape(1, -1)
+        self.K = K = x0.shape[0]
+        self.x = x0.copy()
+        self.sigma = _f64(sigma).reshape(-1)
+        self.seed, self.chain0, self.eq_mode, self.nthreads = int(seed), int(chain0), int(eq_mode), int(nthreads)
+        self.t = 0
+        self.lp = logdensity(fine, self.x)[0]
+        self.acc_count = np.zeros(K, dtype=np.uint64)
+        self.wf_n = np.zeros(K, dtype=np.uint64)
+        self.wf_mean = np.zeros((K, self.d))
+        self.wf_m2 = np.zeros((K, self.d))
+        self.status = np.zeros(K, dtype=np.uint32)
+        self.aem_n = np.zeros(K, dtype=np.uint64)
+        self.aem_mean = np.zeros((K, self.m))
+        self.aem_m2 = np.zeros((K, self.m))
+        self.aem_prec = np.zeros((K, self.m))
+        self.aem_flags = np.zeros((K, 2), dtype=np.int32)   # has_prec, cache fill
+        self.cache_key = np.zeros((K, 3, self.d))
+        self.cache_val = np.zeros((K, 3))
+
+    def advance(self, nsteps, want_sub=False):
+        K, d = self.K, self.d
+        traj = np.empty((nsteps, K, d))
+        acc = np.empty((nsteps, K), dtype=np.uint8)
+        lp_out = np.empty((nsteps, K))
+        sub = np.empty((nsteps, self.S, K), dtype=np.uint8) if want_sub else None
+        fine, k1 = _lower(self.fine)
+        coarse, k2 = _lower(self.coarse)
+        lib().ymo_aem_advance(
+            C.byref(fine), C.byref(coarse), _ptr(self.sigma), C.c_int32(self.S), C.c_int32(self.min_data),
+            C.c_int32(self.heur), C.c_int32(self.eq_mode), C.c_uint64(self.seed), C.c_uint64(self.chain0),
+            C.c_int64(K), C.c_uint64(self.t), C.c_int64(nsteps), _ptr(self.x), _ptr(self.lp), _vp(self.acc_count),
+            _vp(self.wf_n), _ptr(self.wf_mean), _ptr(self.wf_m2), _vp(self.status), _vp(self.aem_n),
+            _ptr(self.aem_mean), _ptr(self.aem_m2), _ptr(self.aem_prec), _vp(self.aem_flags), _ptr(self.cache_key),
+            _ptr(self.cache_val), _ptr(traj), _vp(acc), _vp(sub), _ptr(lp_out), C.c_int32(self.nthreads))
+        self.t += nsteps
+        return dict(traj=traj, acc=acc, logpost=lp_out, sub_acc=sub)
+
+
 def max_threads():
     return int(lib().ymo_max_threads())

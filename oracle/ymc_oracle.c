@@ -728,6 +728,196 @@ void ymo_mlda_nested_advance(int32_t E, const ymo_density *const *P, const ymo_d
     }
 }
 
+/* ------------------------------------------------------------------------ */
+/* Adaptive error model (AEM): two-level delayed acceptance whose coarse      */
+/* likelihood learns the model error (chain/method/aem.py:6-58,               */
+/* statistics/likelihood.py:90-155, noise.py:25-61), ONE surrogate, linear    */
+/* forward maps.  Per chain the coarse AEMLikelihood carries                  */
+/*   - a Welford accumulator of the error F_fine(y) - F_coarse(y) over the    */
+/*     ACCEPTED fine proposals (aem.py:44-56, estimation.py:36-53);           */
+/*   - once nData >= minDataSize the residual is shifted by its mean          */
+/*     (likelihood.py:128-133); once nData > minDataSize the noise variance   */
+/*     becomes scaling * mVar + dataVar (likelihood.py:142-150, noise.py:41-  */
+/*     54), scaling = min(2 max(mVar) / max(min(mVar), 1e-6), 100) if the     */
+/*     heuristic is on, else 1;                                               */
+/*   - the 3-entry AEMCache of log-LIKELIHOOD values keyed by parameter       */
+/*     equality, most recently used last (memoisation.py:76-149).  A hit      */
+/*     returns the value computed when the entry was made, i.e. possibly      */
+/*     under an older error model: that staleness is part of the reference's  */
+/*     behaviour and is reproduced entry by entry.                            */
+/* The fine AEMLikelihood's accumulator is never updated, so it stays the     */
+/* plain likelihood and its cache never changes a value.                      */
+/* ------------------------------------------------------------------------ */
+typedef struct ymo_aem {
+    const ymo_density *coarse;
+    int32_t min_data, use_heuristic, d, m, eq_mode;
+    uint64_t *n;      /* [1] */
+    double *mean, *m2, *prec; /* [m] each */
+    int32_t *has_prec, *nkeys;
+    double *key;      /* [3][d] */
+    double *val;      /* [3] */
+} ymo_aem;
+
+/* AEMLikelihood.compute_log_likelihood under the CURRENT error model */
+static double ymo_aem_loglik_now(const ymo_aem *a, const double *theta)
+{
+    const ymo_density *p = a->coarse;
+    double F[YMO_MMAX], r[YMO_MMAX];
+    ymo_forward_linear(p, theta, F);
+    const int shift = *a->n >= (uint64_t)a->min_data;
+    const double *prec = *a->has_prec ? a->prec : p->noise_precision;
+    double total = 0.0;
+    for (int32_t i = 0; i < p->n_data; ++i) {
+        const double *Di = p->data + (int64_t)i * a->m;
+        for (int32_t j = 0; j < a->m; ++j) {
+            r[j] = F[j] - Di[j];
+            if (shift) r[j] = r[j] + a->mean[j];
+        }
+        total = total + ymo_diag_norm_sq(r, prec, a->m);
+    }
+    return -0.5 * total;
+}
+
+/* AEMLikelihood.query_log_likelihood (likelihood.py:121-126) + update_cache (:135-141) */
+static double ymo_aem_query(ymo_aem *a, const double *theta)
+{
+    const int32_t d = a->d;
+    int32_t nk = *a->nkeys;
+    for (int32_t i = 0; i < nk; ++i) {
+        if (ymo_states_equal(a->key + (int64_t)i * d, theta, d, a->eq_mode)) {
+            /* retrieve: move entry i to the back (memoisation.py:98-103,139-147) */
+            double v = a->val[i];
+            for (int32_t q = i; q + 1 < nk; ++q) {
+                memcpy(a->key + (int64_t)q * d, a->key + (int64_t)(q + 1) * d, sizeof(double) * (size_t)d);
+                a->val[q] = a->val[q + 1];
+            }
+            memcpy(a->key + (int64_t)(nk - 1) * d, theta, sizeof(double) * (size_t)d);
+            a->val[nk - 1] = v;
+            return v;
+        }
+    }
+    double v = ymo_aem_loglik_now(a, theta);
+    if (nk >= 3) { /* evict the oldest (memoisation.py:92-96,113-114) */
+        for (int32_t q = 0; q + 1 < nk; ++q) {
+            memcpy(a->key + (int64_t)q * d, a->key + (int64_t)(q + 1) * d, sizeof(double) * (size_t)d);
+            a->val[q] = a->val[q + 1];
+        }
+        nk = 2;
+    }
+    memcpy(a->key + (int64_t)nk * d, theta, sizeof(double) * (size_t)d);
+    a->val[nk] = v;
+    *a->nkeys = nk + 1;
+    return v;
+}
+
+/* AEMLikelihood.update_error_estimate (likelihood.py:142-150) with error = F_fine(y) - F_coarse(y) */
+static void ymo_aem_update(ymo_aem *a, const ymo_density *fine, const double *y)
+{
+    double Ff[YMO_MMAX], Fc[YMO_MMAX], err[YMO_MMAX];
+    ymo_forward_linear(fine, y, Ff);
+    ymo_forward_linear(a->coarse, y, Fc);
+    for (int32_t j = 0; j < a->m; ++j) err[j] = Ff[j] - Fc[j];
+    ymo_welford(err, a->m, a->n, a->mean, a->m2);
+    if (*a->n > (uint64_t)a->min_data) {
+        double mvar[YMO_MMAX];
+        const double nm1 = (double)(*a->n - 1);
+        double lo = 0.0, hi = 0.0;
+        for (int32_t j = 0; j < a->m; ++j) {
+            mvar[j] = a->m2[j] / nm1;
+            lo = (j == 0 || mvar[j] < lo) ? mvar[j] : lo;
+            hi = (j == 0 || mvar[j] > hi) ? mvar[j] : hi;
+        }
+        double scaling = 1.0;
+        if (a->use_heuristic) { /* noise.py:41-46 */
+            double minval = lo > 1e-6 ? lo : 1e-6;
+            scaling = 2.0 * hi / minval;
+            scaling = scaling < 100.0 ? scaling : 100.0;
+        }
+        for (int32_t j = 0; j < a->m; ++j) {
+            double data_var = 1.0 / a->coarse->noise_precision[j]; /* covariance.py:40-41 */
+            a->prec[j] = 1.0 / (scaling * mvar[j] + data_var);   /* noise.py:51-53, covariance.py:36-37 */
+        }
+        *a->has_prec = 1;
+    }
+}
+
+/* state arrays per chain k: aem_n[k], aem_mean/m2/prec[k][m], aem_flags[k][2] = {has_prec, nkeys},
+ * cache_key[k][3][d], cache_val[k][3]; lpf[k] = fine log-posterior of the carried state */
+void ymo_aem_advance(const ymo_density *fine, const ymo_density *coarse, const double *sigma, int32_t S,
+                     int32_t min_data, int32_t use_heuristic, int32_t eq_mode, uint64_t seed, uint64_t chain0,
+                     int64_t K, uint64_t n0, int64_t nsteps, double *x, double *lpf, uint64_t *acc_count,
+                     uint64_t *wf_n, double *wf_mean, double *wf_m2, uint32_t *status, uint64_t *aem_n,
+                     double *aem_mean, double *aem_m2, double *aem_prec, int32_t *aem_flags, double *cache_key,
+                     double *cache_val, double *traj, uint8_t *acc, uint8_t *sub_acc, double *lp_out,
+                     int32_t nthreads)
+{
+    const int32_t d = fine->dim, m = coarse->data_dim;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(dynamic, 16)
+#endif
+    for (int64_t k = 0; k < K; ++k) {
+        ymo_aem a;
+        a.coarse = coarse;
+        a.min_data = min_data;
+        a.use_heuristic = use_heuristic;
+        a.d = d;
+        a.m = m;
+        a.eq_mode = eq_mode;
+        a.n = aem_n + k;
+        a.mean = aem_mean + k * m;
+        a.m2 = aem_m2 + k * m;
+        a.prec = aem_prec + k * m;
+        a.has_prec = aem_flags + 2 * k;
+        a.nkeys = aem_flags + 2 * k + 1;
+        a.key = cache_key + k * 3 * d;
+        a.val = cache_val + k * 3;
+        const uint32_t chain = (uint32_t)(chain0 + (uint64_t)k);
+        double *xs = x + k * d;
+        uint32_t st = status ? status[k] : 0;
+        double z[YMO_DMAX], y[YMO_DMAX];
+        for (int64_t n = 0; n < nsteps; ++n) {
+            const uint64_t tbase = (n0 + (uint64_t)n) * (uint64_t)(S + 1);
+            memcpy(z, xs, sizeof(double) * (size_t)d);
+            for (int32_t s = 0; s < S; ++s) {
+                const uint64_t t = tbase + (uint64_t)s;
+                ymo_propose(z, sigma, seed, chain, t, d, y);
+                int acc_s = 0;
+                if (!ymo_states_equal(y, z, d, eq_mode)) {
+                    /* mrw.py:51-57: evaluate_log(proposal) first, then evaluate_log(state) */
+                    double ly = ymo_aem_query(&a, y) + ymo_gaussian_prior_log(coarse, y);
+                    double lz = ymo_aem_query(&a, z) + ymo_gaussian_prior_log(coarse, z);
+                    acc_s = ymo_accept(ly - lz, ymo_is_finite(ly), seed, chain, t, &st, NULL);
+                    if (acc_s) memcpy(z, y, sizeof(double) * (size_t)d);
+                }
+                if (sub_acc) sub_acc[(n * S + s) * K + k] = (uint8_t)acc_s;
+            }
+            int accepted = 0;
+            if (!ymo_states_equal(z, xs, d, eq_mode)) {
+                /* mlda.py:146-154: tgt(y), finest(x), finest(y), tgt(x) in this order */
+                double lpfy = ymo_logdensity_one(fine, z, &st);
+                double cx = ymo_aem_query(&a, xs) + ymo_gaussian_prior_log(coarse, xs);
+                double cy = ymo_aem_query(&a, z) + ymo_gaussian_prior_log(coarse, z);
+                double log_ratio = ((lpfy + cx) - cy) - lpf[k];
+                accepted = ymo_accept(log_ratio, ymo_is_finite(lpfy) && ymo_is_finite(cy), seed, chain,
+                                      tbase + (uint64_t)S, &st, NULL);
+                if (wf_n) ymo_welford(xs, d, &wf_n[k], wf_mean + k * d, wf_m2 + k * d);
+                if (accepted) {
+                    ymo_aem_update(&a, fine, z); /* aem.py:26-56, before the chain moves */
+                    memcpy(xs, z, sizeof(double) * (size_t)d);
+                    lpf[k] = lpfy;
+                    if (acc_count) acc_count[k] += 1;
+                }
+            } else if (wf_n) {
+                ymo_welford(xs, d, &wf_n[k], wf_mean + k * d, wf_m2 + k * d);
+            }
+            if (traj) memcpy(traj + (n * K + k) * d, xs, sizeof(double) * (size_t)d);
+            if (acc) acc[n * K + k] = (uint8_t)accepted;
+            if (lp_out) lp_out[n * K + k] = lpf[k];
+        }
+        if (status) status[k] = st;
+    }
+}
+
 int32_t ymo_max_threads(void)
 {
 #ifdef _OPENMP

@@ -629,8 +629,82 @@ def fixture_f11():
                [6, 4, 4, 3], [2.0, -3.0])
 
 
+# ---------------------------------------------------------------------------
+# F12: adaptive error model (chain/method/aem.py) on the linear two-level example's models
+# (example_inference_linearModel_twoLevel.py:33-56,95-100,181-191), with a milder surrogate
+# error and a small minDataSize so that the shift AND the variance inflation become active
+# within the fixture; fresh AEMLikelihood objects per chain (they carry the learned state)
+# ---------------------------------------------------------------------------
+
+def fixture_f12(name="f12_aem_linear.npz", use_heuristic=True, seed=20250112, min_data=8, K=24, n=500, S=5):
+    from numpy.random import seed as np_seed, standard_normal
+    from yagremcmc.chain.method.aem import AEMBuilder
+    from yagremcmc.statistics.likelihood import AEMLikelihood
+    from yagremcmc.statistics.modelHierarchy import BayesianRegressionModelHierarchy
+    from yagremcmc.utility.hierarchy import Hierarchy, SharedComponent
+    np_seed(2222)
+    A_t, b_t = np.array([[1.4, -0.2], [-0.6, 0.7]]), np.zeros(2)
+    A_s, b_s = A_t + 0.25 * np.array([[-0.6, -0.2], [0.4, 1.1]]), 0.25 * np.array([0.5, -0.9])
+    true = np.array([1.5, 0.5])
+    sd = np.sqrt(0.3)
+    data = np.array([A_t @ true + b_t + sd * standard_normal(2) for _ in range(5)])
+    prior_mean = true + np.array([-0.2, 0.4])
+    cov = IIDCovarianceMatrix(2, 0.5)
+    x0 = np.zeros(2)
+    traj = np.empty((n, K, 2))
+    acc = np.empty((n - 1, K), dtype=np.uint8)
+    sub = np.empty((n - 1, S, K), dtype=np.uint8)
+    lp = np.empty((n, K))
+    err_n = np.zeros(K, dtype=np.uint64)
+    err_mean = np.zeros((K, 2))
+    err_mvar = np.zeros((K, 2))
+    aem_prec = np.zeros((K, 2))
+    hits = np.zeros(K, dtype=np.int64)
+    for k in range(K):
+        prior = Gaussian(ParameterVector(prior_mean.copy()), IIDCovarianceMatrix(2, 5.0))
+        noise = CentredGaussianNoise(IIDCovarianceMatrix(2, sd ** 2))
+        lik_s = AEMLikelihood(Data(data), ForwardModel(ExampleLinearModelSolver(A_s, b_s)), noise, min_data,
+                              use_heuristic)
+        lik_t = AEMLikelihood(Data(data), ForwardModel(ExampleLinearModelSolver(A_t, b_t)), noise, min_data,
+                              use_heuristic)
+        model = BayesianRegressionModelHierarchy(Hierarchy([lik_s, lik_t]), SharedComponent(prior, 2))
+        b = AEMBuilder()
+        b.baseProposalCovariance = cov
+        b.subChainLengths = [S]
+        b.bayesModel = model
+        b.surrogateDiagnostics = [AcceptanceRateDiagnostics()]
+        mc = b.build_method()
+        rp = Replay(seed, k, 2, (n - 1) * (S + 1), sub_chain_length=S)
+        rp.install()
+        mark_fine_level(mc, rp)
+        mc.run(n, ParameterVector(x0.copy()), verbose=False)
+        traj[:, k, :] = np.array(mc.chain.trajectory)
+        acc[:, k] = mc.diagnostics._decisions
+        sub[:, :, k] = np.array(mc.surrogate(0).diagnostics._decisions, dtype=np.uint8).reshape(n - 1, S)
+        plain_t = AdditiveGaussianNoiseLikelihood(Data(data), ForwardModel(ExampleLinearModelSolver(A_t, b_t)), noise)
+        from yagremcmc.chain.target import UnnormalisedPosterior
+        lp[:, k] = eval_log_along(UnnormalisedPosterior(plain_t, prior), traj[:, k, :],
+                                  lambda s_: ParameterVector(np.array(s_)))
+        err_n[k] = lik_s.accumulator.nData
+        assert lik_t.accumulator.nData == 0
+        if err_n[k] >= 1:
+            err_mean[k] = lik_s.accumulator.mean()
+        if err_n[k] >= 2:
+            err_mvar[k] = lik_s.accumulator.marginal_variance()
+        if lik_s._noiseModel._aemNoise is not None:
+            aem_prec[k] = lik_s._noiseModel._aemNoise.covariance._precision
+        hits[k] = lik_s._cache.hits
+    np.savez_compressed(
+        os.path.join(HERE, name), seed=seed, n_states=n, S=S, min_data_size=min_data,
+        use_noise_heuristic=int(use_heuristic), A_fine=A_t, b_fine=b_t, A_coarse=A_s, b_coarse=b_s, data=data,
+        noise_precision=np.reciprocal(np.full(2, sd ** 2)), prior_mean=prior_mean,
+        prior_precision=np.reciprocal(np.full(2, 5.0)), sigma=sigma_of(cov), x0=np.zeros((K, 2)), traj=traj,
+        acc=acc, sub_acc=sub, logpost=lp, err_n=err_n, err_mean=err_mean, err_mvar=err_mvar, aem_prec=aem_prec)
+    print(name, acc.mean(), sub.mean(), "accepted per chain", err_n.min(), err_n.max(), "cache hits", hits.mean())
+
+
 def main():
-    which = sys.argv[1:] or ["f1", "f2", "f2b", "f3", "f3b", "f4", "f5", "f7", "f8", "f9", "f10", "f11"]
+    which = sys.argv[1:] or ["f1", "f2", "f2b", "f3", "f3b", "f4", "f5", "f7", "f8", "f9", "f10", "f11", "f12"]
     if "f1" in which:
         fixture_f1()
     if "f2" in which:
@@ -658,6 +732,10 @@ def main():
         fixture_f10()
     if "f11" in which:
         fixture_f11()
+    if "f12" in which:
+        fixture_f12()
+        fixture_f12("f12b_aem_linear_noheuristic.npz", use_heuristic=False, seed=20250113, min_data=5, K=12,
+                    n=400, S=3)
 
 
 if __name__ == "__main__":

@@ -188,6 +188,68 @@ def test_mlda_three_surrogates_fail_like_the_reference():
         b.build_method()
 
 
+def test_adaptive_error_model_through_the_builder(golden):
+    """example_inference_linearModel_twoLevel.py:95-100,181-191 wiring (AEMBuilder over a model
+    hierarchy of AEMLikelihoods); chain 0..K-1 == the live reference's chains of fixture F12."""
+    from yagremcmc_amd.chain.diagnostics import FullDiagnostics
+    from yagremcmc_amd.chain.method.aem import AEMBuilder
+    from yagremcmc_amd.chain.method.mlda import MLDABuilder
+    from yagremcmc_amd.exampleSetup import ExampleLinearModelSolver
+    from yagremcmc_amd.model.forwardModel import ForwardModel
+    from yagremcmc_amd.parameter.vector import ParameterVector
+    from yagremcmc_amd.statistics.covariance import IIDCovarianceMatrix
+    from yagremcmc_amd.statistics.data import Data
+    from yagremcmc_amd.statistics.gaussian import Gaussian
+    from yagremcmc_amd.statistics.likelihood import AdditiveGaussianNoiseLikelihood, AEMLikelihood
+    from yagremcmc_amd.statistics.modelHierarchy import BayesianRegressionModelHierarchy
+    from yagremcmc_amd.statistics.noise import CentredGaussianNoise
+    from yagremcmc_amd.utility.hierarchy import Hierarchy, SharedComponent
+    g = golden("f12_aem_linear.npz")
+    K, n = g["x0"].shape[0], int(g["n_states"])
+    noise = CentredGaussianNoise(IIDCovarianceMatrix(2, np.sqrt(0.3) ** 2))  # as the example forms it
+    assert np.array_equal(noise.covariance._precision, g["noise_precision"])
+    prior = Gaussian(ParameterVector(g["prior_mean"].copy()), IIDCovarianceMatrix(2, 5.0))
+    data = Data(g["data"])
+    mk = lambda A, b, cls, *extra: cls(data, ForwardModel(ExampleLinearModelSolver(A, b)), noise, *extra)
+    lik_s = mk(g["A_coarse"], g["b_coarse"], AEMLikelihood, int(g["min_data_size"]), True)
+    lik_t = mk(g["A_fine"], g["b_fine"], AEMLikelihood, int(g["min_data_size"]), True)
+    with pytest.raises(ValueError, match="Smallest"):
+        mk(g["A_fine"], g["b_fine"], AEMLikelihood, 1)
+    model = BayesianRegressionModelHierarchy(Hierarchy([lik_s, lik_t]), SharedComponent(prior, 2))
+    b = AEMBuilder()
+    b.baseProposalCovariance = IIDCovarianceMatrix(2, 0.5)
+    b.subChainLengths = [int(g["S"])]
+    b.bayesModel = model
+    b.targetDiagnostics = FullDiagnostics()
+    b.nChains, b.seed = K, int(g["seed"])
+    mc = b.build_method()
+    mc.run(n, ParameterVector(np.zeros(2)), verbose=False)
+    assert np.array_equal(mc.chain.trajectory, g["traj"])
+    assert np.array_equal(mc.accept_decisions, g["acc"])
+    acc = lik_s.accumulator
+    assert np.array_equal(acc.nData, g["err_n"])
+    assert np.allclose(acc.mean(), g["err_mean"], rtol=1e-12, atol=0)
+    assert np.allclose(acc.marginal_variance(), g["err_mvar"], rtol=1e-12, atol=0)
+    assert lik_t.accumulator.nData == 0
+    assert mc.diagnostics.marginal_variance().shape == (2,)
+    # builder validation, aem.py:66-79
+    plain = BayesianRegressionModelHierarchy(
+        Hierarchy([mk(g["A_coarse"], g["b_coarse"], AdditiveGaussianNoiseLikelihood), lik_t]), SharedComponent(prior, 2))
+    b.bayesModel = plain
+    with pytest.raises(ValueError, match="Likelihood on level 0 is not adaptive"):
+        b.build_method()
+    # the learned shift moves the coarse posterior towards the fine one: more fine-level acceptances
+    # than vanilla two-level sampling on the same models and draws
+    v = MLDABuilder()
+    v.baseProposalCovariance = IIDCovarianceMatrix(2, 0.5)
+    v.subChainLengths = [int(g["S"])]
+    v.bayesModel = plain
+    v.nChains, v.seed = K, int(g["seed"])
+    mv = v.build_method()
+    mv.run(n, ParameterVector(np.zeros(2)), verbose=False)
+    assert mc.diagnostics.global_acceptance_rate() > mv.diagnostics.global_acceptance_rate()
+
+
 @pytest.mark.parametrize("proposal", ["iid", "indep"])
 def test_lotka_volterra_inference_through_the_builder(proposal):
     """test_inference_mcmc_singleLevel.py:28-118 wiring; posterior mean near the truth."""

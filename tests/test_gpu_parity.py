@@ -331,6 +331,78 @@ def test_nested_full_size_perfect_surrogates_accept_every_move(ffi, ctx, golden)
     assert made1 == n * 3 and np.all(acc1 <= made1) and acc1.mean() > 0.9 * made1
 
 
+def _aem_device_run(ffi, ctx, g, fine_g, coarse_g, sigma, x0, seed, nsteps, S, min_data, heur, splits=1, chain0=0):
+    from yagremcmc_amd import lowering
+    d = x0.shape[1]
+    fine = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, fine_g, fwd_matrix=np.asarray(fine_g["A"]),
+                          fwd_shift=np.asarray(fine_g["b"]))
+    coarse = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, coarse_g, fwd_matrix=np.asarray(coarse_g["A"]),
+                            fwd_shift=np.asarray(coarse_g["b"]))
+    prob = lowering.make_problem(ctx, ffi.METHOD_AEM2, fine, sigma, ffi.EQ_EXACT, surrogate=coarse,
+                                 sub_chain_length=S, aem=(min_data, heur))
+    run = ffi.Run(prob, seed, x0.shape[0], x0, nsteps, _flags(ffi, True, sub=True), chain0)
+    base, rem = divmod(nsteps, splits)
+    for i in range(splits):
+        run.advance(base + (1 if i < rem else 0))
+    run.sync()
+    return dict(traj=run.trajectory(), acc=run.accept(), logpost=run.logpost(), summary=run.summary(),
+                state=run.state(), sub_acc=run.sub_accept(), err=run.error_model())
+
+
+def _same_error_model(dev, e):
+    assert np.array_equal(dev["err"]["n"], e.aem_n)
+    assert np.array_equal(dev["err"]["mean"], e.aem_mean) and np.array_equal(dev["err"]["m2"], e.aem_m2)
+    assert np.array_equal(dev["err"]["precision"], e.aem_prec)
+    assert np.array_equal(dev["err"]["has_precision"], e.aem_flags[:, 0] != 0)
+
+
+@pytest.mark.parametrize("name", ["f12_aem_linear.npz", "f12b_aem_linear_noheuristic.npz"])
+def test_f12_adaptive_error_model(ffi, ctx, golden, name):
+    g = golden(name)
+    n, S = int(g["n_states"]), int(g["S"])
+    common = dict(data=g["data"], noise_precision=g["noise_precision"], prior_mean=g["prior_mean"],
+                  prior_precision=g["prior_precision"])
+    fg = dict(common, A=g["A_fine"], b=g["b_fine"])
+    cg = dict(common, A=g["A_coarse"], b=g["b_coarse"])
+    dev = _aem_device_run(ffi, ctx, g, fg, cg, g["sigma"], g["x0"], int(g["seed"]), n - 1, S,
+                          int(g["min_data_size"]), int(g["use_noise_heuristic"]), splits=3)
+    e = o.AemEnsemble(o.posterior_linear(g["A_fine"], g["b_fine"], **common),
+                      o.posterior_linear(g["A_coarse"], g["b_coarse"], **common), g["sigma"], g["x0"],
+                      int(g["seed"]), S, int(g["min_data_size"]), int(g["use_noise_heuristic"]))
+    out = e.advance(n - 1, want_sub=True)
+    _same_as_oracle(dev, e, out)
+    assert np.array_equal(dev["sub_acc"], out["sub_acc"])
+    _same_error_model(dev, e)
+    _same_as_reference(dev, g)
+    assert np.array_equal(dev["sub_acc"], g["sub_acc"])
+    assert np.array_equal(dev["err"]["n"], g["err_n"])
+    assert np.allclose(dev["err"]["mean"], g["err_mean"], rtol=1e-12, atol=0)
+    assert np.allclose(dev["err"]["precision"], g["aem_prec"], rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("d,m,nd", [(1, 1, 3), (3, 2, 4), (5, 8, 2), (8, 5, 6)])
+def test_aem_other_shapes_vs_oracle(ffi, ctx, d, m, nd):
+    rng = np.random.default_rng(7 * d + m)
+    A = rng.normal(size=(m, d)) / np.sqrt(d)
+    b = rng.normal(size=m) * 0.3
+    As, bs = A + 0.2 * rng.normal(size=(m, d)), b + 0.2 * rng.normal(size=m)
+    theta = rng.normal(size=d)
+    data = np.array([A @ theta + b + 0.5 * rng.normal(size=m) for _ in range(nd)])
+    common = dict(data=data, noise_precision=np.full(m, 4.0) * rng.uniform(0.8, 1.2, size=m),
+                  prior_mean=np.zeros(d), prior_precision=np.full(d, 0.25))
+    sigma = np.full(d, 0.35)
+    x0 = rng.normal(size=(500, d)) * 0.5
+    dev = _aem_device_run(ffi, ctx, None, dict(common, A=A, b=b), dict(common, A=As, b=bs), sigma, x0, 31337, 250, 3,
+                          4, 1, splits=2, chain0=77)
+    e = o.AemEnsemble(o.posterior_linear(A, b, **common), o.posterior_linear(As, bs, **common), sigma, x0, 31337, 3,
+                      4, 1, chain0=77)
+    out = e.advance(250, want_sub=True)
+    _same_as_oracle(dev, e, out)
+    assert np.array_equal(dev["sub_acc"], out["sub_acc"])
+    _same_error_model(dev, e)
+    assert dev["err"]["has_precision"].mean() > 0.5
+
+
 # ---------------------------------------------------------------------------
 # other dimensions of the lane-per-chain kernels vs the oracle
 # ---------------------------------------------------------------------------

@@ -158,6 +158,38 @@ def test_nested_with_one_level_pair_equals_two_level_scheme_when_q_is_p0(golden)
     assert np.array_equal(two["traj"], nest["traj"]) and np.array_equal(two["acc"], nest["acc"])
 
 
+def _aem_from_fixture(g, **kw):
+    common = dict(data=g["data"], noise_precision=g["noise_precision"], prior_mean=g["prior_mean"],
+                  prior_precision=g["prior_precision"])
+    fine = o.posterior_linear(g["A_fine"], g["b_fine"], **common)
+    coarse = o.posterior_linear(g["A_coarse"], g["b_coarse"], **common)
+    return o.AemEnsemble(fine, coarse, g["sigma"], g["x0"], int(g["seed"]), int(g["S"]), int(g["min_data_size"]),
+                         int(g["use_noise_heuristic"]), **kw)
+
+
+@pytest.mark.parametrize("name", ["f12_aem_linear.npz", "f12b_aem_linear_noheuristic.npz"])
+def test_f12_adaptive_error_model(golden, name):
+    """chain/method/aem.py on the linear two-level models: chains, decisions at both levels and the
+    learned error model (count, mean, unbiased variance, inflated noise precision) == the reference's,
+    including the reference's use of stale cached log-likelihoods (AEMCache)."""
+    g = golden(name)
+    n = int(g["n_states"])
+    e = _aem_from_fixture(g)
+    out = e.advance(n - 1, want_sub=True)
+    _check(out, g, n)
+    assert np.array_equal(out["sub_acc"], g["sub_acc"])
+    assert np.array_equal(e.aem_n, g["err_n"]) and e.aem_n.min() > int(g["min_data_size"])
+    assert np.allclose(e.aem_mean, g["err_mean"], rtol=1e-12, atol=0)
+    assert np.allclose(e.aem_m2 / (e.aem_n[:, None] - 1.0), g["err_mvar"], rtol=1e-12, atol=0)
+    assert np.allclose(e.aem_prec, g["aem_prec"], rtol=1e-12, atol=0)
+    assert (e.aem_flags[:, 0] == 1).all() and (e.aem_flags[:, 1] == 3).all()
+    # resumable
+    e2 = _aem_from_fixture(g, nthreads=3)
+    a, b = e2.advance(123), e2.advance(n - 124)
+    assert np.array_equal(np.concatenate([a["traj"], b["traj"]]), out["traj"])
+    assert np.array_equal(e2.aem_mean, e.aem_mean) and np.array_equal(e2.cache_val, e.cache_val)
+
+
 def test_perfect_surrogate_accepts_everything(golden):
     """test_mlda.py:94-130: coarse == fine => every fine proposal that moved is accepted."""
     g = golden("f5_mlda2_2d.npz")

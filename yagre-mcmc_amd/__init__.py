@@ -8,12 +8,13 @@ replacing `yagremcmc` with `yagremcmc_amd` in its imports.
 """
 from . import _ffi
 from ._ffi import YmcError, device_count
-from .builders import ChainBuilder, MLDABuilder, MRWBuilder, PCNBuilder
+from .builders import AEMBuilder, ChainBuilder, MLDABuilder, MRWBuilder, PCNBuilder
 from .diagnostics import AcceptanceRateDiagnostics, DummyDiagnostics, FullDiagnostics
-from .ensemble import MLDA, MetropolisedRandomWalk, PreconditionedCrankNicolson
+from .ensemble import MLDA, AdaptiveErrorModel, MetropolisedRandomWalk, PreconditionedCrankNicolson
 from .lowering import UnsupportedPlugin
 
-__all__ = ["ChainBuilder", "MRWBuilder", "MLDABuilder", "PCNBuilder", "MetropolisedRandomWalk", "MLDA",
+__all__ = ["ChainBuilder", "MRWBuilder", "MLDABuilder", "PCNBuilder", "AEMBuilder", "AdaptiveErrorModel",
+           "MetropolisedRandomWalk", "MLDA",
            "PreconditionedCrankNicolson",
            "AcceptanceRateDiagnostics", "FullDiagnostics", "DummyDiagnostics", "UnsupportedPlugin",
            "YmcError", "device_count"]

@@ -19,7 +19,7 @@ OK, ERR_INVALID, ERR_DEVICE, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_COMM = 0, -1, -2
 # ymc_density_kind
 GAUSS_WHITENED, GAUSS_ISO1D, POSTERIOR_LINEAR, POSTERIOR_LV = 1, 2, 3, 4
 # ymc_method / ymc_state_eq
-METHOD_MRW, METHOD_MLDA2, METHOD_PCN, METHOD_MLDA_NESTED = 1, 2, 3, 4
+METHOD_MRW, METHOD_MLDA2, METHOD_PCN, METHOD_MLDA_NESTED, METHOD_AEM2 = 1, 2, 3, 4, 5
 MAX_LEVELS = 4
 EQ_EXACT, EQ_ISCLOSE = 0, 1
 # record flags
@@ -57,9 +57,9 @@ class ProblemDesc(C.Structure):
     _fields_ = [
         ("method", C.c_int32), ("state_eq", C.c_int32),
         ("target", DensityDesc), ("surrogate", DensityDesc),
-        ("sub_chain_length", C.c_int32), ("reserved_", C.c_int32),
+        ("sub_chain_length", C.c_int32), ("aem_min_data_size", C.c_int32),
         ("proposal_sigma", _dp), ("pcn_step_size", C.c_double),
-        ("n_levels", C.c_int32), ("reserved2_", C.c_int32),
+        ("n_levels", C.c_int32), ("aem_use_noise_heuristic", C.c_int32),
         ("level_target", C.POINTER(DensityDesc)), ("level_correction", C.POINTER(DensityDesc)),
         ("level_steps", C.POINTER(C.c_int32)),
     ]
@@ -101,6 +101,7 @@ _PROTOTYPES = {
     "ymc_run_fetch_logpost": (C.c_int, [_vp, _u64, _u64, _vp, C.c_size_t]),
     "ymc_run_fetch_sub_accept": (C.c_int, [_vp, _u64, _u64, _vp, C.c_size_t]),
     "ymc_run_fetch_level_accept": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "ymc_run_fetch_error_model": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "ymc_run_fetch_state": (C.c_int, [_vp, _vp, _vp]),
     "ymc_run_fetch_summary": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "ymc_logdensity_eval": (C.c_int, [_vp, _vp, C.c_int, _u64, _vp, _vp, _vp]),
@@ -256,7 +257,8 @@ class Problem(Handle):
         self.ctx = ctx
         self.dim = desc.target.dim
         self.method = desc.method
-        self.S = desc.sub_chain_length if desc.method == METHOD_MLDA2 else 0
+        self.S = desc.sub_chain_length if desc.method in (METHOD_MLDA2, METHOD_AEM2) else 0
+        self.data_dim = desc.target.data_dim
         self.n_levels = desc.n_levels if desc.method == METHOD_MLDA_NESTED else 0
         self.kind = desc.target.kind
         self._n_data = (desc.target.n_data, desc.target.data_dim)
@@ -332,6 +334,15 @@ class Run(Handle):
 
     def sub_accept(self, first=0, n=None):
         return self._fetch("ymc_run_fetch_sub_accept", first, n, (self.S, self.K), np.uint8)
+
+    def error_model(self):
+        """AEM2: the coarse likelihood's learned error model per chain."""
+        m = self.problem.data_dim
+        n = np.zeros(self.K, dtype=np.uint64)
+        mean, m2, prec = np.zeros((self.K, m)), np.zeros((self.K, m)), np.zeros((self.K, m))
+        has = np.zeros(self.K, dtype=np.int32)
+        check(lib().ymc_run_fetch_error_model(self.raw, vptr(n), vptr(mean), vptr(m2), vptr(prec), vptr(has)))
+        return dict(n=n, mean=mean, m2=m2, precision=prec, has_precision=has.astype(bool))
 
     def level_accept(self):
         """Nested delayed acceptance: (accepted[E-1][K], made[E-1]) of the lower levels."""

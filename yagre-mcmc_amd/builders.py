@@ -8,7 +8,7 @@ Same property names, validation and error messages as the reference's
 extra properties with defaults that reproduce the single-chain behaviour.
 """
 from . import diagnostics as dg
-from .ensemble import MLDA, MetropolisedRandomWalk, PreconditionedCrankNicolson
+from .ensemble import MLDA, AdaptiveErrorModel, MetropolisedRandomWalk, PreconditionedCrankNicolson
 from .lowering import UnsupportedPlugin
 from .plugins import UnnormalisedPosterior
 
@@ -214,13 +214,35 @@ class MLDABuilder(ChainBuilder):
         surrogates = [UnnormalisedPosterior(model.level(k).likelihood, model.level(k).prior)
                       for k in range(model.size - 1)]
         tgt_diag = self._tgtDgnst if self._tgtDgnst is not None else dg.AcceptanceRateDiagnostics()
-        return MLDA(target, surrogates, self._basePropCov, list(self._nSteps), tgt_diag, self._surrDgnstList,
-                    recordSubChain=self.recordSubChain, **self._ensemble_options())
+        return self.build_mlda(target, surrogates, self._basePropCov, list(self._nSteps), tgt_diag,
+                               self._surrDgnstList)
 
     def build_from_target(self):
         tgt_diag = self._tgtDgnst if self._tgtDgnst is not None else dg.AcceptanceRateDiagnostics()
-        return MLDA(self._explicitTarget, list(self._surrTgts), self._basePropCov, list(self._nSteps), tgt_diag,
-                    self._surrDgnstList, recordSubChain=self.recordSubChain, **self._ensemble_options())
+        return self.build_mlda(self._explicitTarget, list(self._surrTgts), self._basePropCov, list(self._nSteps),
+                               tgt_diag, self._surrDgnstList)
+
+    def build_mlda(self, tgtPost, surPost, bpc, nS, tgtD, surD):
+        """mlda.py:312-313"""
+        return MLDA(tgtPost, surPost, bpc, nS, tgtD, surD, recordSubChain=self.recordSubChain,
+                    **self._ensemble_options())
+
+
+class AEMBuilder(MLDABuilder):
+    """chain/method/aem.py:61-82"""
+
+    def _validate_parameters(self):
+        super()._validate_parameters()
+        if self._bayesModel is None:
+            raise NotImplementedError("Adaptive error correction only makes sense if the target emerges from a "
+                                      "Bayesian model.")
+        for i in range(self._bayesModel.size):
+            if type(self._bayesModel.level(i).likelihood).__name__ != "AEMLikelihood":
+                raise ValueError(f"Likelihood on level {i} is not adaptive.")
+
+    def build_mlda(self, tgtPost, surPost, bpc, nS, tgtD, surD):
+        return AdaptiveErrorModel(tgtPost, surPost, bpc, nS, tgtD, surD, recordSubChain=self.recordSubChain,
+                                  **self._ensemble_options())
 
 
 class PCNBuilder(ChainBuilder):

@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "ymc_aem.h"
 #include "ymc_kernels.h"
 #include "ymc_nested.h"
 #include "ymc_post.h"
@@ -92,6 +93,7 @@ struct ymc_ctx {
 struct ymc_problem {
     ymc_ctx *ctx = nullptr;
     int method = 0, eq_mode = 0, S = 0, D = 0, kind = 0;
+    int aem_min_data = 0, aem_heuristic = 0;
     double pcn_c1 = 0.0, pcn_c2 = 0.0;
     bool tile = false;
     DensityHost tgt, sur;
@@ -112,6 +114,7 @@ struct ymc_run {
     uint64_t capacity = 0, recorded = 0, steps_done = 0;
     DeviceBuf x, lp, lpc, acc_count, wf_mean, wf_m2, status, traj, acc, lp_out, sub_acc, summary, x_before, recip;
     DeviceBuf level_acc; /* MLDA_NESTED: [E-1][K] */
+    DeviceBuf err_n, err_mean, err_m2, aem_prec, aem_flags, cache_key, cache_val; /* AEM2 */
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;  /* launches since the last query */
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
 };
@@ -355,6 +358,69 @@ int launch_advance(ymc_run *r, uint64_t nsteps)
     if (e != hipSuccess) {
         r->pool.push_back(ev);
         return fail(YMC_ERR_DEVICE, "chain kernel launch failed: %s", hipGetErrorString(e));
+    }
+    YMC_HIP(hipEventRecord(ev.second, r->ctx->stream));
+    r->timed.push_back(ev);
+    return YMC_OK;
+}
+
+template <int D>
+int launch_advance_aem(ymc_run *r, uint64_t nsteps)
+{
+    const ymc_problem *p = r->problem;
+    AemArgs<D> a;
+    std::memset(&a, 0, sizeof a);
+    a.fine = device_view<D>(p->tgt);
+    a.coarse = device_view<D>(p->sur);
+    for (int j = 0; j < D; ++j) a.sigma[j] = p->sigma[j];
+    a.seed = r->seed;
+    a.chain0 = r->chain0;
+    a.K = r->K;
+    a.t0 = r->steps_done;
+    a.wf_n0 = r->steps_done;
+    a.nsteps = (uint32_t)nsteps;
+    a.flags = r->flags;
+    a.eq_mode = p->eq_mode;
+    a.S = p->S;
+    a.min_data = p->aem_min_data;
+    a.use_heuristic = p->aem_heuristic;
+    a.x = r->x.as<double>();
+    a.lp = r->lp.as<double>();
+    a.acc_count = r->acc_count.as<uint64_t>();
+    a.wf_mean = r->wf_mean.as<double>();
+    a.wf_m2 = r->wf_m2.as<double>();
+    a.status = r->status.as<uint32_t>();
+    a.err_n = r->err_n.as<uint64_t>();
+    a.err_mean = r->err_mean.as<double>();
+    a.err_m2 = r->err_m2.as<double>();
+    a.aem_prec = r->aem_prec.as<double>();
+    a.aem_flags = r->aem_flags.as<int32_t>();
+    a.cache_key = r->cache_key.as<double>();
+    a.cache_val = r->cache_val.as<double>();
+    if (r->flags & YMC_RECORD_MOMENTS) {
+        if (r->recip.bytes < nsteps * sizeof(double)) YMC_TRY(r->recip.alloc(nsteps * sizeof(double)));
+        YMC_HIP(ymc_launch_recip(r->steps_done, nsteps, r->recip.as<double>(), r->ctx->stream));
+        a.recip = r->recip.as<double>();
+    }
+    const uint64_t row = r->recorded;
+    if (r->flags & YMC_RECORD_TRAJECTORY) a.traj = r->traj.as<double>() + row * r->K * D;
+    if (r->flags & YMC_RECORD_ACCEPT) a.acc = r->acc.as<uint8_t>() + row * r->K;
+    if (r->flags & YMC_RECORD_LOGPOST) a.lp_out = r->lp_out.as<double>() + row * r->K;
+    if (r->flags & YMC_RECORD_SUB_ACCEPT) a.sub_acc = r->sub_acc.as<uint8_t>() + row * (uint64_t)p->S * r->K;
+
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (!r->pool.empty()) {
+        ev = r->pool.back();
+        r->pool.pop_back();
+    } else {
+        YMC_HIP(hipEventCreate(&ev.first));
+        YMC_HIP(hipEventCreate(&ev.second));
+    }
+    YMC_HIP(hipEventRecord(ev.first, r->ctx->stream));
+    hipError_t e = ymc_launch_aem<D>(a, r->ctx->stream);
+    if (e != hipSuccess) {
+        r->pool.push_back(ev);
+        return fail(YMC_ERR_DEVICE, "adaptive-error-model kernel launch failed: %s", hipGetErrorString(e));
     }
     YMC_HIP(hipEventRecord(ev.second, r->ctx->stream));
     r->timed.push_back(ev);
@@ -605,7 +671,7 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
     if (!ctx || !desc || !out) return fail(YMC_ERR_INVALID, "null argument");
     *out = nullptr;
     if (desc->method != YMC_METHOD_MRW && desc->method != YMC_METHOD_MLDA2 && desc->method != YMC_METHOD_PCN &&
-        desc->method != YMC_METHOD_MLDA_NESTED)
+        desc->method != YMC_METHOD_MLDA_NESTED && desc->method != YMC_METHOD_AEM2)
         return fail(YMC_ERR_UNSUPPORTED, "unknown method %d", desc->method);
     if (desc->state_eq != YMC_EQ_EXACT && desc->state_eq != YMC_EQ_ISCLOSE)
         return fail(YMC_ERR_INVALID, "unknown state equality rule %d", desc->state_eq);
@@ -622,7 +688,24 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
         if (p->eq_mode == YMC_EQ_ISCLOSE && p->D != 1)
             rc = fail(YMC_ERR_INVALID, "the isclose equality rule is the scalar parameter's; dim is %d", p->D);
     }
-    if (rc == YMC_OK && desc->method == YMC_METHOD_MLDA2) {
+    if (rc == YMC_OK && desc->method == YMC_METHOD_AEM2) {
+        /* AEMBuilder._validate_parameters (aem.py:66-79), AEMLikelihood.__init__ (likelihood.py:99-100) */
+        if (desc->target.kind != YMC_DENSITY_POSTERIOR_LINEAR || desc->surrogate.kind != YMC_DENSITY_POSTERIOR_LINEAR)
+            rc = fail(YMC_ERR_INVALID, "Adaptive error correction only makes sense if the target emerges from a "
+                                       "Bayesian model.");
+        else if (p->tgt.tile)
+            rc = fail(YMC_ERR_UNSUPPORTED, "only the random-walk sampler is available at this dimension");
+        else if (desc->aem_min_data_size < 2)
+            rc = fail(YMC_ERR_INVALID, "Smallest senisible data size for AEM is 2.");
+        else if (desc->target.likelihood_only || desc->surrogate.likelihood_only)
+            rc = fail(YMC_ERR_INVALID, "the adaptive error model samples posteriors");
+        else if (desc->surrogate.data_dim != desc->target.data_dim)
+            rc = fail(YMC_ERR_INVALID, "the model error needs forward maps of equal output dimension (%d vs %d)",
+                      desc->target.data_dim, desc->surrogate.data_dim);
+        p->aem_min_data = desc->aem_min_data_size;
+        p->aem_heuristic = desc->aem_use_noise_heuristic != 0;
+    }
+    if (rc == YMC_OK && (desc->method == YMC_METHOD_MLDA2 || desc->method == YMC_METHOD_AEM2)) {
         /* MLDABuilder._validate_parameters, mlda.py:218-269 */
         if (desc->sub_chain_length < 1) rc = fail(YMC_ERR_INVALID, "Subchain lengths not set for MLDA");
         if (rc == YMC_OK && desc->surrogate.kind != desc->target.kind)
@@ -756,8 +839,21 @@ int ymc_run_create(ymc_ctx *ctx, const ymc_problem *problem, const ymc_run_desc 
             YMC_TRY(r->traj.alloc(r->capacity * (problem->tile ? tiled_row_doubles(r) : K * D) * sizeof(double)));
         if (r->flags & YMC_RECORD_ACCEPT) YMC_TRY(r->acc.alloc(r->capacity * K));
         if (r->flags & YMC_RECORD_LOGPOST) YMC_TRY(r->lp_out.alloc(r->capacity * K * sizeof(double)));
-        if ((r->flags & YMC_RECORD_SUB_ACCEPT) && problem->method == YMC_METHOD_MLDA2)
+        if ((r->flags & YMC_RECORD_SUB_ACCEPT) &&
+            (problem->method == YMC_METHOD_MLDA2 || problem->method == YMC_METHOD_AEM2))
             YMC_TRY(r->sub_acc.alloc(r->capacity * (uint64_t)S * K));
+        if (problem->method == YMC_METHOD_AEM2) {
+            const uint64_t m = (uint64_t)problem->sur.d.data_dim;
+            DeviceBuf *bufs[] = {&r->err_n, &r->err_mean, &r->err_m2, &r->aem_prec, &r->aem_flags, &r->cache_key,
+                                 &r->cache_val};
+            const size_t sizes[] = {K * sizeof(uint64_t), K * m * sizeof(double), K * m * sizeof(double),
+                                    K * m * sizeof(double), K * 2 * sizeof(int32_t),
+                                    K * YMC_AEM_CACHE * D * sizeof(double), K * YMC_AEM_CACHE * sizeof(double)};
+            for (int i = 0; i < 7; ++i) {
+                YMC_TRY(bufs[i]->alloc(sizes[i]));
+                YMC_HIP(hipMemsetAsync(bufs[i]->p, 0, sizes[i], ctx->stream));
+            }
+        }
         /* logpi of the initial states (metropolisHastings.py:110 + first evaluate_log of mrw.py:54) */
         YMC_TRY(eval_logdensity(ctx, problem, problem->tgt, K, r->x.as<double>(), r->lp.as<double>(), nullptr));
         if (problem->method == YMC_METHOD_MLDA2)
@@ -810,6 +906,8 @@ int ymc_run_advance(ymc_run *run, uint64_t nsteps)
             YMC_TRY(launch_advance_tile(run, chunk));
         } else if (run->problem->method == YMC_METHOD_MLDA_NESTED) {
             YMC_DISPATCH_D(run->problem->D, YMC_TRY(launch_advance_nested<DD>(run, chunk)));
+        } else if (run->problem->method == YMC_METHOD_AEM2) {
+            YMC_DISPATCH_D(run->problem->D, YMC_TRY(launch_advance_aem<DD>(run, chunk)));
         } else {
             YMC_DISPATCH_D(run->problem->D, YMC_TRY(launch_advance<DD>(run, chunk)));
         }
@@ -906,9 +1004,29 @@ int ymc_run_fetch_logpost(ymc_run *run, uint64_t first, uint64_t n, double *dst,
 int ymc_run_fetch_sub_accept(ymc_run *run, uint64_t first, uint64_t n, uint8_t *dst, size_t dst_bytes)
 {
     if (!run) return fail(YMC_ERR_INVALID, "null argument");
-    if (run->problem->method != YMC_METHOD_MLDA2) return fail(YMC_ERR_INVALID, "not a two-level run");
+    if (run->problem->method != YMC_METHOD_MLDA2 && run->problem->method != YMC_METHOD_AEM2)
+        return fail(YMC_ERR_INVALID, "not a two-level run");
     return fetch_rows(run, run->sub_acc, YMC_RECORD_SUB_ACCEPT, "sub-chain decisions", first, n,
                       (uint64_t)run->problem->S * run->K, dst, dst_bytes);
+}
+
+int ymc_run_fetch_error_model(ymc_run *run, uint64_t *n, double *mean, double *m2, double *precision,
+                              int32_t *has_precision)
+{
+    if (!run) return fail(YMC_ERR_INVALID, "null argument");
+    if (run->problem->method != YMC_METHOD_AEM2) return fail(YMC_ERR_INVALID, "not an adaptive-error-model run");
+    YMC_HIP(hipSetDevice(run->ctx->device));
+    YMC_HIP(hipStreamSynchronize(run->ctx->stream));
+    if (n) YMC_HIP(hipMemcpy(n, run->err_n.p, run->err_n.bytes, hipMemcpyDeviceToHost));
+    if (mean) YMC_HIP(hipMemcpy(mean, run->err_mean.p, run->err_mean.bytes, hipMemcpyDeviceToHost));
+    if (m2) YMC_HIP(hipMemcpy(m2, run->err_m2.p, run->err_m2.bytes, hipMemcpyDeviceToHost));
+    if (precision) YMC_HIP(hipMemcpy(precision, run->aem_prec.p, run->aem_prec.bytes, hipMemcpyDeviceToHost));
+    if (has_precision) {
+        std::vector<int32_t> flags(2 * run->K);
+        YMC_HIP(hipMemcpy(flags.data(), run->aem_flags.p, run->aem_flags.bytes, hipMemcpyDeviceToHost));
+        for (uint64_t k = 0; k < run->K; ++k) has_precision[k] = flags[2 * k];
+    }
+    return YMC_OK;
 }
 
 int ymc_run_fetch_level_accept(ymc_run *run, uint64_t *dst, size_t dst_bytes, uint64_t *made)
@@ -965,7 +1083,7 @@ int ymc_logdensity_eval(ymc_ctx *ctx, const ymc_problem *problem, int which, uin
                         double *out, uint32_t *status)
 {
     if (!ctx || !problem || !x || !out) return fail(YMC_ERR_INVALID, "null argument");
-    if (which != 0 && !(which == 1 && problem->method == YMC_METHOD_MLDA2))
+    if (which != 0 && !(which == 1 && (problem->method == YMC_METHOD_MLDA2 || problem->method == YMC_METHOD_AEM2)))
         return fail(YMC_ERR_INVALID, "density %d does not exist in this problem", which);
     if (n == 0) return YMC_OK;
     YMC_HIP(hipSetDevice(ctx->device));
@@ -986,7 +1104,7 @@ int ymc_logdensity_eval(ymc_ctx *ctx, const ymc_problem *problem, int which, uin
 int ymc_forward_eval(ymc_ctx *ctx, const ymc_problem *problem, int which, uint64_t n, const double *x, double *out)
 {
     if (!ctx || !problem || !x || !out) return fail(YMC_ERR_INVALID, "null argument");
-    if (which != 0 && !(which == 1 && problem->method == YMC_METHOD_MLDA2))
+    if (which != 0 && !(which == 1 && (problem->method == YMC_METHOD_MLDA2 || problem->method == YMC_METHOD_AEM2)))
         return fail(YMC_ERR_INVALID, "density %d does not exist in this problem", which);
     const DensityHost &h = which ? problem->sur : problem->tgt;
     uint64_t m = 0;

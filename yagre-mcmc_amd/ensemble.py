@@ -360,6 +360,36 @@ class MLDA(MetropolisHastingsEnsemble):
                                             state_eq, rk4_steps=self.rk4Steps)
 
 
+class AdaptiveErrorModel(MLDA):
+    """chain/method/aem.py:6-58 with one surrogate: two-level delayed acceptance whose coarse
+    AEMLikelihood learns the model error from the accepted fine proposals, per chain
+    (YMC_METHOD_AEM2).  With more surrogates the reference fails at the first accepted step
+    (`d_model_evaluation` does not exist); the same AttributeError is raised here."""
+
+    def run(self, chainLength, initialState, verbose=True):
+        if self.nSurrogates > 1 and int(chainLength) > 1:
+            raise AttributeError("'AEMLikelihood' object has no attribute 'd_model_evaluation'")
+        super().run(chainLength, initialState, verbose)
+
+    def error_model(self):
+        """dict n / mean / m2 / precision / has_precision, one row per chain."""
+        return self._run.error_model()
+
+    def _ingest(self):
+        super()._ingest()
+        lik = getattr(self._surrogates[0], "likelihood", None)
+        acc = getattr(lik, "accumulator", None)
+        if hasattr(acc, "_attach"):
+            acc._attach(self._run.error_model())
+
+    def _make_problem(self, ctx, state_eq):
+        dim = lowering.lower_density(self._tgtDensity, self.rk4Steps).desc.dim
+        sigma = lowering.proposal_sigma(self._proposalCov, dim)
+        aem = lowering.aem_parameters(self._surrogates[0].likelihood)
+        return lowering.make_problem(ctx, _ffi.METHOD_AEM2, self._tgtDensity, sigma, state_eq,
+                                     surrogate=self._surrogates[0], sub_chain_length=self._nSteps[0], aem=aem)
+
+
 class PreconditionedCrankNicolson(MetropolisHastingsEnsemble):
     """chain/method/pcn.py:38-57: proposal sqrt(1-2h) x + sqrt(2h) xi with xi drawn from the
     (centred, Gaussian) prior; the target of the accept/reject step is the likelihood."""

@@ -104,7 +104,8 @@ def lower_solver(solver, low, rk4_steps=None):
 def lower_posterior(likelihood, prior, rk4_steps=None):
     """UnnormalisedPosterior(likelihood, prior) (chain/target.py:4-22) with an
     AdditiveGaussianNoiseLikelihood (statistics/likelihood.py:49-87) and a Gaussian prior."""
-    if _name(likelihood) != "AdditiveGaussianNoiseLikelihood" or not _has(likelihood, "_data", "_fwdModel", "_noiseModel"):
+    if _name(likelihood) not in ("AdditiveGaussianNoiseLikelihood", "AEMLikelihood") \
+            or not _has(likelihood, "_data", "_fwdModel", "_noiseModel"):
         raise UnsupportedPlugin(f"likelihood {_name(likelihood)} has no device lowering")
     if not _has(prior, "mean", "covariance"):
         raise UnsupportedPlugin(f"prior {_name(prior)} has no device lowering (a Gaussian law is needed)")
@@ -118,7 +119,10 @@ def lower_posterior(likelihood, prior, rk4_steps=None):
     low.desc.dim = dim
     low.desc.n_data, low.desc.data_dim = data.shape
     low.set_array("data", data)
-    low.set_array("noise_precision", _diag_precision(likelihood._noiseModel.covariance, data_dim, "noise"))
+    noise = likelihood._noiseModel
+    if _name(noise) == "AEMNoise":  # noise.py:25-39: the measurement noise it wraps is the initial model
+        noise = noise._dataNoise
+    low.set_array("noise_precision", _diag_precision(noise.covariance, data_dim, "noise"))
     pm = np.asarray(prior.mean.coefficient, dtype=np.float64).reshape(-1)
     if pm.size != dim:
         raise ValueError(f"prior mean has dimension {pm.size}, the forward map takes {dim}")
@@ -199,14 +203,21 @@ def make_nested_problem(ctx, target, surrogates, sub_chain_lengths, sigma, state
     return _ffi.Problem(ctx, desc, [tgt, lowP, lowQ, arrP, arrQ, arrS, sigma])
 
 
+def aem_parameters(likelihood):
+    """(minDataSize, useNoiseHeuristic) of an AEMLikelihood (likelihood.py:92-105, noise.py:27-39)."""
+    if _name(likelihood) != "AEMLikelihood" or not _has(likelihood, "_minDataSize", "_noiseModel"):
+        raise ValueError("the likelihood is not adaptive")
+    return int(likelihood._minDataSize), bool(getattr(likelihood._noiseModel, "_useHeuristic", False))
+
+
 def make_problem(ctx, method, target, sigma, state_eq=_ffi.EQ_EXACT, surrogate=None, sub_chain_length=0,
-                 rk4_steps=None, pcn_step_size=0.0):
+                 rk4_steps=None, pcn_step_size=0.0, aem=None):
     tgt = lower_density(target, rk4_steps) if not isinstance(target, Lowered) else target
     desc = _ffi.ProblemDesc()
     desc.method, desc.state_eq = method, state_eq
     desc.target = tgt.desc
     keep = [tgt]
-    if method == _ffi.METHOD_MLDA2:
+    if method in (_ffi.METHOD_MLDA2, _ffi.METHOD_AEM2):
         sur = lower_density(surrogate, rk4_steps) if not isinstance(surrogate, Lowered) else surrogate
         desc.surrogate = sur.desc
         desc.sub_chain_length = int(sub_chain_length)
@@ -216,6 +227,8 @@ def make_problem(ctx, method, target, sigma, state_eq=_ffi.EQ_EXACT, surrogate=N
         raise ValueError(f"proposal covariance has dimension {sigma.size}, the target has {tgt.desc.dim}")
     desc.proposal_sigma = _ffi.dptr(sigma)
     desc.pcn_step_size = float(pcn_step_size)
+    if method == _ffi.METHOD_AEM2:
+        desc.aem_min_data_size, desc.aem_use_noise_heuristic = int(aem[0]), int(bool(aem[1]))
     keep.append(sigma)
     return _ffi.Problem(ctx, desc, keep)
 

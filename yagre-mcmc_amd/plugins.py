@@ -375,6 +375,71 @@ class AdditiveGaussianNoiseLikelihood(_DeviceDensity):
         self._noiseModel = noiseModel
 
 
+class AEMNoise(CentredGaussianNoise):
+    """noise.py:25-61: the measurement noise plus, once learned, the model-error variance.  The
+    learning happens per chain on the device; this object holds the configuration."""
+
+    def __init__(self, measurementNoise, useHeuristic):
+        if not hasattr(measurementNoise.covariance, "_precision"):
+            raise NotImplementedError("Currently, AEM is only implemented for independent measurement noise.")
+        self._dataNoise = measurementNoise
+        self._aemNoise = None
+        self._useHeuristic = useHeuristic
+
+    @property
+    def covariance(self):
+        return self._dataNoise.covariance
+
+    def induced_norm_squared(self, vector):
+        return self._dataNoise.induced_norm_squared(vector)
+
+
+class ErrorModelAccumulator:
+    """WelfordAccumulator surface (estimation.py:4-58) of the model error learned by the chains of
+    the last run: reference shapes for one chain, a leading chain axis otherwise."""
+
+    def __init__(self):
+        self._state = None
+
+    def _attach(self, state):
+        self._state = state
+
+    def _pick(self, a):
+        return a[0] if a.shape[0] == 1 else a
+
+    @property
+    def nData(self):
+        if self._state is None:
+            return 0
+        n = self._state["n"]
+        return int(n[0]) if n.size == 1 else n
+
+    def mean(self):
+        return None if self._state is None else self._pick(self._state["mean"])
+
+    def marginal_variance(self):
+        if self._state is None or np.any(self._state["n"] < 2):
+            raise RuntimeError("Insufficient data for variance estimation.")
+        return self._pick(self._state["m2"] / (self._state["n"][:, None].astype(np.float64) - 1.0))
+
+
+class AEMLikelihood(AdditiveGaussianNoiseLikelihood):
+    """likelihood.py:90-155.  evaluate_log is the likelihood BEFORE any adaptation; inside an
+    AdaptiveErrorModel run every chain adapts its own copy on the device (csrc/ymc_aem.hip) and
+    `accumulator` shows what was learned."""
+
+    def __init__(self, data, forwardModel, noiseModel, minDataSize, useNoiseHeuristic=False):
+        if minDataSize < 2:
+            raise ValueError("Smallest senisible data size for AEM is 2.")
+        self._minDataSize = minDataSize
+        self._accumulator = ErrorModelAccumulator()
+        super().__init__(data, forwardModel, AEMNoise(noiseModel, useNoiseHeuristic))
+
+    @property
+    def accumulator(self):
+        return self._accumulator
+
+
 class BayesianRegressionModel:
     """bayesModel.py:5-29 (non-hierarchical components only)."""
 

@@ -1,1 +1,1 @@
-from ..plugins import AdditiveGaussianNoiseLikelihood  # noqa: F401
+from ..plugins import AdditiveGaussianNoiseLikelihood, AEMLikelihood  # noqa: F401

@@ -1,1 +1,1 @@
-from ..plugins import CentredGaussianNoise  # noqa: F401
+from ..plugins import AEMNoise, CentredGaussianNoise  # noqa: F401
