@@ -403,6 +403,31 @@ def test_aem_other_shapes_vs_oracle(ffi, ctx, d, m, nd):
     assert dev["err"]["has_precision"].mean() > 0.5
 
 
+def test_aem_full_size_invariants(ffi, ctx, golden):
+    """65 536 chains: the error model has seen exactly the accepted fine proposals of its chain
+    (aem.py:26-56), the inflated precision exists iff nData > minDataSize and is below the data
+    precision, and a sample of chains equals the oracle."""
+    g = golden("f12_aem_linear.npz")
+    common = dict(data=g["data"], noise_precision=g["noise_precision"], prior_mean=g["prior_mean"],
+                  prior_precision=g["prior_precision"])
+    K, n, S, md = 65536, 120, 4, 10
+    x0 = np.zeros((K, 2))
+    dev = _aem_device_run(ffi, ctx, g, dict(common, A=g["A_fine"], b=g["b_fine"]),
+                          dict(common, A=g["A_coarse"], b=g["b_coarse"]), g["sigma"], x0, 555, n, S, md, 1)
+    err = dev["err"]
+    assert np.array_equal(err["n"], dev["summary"]["accepted"])
+    assert np.array_equal(err["n"], dev["acc"].sum(axis=0).astype(np.uint64))
+    assert np.array_equal(err["has_precision"], err["n"] > md)
+    assert err["has_precision"].mean() > 0.9
+    assert np.all(err["precision"][err["has_precision"]] < g["noise_precision"][None, :])
+    sel = slice(4096, 4096 + 64)
+    e = o.AemEnsemble(o.posterior_linear(g["A_fine"], g["b_fine"], **common),
+                      o.posterior_linear(g["A_coarse"], g["b_coarse"], **common), g["sigma"], x0[sel], 555, S, md, 1,
+                      chain0=4096)
+    out = e.advance(n)
+    assert np.array_equal(dev["traj"][:, sel], out["traj"]) and np.array_equal(err["mean"][sel], e.aem_mean)
+
+
 # ---------------------------------------------------------------------------
 # other dimensions of the lane-per-chain kernels vs the oracle
 # ---------------------------------------------------------------------------
