@@ -130,6 +130,16 @@ typedef struct ymc_u32x4 {
     uint32_t v[4];
 } ymc_u32x4;
 
+/* a ^ b ^ c: one v_bitop3_b32 on gfx950 (the compiler pairs the xors into two instructions) */
+YMC_FN uint32_t ymc_xor3(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+    return a ^ b ^ c;
+#endif
+}
+
 YMC_FN ymc_u32x4 ymc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                    uint32_t k0, uint32_t k1)
 {
@@ -139,9 +149,9 @@ YMC_FN ymc_u32x4 ymc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32
     for (int r = 0; r < 10; ++r) {
         uint64_t p0 = (uint64_t)YMC_PHILOX_M0 * c0;
         uint64_t p1 = (uint64_t)YMC_PHILOX_M1 * c2;
-        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n0 = ymc_xor3((uint32_t)(p1 >> 32), c1, k0);
         uint32_t n1 = (uint32_t)p1;
-        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n2 = ymc_xor3((uint32_t)(p0 >> 32), c3, k1);
         uint32_t n3 = (uint32_t)p0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += YMC_PHILOX_W0;
