@@ -574,6 +574,32 @@ def test_tile_kernel_other_shapes(ffi, ctx, d, m, nd, K):
     _same_as_oracle(dev, e, out)   # incl. the Welford moments replayed from the record
 
 
+@pytest.mark.parametrize("d,m,nd,K,h", [(128, 128, 5, 80, 0.002), (9, 3, 2, 33, 0.05), (40, 70, 8, 50, 0.01), (7, 30, 5, 40, 0.5)])
+def test_tile_kernel_preconditioned_crank_nicolson(ffi, ctx, d, m, nd, K, h):
+    """pCN (pcn.py:9-57) at dimensions the lane kernels do not cover: proposal sqrt(1-2h) x + sqrt(2h) xi,
+    xi ~ prior, accept on the likelihood alone; bit-exact against the oracle incl. the replayed moments."""
+    from yagremcmc_amd import lowering
+    rng = np.random.default_rng(900 + d + m)
+    g = dict(A=rng.normal(size=(m, d)) / np.sqrt(d), b=rng.normal(size=m), data=rng.normal(size=(nd, m)),
+             noise_precision=rng.uniform(0.5, 3, size=m), prior_mean=np.zeros(d),
+             prior_precision=rng.uniform(0.5, 2, size=d))
+    low = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, g, fwd_matrix=g["A"], fwd_shift=g["b"], likelihood_only=1)
+    prior_sigma = np.sqrt(np.reciprocal(g["prior_precision"]))
+    x0 = rng.normal(size=(K, d)) * 0.3
+    prob = lowering.make_problem(ctx, ffi.METHOD_PCN, low, prior_sigma, pcn_step_size=h)
+    run = ffi.Run(prob, 99, K, x0, 50, _flags(ffi, True), 500)
+    run.advance(20)
+    run.advance(30)
+    run.sync()
+    dev = dict(traj=run.trajectory(), acc=run.accept(), logpost=run.logpost(), summary=run.summary(), state=run.state())
+    p = o.posterior_linear(g["A"], g["b"], g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+    p["likelihood_only"] = 1
+    e = o.Ensemble(p, prior_sigma, x0, 99, chain0=500, pcn_step_size=h)
+    out = e.advance(50)
+    assert 0.01 < out["acc"].mean() < 0.99
+    _same_as_oracle(dev, e, out)
+
+
 def test_tile_kernel_limits(ffi, ctx):
     from yagremcmc_amd import lowering
     rng = np.random.default_rng(1)

@@ -276,6 +276,7 @@ BigLinearArgs big_view(const DensityHost &h)
     b.d = h.d.dim;
     b.m = h.d.data_dim;
     b.n_data = h.d.n_data;
+    b.likelihood_only = h.d.likelihood_only;
     return b;
 }
 
@@ -554,6 +555,9 @@ int launch_advance_tile(ymc_run *r, uint64_t nsteps)
     a.t0 = r->steps_done;
     a.nsteps = (uint32_t)nsteps;
     a.flags = r->flags;
+    a.pcn = p->method == YMC_METHOD_PCN;
+    a.pcn_c1 = p->pcn_c1;
+    a.pcn_c2 = p->pcn_c2;
     a.x = r->x.as<double>();
     a.lp = r->lp.as<double>();
     a.acc_count = r->acc_count.as<uint64_t>();
@@ -755,8 +759,8 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
         }
     }
     if (rc == YMC_OK && p->tgt.tile) {
-        if (p->method != YMC_METHOD_MRW)
-            rc = fail(YMC_ERR_UNSUPPORTED, "only the random-walk sampler is available at this dimension");
+        if (p->method != YMC_METHOD_MRW && p->method != YMC_METHOD_PCN)
+            rc = fail(YMC_ERR_UNSUPPORTED, "only the random-walk and pCN samplers are available at this dimension");
         if (rc == YMC_OK) rc = build_tile_blob(p);
         p->tile = true;
     }

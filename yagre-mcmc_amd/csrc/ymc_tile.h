@@ -20,6 +20,8 @@ struct TileArgs {
     int32_t d, m, n_data, MT;
     uint64_t seed, chain0, K, t0;
     uint32_t nsteps, flags;
+    int32_t pcn, pad_;      /* 1: preconditioned Crank-Nicolson (pcn.py:9-57): sigma is the PRIOR's, lp the log-likelihood */
+    double pcn_c1, pcn_c2;  /* sqrt(1 - 2h), sqrt(2h) */
     double *x, *lp;
     uint64_t *acc_count;
     uint32_t *status;
@@ -30,7 +32,7 @@ struct TileArgs {
 
 struct BigLinearArgs {
     const double *A, *b, *data, *noise_prec, *prior_mean, *prior_prec; /* unpadded, row-major */
-    int32_t d, m, n_data, pad_;
+    int32_t d, m, n_data, likelihood_only;
 };
 
 size_t ymc_tile_lds_bytes(int KS, int MT, int n_data);

@@ -53,7 +53,7 @@ __device__ __forceinline__ double combine4(double s)
     return v + shfl_xor_f64(v, 32);
 }
 
-template <int KS>
+template <int KS, bool PCN>
 __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArgs a)
 {
     extern __shared__ double lds[];
@@ -110,8 +110,15 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
             const double recv = shfl_xor_f64(give, 16);
             const double xi0 = odd ? recv : keep; /* component 8 q + g     (s = 2 q)     */
             const double xi1 = odd ? keep : recv; /* component 8 q + 4 + g (s = 2 q + 1) */
-            y[2 * q] = x[2 * q] + sigma[8 * q + g] * xi0;
-            y[2 * q + 1] = x[2 * q + 1] + sigma[8 * q + 4 + g] * xi1;
+            if constexpr (PCN) { /* pcn.py:27-36: xi ~ prior, y = sqrt(1 - 2h) x + sqrt(2h) xi */
+                const double p0 = pmean[8 * q + g] + sigma[8 * q + g] * xi0;
+                const double p1 = pmean[8 * q + 4 + g] + sigma[8 * q + 4 + g] * xi1;
+                y[2 * q] = a.pcn_c1 * x[2 * q] + a.pcn_c2 * p0;
+                y[2 * q + 1] = a.pcn_c1 * x[2 * q + 1] + a.pcn_c2 * p1;
+            } else {
+                y[2 * q] = x[2 * q] + sigma[8 * q + g] * xi0;
+                y[2 * q + 1] = x[2 * q + 1] + sigma[8 * q + 4 + g] * xi1;
+            }
             moved_l = moved_l || !(y[2 * q] == x[2 * q]) || !(y[2 * q + 1] == x[2 * q + 1]);
         }
         int mv = moved_l ? 1 : 0;
@@ -157,16 +164,19 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
             if (i < n_data) total = total + combine4(S[i]);
         const double logl = -0.5 * total;
 
-        /* Gaussian prior (gaussian.py:19-24) */
-        double P = 0.0;
+        /* Gaussian prior (gaussian.py:19-24); the target of pCN is the likelihood alone (pcn.py:51-57) */
+        double lpy = logl;
+        if constexpr (!PCN) {
+            double P = 0.0;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int j = 4 * s + g;
-            const double dx = y[s] - pmean[j];
-            const double px = pprec[j] * dx;
-            P = P + dx * px;
+            for (int s = 0; s < KS; ++s) {
+                const int j = 4 * s + g;
+                const double dx = y[s] - pmean[j];
+                const double px = pprec[j] * dx;
+                P = P + dx * px;
+            }
+            lpy = logl + (-0.5 * combine4(P));
         }
-        const double lpy = logl + (-0.5 * combine4(P));
 
         /* accept / reject (metropolisHastings.py:55-73, mrw.py:51-57) */
         const double u = ymc_uniform_cached(uc, a.seed, chain, t);
@@ -300,7 +310,7 @@ __global__ __launch_bounds__(256) void linear_big_eval_kernel(const BigLinearArg
             }
         }
     }
-    lp_out[i] = -0.5 * total + (-0.5 * ((P[0] + P[1]) + (P[2] + P[3])));
+    lp_out[i] = p.likelihood_only ? -0.5 * total : -0.5 * total + (-0.5 * ((P[0] + P[1]) + (P[2] + P[3])));
 }
 
 }  // namespace
@@ -311,17 +321,23 @@ size_t ymc_tile_lds_bytes(int KS, int MT, int n_data)
     return ((size_t)MT * KS * 64 + m_pad * (2 + (size_t)n_data) + 3 * d_pad) * sizeof(double);
 }
 
-template <int KS>
-static hipError_t launch_tile(const TileArgs &a, hipStream_t s)
+template <int KS, bool PCN>
+static hipError_t launch_tile_as(const TileArgs &a, hipStream_t s)
 {
     const size_t lds = ymc_tile_lds_bytes(KS, a.MT, a.n_data);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_tile_kernel<KS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_tile_kernel<KS, PCN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const uint64_t nct = (a.K + 15) / 16;
     const unsigned grid = (unsigned)((nct + kTileWaves - 1) / kTileWaves);
-    hipLaunchKernelGGL((linear_tile_kernel<KS>), dim3(grid), dim3(kTileThreads), lds, s, a);
+    hipLaunchKernelGGL((linear_tile_kernel<KS, PCN>), dim3(grid), dim3(kTileThreads), lds, s, a);
     return hipGetLastError();
+}
+
+template <int KS>
+static hipError_t launch_tile(const TileArgs &a, hipStream_t s)
+{
+    return a.pcn ? launch_tile_as<KS, true>(a, s) : launch_tile_as<KS, false>(a, s);
 }
 
 hipError_t ymc_launch_linear_tile(int KS, const TileArgs &a, hipStream_t s)
