@@ -178,14 +178,6 @@ static void ymo_forward_linear(const ymo_density *p, const double *theta, double
     }
 }
 
-/* LotkaVolterraSolver.flow__, testSetup.py:96-99 */
-static void ymo_lv_flow(double x, double y, double alpha, double beta, double gamma, double delta,
-                        double *dx, double *dy)
-{
-    *dx = alpha * x - beta * x * y;
-    *dy = delta * x * y - gamma * y;
-}
-
 /* LotkaVolterraParameter.evaluate (testSetup.py:56-58: exp of the coefficient)
  * + LotkaVolterraSolver.interpolate/invoke (testSetup.py:101-141): one ODE
  * solve per design row, final state only (:139).  The reference integrates
@@ -206,13 +198,7 @@ static int ymo_forward_lv(const ymo_density *p, const double *theta, double *F)
     for (int32_t n = 0; n < p->n_data; ++n) {
         double x = p->design[2 * n], y = p->design[2 * n + 1];
         for (int32_t s = 0; s < p->rk4_steps; ++s) {
-            double k1x, k1y, k2x, k2y, k3x, k3y, k4x, k4y;
-            ymo_lv_flow(x, y, alpha, beta, gamma, delta, &k1x, &k1y);
-            ymo_lv_flow(x + h2 * k1x, y + h2 * k1y, alpha, beta, gamma, delta, &k2x, &k2y);
-            ymo_lv_flow(x + h2 * k2x, y + h2 * k2y, alpha, beta, gamma, delta, &k3x, &k3y);
-            ymo_lv_flow(x + h * k3x, y + h * k3y, alpha, beta, gamma, delta, &k4x, &k4y);
-            x = x + h6 * ((k1x + 2.0 * k2x) + (2.0 * k3x + k4x));
-            y = y + h6 * ((k1y + 2.0 * k2y) + (2.0 * k3y + k4y));
+            ymc_lv_rk4_step(&x, &y, alpha, beta, gamma, delta, h, h2, h6); /* ymc_numerics.h */
         }
         F[2 * n] = x;
         F[2 * n + 1] = y;

@@ -65,14 +65,6 @@ __device__ __forceinline__ double ymc_prior_log(const DensityDev<D> &p, const do
     return -0.5 * ymc_diag_norm_sq<D>(x, p.prior_prec, D);
 }
 
-/* testSetup.py:96-99 */
-__device__ __forceinline__ void ymc_lv_flow(double x, double y, double alpha, double beta, double gamma,
-                                            double delta, double &dx, double &dy)
-{
-    dx = alpha * x - beta * x * y;
-    dy = delta * x * y - gamma * y;
-}
-
 template <int KIND, int D>
 struct Density;
 
@@ -163,13 +155,7 @@ struct Density<YMC_DENSITY_POSTERIOR_LV, D> {
         for (int n = 0; n < p.n_data; ++n) {
             double x = p.design[2 * n], y = p.design[2 * n + 1];
             for (int s = 0; s < p.rk4_steps; ++s) {
-                double k1x, k1y, k2x, k2y, k3x, k3y, k4x, k4y;
-                ymc_lv_flow(x, y, alpha, beta, gamma, delta, k1x, k1y);
-                ymc_lv_flow(x + h2 * k1x, y + h2 * k1y, alpha, beta, gamma, delta, k2x, k2y);
-                ymc_lv_flow(x + h2 * k2x, y + h2 * k2y, alpha, beta, gamma, delta, k3x, k3y);
-                ymc_lv_flow(x + h * k3x, y + h * k3y, alpha, beta, gamma, delta, k4x, k4y);
-                x = x + h6 * ((k1x + 2.0 * k2x) + (2.0 * k3x + k4x));
-                y = y + h6 * ((k1y + 2.0 * k2y) + (2.0 * k3y + k4y));
+                ymc_lv_rk4_step(&x, &y, alpha, beta, gamma, delta, h, h2, h6);
             }
             bad = bad || !ymc_finite(x) || !ymc_finite(y);
             double r[2] = {x - p.data[2 * n], y - p.data[2 * n + 1]};

@@ -258,13 +258,7 @@ __global__ __launch_bounds__(kBlock) void mrw_lv_rows_kernel(const ChainArgs<2> 
         const double beta = ymc_exp(y[0]), delta = ymc_exp(y[1]);
         double sx = dx0, sy = dy0;
         for (int s = 0; s < p.rk4_steps; ++s) {
-            double k1x, k1y, k2x, k2y, k3x, k3y, k4x, k4y;
-            ymc_lv_flow(sx, sy, alpha, beta, gamma, delta, k1x, k1y);
-            ymc_lv_flow(sx + h2 * k1x, sy + h2 * k1y, alpha, beta, gamma, delta, k2x, k2y);
-            ymc_lv_flow(sx + h2 * k2x, sy + h2 * k2y, alpha, beta, gamma, delta, k3x, k3y);
-            ymc_lv_flow(sx + h * k3x, sy + h * k3y, alpha, beta, gamma, delta, k4x, k4y);
-            sx = sx + h6 * ((k1x + 2.0 * k2x) + (2.0 * k3x + k4x));
-            sy = sy + h6 * ((k1y + 2.0 * k2y) + (2.0 * k3y + k4y));
+            ymc_lv_rk4_step(&sx, &sy, alpha, beta, gamma, delta, h, h2, h6);
         }
         const int bad_l = (!ymc_finite(sx) || !ymc_finite(sy)) ? 1 : 0;
         const double res[2] = {sx - obs0, sy - obs1};
@@ -351,13 +345,7 @@ __global__ __launch_bounds__(kBlock) void forward_lv_kernel(const DensityDev<2> 
     for (int r = 0; r < p.n_data; ++r) {
         double x = p.design[2 * r], y = p.design[2 * r + 1];
         for (int s = 0; s < p.rk4_steps; ++s) {
-            double k1x, k1y, k2x, k2y, k3x, k3y, k4x, k4y;
-            ymc_lv_flow(x, y, p.alpha, beta, p.gamma, delta, k1x, k1y);
-            ymc_lv_flow(x + h2 * k1x, y + h2 * k1y, p.alpha, beta, p.gamma, delta, k2x, k2y);
-            ymc_lv_flow(x + h2 * k2x, y + h2 * k2y, p.alpha, beta, p.gamma, delta, k3x, k3y);
-            ymc_lv_flow(x + h * k3x, y + h * k3y, p.alpha, beta, p.gamma, delta, k4x, k4y);
-            x = x + h6 * ((k1x + 2.0 * k2x) + (2.0 * k3x + k4x));
-            y = y + h6 * ((k1y + 2.0 * k2y) + (2.0 * k3y + k4y));
+            ymc_lv_rk4_step(&x, &y, p.alpha, beta, p.gamma, delta, h, h2, h6);
         }
         out[(i * p.n_data + r) * 2] = x;
         out[(i * p.n_data + r) * 2 + 1] = y;
