@@ -98,10 +98,10 @@ def make_workload(name, ffi, ctx, lowering):
         A = rng.standard_normal((d, d)) / np.sqrt(d)
         b = rng.standard_normal(d)
         theta = rng.standard_normal(d)
-        data = np.array([A @ theta + b + np.sqrt(0.3) * rng.standard_normal(d) for _ in range(5)])
+        data = np.array([A @ theta + b + np.sqrt(0.3) * rng.standard_normal(d) for _ in range(int(os.environ.get("YMC_C3_ND", "5")))])
         noise_prec, prior_mean, prior_prec = np.reciprocal(np.full(d, 0.3)), np.zeros(d), np.reciprocal(np.full(d, 5.0))
         low = lowering.Lowered(ffi.POSTERIOR_LINEAR, d)
-        low.desc.n_data, low.desc.data_dim = 5, d
+        low.desc.n_data, low.desc.data_dim = data.shape[0], d
         for k, v in (("data", data), ("noise_precision", noise_prec), ("prior_mean", prior_mean),
                      ("prior_precision", prior_prec), ("fwd_matrix", A), ("fwd_shift", b)):
             low.set_array(k, v)

@@ -34,6 +34,7 @@ class _Density(C.Structure):
         ("fwd_matrix", _dp), ("fwd_shift", _dp),
         ("design", _dp), ("t_final", C.c_double), ("alpha", C.c_double), ("gamma", C.c_double),
         ("rk4_steps", C.c_int32), ("likelihood_only", C.c_int32),
+        ("lin_dbar", _dp), ("lin_nprec", _dp), ("lin_const", C.c_double),
     ]
 
 
@@ -140,6 +141,14 @@ def _lower(p):
     for name in ("n_data", "data_dim", "rk4_steps", "likelihood_only"):
         if name in p:
             setattr(d, name, p[name])
+    if p["kind"] == POST_LINEAR:
+        # the data-only parts of the likelihood (ymc_linear_data_summary), once per lowering
+        m = int(p["data_dim"])
+        dbar, nprec, cst = np.zeros(m), np.zeros(m), C.c_double(0.0)
+        lib().ymo_linear_summary(d.data, d.noise_precision, C.c_int32(int(p["n_data"])), C.c_int32(m), _ptr(dbar),
+                                 _ptr(nprec), C.byref(cst))
+        keep += [dbar, nprec]
+        d.lin_dbar, d.lin_nprec, d.lin_const = _ptr(dbar), _ptr(nprec), cst.value
     return d, keep
 
 

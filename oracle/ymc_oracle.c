@@ -73,6 +73,9 @@ typedef struct ymo_density {
     double t_final, alpha, gamma;
     int32_t rk4_steps;
     int32_t likelihood_only;       /* 1: evaluate the likelihood alone (the target of pCN, pcn.py:77-78) */
+    /* POST_LINEAR: ymc_linear_data_summary of (data, noise_precision), filled by ymo_linear_summary */
+    const double *lin_dbar, *lin_nprec;
+    double lin_const;
 } ymo_density;
 
 /* ---------------------------------------------------------------------- */
@@ -216,6 +219,12 @@ static int ymo_forward_lv(const ymo_density *p, const double *theta, double *F)
  * data row) and (n_data, data_dim) for Lotka-Volterra (row i pairs with D_i). */
 static double ymo_log_likelihood(const ymo_density *p, const double *F, int per_row_eval)
 {
+    if (!per_row_eval) {
+        /* one forward value for all rows: |F - Dbar|^2_{nP} + sum_i |D_i - Dbar|^2_P (ymc_numerics.h) */
+        double r0[YMO_MMAX];
+        for (int32_t j = 0; j < p->data_dim; ++j) r0[j] = F[j] - p->lin_dbar[j];
+        return -0.5 * (ymo_diag_norm_sq(r0, p->lin_nprec, p->data_dim) + p->lin_const);
+    }
     double total = 0.0;
     double r[YMO_MMAX];
     for (int32_t i = 0; i < p->n_data; ++i) {
@@ -902,6 +911,12 @@ void ymo_aem_advance(const ymo_density *fine, const ymo_density *coarse, const d
         }
         if (status) status[k] = st;
     }
+}
+
+void ymo_linear_summary(const double *data, const double *prec, int32_t n, int32_t m, double *dbar,
+                        double *nprec, double *cst)
+{
+    ymc_linear_data_summary(data, prec, n, m, dbar, nprec, cst);
 }
 
 int32_t ymo_max_threads(void)

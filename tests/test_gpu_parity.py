@@ -603,12 +603,17 @@ def test_tile_kernel_preconditioned_crank_nicolson(ffi, ctx, d, m, nd, K, h):
 def test_tile_kernel_limits(ffi, ctx):
     from yagremcmc_amd import lowering
     rng = np.random.default_rng(1)
-    g = dict(data=rng.normal(size=(9, 16)), noise_precision=np.ones(16), prior_mean=np.zeros(16),
+    # any number of data rows: the likelihood goes through the row mean (ymc_linear_data_summary)
+    g = dict(data=rng.normal(size=(37, 16)), noise_precision=rng.uniform(0.5, 2, 16), prior_mean=np.zeros(16),
              prior_precision=np.ones(16))
-    low = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, 16, g, fwd_matrix=rng.normal(size=(16, 16)), fwd_shift=np.zeros(16))
-    with pytest.raises(ffi.YmcError) as err:   # more data rows than the epilogue unrolls
-        lowering.make_problem(ctx, ffi.METHOD_MRW, low, np.ones(16))
-    assert err.value.code == ffi.ERR_UNSUPPORTED
+    A = rng.normal(size=(16, 16)) / 4
+    low = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, 16, g, fwd_matrix=A, fwd_shift=np.zeros(16))
+    x0 = rng.normal(size=(40, 16))
+    dev = _device_run(ffi, ctx, low, np.full(16, 0.05), x0, 5, 30, moments=False)
+    e = o.Ensemble(o.posterior_linear(A, np.zeros(16), g["data"], g["noise_precision"], g["prior_mean"],
+                                      g["prior_precision"]), np.full(16, 0.05), x0, 5)
+    out = e.advance(30)
+    assert np.array_equal(dev["traj"], out["traj"]) and np.array_equal(dev["logpost"], out["logpost"])
     g = dict(data=rng.normal(size=(2, 4)), noise_precision=np.ones(4), prior_mean=np.zeros(200),
              prior_precision=np.ones(200))
     low = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, 200, g, fwd_matrix=rng.normal(size=(4, 200)), fwd_shift=np.zeros(4))

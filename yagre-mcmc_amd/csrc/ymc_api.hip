@@ -74,8 +74,11 @@ struct DeviceBuf {
 struct DensityHost {
     ymc_density_desc d{};
     std::vector<double> mean, whiten, data, noise_prec, prior_mean, prior_prec, A, b, design;
-    DeviceBuf dev;  /* one allocation: data | noise_prec | prior_mean | prior_prec | A | b | design */
-    size_t off_data = 0, off_noise = 0, off_pmean = 0, off_pprec = 0, off_A = 0, off_b = 0, off_design = 0;
+    std::vector<double> dbar, nprec; /* POSTERIOR_LINEAR: ymc_linear_data_summary */
+    double lik_const = 0.0;
+    DeviceBuf dev;  /* one allocation: data | noise_prec | prior_mean | prior_prec | A | b | design | dbar | nprec */
+    size_t off_data = 0, off_noise = 0, off_pmean = 0, off_pprec = 0, off_A = 0, off_b = 0, off_design = 0,
+           off_dbar = 0, off_nprec = 0;
     /* large-dimension linear posterior (ymc_tile.hip): KS k-steps of 4, MT output tiles of 16 */
     bool tile = false;
     int KS = 0, MT = 0;
@@ -171,18 +174,20 @@ int lower_density(ymc_ctx *ctx, const ymc_density_desc &in, DensityHost &out, in
             if (big) {
                 /* the matrix-core tile kernel: A staged in LDS, d <= 128 */
                 if (d > 128) return fail(YMC_ERR_UNSUPPORTED, "parameter dimension %d exceeds the tile kernel's 128", d);
-                if (in.n_data > kTileNDMax)
-                    return fail(YMC_ERR_UNSUPPORTED, "%d data rows exceed the tile kernel's %d", in.n_data, kTileNDMax);
                 const int ks_need = (d + 3) / 4;
                 out.KS = ks_need <= 4 ? 4 : ks_need <= 8 ? 8 : ks_need <= 16 ? 16 : 32;
                 out.MT = (int)((m + 15) / 16);
                 out.MT += out.MT & 1;
-                if (ymc_tile_lds_bytes(out.KS, out.MT, in.n_data) > kTileLdsLimit)
+                if (ymc_tile_lds_bytes(out.KS, out.MT) > kTileLdsLimit)
                     return fail(YMC_ERR_UNSUPPORTED, "forward map %zu x %d does not fit the 160 KB LDS", m, d);
                 out.tile = true;
             }
             YMC_TRY(copy_array(out.A, in.fwd_matrix, m * d, "fwd_matrix"));
             YMC_TRY(copy_array(out.b, in.fwd_shift, m, "fwd_shift"));
+            out.dbar.resize(m);
+            out.nprec.resize(m);
+            ymc_linear_data_summary(out.data.data(), out.noise_prec.data(), in.n_data, in.data_dim, out.dbar.data(),
+                                    out.nprec.data(), &out.lik_const);
         } else {
             if (d != 2 || m != 2) return fail(YMC_ERR_INVALID, "Lotka-Volterra needs dim 2 and data_dim 2");
             if (in.rk4_steps < 1) return fail(YMC_ERR_INVALID, "rk4_steps must be positive");
@@ -203,6 +208,8 @@ int lower_density(ymc_ctx *ctx, const ymc_density_desc &in, DensityHost &out, in
         put(out.A, out.off_A);
         put(out.b, out.off_b);
         put(out.design, out.off_design);
+        put(out.dbar, out.off_dbar);
+        put(out.nprec, out.off_nprec);
         YMC_TRY(out.dev.alloc(blob.size() * sizeof(double)));
         YMC_HIP(hipMemcpy(out.dev.p, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice));
         break;
@@ -235,7 +242,10 @@ DensityDev<D> device_view(const DensityHost &h)
         v.A = base + h.off_A;
         v.b = base + h.off_b;
         v.design = base + h.off_design;
+        v.dbar = base + h.off_dbar;
+        v.nprec = base + h.off_nprec;
     }
+    v.lik_const = h.lik_const;
     v.t_final = h.d.t_final;
     v.alpha = h.d.alpha;
     v.gamma = h.d.gamma;
@@ -269,13 +279,13 @@ BigLinearArgs big_view(const DensityHost &h)
     const double *base = h.dev.as<double>();
     b.A = base + h.off_A;
     b.b = base + h.off_b;
-    b.data = base + h.off_data;
-    b.noise_prec = base + h.off_noise;
+    b.dbar = base + h.off_dbar;
+    b.nprec = base + h.off_nprec;
+    b.lik_const = h.lik_const;
     b.prior_mean = base + h.off_pmean;
     b.prior_prec = base + h.off_pprec;
     b.d = h.d.dim;
     b.m = h.d.data_dim;
-    b.n_data = h.d.n_data;
     b.likelihood_only = h.d.likelihood_only;
     return b;
 }
@@ -507,9 +517,9 @@ int launch_advance_nested(ymc_run *r, uint64_t nsteps)
 int build_tile_blob(ymc_problem *p)
 {
     DensityHost &h = p->tgt;
-    const int KS = h.KS, MT = h.MT, d = h.d.dim, m = h.d.data_dim, nd = h.d.n_data;
+    const int KS = h.KS, MT = h.MT, d = h.d.dim, m = h.d.data_dim;
     const size_t m_pad = 16 * (size_t)MT, d_pad = 4 * (size_t)KS;
-    std::vector<double> blob((size_t)MT * KS * 64 + m_pad * (2 + (size_t)nd) + 3 * d_pad, 0.0);
+    std::vector<double> blob((size_t)MT * KS * 64 + m_pad * 3 + 3 * d_pad, 0.0);
     for (int mt = 0; mt < MT; ++mt)
         for (int s = 0; s < KS; ++s)
             for (int l = 0; l < 64; ++l) {
@@ -517,12 +527,12 @@ int build_tile_blob(ymc_problem *p)
                 if (row < m && col < d) blob[((size_t)mt * KS + s) * 64 + l] = h.A[(size_t)row * d + col];
             }
     double *bias = blob.data() + (size_t)MT * KS * 64;
-    double *nprec = bias + m_pad, *data = nprec + m_pad;
-    double *pmean = data + (size_t)nd * m_pad, *pprec = pmean + d_pad, *sigma = pprec + d_pad;
+    double *nprec = bias + m_pad, *dbar = nprec + m_pad;
+    double *pmean = dbar + m_pad, *pprec = pmean + d_pad, *sigma = pprec + d_pad;
     for (int j = 0; j < m; ++j) {
         bias[j] = h.b[j];
-        nprec[j] = h.noise_prec[j];
-        for (int i = 0; i < nd; ++i) data[(size_t)i * m_pad + j] = h.data[(size_t)i * m + j];
+        nprec[j] = h.nprec[j];
+        dbar[j] = h.dbar[j];
     }
     for (int j = 0; j < d; ++j) {
         pmean[j] = h.prior_mean[j];
@@ -545,9 +555,9 @@ int launch_advance_tile(ymc_run *r, uint64_t nsteps)
     const DensityHost &h = p->tgt;
     TileArgs a{};
     a.blob = h.tile_blob.as<double>();
+    a.lik_const = h.lik_const;
     a.d = p->D;
     a.m = h.d.data_dim;
-    a.n_data = h.d.n_data;
     a.MT = h.MT;
     a.seed = r->seed;
     a.chain0 = r->chain0;

@@ -35,6 +35,9 @@ struct DensityDev {
     int32_t n_data, data_dim, rk4_steps, likelihood_only;
     const double *data, *noise_prec, *prior_mean, *prior_prec, *A, *b, *design;
     double t_final, alpha, gamma;
+    /* POSTERIOR_LINEAR: ymc_linear_data_summary of (data, noise_prec) */
+    const double *dbar, *nprec;
+    double lik_const;
 };
 
 __device__ __forceinline__ bool ymc_finite(double v) { return __builtin_fabs(v) <= YMC_DBL_MAX; }
@@ -123,15 +126,11 @@ struct Density<YMC_DENSITY_POSTERIOR_LINEAR, D> {
         (void)st;
         double F[YMC_LANE_MMAX];
         forward(p, x, F);
-        /* likelihood.py:74-84, :33-39 */
-        double total = 0.0;
-        for (int i = 0; i < p.n_data; ++i) {
-            double r[YMC_LANE_MMAX];
+        /* likelihood.py:74-84, :33-39 through the row-mean identity (ymc_linear_data_summary) */
+        double r[YMC_LANE_MMAX];
 #pragma unroll
-            for (int j = 0; j < YMC_LANE_MMAX; ++j)
-                r[j] = (j < p.data_dim) ? F[j] - p.data[i * p.data_dim + j] : 0.0;
-            total = total + ymc_diag_norm_sq<YMC_LANE_MMAX>(r, p.noise_prec, p.data_dim);
-        }
+        for (int j = 0; j < YMC_LANE_MMAX; ++j) r[j] = (j < p.data_dim) ? F[j] - p.dbar[j] : 0.0;
+        const double total = ymc_diag_norm_sq<YMC_LANE_MMAX>(r, p.nprec, p.data_dim) + p.lik_const;
         double logl = -0.5 * total;
         return p.likelihood_only ? logl : logl + ymc_prior_log<D>(p, x);
     }

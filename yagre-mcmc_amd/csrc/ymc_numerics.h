@@ -413,6 +413,37 @@ YMC_FN void ymc_draw_normal_pair(uint64_t seed, uint32_t chain, uint64_t t, uint
 }
 
 /* ------------------------------------------------------------------------ */
+/* Gaussian-noise likelihood of a forward value F shared by all n data rows */
+/* (the linear model: likelihood.py:74-84 broadcasts F against every row):  */
+/*   sum_i |F - D_i|^2_P  =  |F - Dbar|^2_{nP}  +  sum_i |D_i - Dbar|^2_P   */
+/* with Dbar the row mean.  The right-hand side costs one */
+/* row instead of n per evaluation; its two data-only parts are computed    */
+/* once, here, in the ensemble's canonical order (four interleaved partial  */
+/* sums).  For n = 1 both sides are the same operations.                    */
+/* ------------------------------------------------------------------------ */
+YMC_FN void ymc_linear_data_summary(const double *data, const double *prec, int32_t n, int32_t m,
+                                    double *dbar, double *nprec, double *cst)
+{
+    for (int32_t j = 0; j < m; ++j) {
+        double sum = data[j];
+        for (int32_t i = 1; i < n; ++i) sum = sum + data[(int64_t)i * m + j];
+        dbar[j] = sum / (double)n;
+        nprec[j] = (double)n * prec[j];
+    }
+    double total = 0.0;
+    for (int32_t i = 0; i < n; ++i) {
+        double S[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int32_t j = 0; j < m; ++j) {
+            double r = data[(int64_t)i * m + j] - dbar[j];
+            double pr = prec[j] * r;
+            S[j & 3] = S[j & 3] + r * pr;
+        }
+        total = total + ((S[0] + S[1]) + (S[2] + S[3]));
+    }
+    *cst = total;
+}
+
+/* ------------------------------------------------------------------------ */
 /* Lotka-Volterra flow (testSetup.py:96-99) and one step of classical RK4,  */
 /* the ensemble's integrator (the reference integrates adaptively with      */
 /* scipy's solve_ivp; agreement of the forward map is checked to 1e-3, so   */

@@ -9,15 +9,15 @@
 
 constexpr int kTileWaves = 8;                 /* waves per workgroup (one per SIMD), 16 chains each */
 constexpr int kTileThreads = 64 * kTileWaves;
-constexpr int kTileNDMax = 8;                 /* data rows the likelihood epilogue unrolls over */
 constexpr size_t kTileLdsLimit = 160 * 1024;  /* LDS per CU on gfx950 */
 
 struct TileArgs {
     /* one device block, staged into LDS by every workgroup:
-     * A fragments [MT][KS][64] | bias[m_pad] | noise_prec[m_pad] | data[n_data][m_pad] |
+     * A fragments [MT][KS][64] | bias[m_pad] | n * noise_prec[m_pad] | row mean of the data[m_pad] |
      * prior_mean[d_pad] | prior_prec[d_pad] | sigma[d_pad]   (padding = zeros) */
     const double *blob;
-    int32_t d, m, n_data, MT;
+    double lik_const;      /* sum_i |D_i - Dbar|^2 (ymc_linear_data_summary) */
+    int32_t d, m, pad0_, MT;
     uint64_t seed, chain0, K, t0;
     uint32_t nsteps, flags;
     int32_t pcn, pad_;      /* 1: preconditioned Crank-Nicolson (pcn.py:9-57): sigma is the PRIOR's, lp the log-likelihood */
@@ -31,11 +31,12 @@ struct TileArgs {
 };
 
 struct BigLinearArgs {
-    const double *A, *b, *data, *noise_prec, *prior_mean, *prior_prec; /* unpadded, row-major */
-    int32_t d, m, n_data, likelihood_only;
+    const double *A, *b, *dbar, *nprec, *prior_mean, *prior_prec; /* unpadded, row-major */
+    double lik_const;
+    int32_t d, m, pad0_, likelihood_only;
 };
 
-size_t ymc_tile_lds_bytes(int KS, int MT, int n_data);
+size_t ymc_tile_lds_bytes(int KS, int MT);
 hipError_t ymc_launch_linear_tile(int KS, const TileArgs &a, hipStream_t s);
 hipError_t ymc_launch_untile(const double *tiled, uint64_t row0, uint64_t rows, uint64_t K, int d, int KS,
                              double *out, hipStream_t s);

@@ -57,15 +57,15 @@ template <int KS, bool PCN>
 __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArgs a)
 {
     extern __shared__ double lds[];
-    const int MT = a.MT, m_pad = 16 * MT, d_pad = 4 * KS, n_data = a.n_data;
+    const int MT = a.MT, m_pad = 16 * MT, d_pad = 4 * KS;
     double *Alds = lds;
     double *bias = Alds + (size_t)MT * KS * 64;
     double *nprec = bias + m_pad;
-    double *data = nprec + m_pad;
-    double *pmean = data + (size_t)n_data * m_pad;
+    double *dbar = nprec + m_pad;
+    double *pmean = dbar + m_pad;
     double *pprec = pmean + d_pad;
     double *sigma = pprec + d_pad;
-    const size_t blob_doubles = (size_t)MT * KS * 64 + (size_t)m_pad * (2 + n_data) + 3 * (size_t)d_pad;
+    const size_t blob_doubles = (size_t)MT * KS * 64 + (size_t)m_pad * 3 + 3 * (size_t)d_pad;
 
     const int tid = threadIdx.x;
     for (size_t i = tid; i < blob_doubles / 2; i += kTileThreads)
@@ -126,10 +126,9 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
         mv |= __shfl_xor(mv, 32, 64);
         const bool moved = mv != 0;
 
-        /* forward map on the matrix cores + Gaussian-noise likelihood (likelihood.py:74-84) */
-        double S[kTileNDMax];
-#pragma unroll
-        for (int i = 0; i < kTileNDMax; ++i) S[i] = 0.0;
+        /* forward map on the matrix cores + Gaussian-noise likelihood (likelihood.py:74-84) through
+         * the row-mean identity: |F - Dbar|^2_{n P} + const (ymc_linear_data_summary) */
+        double S = 0.0;
 #pragma unroll 1
         for (int mt = 0; mt < MT; mt += 2) {
             d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
@@ -146,23 +145,13 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
                 for (int r = 0; r < 4; ++r) {
                     const int m = 16 * (mt + h) + 4 * r + g;
                     const double F = (h ? acc1[r] : acc0[r]) + bias[m];
-                    const double pr = nprec[m];
-#pragma unroll
-                    for (int i = 0; i < kTileNDMax; ++i) {
-                        if (i < n_data) {
-                            const double res = F - data[(size_t)i * m_pad + m];
-                            const double px = pr * res;
-                            S[i] = S[i] + res * px;
-                        }
-                    }
+                    const double res = F - dbar[m];
+                    const double px = nprec[m] * res;
+                    S = S + res * px;
                 }
             }
         }
-        double total = 0.0;
-#pragma unroll
-        for (int i = 0; i < kTileNDMax; ++i)
-            if (i < n_data) total = total + combine4(S[i]);
-        const double logl = -0.5 * total;
+        const double logl = -0.5 * (combine4(S) + a.lik_const);
 
         /* Gaussian prior (gaussian.py:19-24); the target of pCN is the likelihood alone (pcn.py:51-57) */
         double lpy = logl;
@@ -267,11 +256,7 @@ __global__ __launch_bounds__(256) void linear_big_eval_kernel(const BigLinearArg
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const double *x = xin + i * p.d;
-    double S[kTileNDMax][4];
-#pragma unroll
-    for (int r = 0; r < kTileNDMax; ++r)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) S[r][q] = 0.0;
+    double S[4] = {0.0, 0.0, 0.0, 0.0};
     for (int m4 = 0; m4 < p.m; m4 += 4) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -281,23 +266,14 @@ __global__ __launch_bounds__(256) void linear_big_eval_kernel(const BigLinearArg
                 for (int j = 0; j < p.d; ++j) acc = ymc_fma(p.A[(size_t)m * p.d + j], x[j], acc);
                 const double F = acc + p.b[m];
                 if (fwd_out) fwd_out[i * p.m + m] = F;
-                const double pr = p.noise_prec[m];
-#pragma unroll
-                for (int r = 0; r < kTileNDMax; ++r) {
-                    if (r < p.n_data) {
-                        const double res = F - p.data[(size_t)r * p.m + m];
-                        const double px = pr * res;
-                        S[r][q] = S[r][q] + res * px;
-                    }
-                }
+                const double res = F - p.dbar[m];
+                const double px = p.nprec[m] * res;
+                S[q] = S[q] + res * px;
             }
         }
     }
     if (!lp_out) return;
-    double total = 0.0;
-#pragma unroll
-    for (int r = 0; r < kTileNDMax; ++r)
-        if (r < p.n_data) total = total + ((S[r][0] + S[r][1]) + (S[r][2] + S[r][3]));
+    const double total = ((S[0] + S[1]) + (S[2] + S[3])) + p.lik_const;
     double P[4] = {0.0, 0.0, 0.0, 0.0};
     for (int j4 = 0; j4 < p.d; j4 += 4) {
 #pragma unroll
@@ -315,16 +291,16 @@ __global__ __launch_bounds__(256) void linear_big_eval_kernel(const BigLinearArg
 
 }  // namespace
 
-size_t ymc_tile_lds_bytes(int KS, int MT, int n_data)
+size_t ymc_tile_lds_bytes(int KS, int MT)
 {
     const size_t m_pad = 16 * (size_t)MT, d_pad = 4 * (size_t)KS;
-    return ((size_t)MT * KS * 64 + m_pad * (2 + (size_t)n_data) + 3 * d_pad) * sizeof(double);
+    return ((size_t)MT * KS * 64 + m_pad * 3 + 3 * d_pad) * sizeof(double);
 }
 
 template <int KS, bool PCN>
 static hipError_t launch_tile_as(const TileArgs &a, hipStream_t s)
 {
-    const size_t lds = ymc_tile_lds_bytes(KS, a.MT, a.n_data);
+    const size_t lds = ymc_tile_lds_bytes(KS, a.MT);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_tile_kernel<KS, PCN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
