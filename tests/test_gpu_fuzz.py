@@ -111,3 +111,112 @@ def test_random_configuration_matches_oracle(case, monkeypatch):
     if flags & ffi.RECORD_MOMENTS:
         assert np.array_equal(s["wf_mean"], e.wf_mean) and np.array_equal(s["wf_m2"], e.wf_m2)
         assert (s["wf_n"] == T).all()
+
+
+class _Pre:
+    """a density that is already lowered (lets the lowering layer pass it through)"""
+
+    def __init__(self, low):
+        self.low = low
+
+
+def _nested_problem(ctx, lowering, tgt, surs, subs, sigma, eq):
+    real = lowering.lower_density
+    lowering.lower_density = lambda d, rk4_steps=None: d.low if isinstance(d, _Pre) else real(d, rk4_steps)
+    try:
+        return lowering.make_nested_problem(ctx, _Pre(tgt), [_Pre(s_) for s_ in surs], subs, sigma, eq)
+    finally:
+        lowering.lower_density = real
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_random_nested_hierarchy_matches_oracle(case):
+    """MLDA over 2, 4 or 6 surrogates of every density kind (the nest of csrc/ymc_nested.hip)."""
+    from yagremcmc_amd import _ffi as ffi, lowering
+    ctx = ffi.default_context(0)
+    rng = np.random.default_rng(7000 + case)
+    kind = ["gauss", "linear", "lv", "iso1d"][case % 4]
+    d = {"iso1d": 1, "lv": 2}.get(kind, int(rng.integers(1, 9)))
+    E = int(rng.integers(2, 5))
+    ns = 2 * (E - 1)
+    tgt_low, tgt_p = _lowered(ffi, kind, d, rng)
+    surs = [_lowered(ffi, kind, d, np.random.default_rng(8000 + 10 * case + i)) for i in range(ns)]
+    if kind == "lv":  # keep the ODE cheap and the shapes of all levels equal (design rows may differ per level)
+        pass
+    subs = [int(v) for v in rng.integers(1, 4, size=ns)]
+    K = int(rng.choice([1, 33, 64, 130]))
+    T = int(rng.integers(1, 25))
+    chain0 = int(rng.choice([0, 5, 2**31]))
+    seed = int(rng.integers(0, 2**63))
+    eq = ffi.EQ_ISCLOSE if kind == "iso1d" and case % 8 >= 4 else ffi.EQ_EXACT
+    flags = ffi.RECORD_ACCEPT | ffi.RECORD_TRAJECTORY | int(rng.choice([0, ffi.RECORD_LOGPOST])) \
+        | int(rng.choice([0, ffi.RECORD_MOMENTS]))
+    sigma = rng.uniform(0.1, 0.5, size=d)
+    x0 = rng.normal(size=(K, d)) * 0.3
+    if kind == "lv":
+        x0 = x0 - np.array([0.6, 0.3])
+    prob = _nested_problem(ctx, lowering, tgt_low, [s_[0] for s_ in surs], subs, sigma, eq)
+    run = ffi.Run(prob, seed, K, x0, T, flags, chain0)
+    cut = int(rng.integers(0, T + 1))
+    run.advance(cut)
+    run.advance(T - cut)
+    P, Q, steps = o.nested_levels([s_[1] for s_ in surs], subs, tgt_p)
+    e = o.NestedEnsemble(P, Q, steps, sigma, x0, seed, chain0=chain0, eq_mode=eq)
+    out = e.advance(T)
+    assert np.array_equal(run.accept(), out["acc"]) and np.array_equal(run.trajectory(), out["traj"])
+    if flags & ffi.RECORD_LOGPOST:
+        assert np.array_equal(run.logpost(), out["logpost"], equal_nan=True)
+    x, lp = run.state()
+    assert np.array_equal(x, e.x) and np.array_equal(lp, e.lp, equal_nan=True)
+    s = run.summary()
+    assert np.array_equal(s["accepted"], e.acc_count) and np.array_equal(s["status"], e.status)
+    assert np.array_equal(run.level_accept()[0], e.level_acc)
+    if flags & ffi.RECORD_MOMENTS:
+        assert np.array_equal(s["wf_mean"], e.wf_mean) and np.array_equal(s["wf_m2"], e.wf_m2)
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_random_adaptive_error_model_matches_oracle(case):
+    from yagremcmc_amd import _ffi as ffi, lowering
+    ctx = ffi.default_context(0)
+    rng = np.random.default_rng(11000 + case)
+    d, m, nd = int(rng.integers(1, 9)), int(rng.integers(1, 9)), int(rng.integers(1, 7))
+    A = rng.normal(size=(m, d)) / np.sqrt(d)
+    b = rng.normal(size=m) * 0.3
+    As, bs = A + 0.3 * rng.normal(size=(m, d)), b + 0.3 * rng.normal(size=m)
+    common = dict(data=rng.normal(size=(nd, m)), noise_precision=rng.uniform(1, 6, size=m), prior_mean=np.zeros(d),
+                  prior_precision=rng.uniform(0.2, 1, size=d))
+
+    def low_of(A_, b_):
+        low = lowering.Lowered(ffi.POSTERIOR_LINEAR, d)
+        low.desc.n_data, low.desc.data_dim = nd, m
+        for k, v in dict(common, fwd_matrix=A_, fwd_shift=b_).items():
+            low.set_array(k, v)
+        return low
+
+    S, md, heur = int(rng.integers(1, 5)), int(rng.integers(2, 7)), int(rng.integers(0, 2))
+    K, T = int(rng.choice([1, 65, 200])), int(rng.integers(20, 150))
+    chain0, seed = int(rng.choice([0, 9, 2**31])), int(rng.integers(0, 2**63))
+    sigma = rng.uniform(0.1, 0.5, size=d)
+    x0 = rng.normal(size=(K, d)) * 0.3
+    flags = ffi.RECORD_ACCEPT | ffi.RECORD_TRAJECTORY | ffi.RECORD_SUB_ACCEPT | int(rng.choice([0, ffi.RECORD_MOMENTS])) \
+        | int(rng.choice([0, ffi.RECORD_LOGPOST]))
+    prob = lowering.make_problem(ctx, ffi.METHOD_AEM2, low_of(A, b), sigma, ffi.EQ_EXACT, surrogate=low_of(As, bs),
+                                 sub_chain_length=S, aem=(md, heur))
+    run = ffi.Run(prob, seed, K, x0, T, flags, chain0)
+    cut = int(rng.integers(0, T + 1))
+    run.advance(cut)
+    run.advance(T - cut)
+    e = o.AemEnsemble(o.posterior_linear(A, b, **common), o.posterior_linear(As, bs, **common), sigma, x0, seed, S, md,
+                      heur, chain0=chain0)
+    out = e.advance(T, want_sub=True)
+    assert np.array_equal(run.accept(), out["acc"]) and np.array_equal(run.trajectory(), out["traj"])
+    assert np.array_equal(run.sub_accept(), out["sub_acc"])
+    err = run.error_model()
+    assert np.array_equal(err["n"], e.aem_n) and np.array_equal(err["mean"], e.aem_mean)
+    assert np.array_equal(err["m2"], e.aem_m2) and np.array_equal(err["precision"], e.aem_prec)
+    x, lp = run.state()
+    assert np.array_equal(x, e.x) and np.array_equal(lp, e.lp)
+    if flags & ffi.RECORD_MOMENTS:
+        s = run.summary()
+        assert np.array_equal(s["wf_mean"], e.wf_mean) and np.array_equal(s["wf_m2"], e.wf_m2)
