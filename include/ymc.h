@@ -127,6 +127,9 @@ typedef struct ymc_problem_desc {
     const ymc_density_desc *level_target;     /* [E-1]: P of levels 0 .. E-2 */
     const ymc_density_desc *level_correction; /* [E-1]: Q of levels 1 .. E-1 */
     const int32_t *level_steps;               /* [E-1]: steps of one run of levels 0 .. E-2 */
+    /* MRW with a DenseCovarianceMatrix proposal (covariance.py:69-94): its lower Cholesky factor
+     * [d][d], row-major; NULL = the diagonal covariance of proposal_sigma.  d <= 8. */
+    const double *proposal_chol;
 } ymc_problem_desc;
 
 /* record_flags */

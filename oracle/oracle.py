@@ -238,10 +238,11 @@ class Ensemble:
     """K chains advanced by the oracle; mirrors the state a device run carries."""
 
     def __init__(self, target, sigma, x0, seed, chain0=0, eq_mode=EQ_EXACT, surrogate=None,
-                 sub_chain_length=0, nthreads=1, pcn_step_size=None):
+                 sub_chain_length=0, nthreads=1, pcn_step_size=None, chol=None):
         """`pcn_step_size`: run preconditioned Crank-Nicolson instead of the random walk; `target`
         must then carry likelihood_only=1 and `sigma` is the PRIOR's standard deviation."""
         self.pcn_step_size = pcn_step_size
+        self.chol = None if chol is None else np.tril(_f64(chol))  # dense proposal covariance: lower Cholesky factor
         self.target, self.surrogate = target, surrogate
         self.S = int(sub_chain_length)
         self.d = target["dim"]
@@ -290,7 +291,7 @@ class Ensemble:
                 C.c_uint64(self.chain0), C.c_int64(K), C.c_uint64(self.t), C.c_int64(nsteps),
                 _ptr(self.x), _ptr(self.lp), _vp(self.acc_count), _vp(self.wf_n),
                 _ptr(self.wf_mean), _ptr(self.wf_m2), _vp(self.status), _ptr(traj), _vp(acc),
-                _ptr(lp_out), _ptr(margin), C.c_int32(self.nthreads))
+                _ptr(lp_out), _ptr(margin), C.c_int32(self.nthreads), _ptr(self.chol))
         else:
             sur, keep2 = _lower(self.surrogate)
             sub = np.empty((nsteps, self.S, K), dtype=np.uint8) if want_sub else None

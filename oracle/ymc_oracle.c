@@ -407,11 +407,26 @@ static int64_t ymo_block_size(int32_t d)
  *   lp_out[nsteps][K]          logpi(state after the transition), or NULL
  *   margin[nsteps][K]          |u - a| (inf where no uniform was drawn), or NULL
  */
+/* y = x + L xi for a DenseCovarianceMatrix proposal (covariance.py:69-94; mrw.py:32-38): row i of
+ * L xi summed left to right with separate multiplies and adds (the reference's order is BLAS') */
+static void ymo_propose_dense(const double *x, const double *chol, uint64_t seed, uint32_t chain, uint64_t t,
+                              int32_t d, double *y)
+{
+    double z[YMO_DMAX + 1];
+    for (int32_t j = 0; 2 * j < d; ++j) ymc_draw_normal_pair(seed, chain, t, (uint32_t)j, &z[2 * j], &z[2 * j + 1]);
+    for (int32_t i = 0; i < d; ++i) {
+        double acc = chol[(int64_t)i * d] * z[0];
+        for (int32_t j = 1; j <= i; ++j) acc = acc + chol[(int64_t)i * d + j] * z[j];
+        y[i] = x[i] + acc;
+    }
+}
+
+/* chol: NULL for the diagonal proposal covariance of sigma, else its dense lower Cholesky factor */
 void ymo_mrw_advance(const ymo_density *tgt, const double *sigma, int32_t eq_mode, uint64_t seed,
                      uint64_t chain0, int64_t K, uint64_t t0, int64_t nsteps, double *x, double *lp,
                      uint64_t *acc_count, uint64_t *wf_n, double *wf_mean, double *wf_m2,
                      uint32_t *status, double *traj, uint8_t *acc, double *lp_out, double *margin,
-                     int32_t nthreads)
+                     int32_t nthreads, const double *chol)
 {
     int32_t d = tgt->dim;
     /* chains are independent, so they are walked in blocks (a block's record
@@ -431,7 +446,10 @@ void ymo_mrw_advance(const ymo_density *tgt, const double *sigma, int32_t eq_mod
                 uint32_t chain = (uint32_t)(chain0 + (uint64_t)k);
                 double *xs = x + k * d;
                 uint32_t st = status ? status[k] : 0;
-                ymo_propose(xs, sigma, seed, chain, t, d, y);       /* :116-117 */
+                if (chol)
+                    ymo_propose_dense(xs, chol, seed, chain, t, d, y);
+                else
+                    ymo_propose(xs, sigma, seed, chain, t, d, y);   /* :116-117 */
                 int accepted = 0;
                 double mg = INFINITY;
                 double lpy = lp[k];

@@ -42,7 +42,7 @@ from yagremcmc.model.interface import SolverInterface  # noqa: E402
 from yagremcmc.parameter.scalar import ScalarParameter  # noqa: E402
 from yagremcmc.parameter.vector import ParameterVector  # noqa: E402
 from yagremcmc.statistics.bayesModel import BayesianRegressionModel  # noqa: E402
-from yagremcmc.statistics.covariance import (DiagonalCovarianceMatrix,  # noqa: E402
+from yagremcmc.statistics.covariance import (DenseCovarianceMatrix, DiagonalCovarianceMatrix,  # noqa: E402
                                              IIDCovarianceMatrix)
 from yagremcmc.statistics.data import Data  # noqa: E402
 from yagremcmc.statistics.gaussian import Gaussian  # noqa: E402
@@ -703,8 +703,40 @@ def fixture_f12(name="f12_aem_linear.npz", use_heuristic=True, seed=20250112, mi
     print(name, acc.mean(), sub.mean(), "accepted per chain", err_n.min(), err_n.max(), "cache hits", hits.mean())
 
 
+# ---------------------------------------------------------------------------
+# F13: random walk with a DenseCovarianceMatrix proposal (covariance.py:69-94).  The reference forms
+# L @ xi with BLAS' dgemv, whose summation order is not the ensemble's: states agree to rounding.
+# ---------------------------------------------------------------------------
+
+def fixture_f13():
+    seed, K, n = 20250114, 16, 600
+    x0 = np.array([-3.0, 2.0])
+    target = GaussianTargetDensity2d(ParameterVector(TGT_MEAN.copy()), TGT_COV.copy())
+    mu, U, c = scipy_whitening(target)
+    prop = 0.6 * TGT_COV + np.array([[0.2, 0.1], [0.1, 0.3]])
+    cov = DenseCovarianceMatrix(prop.copy())
+    traj = np.empty((n, K, 2))
+    acc = np.empty((n - 1, K), dtype=np.uint8)
+    lp = np.empty((n, K))
+    for k in range(K):
+        b = MRWBuilder()
+        b.explicitTarget = target
+        b.proposalCovariance = cov
+        mc = b.build_method()
+        rp = Replay(seed, k, 2, n - 1)
+        rp.install()
+        mc.run(n, ParameterVector(x0.copy()), verbose=False)
+        traj[:, k, :] = np.array(mc.chain.trajectory)
+        acc[:, k] = mc.diagnostics._decisions
+        lp[:, k] = eval_log_along(target, traj[:, k, :], lambda s_: ParameterVector(np.array(s_)))
+    np.savez_compressed(os.path.join(HERE, "f13_mrw_2d_dense_proposal.npz"), seed=seed, n_states=n, mean=mu,
+                        whiten=U, log_norm=c, proposal_cov=prop, chol=np.array(cov.cholFactor_),
+                        x0=np.tile(x0, (K, 1)), traj=traj, acc=acc, logpost=lp)
+    print("F13", acc.mean())
+
+
 def main():
-    which = sys.argv[1:] or ["f1", "f2", "f2b", "f3", "f3b", "f4", "f5", "f7", "f8", "f9", "f10", "f11", "f12"]
+    which = sys.argv[1:] or ["f1", "f2", "f2b", "f3", "f3b", "f4", "f5", "f7", "f8", "f9", "f10", "f11", "f12", "f13"]
     if "f1" in which:
         fixture_f1()
     if "f2" in which:
@@ -732,6 +764,8 @@ def main():
         fixture_f10()
     if "f11" in which:
         fixture_f11()
+    if "f13" in which:
+        fixture_f13()
     if "f12" in which:
         fixture_f12()
         fixture_f12("f12b_aem_linear_noheuristic.npz", use_heuristic=False, seed=20250113, min_data=5, K=12,

@@ -33,7 +33,7 @@ def test_struct_layouts_match_the_header(ffi):
     import ctypes as C
     # sizes computed from the header's field lists (LP64)
     assert C.sizeof(ffi.DensityDesc) == 8 + 2 * 8 + 16 + 8 + 7 * 8 + 24 + 8
-    assert C.sizeof(ffi.ProblemDesc) == 8 + 2 * C.sizeof(ffi.DensityDesc) + 8 + 8 + 8 + 8 + 3 * 8
+    assert C.sizeof(ffi.ProblemDesc) == 8 + 2 * C.sizeof(ffi.DensityDesc) + 8 + 8 + 8 + 8 + 3 * 8 + 8
     assert C.sizeof(ffi.RunDesc) == 7 * 8
     assert C.sizeof(ffi.DeviceInfo) == 128 + 64 + 8 + 8
 
@@ -144,9 +144,15 @@ def test_lowering_of_plugins_and_duck_typed_reference_objects(ffi):
     # anything else raises: no hidden CPU path
     with pytest.raises(lowering.UnsupportedPlugin):
         lowering.lower_density(object())
-    Dense = type("DenseCovarianceMatrix", (), {"cholFactor_": np.eye(2)})
+    # a dense covariance (the reference's object, recognised by its Cholesky factor) lowers to L
+    Dense = type("DenseCovarianceMatrix", (), {"cholFactor_": np.array([[2.0, 9.0], [0.5, 1.0]])})
+    assert np.array_equal(lowering.proposal_chol(Dense(), 2), np.array([[2.0, 0.0], [0.5, 1.0]]))
+    assert lowering.proposal_chol(rc, 2) is None
+    with pytest.raises(ValueError):
+        lowering.proposal_chol(Dense(), 3)
+    Other = type("SomeCovariance", (), {})
     with pytest.raises(lowering.UnsupportedPlugin):
-        lowering.proposal_sigma(Dense(), 2)
+        lowering.proposal_sigma(Other(), 2)
     assert lowering.state_eq_of(ScalarParameter(np.array([1.0]))) == ffi.EQ_ISCLOSE
     assert lowering.state_eq_of(ParameterVector(np.array([1.0, 2.0]))) == ffi.EQ_EXACT
 

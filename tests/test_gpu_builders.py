@@ -188,6 +188,34 @@ def test_mlda_three_surrogates_fail_like_the_reference():
         b.build_method()
 
 
+def test_dense_proposal_covariance_through_the_builder(golden):
+    """MRWBuilder.proposalCovariance = DenseCovarianceMatrix(...) (covariance.py:69-94)."""
+    m = _imports()
+    from yagremcmc_amd.statistics.covariance import DenseCovarianceMatrix
+    g = golden("f13_mrw_2d_dense_proposal.npz")
+    cov = DenseCovarianceMatrix(g["proposal_cov"])
+    assert np.array_equal(cov.cholFactor_, g["chol"])                  # same LAPACK factor as the reference's
+    assert np.allclose(cov.dense(), g["proposal_cov"]) and cov.dimension == 2
+    x = np.array([0.3, -1.2])
+    assert np.allclose(cov.apply_inverse(cov.dense() @ x), x)
+    b = m["MRWBuilder"]()
+    b.explicitTarget = m["GaussianTargetDensity2d"](m["ParameterVector"](np.array([1.0, 1.5])),
+                                                    np.array([[2.4, -0.5], [-0.5, 0.7]]))
+    b.proposalCovariance = cov
+    b.nChains, b.seed = g["x0"].shape[0], int(g["seed"])
+    mc = b.build_method()
+    mc.run(int(g["n_states"]), m["ParameterVector"](g["x0"][0].copy()), verbose=False)
+    assert np.array_equal(mc.accept_decisions, g["acc"])
+    assert np.abs(mc.chain.trajectory - g["traj"]).max() <= 1e-12
+    # not lowered for delayed acceptance
+    from yagremcmc_amd.chain.method.mlda import MLDABuilder
+    b2 = MLDABuilder()
+    b2.explicitTarget, b2.surrogateTargets = b.explicitTarget, [b.explicitTarget]
+    b2.baseProposalCovariance, b2.subChainLengths = cov, [3]
+    with pytest.raises(NotImplementedError):
+        b2.build_method().run(5, m["ParameterVector"](np.zeros(2)), verbose=False)
+
+
 def test_adaptive_error_model_through_the_builder(golden):
     """example_inference_linearModel_twoLevel.py:95-100,181-191 wiring (AEMBuilder over a model
     hierarchy of AEMLikelihoods); chain 0..K-1 == the live reference's chains of fixture F12."""

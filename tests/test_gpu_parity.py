@@ -428,6 +428,45 @@ def test_aem_full_size_invariants(ffi, ctx, golden):
     assert np.array_equal(dev["traj"][:, sel], out["traj"]) and np.array_equal(err["mean"][sel], e.aem_mean)
 
 
+def test_f13_dense_proposal_covariance(ffi, ctx, golden):
+    from yagremcmc_amd import lowering
+    g = golden("f13_mrw_2d_dense_proposal.npz")
+    n = int(g["n_states"])
+    low = _gauss_low(ffi, g["mean"], g["whiten"], g["log_norm"])
+    prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, np.ones(2), chol=g["chol"])
+    run = ffi.Run(prob, int(g["seed"]), g["x0"].shape[0], g["x0"], n - 1, _flags(ffi, True))
+    run.advance(200)
+    run.advance(n - 201)
+    run.sync()
+    dev = dict(traj=run.trajectory(), acc=run.accept(), logpost=run.logpost(), summary=run.summary(), state=run.state())
+    e = o.Ensemble(o.gauss_whitened(g["mean"], g["whiten"], float(g["log_norm"])), np.ones(2), g["x0"],
+                   int(g["seed"]), chol=g["chol"])
+    out = e.advance(n - 1)
+    _same_as_oracle(dev, e, out)
+    assert np.array_equal(dev["acc"], g["acc"])                       # the reference's decisions
+    assert np.abs(dev["traj"] - g["traj"][1:]).max() <= 1e-12          # its states to rounding (BLAS order)
+
+
+@pytest.mark.parametrize("d,kind", [(1, "gauss"), (3, "gauss"), (8, "gauss"), (5, "linear"), (2, "lv")])
+def test_dense_proposal_other_shapes_vs_oracle(ffi, ctx, d, kind):
+    from yagremcmc_amd import lowering
+    from test_gpu_fuzz import _lowered
+    rng = np.random.default_rng(40 + d)
+    low, p = _lowered(ffi, kind, d, rng)
+    A = rng.normal(size=(d, d))
+    L = np.linalg.cholesky(0.05 * (A @ A.T + d * np.eye(d)))
+    x0 = rng.normal(size=(300, d)) * 0.3 - (np.array([0.6, 0.3]) if kind == "lv" else 0.0)
+    prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, np.ones(d), chol=L)
+    run = ffi.Run(prob, 77, 300, x0, 40, _flags(ffi, True), 123)
+    run.advance(40)
+    run.sync()
+    dev = dict(traj=run.trajectory(), acc=run.accept(), logpost=run.logpost(), summary=run.summary(), state=run.state())
+    e = o.Ensemble(p, np.ones(d), x0, 77, chain0=123, chol=L)
+    out = e.advance(40)
+    assert 0.02 < out["acc"].mean() < 0.98
+    _same_as_oracle(dev, e, out)
+
+
 # ---------------------------------------------------------------------------
 # other dimensions of the lane-per-chain kernels vs the oracle
 # ---------------------------------------------------------------------------

@@ -190,6 +190,24 @@ def test_f12_adaptive_error_model(golden, name):
     assert np.array_equal(e2.aem_mean, e.aem_mean) and np.array_equal(e2.cache_val, e.cache_val)
 
 
+def test_f13_dense_proposal_covariance(golden):
+    """DenseCovarianceMatrix proposal (covariance.py:69-94): the reference sums L @ xi in BLAS' order,
+    the ensemble row-wise left to right -- every decision equals the reference's, states agree to
+    rounding (1e-12 allowed, 5e-15 observed)."""
+    g = golden("f13_mrw_2d_dense_proposal.npz")
+    n = int(g["n_states"])
+    e = o.Ensemble(o.gauss_whitened(g["mean"], g["whiten"], float(g["log_norm"])), np.ones(2), g["x0"],
+                   int(g["seed"]), chol=g["chol"])
+    out = e.advance(n - 1)
+    assert np.array_equal(out["acc"], g["acc"])
+    assert np.abs(out["traj"] - g["traj"][1:]).max() <= 1e-12
+    assert np.abs(out["logpost"] - g["logpost"][1:]).max() <= 1e-12 * np.abs(g["logpost"]).max()
+    # a diagonal L is the diagonal proposal, bit for bit
+    a = o.Ensemble(e.target, np.array([0.7, 1.3]), g["x0"], 3).advance(50)
+    b = o.Ensemble(e.target, np.ones(2), g["x0"], 3, chol=np.diag([0.7, 1.3])).advance(50)
+    assert np.array_equal(a["traj"], b["traj"])
+
+
 def test_perfect_surrogate_accepts_everything(golden):
     """test_mlda.py:94-130: coarse == fine => every fine proposal that moved is accepted."""
     g = golden("f5_mlda2_2d.npz")

@@ -62,6 +62,7 @@ class ProblemDesc(C.Structure):
         ("n_levels", C.c_int32), ("aem_use_noise_heuristic", C.c_int32),
         ("level_target", C.POINTER(DensityDesc)), ("level_correction", C.POINTER(DensityDesc)),
         ("level_steps", C.POINTER(C.c_int32)),
+        ("proposal_chol", _dp),
     ]
 
 

@@ -101,6 +101,7 @@ struct ymc_problem {
     bool tile = false;
     DensityHost tgt, sur;
     std::vector<double> sigma;
+    DeviceBuf chol; /* dense proposal covariance: lower Cholesky factor [D][D] */
     /* MLDA_NESTED: P of levels 0..E-2 (level E-1's is tgt), Q of levels 1..E-1 (index 0 unused) */
     int E = 0;
     DensityHost lvlP[YMC_MAX_LEVELS], lvlQ[YMC_MAX_LEVELS];
@@ -337,6 +338,7 @@ int launch_advance(ymc_run *r, uint64_t nsteps)
     a.eq_mode = p->eq_mode;
     a.S = p->S;
     a.lv_rows = choose_lv_rows(r);
+    a.chol = p->chol.as<double>();
     a.x = r->x.as<double>();
     a.lp = r->lp.as<double>();
     a.lpc = r->lpc.as<double>();
@@ -755,6 +757,26 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
         /* MRWBuilder._validate_parameters, mrw.py:88-91 */
         if (!desc->proposal_sigma) rc = fail(YMC_ERR_INVALID, "Proposal Covariance not set");
         if (rc == YMC_OK) rc = copy_array(p->sigma, desc->proposal_sigma, p->D, "proposal_sigma");
+    }
+    if (rc == YMC_OK && desc->proposal_chol) {
+        if (desc->method != YMC_METHOD_MRW || p->tgt.tile)
+            rc = fail(YMC_ERR_UNSUPPORTED, "a dense proposal covariance is available for the random walk at d <= %d",
+                      YMC_LANE_DMAX);
+        else {
+            std::vector<double> L((size_t)p->D * p->D, 0.0);
+            for (int i = 0; rc == YMC_OK && i < p->D; ++i)
+                for (int j = 0; j <= i; ++j) {
+                    L[(size_t)i * p->D + j] = desc->proposal_chol[(size_t)i * p->D + j];
+                    if (!std::isfinite(L[(size_t)i * p->D + j]))
+                        rc = fail(YMC_ERR_INVALID, "proposal_chol is not finite");
+                }
+            auto up = [&]() -> int {
+                YMC_TRY(p->chol.alloc(L.size() * sizeof(double)));
+                YMC_HIP(hipMemcpy(p->chol.p, L.data(), p->chol.bytes, hipMemcpyHostToDevice));
+                return YMC_OK;
+            };
+            if (rc == YMC_OK) rc = up();
+        }
     }
     if (rc == YMC_OK && desc->method == YMC_METHOD_PCN) {
         /* PreconditionedCrankNicolson.__init__, pcn.py:40-49; PCNBuilder, pcn.py:77-83 */

@@ -201,6 +201,26 @@ __device__ __forceinline__ void ymc_propose(const double (&x)[D], const double (
     }
 }
 
+/* the same with a DENSE proposal covariance (covariance.py:69-94): y = x + L xi, L the lower Cholesky
+ * factor (row-major, read through uniform loads).  Row i of L xi is summed left to right with
+ * separate multiplies and adds -- the ensemble's order; the reference leaves it to BLAS' dgemv, so
+ * states agree with it to rounding (1e-15), not bit for bit. */
+template <int D>
+__device__ __forceinline__ void ymc_propose_dense(const double (&x)[D], const double *__restrict__ chol,
+                                                  uint64_t seed, uint32_t chain, uint64_t t, double (&y)[D])
+{
+    double z[D + 1];
+#pragma unroll
+    for (int j = 0; 2 * j < D; ++j) ymc_draw_normal_pair(seed, chain, t, (uint32_t)j, &z[2 * j], &z[2 * j + 1]);
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        double acc = chol[i * D] * z[0];
+#pragma unroll
+        for (int j = 1; j <= i; ++j) acc = acc + chol[i * D + j] * z[j];
+        y[i] = x[i] + acc;
+    }
+}
+
 /* PCNProposal.generate_proposal, pcn.py:23-36: xi = prior mean + sigma_prior * z (the prior's
  * realisation, gaussian.py:61-66), y = sqrt(1 - 2h) * x + sqrt(2h) * xi */
 template <int D>

@@ -22,6 +22,7 @@ struct ChainArgs {
     double *x, *lp, *lpc;
     uint64_t *acc_count;
     double *wf_mean, *wf_m2;
+    const double *chol;  /* dense proposal covariance: lower Cholesky factor [D][D] on the device, else null */
     const double *recip; /* recip[n] = RN(1 / (wf_n0 + n + 1)) for the transitions of this launch (moments only) */
     uint32_t *status;
     /* record rows of this launch (already offset to the write position), or null */

@@ -55,9 +55,12 @@ __device__ __forceinline__ bool states_equal(const double (&p)[D], const double 
     return ymc_states_equal<D>(p, q, EQ < 0 ? runtime_eq : EQ);
 }
 
-/* PCN = true: the preconditioned Crank-Nicolson proposal (pcn.py) in place of the random walk;
- * the accept rule is the same with the likelihood as target (pcn.py:51-57) */
-template <int KIND, int D, unsigned REC, int EQ, bool PCN = false>
+/* PROP: kPropDiag the random walk with a diagonal proposal covariance; kPropPcn the preconditioned
+ * Crank-Nicolson proposal (pcn.py), same accept rule with the likelihood as target (pcn.py:51-57);
+ * kPropDense the random walk with a dense proposal covariance (covariance.py:69-94) */
+constexpr int kPropDiag = 0, kPropPcn = 1, kPropDense = 2;
+
+template <int KIND, int D, unsigned REC, int EQ, int PROP = kPropDiag>
 __global__ __launch_bounds__(kBlock) void mrw_kernel(const ChainArgs<D> a)
 {
     const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -82,8 +85,10 @@ __global__ __launch_bounds__(kBlock) void mrw_kernel(const ChainArgs<D> a)
     auto transition = [&](uint32_t n, double u) {
         const uint64_t t = a.t0 + n;
         double y[D];
-        if constexpr (PCN)
+        if constexpr (PROP == kPropPcn)
             ymc_propose_pcn<D>(x, sigma, a.tgt.prior_mean, a.pcn_c1, a.pcn_c2, a.seed, chain, t, y);
+        else if constexpr (PROP == kPropDense)
+            ymc_propose_dense<D>(x, a.chol, a.seed, chain, t, y);
         else
             ymc_propose<D>(x, sigma, a.seed, chain, t, y);                      /* :116-117 */
         const bool moved = !states_equal<D, EQ>(y, x, a.eq_mode);               /* :60-61 */
@@ -430,7 +435,10 @@ void launch_one(int method, const ChainArgs<D> &a, hipStream_t s)
 {
     if (method == YMC_METHOD_PCN) {
         if constexpr (REC == kRuntimeRec && (KIND == YMC_DENSITY_POSTERIOR_LINEAR || KIND == YMC_DENSITY_POSTERIOR_LV))
-            hipLaunchKernelGGL((mrw_kernel<KIND, D, REC, EQ, true>), dim3(grid_for(a.K)), dim3(kBlock), 0, s, a);
+            hipLaunchKernelGGL((mrw_kernel<KIND, D, REC, EQ, kPropPcn>), dim3(grid_for(a.K)), dim3(kBlock), 0, s, a);
+    } else if (method == YMC_METHOD_MRW && a.chol) {
+        if constexpr (REC == kRuntimeRec)
+            hipLaunchKernelGGL((mrw_kernel<KIND, D, REC, EQ, kPropDense>), dim3(grid_for(a.K)), dim3(kBlock), 0, s, a);
     } else if (method == YMC_METHOD_MRW)
         hipLaunchKernelGGL((mrw_kernel<KIND, D, REC, EQ>), dim3(grid_for(a.K)), dim3(kBlock), 0, s, a);
     else
@@ -446,7 +454,7 @@ hipError_t launch_chain(int method, const ChainArgs<D> &a, hipStream_t s)
     const unsigned rec = (a.traj ? YMC_RECORD_TRAJECTORY : 0u) | (a.acc ? YMC_RECORD_ACCEPT : 0u) |
                          (a.lp_out ? YMC_RECORD_LOGPOST : 0u) | (a.sub_acc ? YMC_RECORD_SUB_ACCEPT : 0u) |
                          (a.flags & YMC_RECORD_MOMENTS);
-    if (method == YMC_METHOD_PCN)
+    if (method == YMC_METHOD_PCN || a.chol)
         launch_one<KIND, D, kRuntimeRec, -1>(method, a, s);
     else if (a.eq_mode == YMC_EQ_EXACT && rec == kTA)
         launch_one<KIND, D, kTA, YMC_EQ_EXACT>(method, a, s);
@@ -472,7 +480,7 @@ hipError_t ymc_launch_chain(int kind, int method, const ChainArgs<D> &a, hipStre
     case YMC_DENSITY_POSTERIOR_LINEAR: return launch_chain<YMC_DENSITY_POSTERIOR_LINEAR, D>(method, a, s);
     case YMC_DENSITY_POSTERIOR_LV:
         if constexpr (D == 2) {
-            if (method == YMC_METHOD_MRW && a.eq_mode == YMC_EQ_EXACT && a.lv_rows && !a.tgt.likelihood_only) {
+            if (method == YMC_METHOD_MRW && a.eq_mode == YMC_EQ_EXACT && a.lv_rows && !a.tgt.likelihood_only && !a.chol) {
                 /* small ensemble: n_data lanes per chain */
                 const int cpw = 64 / a.tgt.n_data;
                 const uint64_t waves = (a.K + cpw - 1) / cpw;

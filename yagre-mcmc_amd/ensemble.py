@@ -246,7 +246,7 @@ class MetropolisedRandomWalk(MetropolisHastingsEnsemble):
         dim = lowering.lower_density(self._tgtDensity, self.rk4Steps).desc.dim
         sigma = lowering.proposal_sigma(self._proposalCov, dim)
         return lowering.make_problem(ctx, _ffi.METHOD_MRW, self._tgtDensity, sigma, state_eq,
-                                     rk4_steps=self.rk4Steps)
+                                     rk4_steps=self.rk4Steps, chol=lowering.proposal_chol(self._proposalCov, dim))
 
 
 class SurrogateLevel:
@@ -352,6 +352,9 @@ class MLDA(MetropolisHastingsEnsemble):
     def _make_problem(self, ctx, state_eq):
         dim = lowering.lower_density(self._tgtDensity, self.rk4Steps).desc.dim
         sigma = lowering.proposal_sigma(self._proposalCov, dim)
+        if lowering.proposal_chol(self._proposalCov, dim) is not None:
+            raise lowering.UnsupportedPlugin("a dense base proposal covariance is lowered for the random-walk "
+                                             "sampler only")
         if self.nSurrogates == 1:
             return lowering.make_problem(ctx, _ffi.METHOD_MLDA2, self._tgtDensity, sigma, state_eq,
                                          surrogate=self._surrogates[0], sub_chain_length=self._nSteps[0],

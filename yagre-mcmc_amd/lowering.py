@@ -28,6 +28,8 @@ def proposal_sigma(cov, dim):
     forms it (statistics/covariance.py:51-52) -- not sqrt(variance)."""
     if cov is None:
         raise ValueError("Proposal Covariance not set")
+    if hasattr(cov, "cholFactor_"):
+        return np.sqrt(np.diag(np.asarray(cov.cholFactor_) @ np.asarray(cov.cholFactor_).T))  # unused by the dense path
     if not hasattr(cov, "_precision"):
         raise UnsupportedPlugin(
             f"proposal covariance {_name(cov)}: only Diagonal/IID covariances have a device lowering")
@@ -35,6 +37,17 @@ def proposal_sigma(cov, dim):
     if prec.size != dim:
         raise ValueError(f"proposal covariance has dimension {prec.size}, the state has {dim}")
     return np.sqrt(np.reciprocal(prec))
+
+
+def proposal_chol(cov, dim):
+    """The lower Cholesky factor of a DenseCovarianceMatrix proposal (covariance.py:69-94), or None."""
+    L = getattr(cov, "cholFactor_", None)
+    if L is None:
+        return None
+    L = np.tril(np.asarray(L, dtype=np.float64))
+    if L.shape != (dim, dim):
+        raise ValueError(f"proposal covariance has dimension {L.shape[0]}, the state has {dim}")
+    return np.ascontiguousarray(L)
 
 
 def _diag_precision(cov, n, what):
@@ -211,7 +224,7 @@ def aem_parameters(likelihood):
 
 
 def make_problem(ctx, method, target, sigma, state_eq=_ffi.EQ_EXACT, surrogate=None, sub_chain_length=0,
-                 rk4_steps=None, pcn_step_size=0.0, aem=None):
+                 rk4_steps=None, pcn_step_size=0.0, aem=None, chol=None):
     tgt = lower_density(target, rk4_steps) if not isinstance(target, Lowered) else target
     desc = _ffi.ProblemDesc()
     desc.method, desc.state_eq = method, state_eq
@@ -227,6 +240,12 @@ def make_problem(ctx, method, target, sigma, state_eq=_ffi.EQ_EXACT, surrogate=N
         raise ValueError(f"proposal covariance has dimension {sigma.size}, the target has {tgt.desc.dim}")
     desc.proposal_sigma = _ffi.dptr(sigma)
     desc.pcn_step_size = float(pcn_step_size)
+    if chol is not None:
+        if method != _ffi.METHOD_MRW:
+            raise UnsupportedPlugin("a dense proposal covariance is lowered for the random-walk sampler only")
+        chol = _ffi.f64(chol)
+        desc.proposal_chol = _ffi.dptr(chol)
+        keep.append(chol)
     if method == _ffi.METHOD_AEM2:
         desc.aem_min_data_size, desc.aem_use_noise_heuristic = int(aem[0]), int(bool(aem[1]))
     keep.append(sigma)

@@ -139,6 +139,35 @@ class IIDCovarianceMatrix(DiagonalCovarianceMatrix):
         super().__init__(np.full(dimension, variance, dtype=float))
 
 
+class DenseCovarianceMatrix(CovarianceMatrix):
+    """covariance.py:69-94: a dense covariance through its lower Cholesky factor.  As a random-walk
+    proposal covariance it is lowered to the device (y = x + L xi); the host methods mirror the
+    reference's."""
+
+    def __init__(self, denseCovMat):
+        from scipy.linalg import cholesky
+        denseCovMat = np.asarray(denseCovMat, dtype=float)
+        s = denseCovMat.shape
+        assert s[0] == s[1]
+        self.dim_ = s[0]
+        self.cholFactor_ = cholesky(denseCovMat, lower=True)
+
+    @property
+    def dimension(self):
+        return self.dim_
+
+    def apply_chol_factor(self, x):
+        return self.cholFactor_ @ x
+
+    def apply_inverse(self, x):
+        from scipy.linalg import solve_triangular
+        y = solve_triangular(self.cholFactor_, x, lower=True)
+        return solve_triangular(self.cholFactor_.T, y, lower=False)
+
+    def dense(self):
+        return np.matmul(self.cholFactor_, self.cholFactor_.T)
+
+
 # --------------------------------------------------------------------------
 # Gaussian law, noise, data (statistics/{gaussian,noise,data}.py)
 # --------------------------------------------------------------------------

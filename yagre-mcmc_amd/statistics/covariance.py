@@ -1,1 +1,2 @@
-from ..plugins import CovarianceMatrix, DiagonalCovarianceMatrix, IIDCovarianceMatrix  # noqa: F401
+from ..plugins import (CovarianceMatrix, DenseCovarianceMatrix, DiagonalCovarianceMatrix,  # noqa: F401
+                       IIDCovarianceMatrix)
