@@ -516,3 +516,39 @@ def test_integrated_autocorrelation_on_device_f9(golden):
     iat = ac.integrated_autocorrelation(x, 'mean')
     assert iat.shape == (3,) and (np.abs(iat - 19) <= 4).all()        # AR(1), phi = 0.9: tau = 19
     del GaussianTargetDensity2d, _ffi
+
+
+def test_lotka_volterra_solver_like_the_reference_tests():
+    """test_solver_setup.py:27-78 and test_solver_invoke.py:62-116 on the device-backed solver: attribute
+    names, shapes, status, and agreement with an independent scipy solve at the reference's 1e-3."""
+    from scipy.integrate import solve_ivp
+    import yagremcmc_amd.test.testSetup as ts
+    from yagremcmc_amd.model.forwardModel import EvaluationStatus
+    from yagremcmc_amd.statistics.data import Data
+    config = {'T': 10, 'alpha': 0.1, 'gamma': 0.1, 'nData': 10, 'dataDim': 2, 'solver': 'LSODA', 'rtol': 1e-4}
+    design = np.random.default_rng(0).random((10, 2))
+    coefficients = np.array([0.2, 0.3])
+    parameter = ts.LotkaVolterraParameter.from_coefficient(coefficients)
+    solver = ts.LotkaVolterraSolver(design, config)
+    assert solver.x_.shape == design.shape and solver.tBoundary_ == (0., config['T'])
+    assert solver.fixedParam_ == [config['alpha'], config['gamma']]
+    assert solver.dataShape_ == (config['nData'], config['dataDim'])
+    assert solver.param_ == [None, None] and solver.evaluation_ is None and solver.status_ == EvaluationStatus.NONE
+    solver.interpolate(parameter)
+    np.testing.assert_allclose(solver.param_, np.exp([0.2, 0.3]), rtol=1e-5, atol=1e-8)
+    solver.invoke()
+    assert solver.status_ == EvaluationStatus.SUCCESS and solver.status == EvaluationStatus.SUCCESS
+    assert solver.evaluation_.shape == (config['nData'], config['dataDim']) and (solver.evaluation_ >= 0).all()
+
+    def flow(t, y):
+        return [0.1 * y[0] - np.exp(0.2) * y[0] * y[1], np.exp(0.3) * y[0] * y[1] - 0.1 * y[1]]
+
+    for i in range(config['nData']):
+        ref = solve_ivp(flow, (0, 10), design[i], method='LSODA', rtol=1e-10, atol=1e-12).y[:, -1]
+        np.testing.assert_allclose(solver.evaluation_[i], ref, rtol=1e-3, atol=1e-6)
+    t, y = solver.full_solution(parameter, np.array([1.0, 0.5]))
+    assert len(t) == 51 and y.shape == (2, 51) and np.array_equal(y[:, 0], [1.0, 0.5])
+    dense = solve_ivp(flow, (0, 10), [1.0, 0.5], method='LSODA', rtol=1e-10, atol=1e-12, t_eval=t).y
+    np.testing.assert_allclose(y, dense, rtol=1e-3, atol=1e-6)
+    data = ts.generate_synthetic_data(parameter, ts.LotkaVolterraSolver(design, config), 0.1)
+    assert isinstance(data, Data) and data.size == config['nData'] and data.array[0, :].size == config['dataDim']

@@ -365,6 +365,37 @@ class LotkaVolterraSolver(_DeviceSolver):
     def _shape_evaluation(self, flat):
         return flat.reshape(self.dataShape_)
 
+    # the reference's attribute names (testSetup.py:75-78, read by test_solver_setup.py / test_solver_invoke.py)
+    @property
+    def param_(self):
+        return [None, None] if self._theta is None else list(np.exp(self._theta))
+
+    @property
+    def evaluation_(self):
+        return self._evaluation
+
+    @property
+    def status_(self):
+        return self._status
+
+    def full_solution(self, parameter, y0):
+        """testSetup.py:142-162: the trajectory from y0 under `parameter`, here on the integrator's own
+        grid t_i = i T / rk4Steps; every state is a forward solve on the device up to t_i.
+        Returns (t (n+1,), y (2, n+1))."""
+        n = self.rk4Steps_
+        T = self.tBoundary_[1]
+        t = np.linspace(0.0, T, n + 1)
+        y = np.empty((2, n + 1))
+        y[:, 0] = np.asarray(y0, dtype=float)
+        cfg = {'alpha': self.fixedParam_[0], 'gamma': self.fixedParam_[1], 'nData': 1, 'dataDim': 2,
+               'rk4Steps': self.rk4Steps_}
+        for i in range(1, n + 1):
+            probe = LotkaVolterraSolver(np.asarray(y0, dtype=float).reshape(1, 2), dict(cfg, T=float(t[i])))
+            probe.interpolate(parameter)
+            probe.invoke()
+            y[:, i] = probe.evaluation[0]
+        return t, y
+
 
 class ForwardModel:
     """model/forwardModel.py:4-19"""
