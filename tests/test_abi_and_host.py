@@ -181,3 +181,62 @@ def test_welford_pooling_matches_numpy():
     N, pm, pm2 = merge_welford(n, mean, m2)
     flat = data.reshape(-1, 3)
     assert N == 3500 and np.allclose(pm, flat.mean(axis=0)) and np.allclose(pm2 / (N - 1), flat.var(axis=0, ddof=1))
+
+
+@pytest.mark.parametrize("testLag", [5, 500])
+def test_acceptance_rate_diagnostics_stand_alone(testLag):
+    """test_diagnostics.py:10-30: the diagnostics object fed per transition on the host."""
+    from yagremcmc_amd.chain.diagnostics import AcceptanceRateDiagnostics
+    from yagremcmc_amd.chain.transition import TransitionData
+    d = AcceptanceRateDiagnostics()
+    d.lag = testLag
+    for outcome in [TransitionData.ACCEPTED] * testLag + [TransitionData.REJECTED] * testLag:
+        d.process(TransitionData(state=None, proposal=None, outcome=outcome))
+    assert np.isclose(d.global_acceptance_rate(), 0.5) and d.rolling_acceptance_rate() == 0.0
+    d.reset()
+    assert d._decisions == []
+    with pytest.raises(RuntimeError):
+        TransitionData(None, None, 2)
+
+
+@pytest.mark.parametrize("shape", [(10, 1), (10, 3), (1000, 5)])
+def test_welford_accumulator_value_type(shape):
+    """test_diagnostics.py:33-66"""
+    from yagremcmc_amd.statistics.estimation import WelfordAccumulator
+    acc = WelfordAccumulator()
+    xs = np.random.default_rng(shape[0]).normal(size=shape)
+    for x in xs:
+        acc.update(x)
+    assert np.allclose(acc.mean(), xs.mean(axis=0)) and np.allclose(acc.marginal_variance(), xs.var(axis=0, ddof=1))
+    assert acc.nData == shape[0]
+    acc.reset()
+    assert acc.nData == 0 and acc.mean() is None
+
+
+def test_module_paths_of_the_reference_resolve():
+    """Every module path user code of the reference imports from exists under yagremcmc_amd."""
+    import importlib
+    for mod, names in {
+        "chain.builder": ["ChainBuilder"], "chain.chain": ["Chain"], "chain.diagnostics": ["FullDiagnostics"],
+        "chain.interface": ["ChainDiagnostics"], "chain.metropolisHastings": ["MetropolisHastings"],
+        "chain.proposal": ["ProposalMethod"], "chain.target": ["UnnormalisedPosterior"],
+        "chain.transition": ["TransitionData"], "chain.method.mrw": ["MRWBuilder", "MetropolisedRandomWalk"],
+        "chain.method.mlda": ["MLDABuilder", "MLDA"], "chain.method.pcn": ["PCNBuilder"],
+        "chain.method.aem": ["AEMBuilder", "AdaptiveErrorModel"], "model.evaluation": ["EvaluationStatus"],
+        "model.forwardModel": ["ForwardModel"], "model.interface": ["SolverInterface"],
+        "parameter.interface": ["ParameterInterface"], "parameter.scalar": ["ScalarParameter"],
+        "parameter.vector": ["ParameterVector"], "postprocessing.autocorrelation": ["integrated_autocorrelation"],
+        "statistics.bayesModel": ["BayesianRegressionModel"],
+        "statistics.covariance": ["IIDCovarianceMatrix", "DiagonalCovarianceMatrix", "DenseCovarianceMatrix"],
+        "statistics.data": ["Data"], "statistics.estimation": ["WelfordAccumulator"], "statistics.gaussian": ["Gaussian"],
+        "statistics.interface": ["DensityInterface", "CovarianceOperatorInterface", "NoiseModelInterface"],
+        "statistics.likelihood": ["AdditiveGaussianNoiseLikelihood", "AEMLikelihood"],
+        "statistics.modelHierarchy": ["BayesianRegressionModelHierarchy"],
+        "statistics.noise": ["CentredGaussianNoise", "AEMNoise"],
+        "statistics.parameterLaw": ["AbsolutelyContinuousParameterLaw"],
+        "test.testSetup": ["GaussianTargetDensity2d", "LotkaVolterraSolver"], "utility.hierarchy": ["Hierarchy"],
+        "exampleSetup": ["ExampleLinearModelSolver"],
+    }.items():
+        m = importlib.import_module("yagremcmc_amd." + mod)
+        for n in names:
+            assert hasattr(m, n), f"{mod}.{n}"

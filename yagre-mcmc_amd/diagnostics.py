@@ -104,7 +104,14 @@ class AcceptanceRateDiagnostics:
         return self._accepted / self._steps
 
     def process(self, transitionData):
-        raise RuntimeError("ensemble diagnostics are filled from the device record, not per transition")
+        """diagnostics.py:48-54 for stand-alone use on the host (one chain); a sampler run fills the
+        object from the device record instead."""
+        if self._fetch is not None:
+            raise RuntimeError("these diagnostics are attached to a device run; reset() first")
+        host = self._matrix_cache if self._matrix_cache is not None else np.zeros((0, 1), dtype=np.uint8)
+        self._matrix_cache = np.concatenate([host, np.array([[int(transitionData.outcome)]], dtype=np.uint8)])
+        self._steps += 1
+        self._accepted = np.array([int(self._matrix_cache.sum())], dtype=np.uint64)
 
     def print_diagnostics(self, logger):
         try:
