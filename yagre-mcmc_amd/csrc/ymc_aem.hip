@@ -167,6 +167,7 @@ struct CoarseLikelihood {
 template <int D>
 __global__ __launch_bounds__(kBlock) void aem2_kernel(const AemArgs<D> a)
 {
+    ymc_stage_tables();
     const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (k >= a.K) return;
     const uint32_t chain = (uint32_t)(a.chain0 + k);

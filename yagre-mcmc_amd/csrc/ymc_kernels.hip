@@ -63,6 +63,7 @@ constexpr int kPropDiag = 0, kPropPcn = 1, kPropDense = 2;
 template <int KIND, int D, unsigned REC, int EQ, int PROP = kPropDiag>
 __global__ __launch_bounds__(kBlock) void mrw_kernel(const ChainArgs<D> a)
 {
+    ymc_stage_tables();
     const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (k >= a.K) return;
     const uint32_t chain = (uint32_t)(a.chain0 + k);
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(kBlock) void mrw_kernel(const ChainArgs<D> a)
 template <int KIND, int D, unsigned REC, int EQ>
 __global__ __launch_bounds__(kBlock) void mlda2_kernel(const ChainArgs<D> a)
 {
+    ymc_stage_tables();
     const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (k >= a.K) return;
     const uint32_t chain = (uint32_t)(a.chain0 + k);
@@ -218,6 +220,7 @@ __global__ __launch_bounds__(kBlock) void mlda2_kernel(const ChainArgs<D> a)
 template <unsigned REC>
 __global__ __launch_bounds__(kBlock) void mrw_lv_rows_kernel(const ChainArgs<2> a)
 {
+    ymc_stage_tables();
     constexpr int D = 2;
     using R = Rec<REC>;
     const DensityDev<2> &p = a.tgt;
@@ -362,6 +365,7 @@ __global__ __launch_bounds__(kBlock) void rng_fill_kernel(uint64_t seed, uint64_
                                                           uint64_t t0, uint64_t nt, int d,
                                                           double *__restrict__ xi, double *__restrict__ u)
 {
+    ymc_stage_tables();
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= K * nt) return;
     const uint64_t t = i / K, k = i % K;
@@ -387,6 +391,7 @@ __global__ __launch_bounds__(kBlock) void recip_kernel(uint64_t n0, uint64_t cou
 __global__ __launch_bounds__(kBlock) void numerics_kernel(int fn, uint64_t n, const double *__restrict__ x,
                                                           double *__restrict__ y0, double *__restrict__ y1)
 {
+    ymc_stage_tables();
     const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     switch (fn) {

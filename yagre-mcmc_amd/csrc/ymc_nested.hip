@@ -94,6 +94,7 @@ struct Walker {
 template <int KIND, int D, int E>
 __global__ __launch_bounds__(kBlock) void mlda_nested_kernel(const NestedArgs<D> a)
 {
+    ymc_stage_tables();
     const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (k >= a.K) return;
 

@@ -227,40 +227,64 @@ YMC_FN double ymc_draw_uniform(uint64_t seed, uint32_t chain, uint64_t t)
 }
 
 /* ------------------------------------------------------------------------ */
-/* log(x), x a positive normal double.  Argument reduction to               */
-/* [sqrt(2)/2, sqrt(2)) and the s = f/(2+f) series (the classic fdlibm      */
-/* scheme); < 1 ulp.                                                        */
+/* log(x), x a positive normal double: table-driven, no division.           */
+/*   x = 2^k z,  z in [0.6855, 1.3711);  interval i of 128 holds z, with    */
+/*   centre c_i;  r = z / c_i - 1 (one fma with the tabulated 1/c_i, |r| <= */
+/*   2^-8);  log x = k ln2 + log c_i + r + r^2 g(r),  g a degree-4 fit of   */
+/*   (log1p(r) - r) / r^2.  1.0 is the centre of its interval (c = 1, log c */
+/*   = 0), so log(1) = 0 exactly and arguments next to 1 lose nothing.      */
+/* Table and coefficients: tools/gen_numerics_tables.py (mpmath).  Measured */
+/* error < 1.7 ulp (tests/test_numerics.py); it replaced an fdlibm-style    */
+/* log with a division (11 fewer VALU instructions per normal pair).        */
+/* On the device the table is read from LDS: every kernel that draws calls  */
+/* ymc_stage_tables() first.                                                */
 /* ------------------------------------------------------------------------ */
+#define YMC_LOG_OFF 0x3fe5f00000000000ull /* 0x3fe6000000000000 - 2^44 */
+
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ const double ymc_logtab_rom[256] = {
+#include "ymc_logtab.inc"
+};
+__shared__ double ymc_logtab_lds[256];
+#define YMC_LOGTAB ymc_logtab_lds
+#else
+static const double ymc_logtab_host[256] = {
+#include "ymc_logtab.inc"
+};
+#define YMC_LOGTAB ymc_logtab_host
+#endif
+
+#if defined(__HIPCC__)
+/* every thread of the workgroup, before the kernel's first draw (and before any early return) */
+__device__ __forceinline__ void ymc_stage_tables()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (unsigned i = threadIdx.x; i < 256u; i += blockDim.x) ymc_logtab_lds[i] = ymc_logtab_rom[i];
+    __syncthreads();
+#endif
+}
+#endif
+
 YMC_FN double ymc_log(double x)
 {
-    const double ln2_hi = 6.93147180369123816490e-01; /* 0x3fe62e42fee00000 */
-    const double ln2_lo = 1.90821492927058770002e-10; /* 0x3dea39ef35793c76 */
-    const double Lg1 = 6.666666666666735130e-01;
-    const double Lg2 = 3.999999999940941908e-01;
-    const double Lg3 = 2.857142874366239149e-01;
-    const double Lg4 = 2.222219843214978396e-01;
-    const double Lg5 = 1.818357216161805012e-01;
-    const double Lg6 = 1.531383769920937332e-01;
-    const double Lg7 = 1.479819860511658591e-01;
-
+    const double Ln2hi = 0x1.62e42fefa3800p-1; /* 42 bits: k * Ln2hi is exact */
+    const double Ln2lo = 0x1.ef35793c76730p-45;
     uint64_t ix = ymc_bits(x);
-    uint32_t hx = (uint32_t)(ix >> 32);
-    int32_t k = (int32_t)(hx >> 20) - 1023;
-    hx &= 0x000fffffu;
-    uint32_t i = (hx + 0x95f64u) & 0x100000u;
-    k += (int32_t)(i >> 20);
-    ix = ((uint64_t)(hx | (i ^ 0x3ff00000u)) << 32) | (ix & 0xffffffffu);
-    double f = ymc_from_bits(ix) - 1.0;
-    double dk = (double)k;
-
-    double s = f / (2.0 + f);
-    double z = s * s;
-    double w = z * z;
-    double t1 = w * ymc_fma_c(w, ymc_fma_c(w, ymc_coeff(Lg6), Lg4), Lg2);
-    double t2 = z * ymc_fma_c(w, ymc_fma_c(w, ymc_fma_c(w, ymc_coeff(Lg7), Lg5), Lg3), Lg1);
-    double R = t2 + t1;
-    double hfsq = 0.5 * f * f;
-    return dk * ln2_hi - ((hfsq - ymc_fma(s, hfsq + R, dk * ln2_lo)) - f);
+    uint64_t tmp = ix - YMC_LOG_OFF;
+    int32_t i = (int32_t)((tmp >> 45) & 127u);
+    int32_t k = (int32_t)((int64_t)tmp >> 52);
+    double z = ymc_from_bits(ix - (tmp & 0xfff0000000000000ull));
+    double invc = YMC_LOGTAB[2 * i], logc = YMC_LOGTAB[2 * i + 1];
+    double r = ymc_fma(z, invc, -1.0);
+    double kd = (double)k;
+    double w = ymc_fma(kd, Ln2hi, logc);
+    double hi = w + r;
+    double lo = ymc_fma(kd, Ln2lo, (w - hi) + r);
+    double r2 = r * r;
+    double p = ymc_fma_c(r, ymc_coeff(-0x1.55569bc4f7488p-3), 0x1.999b0eab6ecccp-3);
+    double q = ymc_fma_c(r, ymc_coeff(-0x1.ffffffffacc02p-3), 0x1.5555555525c32p-2);
+    p = ymc_fma(r2, p, q);
+    return ymc_fma(r * r2, p, ymc_fma(r2, -0.5, lo)) + hi;
 }
 
 /* ------------------------------------------------------------------------ */

@@ -56,6 +56,7 @@ __device__ __forceinline__ double combine4(double s)
 template <int KS, bool PCN>
 __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArgs a)
 {
+    ymc_stage_tables();
     extern __shared__ double lds[];
     const int MT = a.MT, m_pad = 16 * MT, d_pad = 4 * KS;
     double *Alds = lds;
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(256) void linear_big_eval_kernel(const BigLinearArg
 size_t ymc_tile_lds_bytes(int KS, int MT)
 {
     const size_t m_pad = 16 * (size_t)MT, d_pad = 4 * (size_t)KS;
-    return ((size_t)MT * KS * 64 + m_pad * 3 + 3 * d_pad) * sizeof(double);
+    return ((size_t)MT * KS * 64 + m_pad * 3 + 3 * d_pad) * sizeof(double);  /* + 2 KB static (log table) */
 }
 
 template <int KS, bool PCN>
