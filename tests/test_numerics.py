@@ -51,13 +51,20 @@ def test_exp_against_libm():
 
 
 def test_accept_probability_is_clipped_exp():
-    """ymc_accept_prob(d) == min(1, ymc_exp(d)) with NaN -> 1 (mrw.py:54-57), for every kind of input"""
+    """ymc_accept_prob(d) == min(1, ymc_exp(d)) for d >= -64 with NaN -> 1 (mrw.py:54-57); below -64 it
+    is exp(-64) < 2^-53, which decides every u of the 2^-53 grid like the true value does"""
     rng = np.random.default_rng(21)
     d = np.concatenate([rng.uniform(-760, 5, size=300000), rng.normal(size=100000) * 1e-8,
                         [0.0, -0.0, np.inf, -np.inf, np.nan, 800.0, -745.19, -745.21, -708.39, -708.4, 1e-320, -1e-320]])
     e = o.exp(d)
     want = np.where(e < 1.0, e, 1.0)
-    assert np.array_equal(o.accept_prob(d), want)
+    got = o.accept_prob(d)
+    far = d < -64.0
+    assert np.array_equal(got[~far], want[~far])
+    assert np.all(got[far] == o.exp(np.array([-64.0]))[0]) and got[far].max() < 2.0**-53
+    # identical decisions for every u of the grid, including u = 0
+    u = np.concatenate([rng.integers(0, 2**53, size=d.size - 3) * 2.0**-53, [0.0, 2.0**-53, 1 - 2.0**-53]])
+    assert np.array_equal(u <= got, u <= want)
 
 
 def test_division_by_reciprocal_is_the_ieee_quotient():

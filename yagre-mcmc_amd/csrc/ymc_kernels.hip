@@ -61,7 +61,7 @@ __device__ __forceinline__ bool states_equal(const double (&p)[D], const double 
 constexpr int kPropDiag = 0, kPropPcn = 1, kPropDense = 2;
 
 template <int KIND, int D, unsigned REC, int EQ, int PROP = kPropDiag>
-__global__ __launch_bounds__(kBlock) void mrw_kernel(const ChainArgs<D> a)
+__device__ __forceinline__ void mrw_body(const ChainArgs<D> &a)
 {
     ymc_stage_tables();
     const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -130,8 +130,26 @@ __global__ __launch_bounds__(kBlock) void mrw_kernel(const ChainArgs<D> a)
     }
 }
 
+template <int KIND, int D, unsigned REC, int EQ, int PROP = kPropDiag>
+__global__ __launch_bounds__(kBlock) void mrw_kernel(const ChainArgs<D> a)
+{
+    mrw_body<KIND, D, REC, EQ, PROP>(a);
+}
+
+/* The specialised record configurations are built for AT MOST two waves per SIMD (BASELINE
+ * configs[1], 65 536 chains, is one).  Given the register budget of two waves (256 VGPRs) the
+ * scheduler interleaves the independent draw / density chains of a transition pair instead of
+ * minimising registers for a third wave: the kernel is VALU-bound, so what counts is that the one
+ * or two resident waves never stall on their own latencies.  Same instruction count, 170 instead of
+ * 142 VGPRs; measured +8 % at 65 536 chains, +3 % at 131 072, +1 % at 1 M (tools: YMC A/B in DESIGN.md). */
 template <int KIND, int D, unsigned REC, int EQ>
-__global__ __launch_bounds__(kBlock) void mlda2_kernel(const ChainArgs<D> a)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 2))) void mrw_kernel_two_waves(const ChainArgs<D> a)
+{
+    mrw_body<KIND, D, REC, EQ, kPropDiag>(a);
+}
+
+template <int KIND, int D, unsigned REC, int EQ>
+__device__ __forceinline__ void mlda2_body(const ChainArgs<D> &a)
 {
     ymc_stage_tables();
     const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -206,6 +224,12 @@ __global__ __launch_bounds__(kBlock) void mlda2_kernel(const ChainArgs<D> a)
         ymc_store_row<D>(a.wf_mean, k, wmean);
         ymc_store_row<D>(a.wf_m2, k, wm2);
     }
+}
+
+template <int KIND, int D, unsigned REC, int EQ>
+__global__ __launch_bounds__(kBlock) void mlda2_kernel(const ChainArgs<D> a)
+{
+    mlda2_body<KIND, D, REC, EQ>(a);
 }
 
 /*
@@ -444,9 +468,12 @@ void launch_one(int method, const ChainArgs<D> &a, hipStream_t s)
     } else if (method == YMC_METHOD_MRW && a.chol) {
         if constexpr (REC == kRuntimeRec)
             hipLaunchKernelGGL((mrw_kernel<KIND, D, REC, EQ, kPropDense>), dim3(grid_for(a.K)), dim3(kBlock), 0, s, a);
-    } else if (method == YMC_METHOD_MRW)
-        hipLaunchKernelGGL((mrw_kernel<KIND, D, REC, EQ>), dim3(grid_for(a.K)), dim3(kBlock), 0, s, a);
-    else
+    } else if (method == YMC_METHOD_MRW) {
+        if constexpr (REC != kRuntimeRec)
+            hipLaunchKernelGGL((mrw_kernel_two_waves<KIND, D, REC, EQ>), dim3(grid_for(a.K)), dim3(kBlock), 0, s, a);
+        else
+            hipLaunchKernelGGL((mrw_kernel<KIND, D, REC, EQ>), dim3(grid_for(a.K)), dim3(kBlock), 0, s, a);
+    } else
         hipLaunchKernelGGL((mlda2_kernel<KIND, D, REC, EQ>), dim3(grid_for(a.K)), dim3(kBlock), 0, s, a);
 }
 

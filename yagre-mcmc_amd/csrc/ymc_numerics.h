@@ -336,21 +336,37 @@ YMC_FN double ymc_exp(double x)
     return (x == x) ? y : x;                          /* NaN propagates */
 }
 
-/* min(1, exp(d)) for any double d -- the Metropolis acceptance probability    */
-/*   a = exp(log_ratio); a = a if a < 1 else 1        (mrw.py:54-57)           */
-/* Same value as that expression on ymc_exp for every input (NaN and +inf      */
-/* give 1, like the reference's comparison), without the overflow and NaN      */
-/* handling the full-range exp needs: the argument is clamped to <= 0 first.   */
+/* The Metropolis acceptance probability as far as a DECISION needs it              */
+/*   a = exp(log_ratio); a = a if a < 1 else 1;  accept iff u <= a  (mrw.py:54-57) */
+/* u lies on the 2^-53 grid of [0, 1), so every a below 2^-53 decides the same way  */
+/* (accept iff u == 0).  ymc_accept_prob(d) therefore returns min(1, ymc_exp(d))    */
+/* exactly for d >= -64, and exp(-64) (< 2^-92) for d < -64, NaN and +inf giving 1   */
+/* like the reference's comparison: same decisions as the full-range exp for every  */
+/* input, without its overflow / subnormal / NaN selects (two min/max, one exponent */
+/* add instead of fourteen compares and selects).                                  */
+YMC_FN double ymc_min_nonan(double a, double b) /* a unless a is NaN or a > b */
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fmin(a, b); /* v_min_f64: the other operand when one is NaN */
+#else
+    return (a < b) ? a : b;
+#endif
+}
+
 YMC_FN double ymc_accept_prob(double d)
 {
     const double inv_ln2 = 0x1.71547652b82fep+0;
     const double ln2_hi = 0x1.62e42fee00000p-1;
     const double ln2_lo = 0x1.a39ef35793c76p-33;
 
-    double x = (d < 0.0) ? d : 0.0;                   /* NaN, +inf, d >= 0 -> 0 -> exp = 1 */
-    double xc = (x < -746.0) ? -746.0 : x;
+    double x = ymc_min_nonan(d, 0.0);                 /* NaN, +inf, d >= 0 -> 0 -> exp = 1 */
+#if defined(__HIP_DEVICE_COMPILE__)
+    double xc = __builtin_fmax(x, -64.0);
+#else
+    double xc = (x < -64.0) ? -64.0 : x;
+#endif
     double kd = __builtin_rint(xc * inv_ln2);
-    int32_t k = (int32_t)kd;
+    int32_t k = (int32_t)kd;                          /* -93 <= k <= 0 */
     double r = ymc_fma(-kd, ln2_hi, xc);
     r = ymc_fma(-kd, ln2_lo, r);
 
@@ -367,13 +383,8 @@ YMC_FN double ymc_accept_prob(double d)
     p = ymc_fma_c(p, r, 0x1.5555555555555p-3);
     p = ymc_fma_c(p, r, 0.5);
     p = ymc_fma_c(p, r, 1.0);
-    p = ymc_fma_c(p, r, 1.0);
-
-    int32_t k1 = (k < -1021) ? k + 1000 : k;
-    double f2 = (k < -1021) ? 0x1p-1000 : 1.0;
-    double y = ymc_scale2(p, k1) * f2;
-    y = (x < -745.2) ? 0.0 : y;
-    return (y < 1.0) ? y : 1.0;
+    p = ymc_fma_c(p, r, 1.0);                           /* p in [0.70, 1.42] */
+    return ymc_min_nonan(ymc_scale2(p, k), 1.0);
 }
 
 /* ------------------------------------------------------------------------ */
