@@ -47,6 +47,7 @@ __device__ __forceinline__ void tail(const Args& a, uint64_t k, uint32_t n, doub
 
 __global__ __launch_bounds__(256) void fused(const Args a)
 {
+    ymc_stage_tables();
     const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint32_t chain = (uint32_t)k;
     double x[D], wmean[D], wm2[D], sigma[D] = {a.sigma[0], a.sigma[1]};
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(256) void fused(const Args a)
 template <int NP, int R, int PRIO>
 __global__ __launch_bounds__(64 * (NP + 1)) void split(const Args a)
 {
+    ymc_stage_tables();
     constexpr int B = 2 * NP * R;
     __shared__ double ring[2][B][D + 1][64];
     const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
@@ -147,6 +149,7 @@ __global__ __launch_bounds__(64 * (NP + 1)) void split(const Args a)
 template <int NW, int CW, int B>
 __global__ __launch_bounds__(64 * NW) void phased(const Args a)
 {
+    ymc_stage_tables();
     extern __shared__ double ring[];   // [B][D+1][CW*64]
     constexpr int NC = CW * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
