@@ -173,6 +173,9 @@ int ymc_abi_version(void);
 const char *ymc_last_error(void);
 int ymc_device_count(int *count);
 
+/* Lifetime: handles may be destroyed in ANY order (a garbage-collecting host language gives none).  A
+ * context that still has problems, runs or communicators, or a problem that still has runs, is only
+ * marked released by its destroy call and is freed by its last dependent. */
 int ymc_ctx_create(int device, ymc_ctx **out);
 int ymc_ctx_destroy(ymc_ctx *ctx);
 int ymc_ctx_device_info(const ymc_ctx *ctx, ymc_device_info *out);

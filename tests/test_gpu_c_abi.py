@@ -58,3 +58,29 @@ def test_c_client_equals_ctypes_client(tmp_path):
     h = _fnv1a(run.accept().tobytes(), h)
     assert out[0] == f"{h:016x}"
     assert float(out[1]) == run.summary()["accepted"].sum() / (K * T)
+
+
+@pytest.mark.gpu
+def test_handles_may_be_destroyed_in_any_order():
+    """A garbage-collecting host gives no destruction order: a context released before its problems and
+    runs must stay usable by them and be freed by the last one (no use-after-free, no abort at exit)."""
+    import ctypes as C
+    from yagremcmc_amd import _ffi, lowering
+    lib = _ffi.lib()
+    ctx = _ffi.Context(0)
+    low = lowering.Lowered(_ffi.GAUSS_WHITENED, 2)
+    low.set_array("mean", np.zeros(2))
+    low.set_array("whiten", np.eye(2))
+    prob = lowering.make_problem(ctx, _ffi.METHOD_MRW, low, np.ones(2))
+    run = _ffi.Run(prob, 1, 64, np.zeros((1, 2)), 10, _ffi.RECORD_TRAJECTORY | _ffi.RECORD_ACCEPT)
+    raw_ctx, raw_prob, raw_run = ctx.raw, prob.raw, run.raw
+    for h in (ctx, prob, run):   # take the raw handles over from the Python wrappers
+        h.raw = None
+    assert lib.ymc_ctx_destroy(raw_ctx) == 0        # released, still alive: the problem uses it
+    assert lib.ymc_problem_destroy(raw_prob) == 0   # released, still alive: the run uses it
+    assert lib.ymc_run_advance(raw_run, C.c_uint64(10)) == 0 and lib.ymc_run_sync(raw_run) == 0
+    traj = np.empty((10, 64, 2))
+    assert lib.ymc_run_fetch_trajectory(raw_run, C.c_uint64(0), C.c_uint64(10), traj.ctypes.data_as(C.c_void_p),
+                                        C.c_size_t(traj.nbytes)) == 0
+    assert np.isfinite(traj).all()
+    assert lib.ymc_run_destroy(raw_run) == 0        # frees the run, then the problem, then the context

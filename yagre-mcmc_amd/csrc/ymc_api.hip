@@ -87,14 +87,22 @@ struct DensityHost {
 
 }  // namespace
 
+/* Handles may be destroyed in any order (a garbage-collecting host language gives no guarantee): a
+ * context outlives its problems, runs and communicators, a problem its runs.  `users` counts the
+ * dependents; a destroy call on an object that is still in use only marks it released, and the
+ * last dependent to go frees it. */
 struct ymc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipDeviceProp_t prop{};
+    int users = 0;
+    bool released = false;
 };
 
 struct ymc_problem {
     ymc_ctx *ctx = nullptr;
+    mutable int users = 0;
+    mutable bool released = false;
     int method = 0, eq_mode = 0, S = 0, D = 0, kind = 0;
     int aem_min_data = 0, aem_heuristic = 0;
     double pcn_c1 = 0.0, pcn_c2 = 0.0;
@@ -661,14 +669,30 @@ int ymc_ctx_create(int device, ymc_ctx **out)
     return YMC_OK;
 }
 
-int ymc_ctx_destroy(ymc_ctx *ctx)
+static void ctx_free(ymc_ctx *ctx)
 {
-    if (!ctx) return YMC_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+static void ctx_drop_user(ymc_ctx *ctx)
+{
+    if (--ctx->users == 0 && ctx->released) ctx_free(ctx);
+}
+
+int ymc_ctx_destroy(ymc_ctx *ctx)
+{
+    if (!ctx || ctx->released) return YMC_OK;
+    if (ctx->users > 0) {
+        ctx->released = true; /* freed by its last problem / run / communicator */
+        return YMC_OK;
+    }
+    ctx_free(ctx);
     return YMC_OK;
 }
+
+
 
 int ymc_ctx_device_info(const ymc_ctx *ctx, ymc_device_info *out)
 {
@@ -807,16 +831,27 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
         delete p;
         return rc;
     }
+    ctx->users += 1;
     *out = p;
     return YMC_OK;
 }
 
+static void problem_free(const ymc_problem *problem)
+{
+    ymc_ctx *ctx = problem->ctx;
+    (void)hipSetDevice(ctx->device);
+    delete problem;
+    ctx_drop_user(ctx);
+}
+
 int ymc_problem_destroy(ymc_problem *problem)
 {
-    if (problem) {
-        (void)hipSetDevice(problem->ctx->device);
-        delete problem;
+    if (!problem || problem->released) return YMC_OK;
+    if (problem->users > 0) {
+        problem->released = true; /* freed by its last run */
+        return YMC_OK;
     }
+    problem_free(problem);
     return YMC_OK;
 }
 
@@ -908,6 +943,7 @@ int ymc_run_create(ymc_ctx *ctx, const ymc_problem *problem, const ymc_run_desc 
         delete r;
         return rc;
     }
+    problem->users += 1;
     *out = r;
     return YMC_OK;
 }
@@ -922,7 +958,9 @@ int ymc_run_destroy(ymc_run *run)
             (void)hipEventDestroy(ev.first);
             (void)hipEventDestroy(ev.second);
         }
+    const ymc_problem *problem = run->problem;
     delete run;
+    if (--problem->users == 0 && problem->released) problem_free(problem);
     return YMC_OK;
 }
 
@@ -1318,3 +1356,12 @@ int ymc_internal_ctx_device(const ymc_ctx *ctx, hipStream_t *stream)
     return ctx->device;
 }
 uint64_t ymc_internal_run_chains(const ymc_run *run) { return run->K; }
+void ymc_internal_ctx_retain(ymc_ctx *ctx) { ctx->users += 1; }
+void ymc_internal_ctx_release(ymc_ctx *ctx)
+{
+    if (--ctx->users == 0 && ctx->released) {
+        (void)hipSetDevice(ctx->device);
+        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+    }
+}

@@ -21,6 +21,8 @@ int ymc_internal_pack_summary(ymc_run *run, uint64_t **dev_out, uint64_t *words,
 int ymc_internal_fail(int code, const char *msg);
 int ymc_internal_ctx_device(const ymc_ctx *ctx, hipStream_t *stream);
 uint64_t ymc_internal_run_chains(const ymc_run *run);
+void ymc_internal_ctx_retain(ymc_ctx *ctx);
+void ymc_internal_ctx_release(ymc_ctx *ctx);
 
 namespace {
 
@@ -77,6 +79,7 @@ int hip_fail(const char *what, hipError_t e)
 }  // namespace
 
 struct ymc_comm {
+    ymc_ctx *ctx = nullptr;
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0, device = 0;
     hipStream_t stream = nullptr;
@@ -126,6 +129,8 @@ int ymc_comm_create(ymc_ctx *ctx, const void *id, size_t id_bytes, int nranks, i
         delete c;
         return nccl_fail("ncclCommInitRank", r);
     }
+    c->ctx = ctx;
+    ymc_internal_ctx_retain(ctx); /* the communicator works on the context's stream */
     *out = c;
     return YMC_OK;
 }
@@ -138,7 +143,9 @@ int ymc_comm_destroy(ymc_comm *comm)
     if (comm->comm) (void)g_rccl.CommDestroy(comm->comm);
     if (comm->scratch) (void)hipFree(comm->scratch);
     if (comm->gathered) (void)hipFree(comm->gathered);
+    ymc_ctx *ctx = comm->ctx;
     delete comm;
+    if (ctx) ymc_internal_ctx_release(ctx);
     return YMC_OK;
 }
 
