@@ -237,14 +237,18 @@ def main():
     bytes_per_transition = 8 * d + 1
     launch_bytes = K * T * bytes_per_transition
     achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    traffic = None
+    traffic = valu_busy = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
             rec = json.load(open(tpath)).get(f"{args.workload}_K{K}_T{T}")
             traffic = rec["hbm_bytes_per_launch"] if rec else None
+            sq = (rec or {}).get("sq_per_launch") or {}
+            if sq.get("SQ_WAVE_CYCLES"):
+                # what actually bounds these kernels: the share of wave-cycles with the VALU busy
+                valu_busy = sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"]
         except Exception:
-            traffic = None
+            traffic = valu_busy = None
 
     if args.workload == "c3":
         # the forward map is a batched 128 x 128 GEMV on the fp64 matrix cores: 2 d m flop per transition
@@ -273,7 +277,7 @@ def main():
                    "transitions_per_step": T, "record": "trajectory f64 [T][K][d] + accept u8 [T][K]"
                    + ("" if args.no_moments else " + Welford moments"), "parallelism": f"chains sharded over {world} GPU(s)",
                    "rng": "Philox4x32-10, seed 20250103, keyed by global chain id"},
-        "roofline": roofline,
+        "roofline": dict(roofline, valu_busy_frac_profiled=valu_busy),
         "hbm_gb_per_s_whole_node": world * achieved,
         "kernel_steps_per_s_per_gpu": K * T / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0,
         "acceptance_rate": pooled["acceptance_rate"],
