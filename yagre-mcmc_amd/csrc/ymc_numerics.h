@@ -236,8 +236,8 @@ YMC_FN double ymc_draw_uniform(uint64_t seed, uint32_t chain, uint64_t t)
 /* Table and coefficients: tools/gen_numerics_tables.py (mpmath).  Measured */
 /* error < 1.7 ulp (tests/test_numerics.py); it replaced an fdlibm-style    */
 /* log with a division (11 fewer VALU instructions per normal pair).        */
-/* On the device the table is read from LDS: every kernel that draws calls  */
-/* ymc_stage_tables() first.                                                */
+/* On the device the tables (this one and sincospi's, 2 KB each) are read   */
+/* from LDS: every kernel that draws calls ymc_stage_tables() first.        */
 /* ------------------------------------------------------------------------ */
 #define YMC_LOG_OFF 0x3fe5f00000000000ull /* 0x3fe6000000000000 - 2^44 */
 
@@ -245,13 +245,22 @@ YMC_FN double ymc_draw_uniform(uint64_t seed, uint32_t chain, uint64_t t)
 static __device__ const double ymc_logtab_rom[256] = {
 #include "ymc_logtab.inc"
 };
+static __device__ const double ymc_sincostab_rom[256] = {
+#include "ymc_sincostab.inc"
+};
 __shared__ double ymc_logtab_lds[256];
+__shared__ double ymc_sincostab_lds[256];
 #define YMC_LOGTAB ymc_logtab_lds
+#define YMC_SINCOSTAB ymc_sincostab_lds
 #else
 static const double ymc_logtab_host[256] = {
 #include "ymc_logtab.inc"
 };
+static const double ymc_sincostab_host[256] = {
+#include "ymc_sincostab.inc"
+};
 #define YMC_LOGTAB ymc_logtab_host
+#define YMC_SINCOSTAB ymc_sincostab_host
 #endif
 
 #if defined(__HIPCC__)
@@ -259,7 +268,10 @@ static const double ymc_logtab_host[256] = {
 __device__ __forceinline__ void ymc_stage_tables()
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    for (unsigned i = threadIdx.x; i < 256u; i += blockDim.x) ymc_logtab_lds[i] = ymc_logtab_rom[i];
+    for (unsigned i = threadIdx.x; i < 256u; i += blockDim.x) {
+        ymc_logtab_lds[i] = ymc_logtab_rom[i];
+        ymc_sincostab_lds[i] = ymc_sincostab_rom[i];
+    }
     __syncthreads();
 #endif
 }
@@ -388,45 +400,33 @@ YMC_FN double ymc_accept_prob(double d)
 }
 
 /* ------------------------------------------------------------------------ */
-/* sin(pi t), cos(pi t) for |t| < 2^30.  t = q/2 + r exactly, |r| <= 1/4;   */
-/* odd/even Taylor polynomials in r with coefficients pi^n/n! rounded to    */
-/* nearest (tools/gen_numerics_tables.py), then the quadrant fix-up.        */
+/* sin(pi t), cos(pi t) for 0 <= t < 2^24, table-driven: t = j/64 + r        */
+/* exactly, |r| <= 1/128; (S, C) = (sin, cos)(pi j/64) from a 128-entry     */
+/* table (exact 0 and +-1 on the axes); sp = sin(pi r) and cm = cos(pi r)-1 */
+/* by short Taylor polynomials in r^2 (next terms 4e-19 and 3e-18);         */
+/*   sin(pi t) = S + (C sp + S cm),   cos(pi t) = C + (C cm - S sp).        */
+/* No quadrant selects, 17 fewer VALU instructions than the 17-term version */
+/* it replaced; error < 1.6 ulp (tests/test_numerics.py).  Table:           */
+/* tools/gen_numerics_tables.py sincostab; in LDS on the device.            */
 /* ------------------------------------------------------------------------ */
 YMC_FN void ymc_sincospi(double t, double *sn, double *cs)
 {
-    double qd = __builtin_rint(t + t);
-    double r = ymc_fma(-0.5, qd, t);                  /* exact */
-    int32_t q = (int32_t)qd;
+    double qd = __builtin_rint(t * 64.0);
+    double r = ymc_fma(-qd, 0x1p-6, t);               /* exact */
+    int32_t j = (int32_t)qd & 127;
+    double S = YMC_SINCOSTAB[2 * j], C = YMC_SINCOSTAB[2 * j + 1];
     double r2 = r * r;
 
-    double ps = ymc_coeff(0x1.aaec32af93359p-21);                /* +pi^17/17! */
-    ps = ymc_fma_c(ps, r2, -0x1.6fadb9f155744p-16);
-    ps = ymc_fma_c(ps, r2, 0x1.e8f434d018d63p-12);
-    ps = ymc_fma_c(ps, r2, -0x1.e3074fde8871fp-8);
-    ps = ymc_fma_c(ps, r2, 0x1.50783487ee782p-4);
-    ps = ymc_fma_c(ps, r2, -0x1.32d2cce62bd86p-1);
-    ps = ymc_fma_c(ps, r2, 0x1.466bc6775aae2p+1);
-    ps = ymc_fma_c(ps, r2, -0x1.4abbce625be53p+2);
-    ps = ymc_fma_c(ps, r2, 0x1.921fb54442d18p+1);       /* pi */
-    double s = ps * r;
+    double p = ymc_fma_c(r2, ymc_coeff(-0x1.32d2cce62bd86p-1), 0x1.466bc6775aae2p+1); /* -pi^7/7!, pi^5/5! */
+    p = ymc_fma_c(r2, p, -0x1.4abbce625be53p+2);        /* -pi^3/3! */
+    p = ymc_fma_c(r2, p, 0x1.921fb54442d18p+1);         /* pi */
+    double sp = r * p;
+    double q = ymc_fma_c(r2, ymc_coeff(-0x1.55d3c7e3cbffap+0), 0x1.03c1f081b5ac4p+2); /* -pi^6/6!, pi^4/4! */
+    q = ymc_fma_c(r2, q, -0x1.3bd3cc9be45dep+2);        /* -pi^2/2 */
+    double cm = r2 * q;
 
-    double pc = ymc_coeff(0x1.20c62c2f2d7f5p-18);                /* +pi^16/16! */
-    pc = ymc_fma_c(pc, r2, -0x1.b6e24f44b128fp-14);
-    pc = ymc_fma_c(pc, r2, 0x1.f9d38a3763cc3p-10);
-    pc = ymc_fma_c(pc, r2, -0x1.a6d1f2a204a8cp-6);
-    pc = ymc_fma_c(pc, r2, 0x1.e1f506891babbp-3);
-    pc = ymc_fma_c(pc, r2, -0x1.55d3c7e3cbffap+0);
-    pc = ymc_fma_c(pc, r2, 0x1.03c1f081b5ac4p+2);
-    pc = ymc_fma_c(pc, r2, -0x1.3bd3cc9be45dep+2);
-    double c = ymc_fma_c(pc, r2, 1.0);
-
-    /* quadrant q mod 4: 0 -> (s,c); 1 -> (c,-s); 2 -> (-s,-c); 3 -> (-c,s) */
-    double so = (q & 1) ? c : s;
-    double co = (q & 1) ? s : c;
-    if (q & 2) so = -so;
-    if ((q + 1) & 2) co = -co;
-    *sn = so;
-    *cs = co;
+    *sn = S + ymc_fma(C, sp, S * cm);
+    *cs = C + ymc_fma(-S, sp, C * cm);
 }
 
 /* ------------------------------------------------------------------------ */

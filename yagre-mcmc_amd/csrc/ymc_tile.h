@@ -9,7 +9,7 @@
 
 constexpr int kTileWaves = 8;                 /* waves per workgroup (one per SIMD), 16 chains each */
 constexpr int kTileThreads = 64 * kTileWaves;
-constexpr size_t kTileLdsLimit = 158 * 1024;  /* LDS per CU on gfx950 (160 KB) less the 2 KB static log table */
+constexpr size_t kTileLdsLimit = 156 * 1024;  /* LDS per CU on gfx950 (160 KB) less the 4 KB of static draw tables */
 
 struct TileArgs {
     /* one device block, staged into LDS by every workgroup:
