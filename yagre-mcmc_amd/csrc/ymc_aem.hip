@@ -243,7 +243,7 @@ __global__ __launch_bounds__(kBlock) void aem2_kernel(const AemArgs<D> a)
             const double log_ratio = ((lpfy + cx) - cy) - lpf;
             acc = ymc_accept(log_ratio, true, ymc_finite(lpfy) && ymc_finite(cy), u, st);
         }
-        if (moments) ymc_welford<D>(x, (double)(a.wf_n0 + n + 1), a.recip[n], wmean, wm2);
+        if (moments) ymc_welford<D>(x, (double)(a.wf_n0 + n + 1), ymc_recip_at(a.recip, n), wmean, wm2);
         if (acc) {
             L.update(a.fine, z); /* aem.py:26-56 */
 #pragma unroll

@@ -269,6 +269,16 @@ __device__ __forceinline__ bool ymc_accept(double log_ratio, bool moved, bool fi
     return moved && finite && (u <= a);
 }
 
+/* recip[n] of the launch's reciprocal table, read through the SCALAR data cache (constant address
+ * space): a vector load here would share the vmcnt counter with the record stores, and on gfx9-family
+ * hardware waiting for it means waiting for every store issued before it -- at one wave per SIMD a
+ * stall of the whole SIMD per transition.  The table is written by recip_kernel before the launch. */
+__device__ __forceinline__ double ymc_recip_at(const double *table, uint32_t n)
+{
+    typedef const double __attribute__((address_space(4))) *const_ptr;
+    return ((const_ptr)(uintptr_t)table)[n];
+}
+
 /* estimation.py:36-53 with n already incremented.  Every lane divides by the
  * same sample count dn, so delta / dn is formed from rdn = RN(1 / dn) (one IEEE
  * division per transition for the whole ensemble, recip_kernel) by Markstein's

@@ -95,7 +95,7 @@ __device__ __forceinline__ void mrw_body(const ChainArgs<D> &a)
         const bool moved = !states_equal<D, EQ>(y, x, a.eq_mode);               /* :60-61 */
         const double lpy = Density<KIND, D>::eval(a.tgt, y, st);
         const bool acc = ymc_accept(lpy - lp, moved, ymc_finite(lpy), u, st);   /* mrw.py:51-57, :68-70 */
-        if (moments) ymc_welford<D>(x, (double)(a.wf_n0 + n + 1), a.recip[n], wmean, wm2); /* diagnostics.py:91-94 */
+        if (moments) ymc_welford<D>(x, (double)(a.wf_n0 + n + 1), ymc_recip_at(a.recip, n), wmean, wm2); /* diagnostics.py:91-94 */
 #pragma unroll
         for (int j = 0; j < D; ++j) x[j] = acc ? y[j] : x[j];                   /* :79-92 */
         lp = acc ? lpy : lp;
@@ -204,7 +204,7 @@ __device__ __forceinline__ void mlda2_body(const ChainArgs<D> &a)
         const double lpfy = Density<KIND, D>::eval(a.tgt, z, st);
         const double log_ratio = ((lpfy + lpc) - lpcz) - lpf;
         const bool acc = ymc_accept(log_ratio, moved, ymc_finite(lpfy) && ymc_finite(lpcz), u, st);
-        if (moments) ymc_welford<D>(x, (double)(a.wf_n0 + n + 1), a.recip[n], wmean, wm2);
+        if (moments) ymc_welford<D>(x, (double)(a.wf_n0 + n + 1), ymc_recip_at(a.recip, n), wmean, wm2);
 #pragma unroll
         for (int j = 0; j < D; ++j) x[j] = acc ? z[j] : x[j];
         lpf = acc ? lpfy : lpf;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(kBlock) void mrw_lv_rows_kernel(const ChainArgs<2> 
             lpy = -__builtin_inf();
         }
         const bool acc = ymc_accept(lpy - lp, moved, ymc_finite(lpy), u, st);
-        if (moments) ymc_welford<D>(x, (double)(a.wf_n0 + n + 1), a.recip[n], wmean, wm2);
+        if (moments) ymc_welford<D>(x, (double)(a.wf_n0 + n + 1), ymc_recip_at(a.recip, n), wmean, wm2);
 #pragma unroll
         for (int j = 0; j < D; ++j) x[j] = acc ? y[j] : x[j];
         lp = acc ? lpy : lp;

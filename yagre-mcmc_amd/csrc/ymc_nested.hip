@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kBlock) void mlda_nested_kernel(const NestedArgs<D>
 #pragma unroll
         for (int j = 0; j < D; ++j) y[j] = x[j];
         w.template run<E - 2>(y);                                                     /* mlda.py:100-116 */
-        if (moments) ymc_welford<D>(x, (double)(a.wf_n0 + n + 1), a.recip[n], wmean, wm2);
+        if (moments) ymc_welford<D>(x, (double)(a.wf_n0 + n + 1), ymc_recip_at(a.recip, n), wmean, wm2);
         const bool acc = w.decide(a.P[E - 1], a.Q[E - 1], x, y, lpP, lpQ);            /* mlda.py:146-154 */
         accepted += acc ? 1u : 0u;
         if (a.traj) ymc_store_row<D>(a.traj + (uint64_t)n * a.K * D, k, x);
