@@ -253,7 +253,7 @@ int ymc_iat_series(ymc_ctx *ctx, const double *series, uint64_t n_series, uint64
 /* parity hooks: the device's draws and elementary functions, bit-for-bit
  * comparable with the CPU build of csrc/ymc_numerics.h.
  * xi[nt][K][d], u[nt][K]; fn: 0 log, 1 exp, 2 sincospi (y0 = sin, y1 = cos),
- * 3 sqrt, 4 x / y1_in (y1 holds the divisor on entry) */
+ * 3 sqrt, 4 x / y1_in (y1 holds the divisor on entry), 6 the Box-Muller radius sqrt(max(x, 2^-100)) */
 int ymc_rng_fill(ymc_ctx *ctx, uint64_t seed, uint64_t chain0, uint64_t K, uint64_t t0, uint64_t nt,
                  int32_t d, double *xi, double *u);
 int ymc_numerics_eval(ymc_ctx *ctx, int fn, uint64_t n, const double *x, double *y0, double *y1);

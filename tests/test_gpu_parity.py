@@ -121,6 +121,10 @@ def test_sqrt_and_division_correctly_rounded_on_device(ctx):
     rng = np.random.default_rng(6)
     x = np.concatenate([rng.uniform(0, 80, 300000), np.exp(rng.uniform(-700, 700, 100000)), [0.0, 5e-324, 2.0]])
     assert np.array_equal(ctx.numerics(3, x)[0], np.sqrt(x))
+    # the Box-Muller radius (bare Goldschmidt on v_rsq_f64): the host's sqrt over its whole domain and beyond
+    w = np.concatenate([-2.0 * np.log((rng.integers(0, 2**53, 600000) + 1) * 2.0**-53), rng.uniform(0, 80, 300000),
+                        np.exp(rng.uniform(-69, 60, 100000)), [0.0, 2.0**-52, 2.0**-100, 2.0**-101, 73.47, 1e300]])
+    assert np.array_equal(ctx.numerics(6, w)[0], np.sqrt(np.maximum(w, 2.0**-100)))
     a = rng.normal(size=400000) * np.exp(rng.uniform(-30, 30, 400000))
     b = rng.integers(1, 10**7, size=400000).astype(np.float64)
     assert np.array_equal(ctx.numerics(4, a, divisor=b)[0], a / b)

@@ -1304,7 +1304,7 @@ int ymc_rng_fill(ymc_ctx *ctx, uint64_t seed, uint64_t chain0, uint64_t K, uint6
 int ymc_numerics_eval(ymc_ctx *ctx, int fn, uint64_t n, const double *x, double *y0, double *y1)
 {
     if (!ctx || !x || !y0) return fail(YMC_ERR_INVALID, "null argument");
-    if (fn < 0 || fn > 4) return fail(YMC_ERR_INVALID, "unknown function %d", fn);
+    if (fn < 0 || (fn > 4 && fn != 6)) return fail(YMC_ERR_INVALID, "unknown function %d", fn);
     if ((fn == 2 || fn == 4) && !y1) return fail(YMC_ERR_INVALID, "y1 is required for this function");
     if (n == 0) return YMC_OK;
     YMC_HIP(hipSetDevice(ctx->device));

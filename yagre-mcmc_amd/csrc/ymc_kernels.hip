@@ -429,6 +429,7 @@ __global__ __launch_bounds__(kBlock) void numerics_kernel(int fn, uint64_t n, co
         break;
     }
     case 3: y0[i] = __builtin_sqrt(x[i]); break;
+    case 6: y0[i] = ymc_sqrt_radius(x[i]); break;
     case 4: y0[i] = x[i] / y1[i]; break;
     default: break;
     }
