@@ -254,8 +254,8 @@ static double ymo_logdensity_one(const ymo_density *p, const double *x, uint32_t
         double maha = 0.0;
         for (int32_t j = 0; j < d; ++j) {
             double w = dev[0] * p->whiten[j];
-            for (int32_t i = 1; i < d; ++i) w = w + dev[i] * p->whiten[(int64_t)i * d + j];
-            maha = (j == 0) ? w * w : maha + w * w;
+            for (int32_t i = 1; i < d; ++i) w = ymc_fma(dev[i], p->whiten[(int64_t)i * d + j], w);
+            maha = (j == 0) ? w * w : ymc_fma(w, w, maha);
         }
         return -0.5 * (p->log_norm + maha);
     }

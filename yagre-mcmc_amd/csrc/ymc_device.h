@@ -80,13 +80,15 @@ struct Density<YMC_DENSITY_GAUSS_WHITENED, D> {
         double dev[D];
 #pragma unroll
         for (int i = 0; i < D; ++i) dev[i] = x[i] - p.mean[i];
+        /* dev @ U and the sum of squares as fma chains (scipy leaves the order to BLAS / pairwise
+         * summation; values agree with it to 1e-15) */
         double maha = 0.0;
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             double w = dev[0] * p.whiten[j];
 #pragma unroll
-            for (int i = 1; i < D; ++i) w = w + dev[i] * p.whiten[i * D + j];
-            maha = (j == 0) ? w * w : maha + w * w;
+            for (int i = 1; i < D; ++i) w = ymc_fma(dev[i], p.whiten[i * D + j], w);
+            maha = (j == 0) ? w * w : ymc_fma(w, w, maha);
         }
         return -0.5 * (p.log_norm + maha);
     }
