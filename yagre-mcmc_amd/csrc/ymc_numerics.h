@@ -4,8 +4,10 @@
  * Metropolis-Hastings kernels use.
  *
  * Everything in this header is written with IEEE-754 binary64 basic operations
- * only (+, -, *, /, sqrt, fma -- each correctly rounded) and integer
- * arithmetic.  The same source is compiled for gfx950 by hipcc (device code of
+ * only (+, -, *, /, sqrt, fma -- each correctly rounded), integer arithmetic
+ * and two small constant tables (log, sincospi).  (On the device the one square
+ * root is formed from v_rsq_f64 by Goldschmidt's corrections, which deliver the
+ * correctly rounded value: ymc_sqrt_radius, checked against the host's sqrt.)  The same source is compiled for gfx950 by hipcc (device code of
  * the HIP kernels) and for x86-64 by gcc (oracle/, the CPU checker).  Both are
  * built with -ffp-contract=off, and every fused multiply-add below is an
  * explicit ymc_fma(), so the two produce IDENTICAL bits.  That is what makes
