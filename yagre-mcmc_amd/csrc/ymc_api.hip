@@ -1209,7 +1209,7 @@ namespace {
 
 /* IAT of every chain from device-resident states traj[rows][K][d], rows [first, first + n) */
 int iat_from_device_states(ymc_ctx *ctx, const double *traj, uint64_t first, uint64_t n, uint64_t K, int d, int method,
-                           double sokal_const, int32_t *iat)
+                           double sokal_const, int32_t *iat, int tile_KS = 0)
 {
     if (method != 0 && method != 1)
         return fail(YMC_ERR_INVALID, "Invalid IAT - Type: %d. Options are 'mean' (0) and 'max' (1).", method);
@@ -1220,7 +1220,7 @@ int iat_from_device_states(ymc_ctx *ctx, const double *traj, uint64_t first, uin
     YMC_TRY(series.alloc(S * n * sizeof(double)));
     YMC_TRY(out.alloc(S * sizeof(int32_t)));
     hipStream_t st = ctx->stream;
-    YMC_HIP(ymc_launch_series_from_record(traj, first, n, K, d, method == 0, series.as<double>(), st));
+    YMC_HIP(ymc_launch_series_from_record(traj, first, n, K, d, tile_KS, method == 0, series.as<double>(), st));
     YMC_HIP(ymc_launch_iat(series.as<double>(), S, n, sokal_const, out.as<int32_t>(), nullptr, st));
     std::vector<int32_t> host(S);
     YMC_HIP(hipMemcpyAsync(host.data(), out.p, S * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -1241,11 +1241,10 @@ int ymc_run_iat(ymc_run *run, uint64_t first, uint64_t n, int method, double sok
 {
     if (!run || !iat) return fail(YMC_ERR_INVALID, "null argument");
     if (!(run->flags & YMC_RECORD_TRAJECTORY)) return fail(YMC_ERR_INVALID, "the run does not record the trajectory");
-    if (run->problem->tile) return fail(YMC_ERR_UNSUPPORTED, "IAT from the tiled record is not available yet");
     if (first + n > run->recorded) return fail(YMC_ERR_INVALID, "rows beyond the record requested");
     YMC_HIP(hipSetDevice(run->ctx->device));
     return iat_from_device_states(run->ctx, run->traj.as<double>(), first, n, run->K, run->problem->D, method,
-                                  sokal_const, iat);
+                                  sokal_const, iat, run->problem->tile ? run->problem->tgt.KS : 0);
 }
 
 int ymc_iat_states(ymc_ctx *ctx, const double *states, uint64_t n, uint64_t n_chains, int32_t d, int method,

@@ -7,7 +7,7 @@
  * example_mcmc_2d_singleLevel.py:71-79).  With K chains the record never has
  * to leave HBM for it.
  *
- *   series_from_record_kernel  record traj[T][K][d] -> series-major s[S][N]
+ *   series_from_record_kernel  record traj[T][K][d] (or the tile kernel's layout) -> series-major s[S][N]
  *                              ('mean': one series per chain, the mean over the
  *                              d components of every state, :126-129;
  *                              'max': one series per chain and component, :131-138)
@@ -47,32 +47,63 @@ __device__ __forceinline__ double block_sum(double v, double *scratch)
     return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
 }
 
+/* component j of chain k in row n of the record: plain layout [row][K][d], or the tile kernel's
+ * [row][ceil(K/16)][KS][64] with (chain = 16 tile + lane % 16, component = 4 s + lane / 16) */
+struct RecordView {
+    const double *traj;
+    uint64_t K;
+    int d, KS; /* KS == 0: plain layout */
+    __device__ __forceinline__ double at(uint64_t n, uint64_t k, int j) const
+    {
+        if (KS == 0) return traj[(n * K + k) * (uint64_t)d + j];
+        const uint64_t nct = (K + 15) / 16;
+        return traj[(((n * nct + k / 16) * (uint64_t)KS + (uint64_t)(j / 4)) * 64) + (uint64_t)(j % 4) * 16 + k % 16];
+    }
+};
+
+/* np.mean(seq, axis=1) (autocorrelation.py:126-129) in NumPy's own summation order for a contiguous
+ * axis of length d <= 128 (pairwise_sum's unrolled block): fewer than 8 terms left to right; else
+ * eight interleaved partial sums combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), the remainder added
+ * one by one; then a division by d. */
+__device__ __forceinline__ double numpy_row_mean(const RecordView &v, uint64_t n, uint64_t k)
+{
+    const int d = v.d;
+    double res;
+    if (d < 8) {
+        res = v.at(n, k, 0);
+        for (int j = 1; j < d; ++j) res = res + v.at(n, k, j);
+    } else {
+        double r[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r[q] = v.at(n, k, q);
+        int i = 8;
+        for (; i < d - (d % 8); i += 8) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) r[q] = r[q] + v.at(n, k, i + q);
+        }
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < d; ++i) res = res + v.at(n, k, i);
+    }
+    return res / (double)d;
+}
+
 /* s[c][n], c = chain * per_chain + component, for rows [row0, row0 + N) of the record:
  * a 32 x 32 tile transpose through LDS (coalesced reads along c, coalesced writes along n) */
-__global__ __launch_bounds__(256) void series_from_record_kernel(const double *__restrict__ traj, uint64_t row0,
-                                                                 uint64_t N, uint64_t K, int d, int mean_mode,
-                                                                 double *__restrict__ out)
+__global__ __launch_bounds__(256) void series_from_record_kernel(const RecordView v, uint64_t row0, uint64_t N,
+                                                                 int mean_mode, double *__restrict__ out)
 {
     __shared__ double tile[32][33];
-    const int per_chain = mean_mode ? 1 : d;
-    const uint64_t C = K * (uint64_t)per_chain;
+    const int per_chain = mean_mode ? 1 : v.d;
+    const uint64_t C = v.K * (uint64_t)per_chain;
     const uint64_t c0 = (uint64_t)blockIdx.x * 32, n0 = (uint64_t)blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
     for (int r = ty; r < 32; r += 8) {
         const uint64_t n = n0 + r, c = c0 + tx;
-        double v = 0.0;
-        if (n < N && c < C) {
-            const double *row = traj + (row0 + n) * K * d;
-            if (mean_mode) {
-                double sum = row[c * d];              /* np.mean(seq, axis=1): add.reduce over d, then / d */
-                for (int j = 1; j < d; ++j) sum = sum + row[c * d + j];
-                v = sum / (double)d;
-            } else {
-                v = row[c];
-            }
-        }
-        tile[r][tx] = v;
+        double val = 0.0;
+        if (n < N && c < C)
+            val = mean_mode ? numpy_row_mean(v, row0 + n, c) : v.at(row0 + n, c / (uint64_t)v.d, (int)(c % (uint64_t)v.d));
+        tile[r][tx] = val;
     }
     __syncthreads();
 #pragma unroll
@@ -158,12 +189,13 @@ size_t lds_for(uint64_t N) { return N <= (uint64_t)kLdsDoubles ? (size_t)N * siz
 
 }  // namespace
 
-hipError_t ymc_launch_series_from_record(const double *traj, uint64_t row0, uint64_t N, uint64_t K, int d,
+hipError_t ymc_launch_series_from_record(const double *traj, uint64_t row0, uint64_t N, uint64_t K, int d, int tile_KS,
                                          int mean_mode, double *out, hipStream_t s)
 {
     const uint64_t C = K * (uint64_t)(mean_mode ? 1 : d);
+    RecordView v{traj, K, d, tile_KS};
     hipLaunchKernelGGL(series_from_record_kernel, dim3((unsigned)((C + 31) / 32), (unsigned)((N + 31) / 32)), dim3(256), 0,
-                       s, traj, row0, N, K, d, mean_mode, out);
+                       s, v, row0, N, mean_mode, out);
     return hipGetLastError();
 }
 
