@@ -168,7 +168,13 @@ class FileCommunicator:
         return out
 
     def barrier(self):
-        self._exchange(np.zeros(1))
+        """All ranks leave within microseconds of each other: the file exchange alone is only as tight as
+        its polling interval, so the ranks agree on a wall-clock instant shortly after the last arrival
+        (one node, one clock) and spin until it."""
+        stamps = self._exchange(np.array([time.time()]))
+        release = max(float(v[0]) for v in stamps) + 0.05
+        while time.time() < release:
+            pass
 
     def allreduce_max(self, value):
         return float(max(v[0] for v in self._exchange(np.array([float(value)]))))
