@@ -84,3 +84,64 @@ def test_handles_may_be_destroyed_in_any_order():
                                         C.c_size_t(traj.nbytes)) == 0
     assert np.isfinite(traj).all()
     assert lib.ymc_run_destroy(raw_run) == 0        # frees the run, then the problem, then the context
+
+
+@pytest.mark.gpu
+def test_invalid_descriptions_are_refused_with_messages():
+    """Every misconfiguration the new samplers can meet returns a negative status and a message (no abort)."""
+    from yagremcmc_amd import _ffi, lowering
+    ctx = _ffi.default_context(0)
+
+    def gauss(d=2):
+        low = lowering.Lowered(_ffi.GAUSS_WHITENED, d)
+        low.set_array("mean", np.zeros(d))
+        low.set_array("whiten", np.eye(d))
+        return low
+
+    def linear(d=2, m=2, nd=3):
+        low = lowering.Lowered(_ffi.POSTERIOR_LINEAR, d)
+        low.desc.n_data, low.desc.data_dim = nd, m
+        for k, v in dict(data=np.zeros((nd, m)), noise_precision=np.ones(m), prior_mean=np.zeros(d),
+                         prior_precision=np.ones(d), fwd_matrix=np.ones((m, d)), fwd_shift=np.zeros(m)).items():
+            low.set_array(k, v)
+        return low
+
+    class Pre:
+        def __init__(self, low):
+            self.low = low
+
+    real = lowering.lower_density
+    lowering.lower_density = lambda d, rk4_steps=None: d.low if isinstance(d, Pre) else real(d, rk4_steps)
+    try:
+        with pytest.raises(lowering.UnsupportedPlugin, match="nested levels"):     # 8 surrogates = 5 levels
+            lowering.make_nested_problem(ctx, Pre(gauss()), [Pre(gauss())] * 8, [1] * 8, np.ones(2))
+        with pytest.raises(_ffi.YmcError, match="Subchain lengths"):
+            lowering.make_nested_problem(ctx, Pre(gauss()), [Pre(gauss())] * 2, [1, 0], np.ones(2))
+        with pytest.raises(_ffi.YmcError, match="kinds"):
+            lowering.make_nested_problem(ctx, Pre(gauss()), [Pre(gauss()), Pre(linear())], [2, 2], np.ones(2))
+        with pytest.raises(_ffi.YmcError, match="dimension"):
+            lowering.make_nested_problem(ctx, Pre(gauss()), [Pre(gauss(3)), Pre(gauss())], [2, 2], np.ones(2))
+    finally:
+        lowering.lower_density = real
+    with pytest.raises(_ffi.YmcError, match="Smallest senisible data size"):
+        lowering.make_problem(ctx, _ffi.METHOD_AEM2, linear(), np.ones(2), surrogate=linear(), sub_chain_length=3, aem=(1, 0))
+    with pytest.raises(_ffi.YmcError, match="Bayesian model"):
+        lowering.make_problem(ctx, _ffi.METHOD_AEM2, gauss(), np.ones(2), surrogate=gauss(), sub_chain_length=3, aem=(5, 0))
+    with pytest.raises(_ffi.YmcError, match="output dimension"):
+        lowering.make_problem(ctx, _ffi.METHOD_AEM2, linear(m=2), np.ones(2), surrogate=linear(m=3), sub_chain_length=3,
+                              aem=(5, 0))
+    with pytest.raises(lowering.UnsupportedPlugin):
+        lowering.make_problem(ctx, _ffi.METHOD_MLDA2, gauss(), np.ones(2), surrogate=gauss(), sub_chain_length=2,
+                              chol=np.eye(2))
+    with pytest.raises(_ffi.YmcError, match="not finite"):
+        lowering.make_problem(ctx, _ffi.METHOD_MRW, gauss(), np.ones(2), chol=np.array([[1.0, 0.0], [np.nan, 1.0]]))
+    # fetches that do not belong to the method
+    prob = lowering.make_problem(ctx, _ffi.METHOD_MRW, gauss(), np.ones(2))
+    run = _ffi.Run(prob, 1, 8, np.zeros((1, 2)), 4, _ffi.RECORD_ACCEPT)
+    run.advance(4)
+    with pytest.raises(_ffi.YmcError, match="not an adaptive-error-model run"):
+        run.error_model()
+    with pytest.raises(_ffi.YmcError, match="not a two-level run"):
+        run.sub_accept()
+    with pytest.raises(_ffi.YmcError, match="4 of 4 rows"):
+        run.advance(1)
