@@ -1,25 +1,33 @@
 #!/usr/bin/env python3
 """Headline benchmark: MH steps/s of the chain-ensemble hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5|iat]
 
-One bench "step" = one launch of the fused propose/evaluate/accept/record
-kernel advancing every chain of this rank by --transitions MH transitions
-(full trajectory + accept mask + FullDiagnostics' Welford moments, i.e. what
-example_mcmc_2d_singleLevel.py records).  Default workload = BASELINE.json
-configs[1]: the 2-D Gaussian target, random-walk proposal, 65 536 chains per
-GPU.  For N > 1 the driver launches one process per GPU (torchrun env:
-RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); chains shard by global chain id,
-nothing is exchanged while sampling (weak scaling), and the single collective
-is an RCCL all-gather of the per-chain summaries after the timed region.
-No PyTorch anywhere: the host drives libymc.so through ctypes.
+One bench "step" = one pass of the hot path over this rank's batch of chains:
+`launches_per_step` launches of the fused propose / evaluate / accept / record
+kernel, each advancing every chain by `transitions_per_launch` MH transitions
+into the record in HBM (full trajectory + accept mask + FullDiagnostics'
+Welford moments, i.e. what example_mcmc_2d_singleLevel.py records; the record
+is refilled by every launch).  The defaults make a step ~0.1 s, so the
+driver's 20 timed steps are a ~2 s region at the clock the chip SUSTAINS, and
+the W warm-up steps bring it there (no other pre-heating).  Default workload =
+BASELINE.json configs[1]: the 2-D Gaussian target, random-walk proposal,
+65 536 chains per GPU.  For N > 1 the driver launches one process per GPU
+(torchrun env: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); chains shard by
+global chain id, nothing is exchanged while sampling (weak scaling), and the
+single collective is an RCCL all-gather of the per-chain summaries after the
+timed region.  RCCL failing to come up is an error (exit code 1), never a
+silent switch of transport.  No PyTorch anywhere: the host drives libymc.so
+through ctypes.
 
-Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes per
-launch ((8 d + 1) B per transition per chain) / average kernel
-time measured with HIP events on the kernel's stream.
+Rank 0 prints ONE JSON line.  `roofline.achieved` = algorithmic bytes (or
+flops) per launch / average kernel time measured with HIP
+events on the kernel's stream in THIS run; fields copied from committed
+profiles carry a `source`.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -30,7 +38,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD MI355X data sheet, FP64 matrix (the micro-architecture guide lists no f64 MFMA rate)
+FP64_PEAK_TFLOPS = 78.6  # AMD MI355X data sheet: FP64 vector = FP64 matrix = 78.6 TFLOP/s (the guide lists no f64 rate)
+STEP_TARGET_S = 0.1      # a bench step is sized to about this much device time
 
 
 def parse():
@@ -38,16 +47,18 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "c4"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "c4", "iat"])
     ap.add_argument("--chains", type=int, default=0, help="chains per GPU (default: the workload's)")
-    ap.add_argument("--transitions", type=int, default=0, help="MH transitions per chain per step")
+    ap.add_argument("--transitions", type=int, default=0, help="MH transitions per chain per launch")
+    ap.add_argument("--launches-per-step", type=int, default=0, help="kernel launches per bench step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-moments", action="store_true")
     return ap.parse_args()
 
 
 # ---------------------------------------------------------------------------
-# synthetic workloads
+# synthetic workloads: plain arrays; the device problem is built
+# from them here, the CPU checker's (cpu_baseline only) from the same arrays
 # ---------------------------------------------------------------------------
 
 TGT_MEAN = np.array([1.0, 1.5])
@@ -59,38 +70,44 @@ def whitening(mean, cov):
     return v * np.sqrt(1.0 / w), float(mean.size * np.log(2.0 * np.pi) + np.sum(np.log(w)))
 
 
-def lv_problem_arrays():
-    rng = np.random.default_rng(1111)
-    design = rng.uniform(0.5, 1.5, size=(10, 2))
-    return design
+def _gauss(ffi, lowering, mean, cov):
+    U, c = whitening(mean, cov)
+    low = lowering.Lowered(ffi.GAUSS_WHITENED, mean.size)
+    low.set_array("mean", mean)
+    low.set_array("whiten", U)
+    low.desc.log_norm = c
+    return low, dict(kind="gauss", mean=mean, whiten=U, log_norm=c)
+
+
+def _lv_lowered(ffi, lowering, design, data, noise_prec, prior_mean, prior_prec):
+    low = lowering.Lowered(ffi.POSTERIOR_LV, 2)
+    low.desc.n_data, low.desc.data_dim = design.shape[0], 2
+    for k, v in (("data", data), ("noise_precision", noise_prec), ("prior_mean", prior_mean),
+                 ("prior_precision", prior_prec), ("design", design)):
+        low.set_array(k, v)
+    low.desc.t_final, low.desc.alpha, low.desc.gamma, low.desc.rk4_steps = 10.0, 0.8, 0.4, 50
+    return low
 
 
 def make_workload(name, ffi, ctx, lowering):
-    """-> (problem, x0 (1,d), default chains/GPU, default transitions/step, description, d, oracle problem)"""
-    from oracle import oracle  # only to describe the same problem to the cpu_baseline leg
-    if name in ("c2", "c5"):
-        U, c = whitening(TGT_MEAN, TGT_COV)
-        fine = lowering.Lowered(ffi.GAUSS_WHITENED, 2)
-        fine.set_array("mean", TGT_MEAN)
-        fine.set_array("whiten", U)
-        fine.desc.log_norm = c
+    """-> dict(problem, x0 (1,d), K, T, L, desc, d, spec): defaults of chains / GPU, transitions / launch and
+    launches / step; `spec` holds the arrays that describe the same problem to the cpu_baseline leg."""
+    if name in ("c2", "c5", "iat"):
+        fine, s_fine = _gauss(ffi, lowering, TGT_MEAN, TGT_COV)
         sigma = np.sqrt(np.reciprocal(np.reciprocal(np.full(2, 1.0))))
         x0 = np.array([[-8.0, -7.0]])
-        o_fine = oracle.gauss_whitened(TGT_MEAN, U, c)
-        if name == "c2":
+        if name in ("c2", "iat"):
             prob = lowering.make_problem(ctx, ffi.METHOD_MRW, fine, sigma)
-            return (prob, x0, 65536, 1000, "C2: 2-D Gaussian target (example_mcmc_2d_singleLevel.py), "
-                    "random-walk proposal var 1.0, x0=(-8,-7)", 2, dict(target=o_fine, sigma=sigma))
+            return dict(problem=prob, x0=x0, K=65536, T=10000, L=20, d=2,
+                        desc="C2: 2-D Gaussian target (example_mcmc_2d_singleLevel.py), random-walk proposal "
+                             "var 1.0, x0=(-8,-7)", spec=dict(target=s_fine, sigma=sigma))
         cm = TGT_MEAN + np.array([0.15, -0.2])
         cc = 2.0 * TGT_COV + np.array([[0.1, 1.2], [1.2, 0.05]])
-        Uc, c_c = whitening(cm, cc)
-        coarse = lowering.Lowered(ffi.GAUSS_WHITENED, 2)
-        coarse.set_array("mean", cm)
-        coarse.set_array("whiten", Uc)
-        coarse.desc.log_norm = c_c
+        coarse, s_coarse = _gauss(ffi, lowering, cm, cc)
         prob = lowering.make_problem(ctx, ffi.METHOD_MLDA2, fine, sigma, surrogate=coarse, sub_chain_length=6)
-        return (prob, x0, 131072, 200, "C5: two-level delayed acceptance (example_mcmc_2d_twoLevel.py), S=6",
-                2, dict(target=o_fine, sigma=sigma, surrogate=oracle.gauss_whitened(cm, Uc, c_c), S=6))
+        return dict(problem=prob, x0=x0, K=131072, T=1000, L=20, d=2,
+                    desc="C5: two-level delayed acceptance (example_mcmc_2d_twoLevel.py), S=6",
+                    spec=dict(target=s_fine, sigma=sigma, surrogate=s_coarse, S=6))
     if name == "c3":
         # linear forward model, d = m = 128, nData = 5 (SURVEY.md 8d)
         d = 128
@@ -98,7 +115,8 @@ def make_workload(name, ffi, ctx, lowering):
         A = rng.standard_normal((d, d)) / np.sqrt(d)
         b = rng.standard_normal(d)
         theta = rng.standard_normal(d)
-        data = np.array([A @ theta + b + np.sqrt(0.3) * rng.standard_normal(d) for _ in range(int(os.environ.get("YMC_C3_ND", "5")))])
+        data = np.array([A @ theta + b + np.sqrt(0.3) * rng.standard_normal(d)
+                         for _ in range(int(os.environ.get("YMC_C3_ND", "5")))])
         noise_prec, prior_mean, prior_prec = np.reciprocal(np.full(d, 0.3)), np.zeros(d), np.reciprocal(np.full(d, 5.0))
         low = lowering.Lowered(ffi.POSTERIOR_LINEAR, d)
         low.desc.n_data, low.desc.data_dim = data.shape[0], d
@@ -107,45 +125,51 @@ def make_workload(name, ffi, ctx, lowering):
             low.set_array(k, v)
         sigma = np.sqrt(np.reciprocal(np.reciprocal(np.full(d, 1.1e-3))))
         prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, sigma)
-        o_prob = oracle.posterior_linear(A, b, data, noise_prec, prior_mean, prior_prec)
-        return (prob, np.zeros((1, d)), 262144, 20, "C3: linear forward model posterior d = m = 128, nData = 5 "
-                "(fp64 MFMA tile kernel)", d, dict(target=o_prob, sigma=sigma))
-    # c4: Lotka-Volterra, nData=10, T=10, RK4 x 50
-    design = lv_problem_arrays()
+        return dict(problem=prob, x0=np.zeros((1, d)), K=262144, T=100, L=5, d=d,
+                    desc="C3: linear forward model posterior d = m = 128, nData = 5 (fp64 MFMA tile kernel)",
+                    spec=dict(target=dict(kind="linear", A=A, b=b, data=data, noise_prec=noise_prec,
+                                          prior_mean=prior_mean, prior_prec=prior_prec), sigma=sigma))
+    # c4: Lotka-Volterra, nData=10, T=10, RK4 x 50.  The synthetic observations are the PRODUCT's own forward
+    # map (ymc_forward_eval) at the true parameter plus noise.
+    design = np.random.default_rng(1111).uniform(0.5, 1.5, size=(10, 2))
     truth = np.log(np.array([0.4, 0.6]))
     noise_prec, prior_mean, prior_prec = np.reciprocal(np.full(2, 0.04)), np.zeros(2), np.reciprocal(np.full(2, 1.4))
-    o_prob = oracle.posterior_lv(design, 10.0, 0.8, 0.4, 50, np.zeros((10, 2)), noise_prec, prior_mean, prior_prec)
-    clean = oracle.forward(o_prob, truth).reshape(10, 2)
-    data = clean + np.sqrt(0.04) * np.random.default_rng(2222).standard_normal((10, 2))
-    o_prob = oracle.posterior_lv(design, 10.0, 0.8, 0.4, 50, data, noise_prec, prior_mean, prior_prec)
-    low = lowering.Lowered(ffi.POSTERIOR_LV, 2)
-    low.desc.n_data, low.desc.data_dim = 10, 2
-    for k, v in (("data", data), ("noise_precision", noise_prec), ("prior_mean", prior_mean),
-                 ("prior_precision", prior_prec), ("design", design)):
-        low.set_array(k, v)
-    low.desc.t_final, low.desc.alpha, low.desc.gamma, low.desc.rk4_steps = 10.0, 0.8, 0.4, 50
     sigma = np.sqrt(np.reciprocal(np.reciprocal(np.full(2, 0.15))))
-    prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, sigma)
-    return (prob, np.array([[-0.6, -0.3]]), 16384, 100,
-            "C4: Lotka-Volterra posterior, nData=10, T=10, RK4 x 50", 2, dict(target=o_prob, sigma=sigma))
+    probe = lowering.make_problem(ctx, ffi.METHOD_MRW,
+                                  _lv_lowered(ffi, lowering, design, np.zeros((10, 2)), noise_prec, prior_mean, prior_prec),
+                                  sigma)
+    clean = probe.forward(truth).reshape(10, 2)
+    data = clean + np.sqrt(0.04) * np.random.default_rng(2222).standard_normal((10, 2))
+    prob = lowering.make_problem(ctx, ffi.METHOD_MRW,
+                                 _lv_lowered(ffi, lowering, design, data, noise_prec, prior_mean, prior_prec), sigma)
+    return dict(problem=prob, x0=np.array([[-0.6, -0.3]]), K=16384, T=1000, L=10, d=2,
+                desc="C4: Lotka-Volterra posterior, nData=10, T=10, RK4 x 50",
+                spec=dict(target=dict(kind="lv", design=design, data=data, noise_prec=noise_prec,
+                                      prior_mean=prior_mean, prior_prec=prior_prec), sigma=sigma))
 
 
-def cpu_baseline(wl, d):
-    """The oracle (CPU restatement, kind "port") timed on the host cores on a
-    bounded sample of the same workload: same target, same recording, fewer
-    chains and transitions (~10-20 s of CPU work)."""
-    from oracle import oracle
+def cpu_baseline(spec, x0):
+    """The oracle (CPU restatement, kind "port") timed on the host cores on a bounded sample of the same
+    workload: same target, same recording, fewer chains and transitions (~20 s of CPU work in all): all
+    hardware threads the process may use, 16 threads (one GPU's share of an 8-GPU host) and one thread."""
+    from oracle import oracle  # the ONLY place the benchmark touches the checker
+
+    def lower(s):
+        if s["kind"] == "gauss":
+            return oracle.gauss_whitened(s["mean"], s["whiten"], s["log_norm"])
+        if s["kind"] == "linear":
+            return oracle.posterior_linear(s["A"], s["b"], s["data"], s["noise_prec"], s["prior_mean"], s["prior_prec"])
+        return oracle.posterior_lv(s["design"], 10.0, 0.8, 0.4, 50, s["data"], s["noise_prec"], s["prior_mean"],
+                                   s["prior_prec"])
+
+    target = lower(spec["target"])
+    surrogate = lower(spec["surrogate"]) if "surrogate" in spec else None
     visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = min(visible, 16)     # one GPU's share of the host (the box exposes all 256 hardware threads)
-
-    x0 = wl.get("x0")
-
-    def ensemble(K, threads):
-        return oracle.Ensemble(wl["target"], wl["sigma"], np.tile(x0, (K, 1)), 20250103,
-                               surrogate=wl.get("surrogate"), sub_chain_length=wl.get("S", 0), nthreads=threads)
+    visible = max(1, min(visible, oracle.max_threads()))
 
     def timed(K, T, threads, min_seconds):
-        e = ensemble(K, threads)
+        e = oracle.Ensemble(target, spec["sigma"], np.tile(x0, (K, 1)), 20250103, surrogate=surrogate,
+                            sub_chain_length=spec.get("S", 0), nthreads=threads)
         bufs = e.advance(T)          # untimed: faults the record buffers in, like the GPU warm-up
         reps, t = 0, time.perf_counter()
         while True:
@@ -155,16 +179,109 @@ def cpu_baseline(wl, d):
             if dt >= min_seconds:
                 return K * T * reps / dt, reps, dt
 
-    T = 500
-    K = 1024 * cores             # 25 B per transition of record: ~100 MB per 8 cores
-    rate, reps, dt = timed(K, T, cores, 10.0)
-    K1 = 1024
-    rate1, reps1, dt1 = timed(K1, T, 1, 4.0)
-    return {"value": rate, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"{K} chains x {T} transitions x {reps} passes of the same workload (trajectory, mask, log-density and "
-                      f"moments recorded, record buffers resident), {cores} OpenMP threads, {dt:.1f} s",
-            "host_threads_visible": visible, "single_thread_steps_per_s": rate1,
+    heavy = spec["target"]["kind"] != "gauss"
+    T = 50 if heavy else 500
+    per_thread = 16 if heavy else 1024    # ~25 B of record per transition (d = 2)
+    rate_all, reps, dt = timed(per_thread * visible, T, visible, 8.0)
+    n16 = min(16, visible)
+    rate16 = timed(per_thread * n16, T, n16, 4.0)[0] if n16 != visible else rate_all
+    rate1 = timed(per_thread, T, 1, 4.0)[0]
+    return {"value": rate_all, "unit": "steps/s", "cores": visible, "kind": "port",
+            "sample": f"{per_thread * visible} chains x {T} transitions x {reps} passes of the same workload "
+                      f"(trajectory, mask, log-density and moments recorded, record buffers resident), "
+                      f"{visible} OpenMP threads, {dt:.1f} s",
+            "threads_16_steps_per_s": rate16, "single_thread_steps_per_s": rate1,
             "reference_single_core_steps_per_s_survey_container": 2.2e4}
+
+
+def profiled(workload, K, T):
+    """What the committed rocprofv3 passes of this configuration say (profiles/pmc_traffic.json): HBM bytes
+    per launch and the SQ instruction counts.  Copied, not measured in this run -- hence the `source`."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(path)).get(f"{workload}_K{K}_T{T}")
+    except (OSError, ValueError):
+        rec = None
+    return rec or {}
+
+
+def roofline_block(args, wl, K, T, kernel_ms, launches, clock_mhz, info):
+    d = wl["d"]
+    ksec = kernel_ms * 1e-3
+    bytes_launch = K * T * (8 * d + 1)
+    hbm = bytes_launch / ksec / 1e9 if ksec > 0 else 0.0
+    rec = profiled(args.workload, K, T)
+    traffic = rec.get("hbm_bytes_per_launch")
+    common = {"traffic": traffic, "traffic_source": rec.get("source") if traffic else None,
+              "kernel_ms_avg": kernel_ms, "launches_timed": launches,
+              "algorithmic_bytes_per_launch": bytes_launch, "hbm_gb_per_s": hbm, "hbm_frac": hbm / HBM_PEAK_GBPS}
+    # VALU issue: what bounds the lane-per-chain kernels.  One wave64 VALU instruction occupies its SIMD's
+    # issue port for 4 cycles; the chip has 4 SIMDs per CU.
+    sq = rec.get("sq_per_launch") or {}
+    valu = None
+    if sq.get("SQ_INSTS_VALU") and clock_mhz and ksec > 0:
+        waves = rec.get("waves_per_launch") or math.ceil(K / 64)
+        simds = 4 * info["compute_units"]
+        avail = ksec * clock_mhz * 1e6 * simds          # SIMD issue cycles in one launch
+        ipt = sq["SQ_INSTS_VALU"] / (waves * T)
+        valu = {"instr_per_transition": ipt, "salu_instr_per_transition": sq.get("SQ_INSTS_SALU", 0.0) / (waves * T),
+                "cycles_per_transition": avail / (waves * T), "frac": 4.0 * sq["SQ_INSTS_VALU"] / avail,
+                "clock_mhz": clock_mhz, "waves_per_simd": waves / simds,
+                "note": "frac = 4 cycles x wave-level VALU instructions per launch / (kernel time x sustained clock x "
+                        "SIMDs); instruction counts per wave and transition",
+                "source": {"instr": rec.get("source"), "kernel_time_and_clock": "this run"}}
+    if args.workload == "c3":
+        flops = 2.0 * d * d * K * T
+        tf = flops / ksec / 1e12 if ksec > 0 else 0.0
+        return dict(common, bound="mfma", achieved=tf, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / FP64_PEAK_TFLOPS,
+                    algorithmic_flops_per_launch=flops, valu=valu,
+                    note="per GPU (rank 0); v_mfma_f64_16x16x4_f64 GEMV (2 d m flop per transition); the 128 normal "
+                         "draws per transition are VALU work on top of it -- DESIGN.md")
+    if args.workload == "c4":
+        flops = 10 * 50 * 50.0 * K * T   # n_data x rk4_steps x 50 flop (30 fp64 instructions, 20 of them fma)
+        tf = flops / ksec / 1e12 if ksec > 0 else 0.0
+        return dict(common, bound="valu", achieved=tf, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / FP64_PEAK_TFLOPS,
+                    algorithmic_flops_per_launch=flops, valu=valu,
+                    note="per GPU (rank 0); fp64 vector flops of the RK4 integrator alone (10 design rows x 50 steps x "
+                         "50 flop per transition) against the 78.6 TFLOP/s vector peak; HBM figures alongside")
+    return dict(common, bound="hbm", achieved=hbm, peak=HBM_PEAK_GBPS, unit="GB/s", frac=hbm / HBM_PEAK_GBPS, valu=valu,
+                note="per GPU (rank 0); bytes = (8 d + 1) per transition per chain"
+                     + (" (per FINE step; every fine step also makes 6 coarse transitions)" if args.workload == "c5" else "")
+                     + "; the kernel is VALU-issue bound (Philox + Box-Muller + exp per transition) -- see `valu` "
+                       "and DESIGN.md")
+
+
+def bench_iat(args, ffi, ctx, wl, K, info):
+    """Post-processing workload: integrated autocorrelation time of every chain from the record
+    in HBM (autocorrelation.py:92-140), 'mean' and 'max'.  One step = both modes over all chains."""
+    N = args.transitions or 10000
+    run = ffi.Run(wl["problem"], 20250103, K, wl["x0"], N, ffi.RECORD_TRAJECTORY)
+    run.advance(N)
+    run.sync()
+    burn = 200
+    n = N - burn
+    for _ in range(max(args.warmup, 1)):
+        iat_mean = run.iat(burn, n, 0)
+        iat_max = run.iat(burn, n, 1)
+    steps = max(1, args.steps)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        iat_mean = run.iat(burn, n, 0)
+        iat_max = run.iat(burn, n, 1)
+    elapsed = time.perf_counter() - t0
+    bytes_step = 2.0 * K * n * 2 * 8          # both modes read the d = 2 record once
+    out = {"metric": "IAT post-processing, chains/s", "value": 2.0 * K * steps / elapsed, "unit": "chain-IATs/s",
+           "n_gpus": 1, "steps": steps, "warmup": args.warmup, "ms_per_step": elapsed / steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"IAT ('mean' + 'max') of {K} chains x {n} states x d=2 from the HBM record of C2",
+                      "chains_per_gpu": K, "states": n},
+           "timed_region_s": elapsed,
+           "roofline": {"bound": "hbm", "achieved": bytes_step * steps / elapsed / 1e9, "peak": HBM_PEAK_GBPS,
+                        "unit": "GB/s", "frac": bytes_step * steps / elapsed / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                        "note": "algorithmic bytes = one read of the record per mode; end-to-end time of ymc_run_iat "
+                                "(series extraction + lag sums + result copy)"},
+           "iat_mean_median": float(np.median(iat_mean)), "iat_max_median": float(np.median(iat_max)), "device": info}
+    print(json.dumps(out))
 
 
 def main():
@@ -183,58 +300,79 @@ def main():
         device %= ffi.device_count()  # rehearsal of the N > 1 flow on a box with fewer GPUs than ranks
     ctx = ffi.Context(device)
     info = ctx.info()
-    prob, x0, def_chains, def_T, desc, d, wl = make_workload(args.workload, ffi, ctx, lowering)
-    wl["x0"] = x0
-    K = args.chains or def_chains
-    T = args.transitions or def_T
+    wl = make_workload(args.workload, ffi, ctx, lowering)
+    K = args.chains or wl["K"]
+    if args.workload == "iat":
+        return bench_iat(args, ffi, ctx, wl, K, info)
+    T = args.transitions or wl["T"]
+    L = args.launches_per_step or wl["L"]
+    d, x0 = wl["d"], wl["x0"]
     if args.workload == "c3":
         args.no_moments = True   # the reference's default diagnostics; the tile kernel keeps no Welford state
     flags = ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT | (0 if args.no_moments else ffi.RECORD_MOMENTS)
-    run = ffi.Run(prob, 20250103, K, x0, T, flags, chain_offset=rank * K)
+    run = ffi.Run(wl["problem"], 20250103, K, x0, T, flags, chain_offset=rank * K)
 
     # YMC_BENCH_FORCE_COMM=1 exercises the RCCL path with a single rank (1-GPU rehearsal of the N > 1 flow)
     use_comm = world > 1 or os.environ.get("YMC_BENCH_FORCE_COMM") == "1"
-    comm = distributed.make_communicator(ctx, rank, world) if use_comm else None
+    comm = None
+    if use_comm:
+        try:
+            comm = distributed.make_communicator(ctx, rank, world)
+        except distributed.CommError as e:
+            print(f"bench.py: rank {rank}: {e}", file=sys.stderr, flush=True)
+            sys.exit(1)
+
+    def step():
+        for _ in range(L):
+            run.rewind_record()
+            run.advance(T)
 
     def barrier():
         run.sync()
         if comm is not None:
             comm.barrier()
 
-    # Untimed pre-heat: a cold MI355X takes some 50-100 ms of load to reach its sustained clock (measured:
-    # the same kernel runs 14 % slower during the first milliseconds of a process).  The W warm-up steps
-    # of the contract follow; with small W they alone would leave the ramp inside the timed region.
-    preheat_ms = float(os.environ.get("YMC_BENCH_PREHEAT_MS", "400"))
-    t_heat = time.perf_counter()
-    while (time.perf_counter() - t_heat) * 1e3 < preheat_ms:
-        for _ in range(8):
-            run.rewind_record()
-            run.advance(T)
-        run.sync()
+    t_w = time.perf_counter()
     for _ in range(args.warmup):
-        run.rewind_record()
-        run.advance(T)
+        step()
     run.sync()
-    run.kernel_time_ms()  # drop pre-heat and warm-up launches from the kernel-time average
+    warm_s = time.perf_counter() - t_w
+    run.kernel_time_ms()  # drop the warm-up launches from the kernel-time average
+
+    # the clock the chip holds DURING the timed region: a one-wave probe next to the chain kernels for
+    # ~80 % of the region's expected length (from the warm-up; without one, a calibration step)
+    if args.warmup > 0:
+        expect_s = warm_s / args.warmup * args.steps
+    else:
+        t_c = time.perf_counter()
+        step()
+        run.sync()
+        expect_s = (time.perf_counter() - t_c) * args.steps
+        run.kernel_time_ms()
+    probe_ms = min(max(0.8 * expect_s * 1e3, 1.0), 20000.0)
 
     barrier()
     t0 = time.perf_counter()
+    ctx.clock_probe_start(probe_ms)
     for _ in range(args.steps):
-        run.rewind_record()
-        run.advance(T)
+        step()
     run.sync()
     elapsed = time.perf_counter() - t0
     if comm is not None:
         elapsed = comm.allreduce_max(elapsed)
     kernel_ms, launches = run.kernel_time_ms()
+    clock_mhz, probe_ran_ms = ctx.clock_probe_read()
 
     # the single collective of the run: gather the per-chain summaries
-    gather_ms = None
+    gather_ms = nranks_seen = None
     if comm is not None:
         tg = time.perf_counter()
         packed = comm.allgather_summary(run)  # (world, K, 3d+5) u64
         gather_ms = (time.perf_counter() - tg) * 1e3
         summary = distributed.unpack_summaries(packed, d)
+        nranks_seen = comm.count()
+        backend = comm.backend
+        comm.close()
     else:
         summary = run.summary()
     if rank != 0:
@@ -242,64 +380,37 @@ def main():
     total_steps = run.steps_done()[0]
     pooled = distributed.pooled_diagnostics(summary, total_steps)
 
-    transitions = float(world) * K * T * args.steps
+    transitions = float(world) * K * T * L * args.steps
     value = transitions / elapsed
-    bytes_per_transition = 8 * d + 1
-    launch_bytes = K * T * bytes_per_transition
-    achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    traffic = valu_busy = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            rec = json.load(open(tpath)).get(f"{args.workload}_K{K}_T{T}")
-            traffic = rec["hbm_bytes_per_launch"] if rec else None
-            sq = (rec or {}).get("sq_per_launch") or {}
-            if sq.get("SQ_WAVE_CYCLES"):
-                # what actually bounds these kernels: the share of wave-cycles with the VALU busy
-                valu_busy = sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"]
-        except Exception:
-            traffic = valu_busy = None
-
-    if args.workload == "c3":
-        # the forward map is a batched 128 x 128 GEMV on the fp64 matrix cores: 2 d m flop per transition
-        flops = 2.0 * d * d * K * T
-        tf = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
-        roofline = {"bound": "mfma", "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tf / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "kernel_ms_avg": kernel_ms,
-                    "launches_timed": launches, "algorithmic_flops_per_launch": flops,
-                    "algorithmic_bytes_per_launch": launch_bytes, "hbm_gb_per_s": achieved,
-                    "note": "per GPU (rank 0); v_mfma_f64_16x16x4_f64 GEMV (2 d m flop per transition); on gfx950 the "
-                            "f64 MFMA shares the SIMD's fp64 datapath with the VALU, so the 128 normal draws per "
-                            "transition (VALU) add to, rather than hide behind, the matrix time -- DESIGN.md"}
-    else:
-        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel_ms_avg": kernel_ms,
-                    "launches_timed": launches, "algorithmic_bytes_per_launch": launch_bytes,
-                    "note": "per GPU (rank 0); bytes = (8 d + 1) per transition per chain, traffic = PMC WRITE_SIZE + "
-                            "2 x FETCH_SIZE of the same configuration (profiles/); the kernel is VALU-issue bound "
-                            "(Philox + Box-Muller + exp per transition, one wave per SIMD at 65 536 chains), "
-                            "see DESIGN.md"}
+    roofline = roofline_block(args, wl, K, T, kernel_ms, launches, clock_mhz, info)
     out = {
         "metric": "MH steps/sec (whole node)", "value": value, "unit": "steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": desc, "chains_per_gpu": K, "chains_total": world * K,
-                   "transitions_per_step": T, "record": "trajectory f64 [T][K][d] + accept u8 [T][K]"
-                   + ("" if args.no_moments else " + Welford moments"), "parallelism": f"chains sharded over {world} GPU(s)",
+        "config": {"workload": wl["desc"], "chains_per_gpu": K, "chains_total": world * K,
+                   "transitions_per_launch": T, "launches_per_step": L, "transitions_per_step": T * L,
+                   "record": "trajectory f64 [T][K][d] + accept u8 [T][K]"
+                   + ("" if args.no_moments else " + Welford moments") + ", refilled by every launch",
+                   "parallelism": f"chains sharded over {world} GPU(s)",
                    "rng": "Philox4x32-10, seed 20250103, keyed by global chain id"},
-        "roofline": dict(roofline, valu_busy_frac_profiled=valu_busy),
-        "hbm_gb_per_s_whole_node": world * achieved,
+        "timed_region_s": elapsed,
+        "sustained_clock_mhz": clock_mhz,
+        "clock_probe_ms": probe_ran_ms,
+        "roofline": roofline,
+        "hbm_gb_per_s_whole_node": world * roofline["hbm_gb_per_s"],
         "kernel_steps_per_s_per_gpu": K * T / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0,
         "acceptance_rate": pooled["acceptance_rate"],
         "pooled_mean": None if args.no_moments else [float(v) for v in pooled["mean"]],
         "chains_flagged_nonfinite": pooled["flagged"],
         "gather_ms": gather_ms,
-        "preheat_ms": preheat_ms,
-        "collective": None if comm is None else comm.backend,
+        "collective": None if comm is None else backend,
+        "nranks_seen": nranks_seen,
         "device": info,
     }
+    if args.workload == "c5":
+        out["coarse_sub_steps_per_s"] = value * 6
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(wl, d)
+        out["cpu_baseline"] = cpu_baseline(wl["spec"], x0)
     print(json.dumps(out))
 
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define YMC_ABI_VERSION 2
+#define YMC_ABI_VERSION 3
 
 typedef enum ymc_status {
     YMC_OK = 0,
@@ -153,7 +153,13 @@ typedef struct ymc_run_desc {
     uint64_t x0_rows;              /* 1 (broadcast) or n_chains */
     uint64_t record_capacity;      /* transitions the record buffers hold */
     uint32_t record_flags;
-    uint32_t reserved_;
+    /* thinned record (SURVEY 8b record_mode; the examples thin by the IAT right after run,
+     * example_mcmc_2d_singleLevel.py:71-79): 0 or 1 = every transition is recorded; s > 1 = the
+     * trajectory / log-density rows hold the states after transitions s, 2s, 3s, ... of the run
+     * (rows s-1::s of the full record), so record_capacity counts THINNED rows.  Accept counts and
+     * Welford moments still see every transition; the per-transition decision records
+     * (YMC_RECORD_ACCEPT, YMC_RECORD_SUB_ACCEPT) are full-rate data and cannot be combined with s > 1. */
+    uint32_t record_stride;
 } ymc_run_desc;
 
 typedef struct ymc_device_info {
@@ -179,6 +185,13 @@ int ymc_device_count(int *count);
 int ymc_ctx_create(int device, ymc_ctx **out);
 int ymc_ctx_destroy(ymc_ctx *ctx);
 int ymc_ctx_device_info(const ymc_ctx *ctx, ymc_device_info *out);
+/* The shader clock the device HOLDS while it works (the data-sheet clock_mhz is a ceiling: under a
+ * sustained fp64 load the MI355X is power-limited and runs below it).  _start launches a one-wave
+ * probe on a side stream that sleeps for duration_ms (<= 20 000) next to whatever the context's
+ * stream is running and counts shader cycles (s_memtime) against the 100 MHz reference counter
+ * (s_memrealtime); _read waits for it and returns cycles / time. */
+int ymc_ctx_clock_probe_start(ymc_ctx *ctx, double duration_ms);
+int ymc_ctx_clock_probe_read(ymc_ctx *ctx, double *mhz, double *measured_ms);
 
 /* ChainBuilder.build_method(), chain/builder.py:72-83 */
 int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem **out);
@@ -225,6 +238,10 @@ int ymc_run_fetch_state(ymc_run *run, double *state, double *logpost);
 int ymc_run_fetch_summary(ymc_run *run, uint64_t *accepted, uint64_t *wf_n, double *wf_mean,
                           double *wf_m2, uint32_t *status);
 
+/* the packed per-chain summary records of this run (the payload of the multi-GPU gather below,
+ * written by the same kernel): dst[n_chains][ymc_summary_words] */
+int ymc_run_fetch_packed_summary(ymc_run *run, uint64_t *dst, size_t dst_bytes);
+
 /* DensityInterface.evaluate_log for a batch: which = 0 target, 1 surrogate.
  * x[n][d] -> out[n], status[n] (may be NULL) */
 int ymc_logdensity_eval(ymc_ctx *ctx, const ymc_problem *problem, int which, uint64_t n,
@@ -263,9 +280,13 @@ int ymc_numerics_eval(ymc_ctx *ctx, int fn, uint64_t n, const double *x, double 
  * exchanged while sampling.  The single collective is the gather of the
  * per-chain summaries at the end. */
 #define YMC_UNIQUE_ID_BYTES 128
+/* loads librccl (every rank can find out that it is missing BEFORE any rank blocks in the bring-up) */
+int ymc_comm_preload(void);
 int ymc_comm_unique_id(void *id, size_t id_bytes);
 int ymc_comm_create(ymc_ctx *ctx, const void *id, size_t id_bytes, int nranks, int rank, ymc_comm **out);
 int ymc_comm_destroy(ymc_comm *comm);
+/* ncclCommCount / ncclCommUserRank: the size and rank RCCL itself reports (either may be NULL) */
+int ymc_comm_count(const ymc_comm *comm, int *nranks, int *rank);
 int ymc_comm_barrier(ymc_comm *comm);
 int ymc_comm_allreduce_max(ymc_comm *comm, double *value);
 /* words per chain of a packed summary record: 3*d + 5 (state, logpost,

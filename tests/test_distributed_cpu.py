@@ -6,6 +6,7 @@ result must equal the single-rank run over all chains."""
 import os
 import socket
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -89,22 +90,97 @@ def test_two_ranks_equal_one(tmp_path):
     assert np.array_equal(pooled["mean"], one["mean"]) and np.array_equal(pooled["marginal_variance"], one["marginal_variance"])
 
 
-def test_shard_and_rendezvous(tmp_path, monkeypatch):
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_shard():
     from yagremcmc_amd import distributed
     assert [distributed.shard(1024, r, 4) for r in range(4)] == [(0, 256), (256, 256), (512, 256), (768, 256)]
     with pytest.raises(ValueError):
         distributed.shard(10, 0, 3)
     with pytest.raises(ValueError):
         distributed.shard(8, 2, 2)
-    monkeypatch.setenv("MASTER_PORT", "29517")
-    a, b = distributed.FileRendezvous(str(tmp_path)), distributed.FileRendezvous(str(tmp_path))
-    assert a.path == b.path
-    with pytest.raises(RuntimeError):
-        b.wait(128, timeout=0.2)
-    a.publish(b"x" * 128)
-    assert b.wait(128, timeout=1.0) == b"x" * 128
-    a.cleanup()
-    assert not os.path.exists(a.path)
+
+
+def _store_ranks(world, port, body, **kw):
+    """run body(store) on `world` ranks (threads; every TcpStore is its own client, rank 0 also serves)"""
+    import threading
+    from yagremcmc_amd import distributed
+    out, errs = [None] * world, []
+
+    def one(r):
+        try:
+            st = distributed.TcpStore(r, world, "127.0.0.1", port, **kw)
+            try:
+                out[r] = body(st)
+            finally:
+                st.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, e))
+
+    ts = [threading.Thread(target=one, args=(r,)) for r in range(world)]
+    for t in reversed(ts):  # rank 0 last: the others must wait for it
+        t.start()
+        time.sleep(0.05)
+    for t in ts:
+        t.join(60)
+    assert not errs, errs
+    return out
+
+
+def test_tcp_store_allgather_and_broadcast():
+    """The store that carries the RCCL unique id: rank 0 serves next to MASTER_PORT (which the
+    launcher's own store may hold), every rank gets every part in rank order, large payloads included."""
+    port = _free_port()
+    with socket.socket() as holder:  # somebody (torchrun's c10d store) owns MASTER_PORT itself
+        holder.bind(("127.0.0.1", port))
+        holder.listen(1)
+
+        def body(st):
+            a = st.allgather(bytes([st.rank]) * (st.rank + 1))
+            b = st.broadcast(b"I" * 128 if st.rank == 0 else b"")
+            big = st.allgather(np.full(200_000, st.rank, dtype=np.uint64).tobytes())
+            return a, b, [np.frombuffer(x, dtype=np.uint64)[[0, -1]].tolist() for x in big], st.nonce, st.port
+        res = _store_ranks(3, port, body, timeout=20)
+    for a, b, big, nonce, p in res:
+        assert a == [b"\0", b"\1\1", b"\2\2\2"] and b == b"I" * 128
+        assert big == [[0, 0], [1, 1], [2, 2]]
+        assert nonce == res[0][3] and p == res[0][4] and p != port
+
+
+def test_tcp_store_back_to_back_same_key():
+    """Two launches with the same MASTER_PORT and run id, one after the other (a torchrun restart, a
+    second launch from the same shell): nothing of the first is visible to the second."""
+    port = _free_port()
+    first = _store_ranks(2, port, lambda st: (st.allgather(b"first%d" % st.rank), st.nonce), timeout=20)
+    second = _store_ranks(2, port, lambda st: (st.allgather(b"second%d" % st.rank), st.nonce), timeout=20)
+    assert first[0][0] == first[1][0] == [b"first0", b"first1"]
+    assert second[0][0] == second[1][0] == [b"second0", b"second1"]
+    assert first[0][1] != second[0][1]  # a fresh nonce per launch
+
+
+def test_tcp_store_times_out_without_rank0():
+    from yagremcmc_amd import distributed
+    with pytest.raises(distributed.CommError, match="no store of this launch answered"):
+        distributed.TcpStore(1, 2, "127.0.0.1", _free_port(), timeout=0.5)
+
+
+def test_tcp_store_rejects_other_launches(monkeypatch):
+    """A store of ANOTHER launch on a candidate port is passed over (handshake key mismatch)."""
+    from yagremcmc_amd import distributed
+    port = _free_port()
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job-a")
+    a = distributed.TcpStore(0, 2, "127.0.0.1", port, timeout=5)
+    try:
+        monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job-b")
+        with pytest.raises(distributed.CommError):
+            distributed.TcpStore(1, 2, "127.0.0.1", port, timeout=0.6)
+    finally:
+        a.sock.close()
+        a.server.stop.set()
 
 
 class _FakeRun:
@@ -121,13 +197,14 @@ class _FakeRun:
         return self.e.x, self.e.lp
 
 
-def _file_comm_worker(rank, world, port, total, steps, q):
+def _tcp_comm_worker(rank, world, port, total, steps, q):
     sys.path.insert(0, ROOT)
     from oracle import oracle as o
     from yagremcmc_amd import distributed
-    os.environ.update(MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), YMC_COMM="file")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      YMC_COMM="tcp")
     comm = distributed.make_communicator(None, rank, world)
-    assert comm.backend == "file"
+    assert comm.backend == "tcp" and comm.count() == world
     g = np.load(os.path.join(ROOT, "tests", "golden", "f2_mrw_2d.npz"))
     p = o.gauss_whitened(g["mean"], g["whiten"], float(g["log_norm"]))
     off, k = distributed.shard(total, rank, world)
@@ -137,23 +214,22 @@ def _file_comm_worker(rank, world, port, total, steps, q):
     tmax = comm.allreduce_max(float(rank + 1))
     packed = comm.allgather_summary(_FakeRun(e))
     for _ in range(3):
-        comm.barrier()  # exercises the clean-up of earlier collectives
+        comm.barrier()
+    comm.close()
     if rank == 0:
         q.put((packed, tmax))
 
 
-def test_file_communicator_two_ranks(tmp_path):
-    """The stand-in used when RCCL cannot come up: same gather result as the device layout."""
+def test_tcp_communicator_two_ranks():
+    """YMC_COMM=tcp (explicit only): the rehearsal communicator gives the device layout's gather."""
     import multiprocessing as mp
     from oracle import oracle as o
     from yagremcmc_amd import distributed
     total, steps, world = 64, 100, 2
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_file_comm_worker, args=(r, world, port, total, steps, q)) for r in range(world)]
+    procs = [ctx.Process(target=_tcp_comm_worker, args=(r, world, port, total, steps, q)) for r in range(world)]
     for p_ in procs:
         p_.start()
     packed, tmax = q.get(timeout=120)
@@ -168,3 +244,42 @@ def test_file_communicator_two_ranks(tmp_path):
     assert np.array_equal(packed.reshape(-1, 11), _pack_like_device(e, 2))
     summary = distributed.unpack_summaries(packed, 2)
     assert np.array_equal(summary["state"], e.x) and np.array_equal(summary["accepted"], e.acc_count)
+
+
+def _rccl_must_fail_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from yagremcmc_amd import distributed
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.pop("YMC_COMM", None)
+    try:
+        # no GPU context here: the RCCL bring-up cannot succeed on any rank
+        distributed.make_communicator(None, rank, world)
+    except distributed.CommError as e:
+        q.put((rank, str(e)))
+        sys.exit(7)
+    q.put((rank, "a communicator came back"))
+
+
+def test_rccl_failure_is_an_error_on_every_rank():
+    """No stand-in: when RCCL cannot be brought up, every rank raises (and the bench exits non-zero)
+    instead of switching to another transport."""
+    import multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_must_fail_worker, args=(r, world, port, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p_ in procs:
+        p_.join(timeout=60)
+        assert p_.exitcode == 7
+    for r in range(world):
+        assert "failed" in got[r] and "RCCL is required" in got[r], got[r]
+    from yagremcmc_amd import distributed
+    with pytest.raises(distributed.CommError, match="'rccl' and 'tcp'"):
+        os.environ["YMC_COMM"] = "file"
+        try:
+            distributed.make_communicator(None, 0, 1)
+        finally:
+            del os.environ["YMC_COMM"]

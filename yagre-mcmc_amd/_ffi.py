@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libymc.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # ymc_status
 OK, ERR_INVALID, ERR_DEVICE, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_COMM = 0, -1, -2, -3, -4, -5
@@ -70,7 +70,7 @@ class RunDesc(C.Structure):
     _fields_ = [
         ("seed", C.c_uint64), ("chain_offset", C.c_uint64), ("n_chains", C.c_uint64),
         ("initial_state", _dp), ("x0_rows", C.c_uint64), ("record_capacity", C.c_uint64),
-        ("record_flags", C.c_uint32), ("reserved_", C.c_uint32),
+        ("record_flags", C.c_uint32), ("record_stride", C.c_uint32),
     ]
 
 
@@ -88,6 +88,8 @@ _PROTOTYPES = {
     "ymc_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "ymc_ctx_destroy": (C.c_int, [_vp]),
     "ymc_ctx_device_info": (C.c_int, [_vp, C.POINTER(DeviceInfo)]),
+    "ymc_ctx_clock_probe_start": (C.c_int, [_vp, C.c_double]),
+    "ymc_ctx_clock_probe_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ymc_problem_create": (C.c_int, [_vp, C.POINTER(ProblemDesc), C.POINTER(_vp)]),
     "ymc_problem_destroy": (C.c_int, [_vp]),
     "ymc_run_create": (C.c_int, [_vp, _vp, C.POINTER(RunDesc), C.POINTER(_vp)]),
@@ -105,6 +107,7 @@ _PROTOTYPES = {
     "ymc_run_fetch_error_model": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "ymc_run_fetch_state": (C.c_int, [_vp, _vp, _vp]),
     "ymc_run_fetch_summary": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "ymc_run_fetch_packed_summary": (C.c_int, [_vp, _vp, C.c_size_t]),
     "ymc_logdensity_eval": (C.c_int, [_vp, _vp, C.c_int, _u64, _vp, _vp, _vp]),
     "ymc_forward_eval": (C.c_int, [_vp, _vp, C.c_int, _u64, _vp, _vp]),
     "ymc_run_iat": (C.c_int, [_vp, _u64, _u64, C.c_int, C.c_double, _vp]),
@@ -112,9 +115,11 @@ _PROTOTYPES = {
     "ymc_iat_series": (C.c_int, [_vp, _vp, _u64, _u64, C.c_double, _vp, _vp, _u64]),
     "ymc_rng_fill": (C.c_int, [_vp, _u64, _u64, _u64, _u64, _u64, C.c_int32, _vp, _vp]),
     "ymc_numerics_eval": (C.c_int, [_vp, C.c_int, _u64, _vp, _vp, _vp]),
+    "ymc_comm_preload": (C.c_int, []),
     "ymc_comm_unique_id": (C.c_int, [_vp, C.c_size_t]),
     "ymc_comm_create": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(_vp)]),
     "ymc_comm_destroy": (C.c_int, [_vp]),
+    "ymc_comm_count": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ymc_comm_barrier": (C.c_int, [_vp]),
     "ymc_comm_allreduce_max": (C.c_int, [_vp, C.POINTER(C.c_double)]),
     "ymc_summary_words": (C.c_int, [_vp, C.POINTER(_u64)]),
@@ -201,6 +206,16 @@ class Context(Handle):
         return dict(name=di.name.decode(), arch=di.arch.decode(), compute_units=di.compute_units,
                     clock_mhz=di.clock_mhz, hbm_bytes=di.hbm_bytes)
 
+    def clock_probe_start(self, duration_ms):
+        """Start measuring the shader clock the device holds for the next duration_ms (next to whatever runs)."""
+        check(lib().ymc_ctx_clock_probe_start(self.raw, float(duration_ms)))
+
+    def clock_probe_read(self):
+        """-> (MHz, measured ms) of the probe started last."""
+        mhz, ms = C.c_double(0.0), C.c_double(0.0)
+        check(lib().ymc_ctx_clock_probe_read(self.raw, C.byref(mhz), C.byref(ms)))
+        return mhz.value, ms.value
+
     def rng_fill(self, seed, chain0, K, t0, nt, d, normals=True, uniforms=True):
         xi = np.empty((nt, K, d)) if normals else None
         u = np.empty((nt, K)) if uniforms else None
@@ -283,20 +298,22 @@ class Problem(Handle):
 class Run(Handle):
     _destroy = "ymc_run_destroy"
 
-    def __init__(self, problem, seed, n_chains, x0, record_capacity, record_flags, chain_offset=0):
+    def __init__(self, problem, seed, n_chains, x0, record_capacity, record_flags, chain_offset=0, record_stride=1):
         x0 = f64(x0)
         if x0.ndim == 1:
             x0 = x0.reshape(1, -1)
         if x0.shape[1] != problem.dim or x0.shape[0] not in (1, n_chains):
             raise ValueError(f"initial state has shape {x0.shape}; expected (1|{n_chains}, {problem.dim})")
         desc = RunDesc(seed=seed, chain_offset=chain_offset, n_chains=n_chains, initial_state=dptr(x0),
-                       x0_rows=x0.shape[0], record_capacity=record_capacity, record_flags=record_flags)
+                       x0_rows=x0.shape[0], record_capacity=record_capacity, record_flags=record_flags,
+                       record_stride=int(record_stride))
         out = _vp()
         check(lib().ymc_run_create(problem.ctx.raw, problem.raw, C.byref(desc), C.byref(out)))
         super().__init__(out)
         self.problem = problem
         self.K, self.d, self.S = int(n_chains), problem.dim, problem.S
         self.flags = record_flags
+        self.stride = max(int(record_stride), 1)
 
     def advance(self, nsteps):
         check(lib().ymc_run_advance(self.raw, int(nsteps)))
@@ -376,6 +393,12 @@ class Run(Handle):
         check(lib().ymc_run_iat(self.raw, first, n, method, float(sokal_const), vptr(out)))
         return out
 
+    def packed_summary(self):
+        """(K, 3d+5) u64: the records pack_summary_kernel writes (the payload of the multi-GPU gather)."""
+        out = np.empty((self.K, self.summary_words()), dtype=np.uint64)
+        check(lib().ymc_run_fetch_packed_summary(self.raw, vptr(out), out.nbytes))
+        return out
+
     def summary_words(self):
         w = _u64(0)
         check(lib().ymc_summary_words(self.raw, C.byref(w)))
@@ -393,6 +416,23 @@ class Communicator(Handle):
         buf = C.create_string_buffer(UNIQUE_ID_BYTES)
         check(lib().ymc_comm_unique_id(buf, UNIQUE_ID_BYTES))
         return bytes(buf.raw)
+
+    @staticmethod
+    def preload():
+        """Load librccl now (raises YmcError if it cannot be found)."""
+        check(lib().ymc_comm_preload())
+
+    def count(self):
+        """The communicator's size as RCCL reports it (ncclCommCount)."""
+        n = C.c_int(0)
+        check(lib().ymc_comm_count(self.raw, C.byref(n), None))
+        return n.value
+
+    def close(self):
+        super().close()
+        store, self.store = getattr(self, "store", None), None
+        if store is not None:
+            store.close()
 
     def __init__(self, ctx, unique_id, nranks, rank):
         out = _vp()

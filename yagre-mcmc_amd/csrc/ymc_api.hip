@@ -19,6 +19,8 @@
 #include "ymc_post.h"
 #include "ymc_tile.h"
 
+int ymc_internal_pack_summary(ymc_run *run, uint64_t **dev_out, uint64_t *words, hipStream_t *stream, int *device);
+
 namespace {
 
 thread_local std::string g_error;
@@ -97,6 +99,10 @@ struct ymc_ctx {
     hipDeviceProp_t prop{};
     int users = 0;
     bool released = false;
+    /* clock probe (ymc_ctx_clock_probe_*): its own stream, so that it runs NEXT to the chain kernels */
+    hipStream_t probe_stream = nullptr;
+    uint64_t *probe_out = nullptr;
+    bool probe_pending = false;
 };
 
 struct ymc_problem {
@@ -672,6 +678,11 @@ int ymc_ctx_create(int device, ymc_ctx **out)
 static void ctx_free(ymc_ctx *ctx)
 {
     (void)hipSetDevice(ctx->device);
+    if (ctx->probe_stream) {
+        (void)hipStreamSynchronize(ctx->probe_stream);
+        (void)hipStreamDestroy(ctx->probe_stream);
+    }
+    if (ctx->probe_out) (void)hipFree(ctx->probe_out);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -703,6 +714,35 @@ int ymc_ctx_device_info(const ymc_ctx *ctx, ymc_device_info *out)
     out->compute_units = ctx->prop.multiProcessorCount;
     out->clock_mhz = ctx->prop.clockRate / 1000;
     out->hbm_bytes = ctx->prop.totalGlobalMem;
+    return YMC_OK;
+}
+
+int ymc_ctx_clock_probe_start(ymc_ctx *ctx, double duration_ms)
+{
+    if (!ctx) return fail(YMC_ERR_INVALID, "null argument");
+    if (!(duration_ms > 0.0) || duration_ms > 20000.0)
+        return fail(YMC_ERR_INVALID, "probe duration must be in (0, 20000] ms, got %g", duration_ms);
+    if (ctx->probe_pending) return fail(YMC_ERR_INVALID, "a clock probe is already running; read it first");
+    YMC_HIP(hipSetDevice(ctx->device));
+    if (!ctx->probe_stream) YMC_HIP(hipStreamCreateWithFlags(&ctx->probe_stream, hipStreamNonBlocking));
+    if (!ctx->probe_out) YMC_HIP(hipMalloc((void **)&ctx->probe_out, 2 * sizeof(uint64_t)));
+    YMC_HIP(ymc_launch_clock_probe((uint64_t)(duration_ms * 1e5), ctx->probe_out, ctx->probe_stream));
+    ctx->probe_pending = true;
+    return YMC_OK;
+}
+
+int ymc_ctx_clock_probe_read(ymc_ctx *ctx, double *mhz, double *measured_ms)
+{
+    if (!ctx || !mhz) return fail(YMC_ERR_INVALID, "null argument");
+    if (!ctx->probe_pending) return fail(YMC_ERR_INVALID, "no clock probe was started");
+    YMC_HIP(hipSetDevice(ctx->device));
+    uint64_t host[2] = {0, 0};
+    YMC_HIP(hipMemcpyAsync(host, ctx->probe_out, sizeof host, hipMemcpyDeviceToHost, ctx->probe_stream));
+    YMC_HIP(hipStreamSynchronize(ctx->probe_stream));
+    ctx->probe_pending = false;
+    if (host[1] == 0) return fail(YMC_ERR_DEVICE, "the clock probe reported no elapsed time");
+    *mhz = (double)host[0] / (double)host[1] * 100.0; /* cycles per tick of the 100 MHz reference */
+    if (measured_ms) *measured_ms = (double)host[1] * 1e-5;
     return YMC_OK;
 }
 
@@ -868,6 +908,8 @@ int ymc_run_create(ymc_ctx *ctx, const ymc_problem *problem, const ymc_run_desc 
         return fail(YMC_ERR_INVALID, "initial_state must have 1 or n_chains rows");
     if (records_anything(desc->record_flags) && desc->record_capacity == 0)
         return fail(YMC_ERR_INVALID, "record_capacity must be positive when something is recorded");
+    if (desc->record_stride > 1)
+        return fail(YMC_ERR_UNSUPPORTED, "thinned records are not available yet");
     if (problem->tile && (desc->record_flags & YMC_RECORD_MOMENTS) && !(desc->record_flags & YMC_RECORD_TRAJECTORY))
         return fail(YMC_ERR_UNSUPPORTED,
                     "at this dimension the Welford moments are replayed from the record: record the trajectory too");
@@ -1153,6 +1195,20 @@ int ymc_run_fetch_summary(ymc_run *run, uint64_t *accepted, uint64_t *wf_n, doub
     return YMC_OK;
 }
 
+int ymc_run_fetch_packed_summary(ymc_run *run, uint64_t *dst, size_t dst_bytes)
+{
+    if (!run || !dst) return fail(YMC_ERR_INVALID, "null argument");
+    uint64_t *packed = nullptr, words = 0;
+    hipStream_t stream = nullptr;
+    int device = 0;
+    YMC_TRY(ymc_internal_pack_summary(run, &packed, &words, &stream, &device));
+    const size_t total = (size_t)run->K * words * sizeof(uint64_t);
+    if (dst_bytes < total) return fail(YMC_ERR_INVALID, "destination holds %zu bytes, %zu needed", dst_bytes, total);
+    YMC_HIP(hipMemcpyAsync(dst, packed, total, hipMemcpyDeviceToHost, stream));
+    YMC_HIP(hipStreamSynchronize(stream));
+    return YMC_OK;
+}
+
 int ymc_logdensity_eval(ymc_ctx *ctx, const ymc_problem *problem, int which, uint64_t n, const double *x,
                         double *out, uint32_t *status)
 {
@@ -1356,11 +1412,4 @@ int ymc_internal_ctx_device(const ymc_ctx *ctx, hipStream_t *stream)
 }
 uint64_t ymc_internal_run_chains(const ymc_run *run) { return run->K; }
 void ymc_internal_ctx_retain(ymc_ctx *ctx) { ctx->users += 1; }
-void ymc_internal_ctx_release(ymc_ctx *ctx)
-{
-    if (--ctx->users == 0 && ctx->released) {
-        (void)hipSetDevice(ctx->device);
-        if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-        delete ctx;
-    }
-}
+void ymc_internal_ctx_release(ymc_ctx *ctx) { ctx_drop_user(ctx); }

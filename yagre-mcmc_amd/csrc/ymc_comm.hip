@@ -31,6 +31,8 @@ struct Rccl {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -53,10 +55,13 @@ int load_rccl()
     r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.CommCount = (decltype(r.CommCount))dlsym(h, "ncclCommCount");
+    r.CommUserRank = (decltype(r.CommUserRank))dlsym(h, "ncclCommUserRank");
     r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
     r.AllReduce = (decltype(r.AllReduce))dlsym(h, "ncclAllReduce");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
-    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.AllReduce || !r.GetErrorString)
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.CommCount || !r.CommUserRank || !r.AllGather ||
+        !r.AllReduce || !r.GetErrorString)
         return ymc_internal_fail(YMC_ERR_COMM, "librccl.so lacks a required symbol");
     g_rccl = r;
     return YMC_OK;
@@ -89,6 +94,23 @@ struct ymc_comm {
 };
 
 extern "C" {
+
+int ymc_comm_preload(void) { return load_rccl(); }
+
+int ymc_comm_count(const ymc_comm *comm, int *nranks, int *rank)
+{
+    if (!comm) return ymc_internal_fail(YMC_ERR_INVALID, "null argument");
+    /* what RCCL itself says, not what the caller passed to ymc_comm_create */
+    if (nranks) {
+        ncclResult_t r = g_rccl.CommCount(comm->comm, nranks);
+        if (r != ncclSuccess) return nccl_fail("ncclCommCount", r);
+    }
+    if (rank) {
+        ncclResult_t r = g_rccl.CommUserRank(comm->comm, rank);
+        if (r != ncclSuccess) return nccl_fail("ncclCommUserRank", r);
+    }
+    return YMC_OK;
+}
 
 int ymc_comm_unique_id(void *id, size_t id_bytes)
 {

@@ -44,6 +44,7 @@ hipError_t ymc_launch_recip(uint64_t n0, uint64_t count, double *out, hipStream_
 hipError_t ymc_launch_rng_fill(uint64_t seed, uint64_t chain0, uint64_t K, uint64_t t0, uint64_t nt, int d,
                                double *xi, double *u, hipStream_t s);
 hipError_t ymc_launch_numerics(int fn, uint64_t n, const double *x, double *y0, double *y1, hipStream_t s);
+hipError_t ymc_launch_clock_probe(uint64_t ticks_100mhz, uint64_t *out, hipStream_t s);
 hipError_t ymc_launch_pack_summary(uint64_t K, int d, uint64_t wf_n, const double *x, const double *lp,
                                    const uint64_t *accepted, const double *wmean, const double *wm2,
                                    const uint32_t *status, uint64_t *out, hipStream_t s);

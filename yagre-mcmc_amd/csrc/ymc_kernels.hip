@@ -435,6 +435,25 @@ __global__ __launch_bounds__(kBlock) void numerics_kernel(int fn, uint64_t n, co
     }
 }
 
+/* One wave that sleeps next to the working kernels for `ticks` periods of the 100 MHz reference
+ * counter and reports how many shader cycles went by: out[0] = s_memtime delta, out[1] =
+ * s_memrealtime delta.  Always terminates: the reference counter advances whatever the chip does. */
+__global__ __launch_bounds__(64) void clock_probe_kernel(uint64_t ticks, uint64_t *__restrict__ out)
+{
+    const uint64_t r0 = __builtin_amdgcn_s_memrealtime();
+    const uint64_t c0 = __builtin_amdgcn_s_memtime();
+    uint64_t r1;
+    do {
+        __builtin_amdgcn_s_sleep(127);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    } while (r1 - r0 < ticks);
+    const uint64_t c1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) {
+        out[0] = c1 - c0;
+        out[1] = r1 - r0;
+    }
+}
+
 /* per-chain summary record, 3d+5 eight-byte words:
  * state[d], logpost, accepted, wf_n, wf_mean[d], wf_m2[d], status */
 __global__ __launch_bounds__(kBlock) void pack_summary_kernel(uint64_t K, int d, uint64_t wf_n,
@@ -600,6 +619,12 @@ hipError_t ymc_launch_recip(uint64_t n0, uint64_t count, double *out, hipStream_
 hipError_t ymc_launch_numerics(int fn, uint64_t n, const double *x, double *y0, double *y1, hipStream_t s)
 {
     hipLaunchKernelGGL(numerics_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, fn, n, x, y0, y1);
+    return hipGetLastError();
+}
+
+hipError_t ymc_launch_clock_probe(uint64_t ticks, uint64_t *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, s, ticks, out);
     return hipGetLastError();
 }
 

@@ -6,14 +6,32 @@ global chain ids [r*K, (r+1)*K) and every chain draws from the stream of its
 GLOBAL id, so per-chain results do not depend on W.  After sampling each rank
 contributes its packed summaries (3d+5 eight-byte words per chain, written by
 pack_summary_kernel) to one RCCL all-gather (`_ffi.Communicator`).
+
+Bring-up (no PyTorch in these processes): the RCCL unique id travels over a
+small TCP store that rank 0 serves next to MASTER_ADDR:MASTER_PORT
+(`TcpStore`), so any launcher that exports RANK / WORLD_SIZE / MASTER_ADDR /
+MASTER_PORT works -- torchrun, mpirun wrappers, a shell loop.  A failure to
+bring RCCL up is an ERROR on every rank (`CommError`): there is no stand-in
+that a benchmark could silently fall back to.  `YMC_COMM=tcp` selects, on
+request only, a communicator over the same store (CPU rehearsals of the N > 1
+flow and ranks sharing one GPU, where RCCL refuses to initialise).
 """
+import hashlib
 import os
+import selectors
+import socket
+import struct
 import sys
+import threading
 import time
 
 import numpy as np
 
 from .diagnostics import merge_welford
+
+
+class CommError(RuntimeError):
+    """The inter-rank communicator could not be brought up, or the ranks disagree."""
 
 
 def launch_env():
@@ -60,39 +78,233 @@ def pooled_diagnostics(summary, steps):
                 flagged=int((summary["status"] != 0).sum()))
 
 
-class FileRendezvous:
-    """Exchange of the RCCL unique id without PyTorch: rank 0 publishes the id in
-    a file keyed by the launcher's pid, MASTER_PORT and run id; the others poll."""
+# ---------------------------------------------------------------------------
+# the TCP store
+# ---------------------------------------------------------------------------
 
-    def __init__(self, directory="/tmp"):
-        key = f"{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}"
-        self.path = os.path.join(directory, f"ymc_rdzv_{key}")
+_MAGIC = b"YMCSTOR2"
+_PORT_SPAN = 32          # candidate ports after MASTER_PORT
+_HELLO = struct.Struct("<8s16sII")     # magic, key, rank, world
+_WELCOME = struct.Struct("<8s16s")     # magic, nonce of this launch
+_MSG = struct.Struct("<QQ")            # collective sequence number, payload bytes
 
-    def publish(self, payload):
-        tmp = f"{self.path}.{os.getpid()}"
-        with open(tmp, "wb") as f:
-            f.write(payload)
-        os.replace(tmp, self.path)
 
-    def wait(self, nbytes, timeout=300.0):
-        deadline = time.time() + timeout
-        while time.time() < deadline:
-            try:
-                with open(self.path, "rb") as f:
-                    payload = f.read()
-                if len(payload) == nbytes:
-                    return payload
-            except FileNotFoundError:
-                pass
-            time.sleep(0.05)
-        raise RuntimeError("rank 0 never published the RCCL unique id")
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(min(n - len(buf), 1 << 20))
+        if not chunk:
+            raise ConnectionError("peer closed the store connection")
+        buf += chunk
+    return bytes(buf)
 
-    def cleanup(self):
+
+def _launch_key(world, port):
+    """Identifies ONE launch: ranks of another job that shares the machine (and possibly a
+    candidate port) never pass each other's handshake."""
+    run_id = os.environ.get("TORCHELASTIC_RUN_ID", "none")
+    restart = os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+    return hashlib.sha256(f"{run_id}|{restart}|{world}|{port}".encode()).digest()[:16]
+
+
+def candidate_ports(master_port):
+    """Where rank 0 may serve the store.  MASTER_PORT itself is NOT used: under
+    `python -m torch.distributed.run --master-port P` (static rendezvous) the launcher's own c10d
+    store already listens on P, so rank 0 takes the first free port of P+1 .. P+32 and the other
+    ranks find it by the handshake."""
+    override = os.environ.get("YMC_STORE_PORT")
+    if override:
+        return [int(override)]
+    out = []
+    for i in range(1, _PORT_SPAN + 1):
+        p = master_port + i
+        if p > 65535:
+            p = 1024 + (p - 65536)
+        out.append(p)
+    return out
+
+
+class _StoreServer(threading.Thread):
+    """Rank 0's side: W persistent connections; collective number `seq` completes when every rank has
+    sent its part, and every rank then receives all parts in rank order."""
+
+    def __init__(self, listener, world, key, nonce):
+        super().__init__(name="ymc-store", daemon=True)
+        self.listener, self.world, self.key, self.nonce = listener, world, key, nonce
+        self.sel = selectors.DefaultSelector()
+        self.conns = {}          # sock -> rank
+        self.parts = {}          # seq -> {rank: payload}
+        self.stop = threading.Event()
+        listener.setblocking(False)
+        self.sel.register(listener, selectors.EVENT_READ, None)
+
+    def run(self):
         try:
-            os.remove(self.path)
+            while not self.stop.is_set():
+                for key, _ in self.sel.select(timeout=0.2):
+                    if key.fileobj is self.listener:
+                        self._accept()
+                    else:
+                        self._serve(key.fileobj)
+        finally:
+            for s in list(self.conns) + [self.listener]:
+                try:
+                    s.close()
+                except OSError:
+                    pass
+
+    def _accept(self):
+        try:
+            sock, _ = self.listener.accept()
+        except OSError:
+            return
+        sock.settimeout(5.0)
+        try:
+            magic, key, rank, world = _HELLO.unpack(_recv_exact(sock, _HELLO.size))
+            if magic != _MAGIC or key != self.key or world != self.world or not 0 <= rank < world \
+                    or rank in self.conns.values():
+                sock.close()
+                return
+            sock.sendall(_WELCOME.pack(_MAGIC, self.nonce))
+        except (OSError, ConnectionError, struct.error):
+            sock.close()
+            return
+        sock.settimeout(None)
+        sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+        self.conns[sock] = rank
+        self.sel.register(sock, selectors.EVENT_READ, None)
+
+    def _drop(self, sock):
+        self.sel.unregister(sock)
+        self.conns.pop(sock, None)
+        sock.close()
+
+    def _serve(self, sock):
+        try:
+            seq, nbytes = _MSG.unpack(_recv_exact(sock, _MSG.size))
+            payload = _recv_exact(sock, nbytes) if nbytes else b""
+        except (OSError, ConnectionError):
+            self._drop(sock)
+            return
+        got = self.parts.setdefault(seq, {})
+        got[self.conns[sock]] = payload
+        if len(got) == self.world:
+            body = b"".join(struct.pack("<Q", len(got[r])) + got[r] for r in range(self.world))
+            del self.parts[seq]
+            for s in list(self.conns):
+                try:
+                    s.sendall(_MSG.pack(seq, len(body)) + body)
+                except OSError:
+                    self._drop(s)
+
+
+class TcpStore:
+    """All-gather of byte strings among the ranks of one launch over loopback / the node's network.
+    Rank 0 serves (a daemon thread in its process); every rank, 0 included, is a client."""
+
+    def __init__(self, rank, world, addr=None, port=None, timeout=None):
+        self.rank, self.world = int(rank), int(world)
+        self.addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        self.master_port = int(port if port is not None else os.environ.get("MASTER_PORT", "29500"))
+        self.timeout = float(timeout if timeout is not None else os.environ.get("YMC_COMM_TIMEOUT", "300"))
+        self.key = _launch_key(self.world, self.master_port)
+        self.seq = 0
+        self.server = None
+        self.nonce = None
+        self.port = None
+        if self.rank == 0:
+            self._serve()
+        self.sock = self._connect()
+
+    def _serve(self):
+        last = None
+        for p in candidate_ports(self.master_port):
+            s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            try:
+                s.bind((self.addr, p))
+                s.listen(self.world + 8)
+            except OSError as e:
+                last = e
+                s.close()
+                continue
+            self.server = _StoreServer(s, self.world, self.key, os.urandom(16))
+            self.server.start()
+            self.port = p
+            return
+        raise CommError(f"rank 0 cannot serve the store on any of {candidate_ports(self.master_port)} "
+                        f"at {self.addr}: {last}")
+
+    def _connect(self):
+        deadline = time.time() + self.timeout
+        ports = [self.port] if self.port else candidate_ports(self.master_port)
+        while True:
+            for p in ports:
+                try:
+                    s = socket.create_connection((self.addr, p), timeout=2.0)
+                except OSError:
+                    continue
+                try:
+                    s.settimeout(5.0)
+                    s.sendall(_HELLO.pack(_MAGIC, self.key, self.rank, self.world))
+                    magic, nonce = _WELCOME.unpack(_recv_exact(s, _WELCOME.size))
+                    if magic != _MAGIC:
+                        raise ConnectionError("not this launch's store")
+                except (OSError, ConnectionError, struct.error):
+                    s.close()
+                    continue
+                s.settimeout(self.timeout)
+                s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                self.nonce, self.port = nonce, p
+                return s
+            if time.time() > deadline:
+                raise CommError(f"rank {self.rank}: no store of this launch answered on {self.addr} ports {ports} "
+                                f"within {self.timeout:.0f} s (is rank 0 running with the same MASTER_ADDR / "
+                                "MASTER_PORT / WORLD_SIZE?)")
+            time.sleep(0.05)
+
+    def allgather(self, payload):
+        """-> [payload of rank 0, ..., payload of rank W-1]; blocks until every rank has called."""
+        seq, self.seq = self.seq, self.seq + 1
+        payload = bytes(payload)
+        try:
+            self.sock.sendall(_MSG.pack(seq, len(payload)) + payload)
+            rseq, nbytes = _MSG.unpack(_recv_exact(self.sock, _MSG.size))
+            body = _recv_exact(self.sock, nbytes)
+        except (OSError, ConnectionError) as e:
+            raise CommError(f"rank {self.rank}: store collective {seq} failed ({e}); another rank has "
+                            "probably exited") from e
+        if rseq != seq:
+            raise CommError(f"rank {self.rank}: store answered collective {rseq}, expected {seq}")
+        out, off = [], 0
+        for _ in range(self.world):
+            (n,) = struct.unpack_from("<Q", body, off)
+            out.append(body[off + 8:off + 8 + n])
+            off += 8 + n
+        return out
+
+    def broadcast(self, payload, root=0):
+        return self.allgather(payload if self.rank == root else b"")[root]
+
+    def close(self):
+        try:
+            self.sock.settimeout(5.0)      # a peer that died without saying goodbye is not waited for
+            self.allgather(b"bye")         # nobody tears the server down under a peer's last collective
+        except CommError:
+            pass
+        try:
+            self.sock.close()
         except OSError:
             pass
+        if self.server is not None:
+            self.server.stop.set()
+            self.server.join(timeout=2.0)
+            self.server = None
 
+
+# ---------------------------------------------------------------------------
+# communicators
+# ---------------------------------------------------------------------------
 
 class _StdoutToStderr:
     """RCCL prints a version banner on the C stdout while a communicator is
@@ -101,7 +313,6 @@ class _StdoutToStderr:
 
     def __enter__(self):
         import ctypes
-        import sys
         sys.stdout.flush()
         self._libc = ctypes.CDLL(None)
         self._saved = os.dup(1)
@@ -128,93 +339,103 @@ def pack_summary_host(run, d):
     return out
 
 
-class FileCommunicator:
-    """The communicator's interface over files of one node's /tmp: the stand-in when RCCL cannot be
-    brought up (library missing, bootstrap refused).  Nothing on the sampling path uses it; it only
-    keeps the barrier, the max-over-ranks timing and the final gather of summaries working."""
+class TcpCommunicator:
+    """The communicator's interface over the TCP store.  Selected ONLY by YMC_COMM=tcp: rehearsals of
+    the N > 1 flow without N GPUs.  Nothing on the sampling path uses it; it carries the barrier, the
+    max-over-ranks timing and the final gather of summaries."""
 
-    backend = "file"
+    backend = "tcp"
 
-    def __init__(self, rank, world, directory="/tmp", timeout=600.0):
-        self.rank, self.nranks, self.timeout = rank, world, timeout
-        self.dir = FileRendezvous(directory).path + "_comm"
-        os.makedirs(self.dir, exist_ok=True)
-        self.seq = 0
+    def __init__(self, store):
+        self.store, self.rank, self.nranks = store, store.rank, store.world
 
-    def _path(self, seq, rank):
-        return os.path.join(self.dir, f"op{seq}_r{rank}.npy")
-
-    def _exchange(self, array):
-        seq, self.seq = self.seq, self.seq + 1
-        if seq >= 2:
-            try:
-                os.remove(self._path(seq - 2, self.rank))  # every rank has read it (it wrote op seq-1 since)
-            except OSError:
-                pass
-        tmp = self._path(seq, self.rank) + f".{os.getpid()}.tmp"
-        with open(tmp, "wb") as f:
-            np.save(f, np.ascontiguousarray(array))
-        os.replace(tmp, self._path(seq, self.rank))
-        out, deadline = [], time.time() + self.timeout
-        for r in range(self.nranks):
-            while True:
-                try:
-                    out.append(np.load(self._path(seq, r)))
-                    break
-                except (FileNotFoundError, ValueError, EOFError):
-                    if time.time() > deadline:
-                        raise RuntimeError(f"rank {r} did not reach collective {seq}")
-                    time.sleep(0.002)
-        return out
+    def count(self):
+        return self.nranks
 
     def barrier(self):
-        """All ranks leave within microseconds of each other: the file exchange alone is only as tight as
-        its polling interval, so the ranks agree on a wall-clock instant shortly after the last arrival
-        (one node, one clock) and spin until it."""
-        stamps = self._exchange(np.array([time.time()]))
-        release = max(float(v[0]) for v in stamps) + 0.05
-        while time.time() < release:
-            pass
+        self.store.allgather(b"")
 
     def allreduce_max(self, value):
-        return float(max(v[0] for v in self._exchange(np.array([float(value)]))))
+        return max(struct.unpack("<d", p)[0] for p in self.store.allgather(struct.pack("<d", float(value))))
 
     def allgather_summary(self, run):
-        return np.stack(self._exchange(pack_summary_host(run, run.d)))
+        mine = run.packed_summary() if hasattr(run, "packed_summary") else pack_summary_host(run, run.d)
+        parts = self.store.allgather(np.ascontiguousarray(mine, dtype=np.uint64).tobytes())
+        return np.stack([np.frombuffer(p, dtype=np.uint64).reshape(mine.shape) for p in parts])
+
+    def close(self):
+        self.store.close()
 
 
-_FALLBACK_MARK = b"YMC-NO-RCCL"
+class _Watchdog:
+    """ncclCommInitRank blocks inside C for as long as a peer is missing.  If it has not returned after
+    `seconds`, say so and end the process: a hung rank must not outlive its launcher's patience."""
+
+    def __init__(self, seconds, what, rank):
+        self.done = threading.Event()
+        self.t = threading.Thread(target=self._run, args=(seconds, what, rank), daemon=True)
+
+    def _run(self, seconds, what, rank):
+        if not self.done.wait(seconds):
+            print(f"ymc: rank {rank}: {what} did not finish within {seconds:.0f} s; exiting", file=sys.stderr, flush=True)
+            os._exit(3)
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.done.set()
+        return False
+
+
+def _agree(store, ok, message, what):
+    """Every rank reports ok / its error; all of them raise if any failed."""
+    answers = store.allgather((b"ok" if ok else b"E:" + message.encode("utf-8", "replace")))
+    bad = [(r, a[2:].decode("utf-8", "replace")) for r, a in enumerate(answers) if a != b"ok"]
+    if bad:
+        detail = "; ".join(f"rank {r}: {m}" for r, m in bad)
+        raise CommError(f"{what} failed ({detail}). RCCL is required for more than one rank; "
+                        "set YMC_COMM=tcp only to rehearse the flow without it.")
 
 
 def make_communicator(ctx, rank, world):
-    """The RCCL communicator of this rank; a FileCommunicator if YMC_COMM=file is set or RCCL fails to
-    come up (rank 0 then tells the others through the rendezvous file, so all ranks agree)."""
+    """The communicator of this rank: RCCL (default, `backend == "rccl"`), or the TCP stand-in when
+    YMC_COMM=tcp is set explicitly.  RCCL failing to come up raises CommError on EVERY rank -- the
+    caller exits non-zero; nothing falls back."""
     from . import _ffi
-    if os.environ.get("YMC_COMM", "rccl") == "file":
-        return FileCommunicator(rank, world)
+    mode = os.environ.get("YMC_COMM", "rccl")
+    if mode not in ("rccl", "tcp"):
+        raise CommError(f"YMC_COMM={mode!r}: the communicators are 'rccl' and 'tcp'")
+    store = TcpStore(rank, world)
+    if mode == "tcp":
+        return TcpCommunicator(store)
     # one node: RCCL's bootstrap sockets go over loopback (the container hostname may not resolve)
     os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
-    rdzv = FileRendezvous()
-    mark = _FALLBACK_MARK.ljust(_ffi.UNIQUE_ID_BYTES, b"\0")
+    timeout = store.timeout
     with _StdoutToStderr():
-        if rank == 0:
-            try:
-                uid = _ffi.Communicator.unique_id()
-            except (OSError, _ffi.YmcError) as e:
-                print(f"ymc: RCCL unavailable ({e}); using the file communicator", file=sys.stderr)
-                uid = mark
-            rdzv.publish(uid)
-        else:
-            uid = rdzv.wait(_ffi.UNIQUE_ID_BYTES)
-        if uid == mark:
-            return FileCommunicator(rank, world)
+        # 1. what can fail on ONE rank (librccl missing, unique id) is settled before anyone blocks
+        uid, err = b"", ""
         try:
-            comm = _ffi.Communicator(ctx, uid, world, rank)
-            comm.barrier()
+            if rank == 0:
+                uid = _ffi.Communicator.unique_id()
+            else:
+                _ffi.Communicator.preload()
+        except (OSError, _ffi.YmcError) as e:
+            err = str(e)
+        _agree(store, not err, err, "loading RCCL")
+        uid = store.broadcast(uid)
+        # 2. the collective bring-up, under a watchdog
+        comm, err = None, ""
+        try:
+            with _Watchdog(timeout, "ncclCommInitRank", rank):
+                comm = _ffi.Communicator(ctx, uid, world, rank)
+                comm.barrier()
+                seen = comm.count()
+            if seen != world:
+                err = f"RCCL reports {seen} ranks, the launch has {world}"
         except _ffi.YmcError as e:
-            # ncclCommInitRank fails on every rank or on none (it is itself a collective)
-            print(f"ymc: RCCL communicator failed on rank {rank} ({e}); using the file communicator", file=sys.stderr)
-            return FileCommunicator(rank, world)
-    if rank == 0:
-        rdzv.cleanup()
+            err = str(e)
+        _agree(store, not err, err, "ncclCommInitRank")
+    comm.store = store
     return comm
