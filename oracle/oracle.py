@@ -15,7 +15,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libymc_oracle.so")
+# YMC_ORACLE_LIB: another build of the same source (the sanitizer build of tests/test_sanitizers.py)
+_LIB_PATH = os.environ.get("YMC_ORACLE_LIB") or os.path.join(_HERE, "libymc_oracle.so")
 
 GAUSS_WHITENED, GAUSS_ISO1D, POST_LINEAR, POST_LV = 1, 2, 3, 4
 EQ_EXACT, EQ_ISCLOSE = 0, 1

@@ -168,6 +168,43 @@ def test_tcp_store_times_out_without_rank0():
         distributed.TcpStore(1, 2, "127.0.0.1", _free_port(), timeout=0.5)
 
 
+def test_tcp_store_is_not_fooled_by_an_echo():
+    """A peer that echoes the hello back -- what a TCP self-connection on a candidate port does (the client's
+    ephemeral source port can equal the port it probes) -- is not a store."""
+    import threading
+    from yagremcmc_amd import distributed
+    port = _free_port()
+    srv = socket.socket()
+    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    srv.bind(("127.0.0.1", port + 1))
+    srv.listen(4)
+    srv.settimeout(0.2)
+    stop = threading.Event()
+
+    def echo():
+        while not stop.is_set():
+            try:
+                c, _ = srv.accept()
+            except OSError:
+                continue
+            try:
+                c.settimeout(1.0)
+                c.sendall(c.recv(4096))
+            except OSError:
+                pass
+            c.close()
+
+    t = threading.Thread(target=echo, daemon=True)
+    t.start()
+    try:
+        with pytest.raises(distributed.CommError, match="no store of this launch answered"):
+            distributed.TcpStore(1, 2, "127.0.0.1", port, timeout=1.0)
+    finally:
+        stop.set()
+        t.join(2)
+        srv.close()
+
+
 def test_tcp_store_rejects_other_launches(monkeypatch):
     """A store of ANOTHER launch on a candidate port is passed over (handshake key mismatch)."""
     from yagremcmc_amd import distributed

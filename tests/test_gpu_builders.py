@@ -600,6 +600,27 @@ def test_two_level_lotka_volterra_model_hierarchy_vs_oracle():
     assert 0.05 < out["acc"].mean() < 0.999 and not np.array_equal(out["acc"], out["sub_acc"][:, -1, :])
 
 
+def test_iat_of_a_stuck_chain_is_reported_not_invented():
+    """A chain that never moves (or was flagged non-finite and froze) has a constant series: c0 = 0 and the
+    autocorrelation is 0 / 0.  The device reports IAT_UNDEFINED for it; the Python layer raises unless asked."""
+    from yagremcmc_amd import _ffi
+    from yagremcmc_amd.postprocessing import autocorrelation as ac
+    rng = np.random.default_rng(4)
+    x = np.empty((400, 3, 2))
+    x[:, 0] = rng.standard_normal((400, 2)).cumsum(axis=0) * 0.1
+    x[:, 1] = [0.25, -1.5]                      # stuck
+    x[:, 2, 0] = rng.standard_normal(400)       # one moving, one constant component
+    x[:, 2, 1] = 3.0
+    with pytest.raises(ValueError, match="constant"):
+        ac.integrated_autocorrelation(x, 'mean')
+    got = ac.integrated_autocorrelation(x, 'mean', allowUndefined=True)
+    assert got[1] == _ffi.IAT_UNDEFINED and got[0] > 0 and got[2] > 0
+    got = ac.integrated_autocorrelation(x, 'max', allowUndefined=True)
+    assert got[0] > 0 and got[1] == _ffi.IAT_UNDEFINED and got[2] == _ffi.IAT_UNDEFINED
+    iat, _ = _ffi.default_context(0).iat_series(np.stack([x[:, 0, 0], np.full(400, 7.0)]), allow_undefined=True)
+    assert iat[0] > 0 and iat[1] == _ffi.IAT_UNDEFINED
+
+
 def _reference_iat(series, c=5.0):
     """postprocessing/autocorrelation.py:5-29,32-89 restated with NumPy (direct lag sums)."""
     x = np.asarray(series, dtype=float)

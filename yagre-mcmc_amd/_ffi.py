@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libymc.so")
+# YMC_LIBRARY: another build of the same library (the host-sanitizer build of tests/test_sanitizers.py)
+LIB_PATH = os.environ.get("YMC_LIBRARY") or os.path.join(_HERE, "libymc.so")
 
 ABI_VERSION = 3
 
@@ -25,6 +26,7 @@ EQ_EXACT, EQ_ISCLOSE = 0, 1
 # record flags
 RECORD_TRAJECTORY, RECORD_ACCEPT, RECORD_LOGPOST, RECORD_SUB_ACCEPT, RECORD_MOMENTS = 1, 2, 4, 8, 16
 CHAIN_NONFINITE = 1
+IAT_UNDEFINED = -1
 UNIQUE_ID_BYTES = 128
 
 LANE_DMAX = 8
@@ -159,6 +161,16 @@ def check(code):
         raise YmcError(code, msg.decode("utf-8", "replace") if msg else "")
 
 
+def checked_iat(iat, allow_undefined=False):
+    """A constant series has no autocorrelation (0 / 0; the reference fails on it): raise unless the
+    caller asked for the IAT_UNDEFINED markers."""
+    bad = int((iat == IAT_UNDEFINED).sum())
+    if bad and not allow_undefined:
+        raise ValueError(f"{bad} of {iat.size} series are constant (zero variance): their integrated autocorrelation "
+                         "time is undefined. Pass allowUndefined=True to get -1 for them.")
+    return iat
+
+
 def f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
@@ -222,22 +234,22 @@ class Context(Handle):
         check(lib().ymc_rng_fill(self.raw, seed, chain0, K, t0, nt, d, vptr(xi), vptr(u)))
         return xi, u
 
-    def iat_states(self, states, method=0, sokal_const=5.0):
+    def iat_states(self, states, method=0, sokal_const=5.0, allow_undefined=False):
         """states (n, K, d) -> IAT per chain"""
         states = f64(states)
         n, K, d = states.shape
         out = np.empty(K, dtype=np.int32)
         check(lib().ymc_iat_states(self.raw, vptr(states), n, K, d, method, float(sokal_const), vptr(out)))
-        return out
+        return checked_iat(out, allow_undefined)
 
-    def iat_series(self, series, sokal_const=5.0, acf_lags=0):
+    def iat_series(self, series, sokal_const=5.0, acf_lags=0, allow_undefined=False):
         """series (S, N) -> (IAT per series, acf (S, acf_lags) or None)"""
         series = f64(series)
         S, N = series.shape
         out = np.empty(S, dtype=np.int32)
         acf = np.empty((S, acf_lags)) if acf_lags else None
         check(lib().ymc_iat_series(self.raw, vptr(series), S, N, float(sokal_const), vptr(out), vptr(acf), acf_lags))
-        return out, acf
+        return checked_iat(out, allow_undefined), acf
 
     def numerics(self, fn, x, divisor=None):
         x = f64(x).reshape(-1)
@@ -385,13 +397,13 @@ class Run(Handle):
         check(lib().ymc_run_fetch_summary(self.raw, vptr(acc), vptr(n), vptr(mean), vptr(m2), vptr(st)))
         return dict(accepted=acc, wf_n=n, wf_mean=mean, wf_m2=m2, status=st)
 
-    def iat(self, first=0, n=None, method=0, sokal_const=5.0):
+    def iat(self, first=0, n=None, method=0, sokal_const=5.0, allow_undefined=False):
         """Integrated autocorrelation time of every chain from record rows [first, first+n)."""
         if n is None:
             n = self.steps_done()[1] - first
         out = np.empty(self.K, dtype=np.int32)
         check(lib().ymc_run_iat(self.raw, first, n, method, float(sokal_const), vptr(out)))
-        return out
+        return checked_iat(out, allow_undefined)
 
     def packed_summary(self):
         """(K, 3d+5) u64: the records pack_summary_kernel writes (the payload of the multi-GPU gather)."""

@@ -1,11 +1,18 @@
 """Builders: the drop-in boundary of the chain-ensemble path.
 
-Same property names, validation and error messages as the reference's
+The PUBLIC surface is the reference's: property names, `build_method()`,
+`validate_target_measure()`, and the text of every misconfiguration error of
 `ChainBuilder` (yagremcmc/chain/builder.py:7-83), `MRWBuilder`
-(chain/method/mrw.py:60-91) and `MLDABuilder` (chain/method/mlda.py:157-344);
-`build_method()` returns an ensemble sampler with the reference's
-`run / chain / diagnostics / target / clear` surface.  Ensemble extensions are
-extra properties with defaults that reproduce the single-chain behaviour.
+(chain/method/mrw.py:60-91), `MLDABuilder` (chain/method/mlda.py:157-344),
+`PCNBuilder` (chain/method/pcn.py:60-88) and `AEMBuilder`
+(chain/method/aem.py:61-82) -- example scripts and the reference's builder
+tests (test_builder.py matches the messages by regex) run unchanged.
+Underneath, a builder is a bag of settings: every settable property is an
+`Option` over one dictionary, and each class lists its consistency rules as
+(predicate, exception, message) rows that `build_method()` walks in order.
+Ensemble extensions (`nChains`, `seed`, `device`, `chainOffset`,
+`recordTrajectory`, `recordLogPosterior`, `recordStride`, `rk4Steps`) are
+further options whose defaults reproduce the single-chain behaviour.
 """
 from . import diagnostics as dg
 from .ensemble import MLDA, AdaptiveErrorModel, MetropolisedRandomWalk, PreconditionedCrankNicolson
@@ -13,65 +20,76 @@ from .lowering import UnsupportedPlugin
 from .plugins import UnnormalisedPosterior
 
 
+class Option:
+    """A settable builder property stored in the builder's settings dictionary."""
+
+    def __init__(self, default=None):
+        self.default = default
+
+    def __set_name__(self, owner, name):
+        self.name = name
+
+    def __get__(self, obj, owner=None):
+        if obj is None:
+            return self
+        value = obj._settings.get(self.name, self)
+        if value is self:  # first read: materialise the default (callables make per-builder objects)
+            value = self.default() if callable(self.default) else self.default
+            obj._settings[self.name] = value
+        return value
+
+    def __set__(self, obj, value):
+        obj._settings[self.name] = value
+
+
+ENSEMBLE_OPTIONS = ("nChains", "seed", "device", "chainOffset", "recordTrajectory", "recordLogPosterior",
+                    "recordStride", "rk4Steps")
+
+
 class ChainBuilder:
     """chain/builder.py:7-83"""
 
+    bayesModel = Option()
+    explicitTarget = Option()
+    diagnostics = Option(dg.AcceptanceRateDiagnostics)
+    # ensemble extensions
+    nChains = Option(1)
+    seed = Option(0)
+    device = Option(0)
+    chainOffset = Option(0)
+    recordTrajectory = Option(True)
+    recordLogPosterior = Option(False)
+    recordStride = Option(1)
+    rk4Steps = Option()
+
+    #: consistency rules of the concrete builder: (predicate(builder) -> bool "violated", exception, message)
+    rules = ()
+
     def __init__(self):
-        self._bayesModel = None
-        self._explicitTarget = None
-        self._diagnostics = dg.AcceptanceRateDiagnostics()
-        # ensemble extensions
-        self.nChains = 1
-        self.seed = 0
-        self.device = 0
-        self.chainOffset = 0
-        self.recordTrajectory = True
-        self.recordLogPosterior = False
-        self.rk4Steps = None
-
-    @property
-    def bayesModel(self):
-        return self._bayesModel
-
-    @bayesModel.setter
-    def bayesModel(self, model):
-        self._bayesModel = model
-
-    @property
-    def explicitTarget(self):
-        return self._explicitTarget
-
-    @explicitTarget.setter
-    def explicitTarget(self, density):
-        self._explicitTarget = density
-
-    @property
-    def diagnostics(self):
-        return self._diagnostics
-
-    @diagnostics.setter
-    def diagnostics(self, diagnostics):
-        self._diagnostics = diagnostics
+        self._settings = {}
 
     def _ensemble_options(self):
-        return dict(nChains=self.nChains, seed=self.seed, device=self.device, chainOffset=self.chainOffset,
-                    recordTrajectory=self.recordTrajectory, recordLogPosterior=self.recordLogPosterior,
-                    rk4Steps=self.rk4Steps)
-
-    def validate_target_measure(self):
-        if self._bayesModel is None and self._explicitTarget is None:
-            raise ValueError("Either bayesian model or explicit target density must be provided for chain setup")
-        if self._bayesModel is not None and self._explicitTarget is not None:
-            raise ValueError("Only one of bayes model or explicit target density should be provided.")
+        return {name: getattr(self, name) for name in ENSEMBLE_OPTIONS}
 
     def target_is_posterior(self):
-        return self._bayesModel is not None
+        return self.bayesModel is not None
 
     def target_is_explicit(self):
-        return self._explicitTarget is not None
+        return self.explicitTarget is not None
+
+    def validate_target_measure(self):
+        """builder.py:40-50"""
+        given = self.target_is_posterior() + self.target_is_explicit()
+        if given == 0:
+            raise ValueError("Either bayesian model or explicit target density must be provided for chain setup")
+        if given == 2:
+            raise ValueError("Only one of bayes model or explicit target density should be provided.")
 
     def _validate_parameters(self):
-        raise NotImplementedError
+        for klass in reversed(type(self).__mro__):
+            for violated, exc, message in vars(klass).get("rules", ()):
+                if violated(self):
+                    raise exc(message(self) if callable(message) else message)
 
     def build_from_model(self):
         raise NotImplementedError
@@ -80,193 +98,136 @@ class ChainBuilder:
         raise NotImplementedError
 
     def build_method(self):
+        """builder.py:72-83"""
         self._validate_parameters()
         self.validate_target_measure()
-        if self.target_is_posterior():
-            return self.build_from_model()
-        if self.target_is_explicit():
-            return self.build_from_target()
-        raise ValueError("Invalid target distribution")
+        return self.build_from_model() if self.target_is_posterior() else self.build_from_target()
+
+
+def _posterior_of(model):
+    return UnnormalisedPosterior(model.likelihood, model.prior)
 
 
 class MRWBuilder(ChainBuilder):
     """chain/method/mrw.py:60-91"""
 
-    def __init__(self):
-        super().__init__()
-        self._proposalCov = None
+    proposalCovariance = Option()
+    rules = ((lambda b: b.proposalCovariance is None, ValueError, "Proposal Covariance not set for MRW"),)
 
-    @property
-    def proposalCovariance(self):
-        return self._proposalCov
-
-    @proposalCovariance.setter
-    def proposalCovariance(self, covariance):
-        self._proposalCov = covariance
+    def _sampler(self, target):
+        return MetropolisedRandomWalk(target, self.proposalCovariance, self.diagnostics, **self._ensemble_options())
 
     def build_from_model(self):
-        target = UnnormalisedPosterior(self._bayesModel.likelihood, self._bayesModel.prior)
-        return MetropolisedRandomWalk(target, self._proposalCov, self._diagnostics, **self._ensemble_options())
+        return self._sampler(_posterior_of(self.bayesModel))
 
     def build_from_target(self):
-        return MetropolisedRandomWalk(self._explicitTarget, self._proposalCov, self._diagnostics,
-                                      **self._ensemble_options())
+        return self._sampler(self.explicitTarget)
 
-    def _validate_parameters(self):
-        if self._proposalCov is None:
-            raise ValueError("Proposal Covariance not set for MRW")
+
+def _is_hierarchy(model):
+    return hasattr(model, "level") and hasattr(model, "size")
+
+
+def _n_surrogates(b):
+    """how many coarse levels the configured target has (mlda.py:228-262)"""
+    return b.bayesModel.size - 1 if b.target_is_posterior() else len(b.surrogateTargets)
 
 
 class MLDABuilder(ChainBuilder):
     """chain/method/mlda.py:157-344: one surrogate (two-level delayed acceptance) or an even number
     of them (the nest the reference executes, ensemble.MLDA)."""
 
-    def __init__(self):
-        super().__init__()
-        self._basePropCov = None
-        self._nSteps = None
-        self._surrTgts = None
-        self._surrDgnstList = None
-        self._tgtDgnst = None
-        self._biasCorrection = None
-        self.recordSubChain = False
+    baseProposalCovariance = Option()
+    subChainLengths = Option()
+    surrogateTargets = Option()
+    targetDiagnostics = Option()
+    surrogateDiagnostics = Option()
+    biasCorrection = Option()
+    recordSubChain = Option(False)
 
-    @property
-    def baseProposalCovariance(self):
-        return self._basePropCov
+    sampler = MLDA
 
-    @baseProposalCovariance.setter
-    def baseProposalCovariance(self, cov):
-        self._basePropCov = cov
+    rules = (
+        (lambda b: b.baseProposalCovariance is None, ValueError, "Coarse proposal covariance not set for MLDA"),
+        (lambda b: b.subChainLengths is None, ValueError, "Subchain lengths not set for MLDA"),
+        # a model hierarchy as target (mlda.py:228-249)
+        (lambda b: b.target_is_posterior() and not _is_hierarchy(b.bayesModel), ValueError,
+         "MLDA requires a hierarchy of models."),
+        (lambda b: b.target_is_posterior() and b.surrogateTargets is not None, ValueError,
+         "Cannot set explicit surrogate targets for a hierarchy of Bayesian models."),
+        (lambda b: b.target_is_posterior() and len(b.subChainLengths) != _n_surrogates(b), ValueError,
+         "Number of sub-chain lengths does not match the size of the model hierarchy."),
+        # explicit densities as target (mlda.py:251-269)
+        (lambda b: b.target_is_explicit() and b.surrogateTargets is None, ValueError,
+         "Surrogate targets not set for MLDA"),
+        (lambda b: b.target_is_explicit() and len(b.subChainLengths) != _n_surrogates(b), ValueError,
+         "Number of sub-chain lengths does not match number of surrogate targets"),
+        (lambda b: (b.target_is_posterior() or b.target_is_explicit()) and b.surrogateDiagnostics is not None
+         and len(b.surrogateDiagnostics) != _n_surrogates(b), ValueError,
+         "Number of diagnostics does not match the size of the model hierarchy"),
+        (lambda b: (b.target_is_posterior() or b.target_is_explicit()) and b.biasCorrection is not None,
+         UnsupportedPlugin, "bias correction has no device lowering"),
+    )
 
-    @property
-    def subChainLengths(self):
-        return self._nSteps
+    def _levels(self):
+        """(target, [surrogates coarsest first]) -- mlda.py:315-344: for a model hierarchy the finest level is
+        the target and the coarser ones are the surrogates."""
+        if self.target_is_posterior():
+            m = self.bayesModel
+            return _posterior_of(m.level(-1)), [_posterior_of(m.level(k)) for k in range(m.size - 1)]
+        return self.explicitTarget, list(self.surrogateTargets)
 
-    @subChainLengths.setter
-    def subChainLengths(self, nSteps):
-        self._nSteps = nSteps
-
-    @property
-    def surrogateTargets(self):
-        return self._surrTgts
-
-    @surrogateTargets.setter
-    def surrogateTargets(self, tgts):
-        self._surrTgts = tgts
-
-    @property
-    def targetDiagnostics(self):
-        return self._tgtDgnst
-
-    @targetDiagnostics.setter
-    def targetDiagnostics(self, diagnostics):
-        self._tgtDgnst = diagnostics
-
-    @property
-    def surrogateDiagnostics(self):
-        return self._surrDgnstList
-
-    @surrogateDiagnostics.setter
-    def surrogateDiagnostics(self, surrDgnstList):
-        self._surrDgnstList = surrDgnstList
-
-    @property
-    def biasCorrection(self):
-        return self._biasCorrection
-
-    @biasCorrection.setter
-    def biasCorrection(self, bias):
-        self._biasCorrection = bias
-
-    def _validate_parameters(self):
-        if self._basePropCov is None:
-            raise ValueError("Coarse proposal covariance not set for MLDA")
-        if self._nSteps is None:
-            raise ValueError("Subchain lengths not set for MLDA")
-        if self._bayesModel is not None:
-            # mlda.py:228-249
-            if not (hasattr(self._bayesModel, "level") and hasattr(self._bayesModel, "size")):
-                raise ValueError("MLDA requires a hierarchy of models.")
-            if self._surrTgts is not None:
-                raise ValueError("Cannot set explicit surrogate targets for a hierarchy of Bayesian models.")
-            if not len(self._nSteps) == self._bayesModel.size - 1:
-                raise ValueError("Number of sub-chain lengths does not match the size of the model hierarchy.")
-            if self._surrDgnstList is not None and not len(self._surrDgnstList) == self._bayesModel.size - 1:
-                raise ValueError("Number of diagnostics does not match the size of the model hierarchy")
-            if self._biasCorrection is not None:
-                raise UnsupportedPlugin("bias correction has no device lowering")
-        if self._explicitTarget is not None:
-            if self._surrTgts is None:
-                raise ValueError("Surrogate targets not set for MLDA")
-            if not len(self._nSteps) == len(self._surrTgts):
-                raise ValueError("Number of sub-chain lengths does not match number of surrogate targets")
-            if self._surrDgnstList is not None and not len(self._surrDgnstList) == len(self._surrTgts):
-                raise ValueError("Number of diagnostics does not match the size of the model hierarchy")
-            if self._biasCorrection is not None:
-                raise UnsupportedPlugin("bias correction has no device lowering")
+    def _build(self):
+        target, surrogates = self._levels()
+        top = self.targetDiagnostics if self.targetDiagnostics is not None else dg.AcceptanceRateDiagnostics()
+        return self.build_mlda(target, surrogates, self.baseProposalCovariance, list(self.subChainLengths), top,
+                               self.surrogateDiagnostics)
 
     def build_from_model(self):
-        """mlda.py:315-335: the finest level is the target, the coarser ones are the surrogates."""
         self._validate_parameters()
-        model = self._bayesModel
-        target = UnnormalisedPosterior(model.level(-1).likelihood, model.level(-1).prior)
-        surrogates = [UnnormalisedPosterior(model.level(k).likelihood, model.level(k).prior)
-                      for k in range(model.size - 1)]
-        tgt_diag = self._tgtDgnst if self._tgtDgnst is not None else dg.AcceptanceRateDiagnostics()
-        return self.build_mlda(target, surrogates, self._basePropCov, list(self._nSteps), tgt_diag,
-                               self._surrDgnstList)
+        return self._build()
 
     def build_from_target(self):
-        tgt_diag = self._tgtDgnst if self._tgtDgnst is not None else dg.AcceptanceRateDiagnostics()
-        return self.build_mlda(self._explicitTarget, list(self._surrTgts), self._basePropCov, list(self._nSteps),
-                               tgt_diag, self._surrDgnstList)
+        return self._build()
 
-    def build_mlda(self, tgtPost, surPost, bpc, nS, tgtD, surD):
+    def build_mlda(self, target, surrogates, baseProposalCov, subChainLengths, targetDiag, surrogateDiags):
         """mlda.py:312-313"""
-        return MLDA(tgtPost, surPost, bpc, nS, tgtD, surD, recordSubChain=self.recordSubChain,
-                    **self._ensemble_options())
+        return self.sampler(target, surrogates, baseProposalCov, subChainLengths, targetDiag, surrogateDiags,
+                            recordSubChain=self.recordSubChain, **self._ensemble_options())
+
+
+def _non_adaptive_level(b):
+    """index of the first level whose likelihood is not an AEMLikelihood, or None (aem.py:66-79)"""
+    if not b.target_is_posterior() or not _is_hierarchy(b.bayesModel):
+        return None
+    for i in range(b.bayesModel.size):
+        if type(b.bayesModel.level(i).likelihood).__name__ != "AEMLikelihood":
+            return i
+    return None
 
 
 class AEMBuilder(MLDABuilder):
     """chain/method/aem.py:61-82"""
 
-    def _validate_parameters(self):
-        super()._validate_parameters()
-        if self._bayesModel is None:
-            raise NotImplementedError("Adaptive error correction only makes sense if the target emerges from a "
-                                      "Bayesian model.")
-        for i in range(self._bayesModel.size):
-            if type(self._bayesModel.level(i).likelihood).__name__ != "AEMLikelihood":
-                raise ValueError(f"Likelihood on level {i} is not adaptive.")
+    sampler = AdaptiveErrorModel
 
-    def build_mlda(self, tgtPost, surPost, bpc, nS, tgtD, surD):
-        return AdaptiveErrorModel(tgtPost, surPost, bpc, nS, tgtD, surD, recordSubChain=self.recordSubChain,
-                                  **self._ensemble_options())
+    rules = (
+        (lambda b: not b.target_is_posterior(), NotImplementedError,
+         "Adaptive error correction only makes sense if the target emerges from a Bayesian model."),
+        (lambda b: _non_adaptive_level(b) is not None, ValueError,
+         lambda b: f"Likelihood on level {_non_adaptive_level(b)} is not adaptive."),
+    )
 
 
 class PCNBuilder(ChainBuilder):
     """chain/method/pcn.py:60-88"""
 
-    def __init__(self):
-        super().__init__()
-        self._stepSize = None
-
-    @property
-    def stepSize(self):
-        return self._stepSize
-
-    @stepSize.setter
-    def stepSize(self, h):
-        self._stepSize = h
+    stepSize = Option()
+    rules = ((lambda b: b.stepSize is None, ValueError, "Step size not set in PCN."),)
 
     def build_from_model(self):
-        return PreconditionedCrankNicolson(self._bayesModel.likelihood, self._bayesModel.prior, self._stepSize,
-                                           self._diagnostics, **self._ensemble_options())
+        return PreconditionedCrankNicolson(self.bayesModel.likelihood, self.bayesModel.prior, self.stepSize,
+                                           self.diagnostics, **self._ensemble_options())
 
     def build_from_target(self):
         raise RuntimeError("PCN is only defined in relation to a Bayesian model")
-
-    def _validate_parameters(self):
-        if self._stepSize is None:
-            raise ValueError("Step size not set in PCN.")

@@ -792,6 +792,12 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
             rc = fail(YMC_ERR_UNSUPPORTED, "surrogate density kind %d differs from target kind %d",
                       desc->surrogate.kind, desc->target.kind);
         if (rc == YMC_OK) rc = lower_density(ctx, desc->surrogate, p->sur, p->D);
+        /* the lane kernels hold at most YMC_LANE_MMAX forward outputs per level: a surrogate that needs
+         * the tile path under a lane-path target would be evaluated truncated */
+        if (rc == YMC_OK && p->sur.tile && !p->tgt.tile)
+            rc = fail(YMC_ERR_UNSUPPORTED, "the surrogate's forward map has %d outputs; with a target of %d "
+                                           "parameters and %d outputs both levels must fit the lane kernels (<= %d)",
+                      desc->surrogate.data_dim, p->D, desc->target.data_dim, YMC_LANE_MMAX);
         p->S = desc->sub_chain_length;
     }
     if (rc == YMC_OK && desc->method == YMC_METHOD_MLDA_NESTED) {
@@ -1283,8 +1289,12 @@ int iat_from_device_states(ymc_ctx *ctx, const double *traj, uint64_t first, uin
     YMC_HIP(hipStreamSynchronize(st));
     for (uint64_t k = 0; k < K; ++k) {
         int32_t best = host[k * per_chain]; /* 'max': autocorrelation.py:131-138 */
-        for (uint64_t j = 1; j < per_chain; ++j) best = std::max(best, host[k * per_chain + j]);
-        iat[k] = best;
+        bool undefined = best == YMC_IAT_UNDEFINED;
+        for (uint64_t j = 1; j < per_chain; ++j) {
+            undefined = undefined || host[k * per_chain + j] == YMC_IAT_UNDEFINED;
+            best = std::max(best, host[k * per_chain + j]);
+        }
+        iat[k] = undefined ? YMC_IAT_UNDEFINED : best;
     }
     return YMC_OK;
 }

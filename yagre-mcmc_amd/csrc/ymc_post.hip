@@ -155,7 +155,12 @@ __global__ __launch_bounds__(kPostThreads) void iat_kernel(const double *__restr
         }
     }
     if (tid == 0) {
-        iat_out[blockIdx.x] = (int32_t)__builtin_rint(found ? iat_at : 1.0);
+        /* a constant series (a chain that never moved, or one flagged NONFINITE) has c0 = 0: its
+         * autocorrelation is 0 / 0 and the reference fails on it; report YMC_IAT_UNDEFINED instead of
+         * converting a NaN to an integer */
+        const double value = found ? iat_at : 1.0;
+        const bool defined = c0 > 0.0 && __builtin_fabs(value) < 2147483647.0;
+        iat_out[blockIdx.x] = defined ? (int32_t)__builtin_rint(value) : -1;
         if (lag_out) lag_out[blockIdx.x] = (int32_t)stop;
     }
 }

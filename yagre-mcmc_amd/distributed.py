@@ -82,7 +82,10 @@ def pooled_diagnostics(summary, steps):
 # the TCP store
 # ---------------------------------------------------------------------------
 
-_MAGIC = b"YMCSTOR2"
+_MAGIC = b"YMCSTOR2"           # client -> server
+_MAGIC_REPLY = b"YMCSTOK2"     # server -> client: differs, so a TCP self-connection (a client whose ephemeral
+#                                source port equals the candidate port it probes, which echoes its own hello
+#                                back) cannot pass for a store
 _PORT_SPAN = 32          # candidate ports after MASTER_PORT
 _HELLO = struct.Struct("<8s16sII")     # magic, key, rank, world
 _WELCOME = struct.Struct("<8s16s")     # magic, nonce of this launch
@@ -165,7 +168,7 @@ class _StoreServer(threading.Thread):
                     or rank in self.conns.values():
                 sock.close()
                 return
-            sock.sendall(_WELCOME.pack(_MAGIC, self.nonce))
+            sock.sendall(_WELCOME.pack(_MAGIC_REPLY, self.nonce))
         except (OSError, ConnectionError, struct.error):
             sock.close()
             return
@@ -245,10 +248,12 @@ class TcpStore:
                 except OSError:
                     continue
                 try:
+                    if s.getsockname() == s.getpeername():
+                        raise ConnectionError("connected to itself")
                     s.settimeout(5.0)
                     s.sendall(_HELLO.pack(_MAGIC, self.key, self.rank, self.world))
                     magic, nonce = _WELCOME.unpack(_recv_exact(s, _WELCOME.size))
-                    if magic != _MAGIC:
+                    if magic != _MAGIC_REPLY:
                         raise ConnectionError("not this launch's store")
                 except (OSError, ConnectionError, struct.error):
                     s.close()

@@ -66,7 +66,7 @@ class MetropolisHastingsEnsemble:
     _logger = None
 
     def __init__(self, targetDensity, proposalCov, diagnostics, *, nChains=1, seed=0, device=0,
-                 chainOffset=0, recordTrajectory=True, recordLogPosterior=False, rk4Steps=None):
+                 chainOffset=0, recordTrajectory=True, recordLogPosterior=False, recordStride=1, rk4Steps=None):
         self._tgtDensity = targetDensity
         self._proposalCov = proposalCov
         self._diagnostics = dg.adopt(diagnostics)
@@ -77,11 +77,14 @@ class MetropolisHastingsEnsemble:
         self.chainOffset = int(chainOffset)
         self.recordTrajectory = bool(recordTrajectory)
         self.recordLogPosterior = bool(recordLogPosterior)
+        self.recordStride = int(recordStride)
         self.rk4Steps = rk4Steps
         self._run = None
         self._problem = None
         if self.nChains < 1:
             raise ValueError("nChains must be positive")
+        if self.recordStride < 1:
+            raise ValueError("recordStride must be at least 1")
 
     # -- reference surface ---------------------------------------------------
     @property
@@ -155,10 +158,11 @@ class MetropolisHastingsEnsemble:
     def kernel_time_ms(self):
         return self._run.kernel_time_ms()
 
-    def integrated_autocorrelation(self, method='mean', burnin=0, sokalConst=5.):
+    def integrated_autocorrelation(self, method='mean', burnin=0, sokalConst=5., allowUndefined=False):
         """postprocessing/autocorrelation.py:92-140 for every chain, computed on the device from the
         record: the equivalent of `ac.integrated_autocorrelation(states[burnin:], method)` per chain.
-        Returns an int for one chain, an array of nChains ints otherwise."""
+        Returns an int for one chain, an array of nChains ints otherwise.  A chain that never moved has no
+        autocorrelation: ValueError, or -1 in its place with allowUndefined."""
         methods = {"mean": 0, "max": 1}
         if method not in methods:
             raise ValueError(f"Invalid IAT - Type: {method}. Options are 'mean' and 'max'.")
@@ -166,9 +170,9 @@ class MetropolisHastingsEnsemble:
             # row 0 of the reference's trajectory is the initial state, which the device record
             # does not hold: go through the fetched states so that it is included
             states = self._chain.ensemble_trajectory
-            out = _ffi.default_context(self.device).iat_states(states, methods[method], sokalConst)
+            out = _ffi.default_context(self.device).iat_states(states, methods[method], sokalConst, allowUndefined)
         else:
-            out = self._run.iat(burnin - 1, None, methods[method], sokalConst)
+            out = self._run.iat(burnin - 1, None, methods[method], sokalConst, allowUndefined)
         return int(out[0]) if self.nChains == 1 else out
 
     # -- internals -------------------------------------------------------------

@@ -23,6 +23,27 @@ def _has(obj, *attrs):
     return all(hasattr(obj, a) for a in attrs)
 
 
+# Classes are recognised by NAME (the reference is never imported here), so the name alone must not be
+# trusted with the arithmetic: a user class that happens to be called GaussianTargetDensity2d -- or a
+# subclass of the stock one -- which brings its own evaluate_log would otherwise be lowered as the stock
+# density, silently.  A recognised object is lowered only if every method that defines its arithmetic is
+# the one the reference's package or this package defines (or is absent: a data-only stand-in).
+_STOCK_PACKAGES = ("yagremcmc", __package__ or "yagremcmc_amd")
+
+
+def _require_stock(obj, what, *methods):
+    for name in methods:
+        for klass in type(obj).__mro__:
+            if name in vars(klass):
+                top = (klass.__module__ or "").split(".")[0]
+                if top not in _STOCK_PACKAGES:
+                    raise UnsupportedPlugin(
+                        f"{what} {_name(obj)}: its {name}() is defined by {klass.__module__}.{klass.__qualname__}, not "
+                        "by the stock class of that name; a custom implementation has no device lowering "
+                        "(and there is no CPU fallback)")
+                break
+
+
 def proposal_sigma(cov, dim):
     """sqrt(reciprocal(precision)) exactly as DiagonalCovarianceMatrix.apply_chol_factor
     forms it (statistics/covariance.py:51-52) -- not sqrt(variance)."""
@@ -33,6 +54,7 @@ def proposal_sigma(cov, dim):
     if not hasattr(cov, "_precision"):
         raise UnsupportedPlugin(
             f"proposal covariance {_name(cov)}: only Diagonal/IID covariances have a device lowering")
+    _require_stock(cov, "proposal covariance", "apply_chol_factor")
     prec = np.asarray(cov._precision, dtype=np.float64).reshape(-1)
     if prec.size != dim:
         raise ValueError(f"proposal covariance has dimension {prec.size}, the state has {dim}")
@@ -44,6 +66,7 @@ def proposal_chol(cov, dim):
     L = getattr(cov, "cholFactor_", None)
     if L is None:
         return None
+    _require_stock(cov, "proposal covariance", "apply_chol_factor")
     L = np.tril(np.asarray(L, dtype=np.float64))
     if L.shape != (dim, dim):
         raise ValueError(f"proposal covariance has dimension {L.shape[0]}, the state has {dim}")
@@ -53,6 +76,7 @@ def proposal_chol(cov, dim):
 def _diag_precision(cov, n, what):
     if not hasattr(cov, "_precision"):
         raise UnsupportedPlugin(f"{what} covariance {_name(cov)}: only Diagonal/IID covariances are lowered")
+    _require_stock(cov, f"{what} covariance", "apply_inverse", "induced_norm_squared")
     prec = np.asarray(cov._precision, dtype=np.float64).reshape(-1)
     if prec.size != n:
         raise ValueError(f"{what} covariance has dimension {prec.size}, expected {n}")
@@ -89,9 +113,33 @@ def _whitening_of(target):
     return mean, v * np.sqrt(1.0 / w), float(mean.size * np.log(2.0 * np.pi) + np.sum(np.log(w)))
 
 
+def rk4_steps_for_rtol(rtol):
+    """The reference configures the accuracy of a Lotka-Volterra level through scipy's `rtol`
+    (test/testSetup.py:69-70,124-126); the device integrates with fixed-step classical RK4, whose global
+    error scales with h^4.  Anchored at north_star's 50 steps for the reference's default rtol 1e-4:
+    steps = ceil(50 (1e-4 / rtol)^(1/4)), clamped to [8, 400] -- 1e-2 -> 16, 1e-4 -> 50, 1e-5 -> 89.
+    So a hierarchy defined only by rtol (example_inference_lotkaVolterra_twoLevel.py: RK23 at 1e-2 under
+    DOP853 at 1e-5) lowers to DIFFERENT levels."""
+    rtol = float(rtol)
+    if not (rtol > 0.0) or not np.isfinite(rtol):
+        raise ValueError(f"rtol must be positive and finite, got {rtol}")
+    return int(min(400, max(8, int(np.ceil(50.0 * (1e-4 / rtol) ** 0.25)))))
+
+
+def _lv_steps(solver, override):
+    if override:
+        return int(override)
+    explicit = getattr(solver, "rk4Steps_", None)
+    if explicit:
+        return int(explicit)
+    rtol = getattr(solver, "_solverRTol", None)
+    return rk4_steps_for_rtol(rtol) if rtol is not None else 50
+
+
 def lower_solver(solver, low, rk4_steps=None):
     """SolverInterface -> forward-map fields of the descriptor."""
     n = _name(solver)
+    _require_stock(solver, "solver", "invoke", "interpolate", "evaluation", "flow__")
     if n == "ExampleLinearModelSolver" and _has(solver, "_A", "_b"):
         A = np.asarray(solver._A, dtype=np.float64)
         if A.ndim != 2:
@@ -107,7 +155,7 @@ def lower_solver(solver, low, rk4_steps=None):
         low.desc.t_final = float(solver.tBoundary_[1])
         low.desc.alpha = float(solver.fixedParam_[0])
         low.desc.gamma = float(solver.fixedParam_[1])
-        low.desc.rk4_steps = int(rk4_steps or getattr(solver, "rk4Steps_", 50))
+        low.desc.rk4_steps = _lv_steps(solver, rk4_steps)
         return 2, 2
     raise UnsupportedPlugin(
         f"solver {n} has no device lowering (known: ExampleLinearModelSolver, LotkaVolterraSolver); "
@@ -122,6 +170,13 @@ def lower_posterior(likelihood, prior, rk4_steps=None):
         raise UnsupportedPlugin(f"likelihood {_name(likelihood)} has no device lowering")
     if not _has(prior, "mean", "covariance"):
         raise UnsupportedPlugin(f"prior {_name(prior)} has no device lowering (a Gaussian law is needed)")
+    _require_stock(likelihood, "likelihood", "evaluate_log", "compute_log_likelihood", "compute_residual",
+                   "compute_residual_norm_squared", "query_log_likelihood")
+    _require_stock(likelihood._fwdModel, "forward model", "evaluate")
+    _require_stock(likelihood._noiseModel, "noise model", "induced_norm_squared")
+    _require_stock(prior, "prior", "density")
+    if hasattr(prior, "density"):
+        _require_stock(prior.density, "prior density", "evaluate_log")
     low = Lowered(0, 0)
     dim, data_dim = lower_solver(likelihood._fwdModel.solver_, low, rk4_steps)
     data = np.asarray(likelihood._data.array, dtype=np.float64)
@@ -147,6 +202,7 @@ def lower_posterior(likelihood, prior, rk4_steps=None):
 def lower_density(density, rk4_steps=None):
     """DensityInterface -> Lowered."""
     n = _name(density)
+    _require_stock(density, "density", "evaluate_log")
     if n == "GaussianTargetDensity2d" and (_has(density, "dist_") or _has(density, "whiten_")):
         mean, U, log_norm = _whitening_of(density)
         low = Lowered(_ffi.GAUSS_WHITENED, int(np.size(mean)))
@@ -164,6 +220,31 @@ def lower_density(density, rk4_steps=None):
     raise UnsupportedPlugin(
         f"density {n} has no device lowering (known: GaussianTargetDensity1d/2d, UnnormalisedPosterior over "
         "AdditiveGaussianNoiseLikelihood + Gaussian prior); there is no CPU fallback")
+
+
+def same_lowering(a, b):
+    """Do two Lowered densities describe the same function (every scalar and every array equal)?"""
+    for name, ctype in _ffi.DensityDesc._fields_:
+        va, vb = getattr(a.desc, name), getattr(b.desc, name)
+        if ctype is _ffi._dp:
+            continue
+        if va != vb:
+            return False
+    if len(a.keep) != len(b.keep):
+        return False
+    return all(x.shape == y.shape and np.array_equal(x, y) for x, y in zip(a.keep, b.keep))
+
+
+def warn_if_degenerate(target_low, surrogate_lows, what="surrogate"):
+    """A surrogate identical to its target makes delayed acceptance pointless (every proposal that the
+    coarse walk accepted is accepted again, at S + 1 density evaluations per step): most often the levels
+    were meant to differ in a setting that has no device counterpart."""
+    import warnings
+    for i, sur in enumerate(surrogate_lows):
+        if same_lowering(target_low, sur):
+            warnings.warn(f"{what} {i} lowers to exactly the target density: delayed acceptance degenerates (every "
+                          "fine step repeats the coarse decision). For Lotka-Volterra levels give each solver its own "
+                          "'rk4Steps' (or distinct 'rtol').", RuntimeWarning, stacklevel=3)
 
 
 def state_eq_of(state):
@@ -201,6 +282,7 @@ def make_nested_problem(ctx, target, surrogates, sub_chain_lengths, sigma, state
                                 f"{_ffi.MAX_LEVELS}")
     lowP = [lower_density(p, rk4_steps) for p in P]
     lowQ = [lower_density(q, rk4_steps) for q in Q]
+    warn_if_degenerate(tgt, [lower_density(s, rk4_steps) for s in surrogates])
     desc = _ffi.ProblemDesc()
     desc.method, desc.state_eq = _ffi.METHOD_MLDA_NESTED, state_eq
     desc.target = tgt.desc
@@ -235,6 +317,8 @@ def make_problem(ctx, method, target, sigma, state_eq=_ffi.EQ_EXACT, surrogate=N
         desc.surrogate = sur.desc
         desc.sub_chain_length = int(sub_chain_length)
         keep.append(sur)
+        if method == _ffi.METHOD_MLDA2:
+            warn_if_degenerate(tgt, [sur])
     sigma = _ffi.f64(sigma).reshape(-1)
     if sigma.size != tgt.desc.dim:
         raise ValueError(f"proposal covariance has dimension {sigma.size}, the target has {tgt.desc.dim}")

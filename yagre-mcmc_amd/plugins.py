@@ -335,10 +335,12 @@ class ExampleLinearModelSolver(_DeviceSolver):
 
 
 class LotkaVolterraSolver(_DeviceSolver):
-    """test/testSetup.py:61-141.  `config` takes the reference's keys (T, alpha,
-    gamma, nData, dataDim; solver/rtol are accepted and ignored) plus the
-    optional 'rk4Steps' (default 50): the ensemble integrates with fixed-step
-    classical RK4 instead of scipy's adaptive solve_ivp."""
+    """test/testSetup.py:61-141.  `config` takes the reference's keys (T, alpha, gamma, nData, dataDim,
+    solver, rtol) plus the optional 'rk4Steps': the ensemble integrates with fixed-step classical RK4
+    instead of scipy's adaptive solve_ivp.  Without 'rk4Steps' the step count follows from 'rtol'
+    (lowering.rk4_steps_for_rtol: 50 steps at the reference's default 1e-4, fewer for a looser, more for a
+    tighter tolerance), so levels that differ only in 'rtol' stay different; 'solver' (the name of a scipy
+    method) has no counterpart and is recorded only."""
 
     def __init__(self, design, config):
         super().__init__()
@@ -346,7 +348,13 @@ class LotkaVolterraSolver(_DeviceSolver):
         self.tBoundary_ = (0.0, float(config['T']))
         self.fixedParam_ = [float(config['alpha']), float(config['gamma'])]
         self.dataShape_ = (int(config['nData']), int(config['dataDim']))
-        self.rk4Steps_ = int(config.get('rk4Steps', 50))
+        self._solverMethod = config.get('solver')
+        self._solverRTol = config.get('rtol')
+        if config.get('rk4Steps'):
+            self.rk4Steps_ = int(config['rk4Steps'])
+        else:
+            from .lowering import rk4_steps_for_rtol
+            self.rk4Steps_ = rk4_steps_for_rtol(self._solverRTol) if self._solverRTol is not None else 50
         if self.x_.shape != (self.dataShape_[0], 2) or self.dataShape_[1] != 2:
             raise ValueError("design must have shape (nData, 2) and dataDim must be 2")
 

@@ -17,9 +17,10 @@ def estimate_autocorrelation_function_1d(sequence, device=0):
     return acf[0]
 
 
-def integrated_autocorrelation(seq, method='mean', sokalConst=5., device=0):
+def integrated_autocorrelation(seq, method='mean', sokalConst=5., device=0, allowUndefined=False):
     """autocorrelation.py:92-140.  `seq`: (n, d) states of one chain -> int, or
-    (n, K, d) states of K chains -> array of K ints."""
+    (n, K, d) states of K chains -> array of K ints.  A constant series has no autocorrelation:
+    ValueError (the reference fails on 0 / 0 too), or -1 in its place with allowUndefined."""
     if method not in _METHODS:
         raise ValueError(f"Invalid IAT - Type: {method}. Options are 'mean' and 'max'.")
     arr = np.asarray(seq, dtype=np.float64)
@@ -28,5 +29,5 @@ def integrated_autocorrelation(seq, method='mean', sokalConst=5., device=0):
     single = arr.ndim == 2
     if single:
         arr = arr[:, None, :]
-    out = _ffi.default_context(device).iat_states(arr, _METHODS[method], sokalConst)
+    out = _ffi.default_context(device).iat_states(arr, _METHODS[method], sokalConst, allowUndefined)
     return int(out[0]) if single else out
