@@ -791,6 +791,126 @@ def test_c4_full_size_lotka_volterra(ffi, ctx, golden):
     assert np.array_equal(stiff.trajectory()[:, :64], out["traj"]) and np.array_equal(st[:64], e.status)
 
 
+@pytest.mark.parametrize("S", [2, 3, 4, 5, 6, 10, 7])
+def test_two_level_compile_time_sub_chain_lengths(ffi, ctx, golden, S):
+    """mlda2_static_kernel (csrc/ymc_mlda2.hip: the sub-chain unrolled, accept uniforms from whole Philox
+    blocks on a fixed schedule) against the oracle for every instantiated length (7 is not one: run-time
+    kernel), launches that start on odd and even fine steps and end inside a unit, a ragged ensemble."""
+    from yagremcmc_amd import lowering
+    g = golden("f5_mlda2_2d.npz")
+    fine = _gauss_low(ffi, g["fine_mean"], g["fine_whiten"], g["fine_log_norm"])
+    coarse = _gauss_low(ffi, g["coarse_mean"], g["coarse_whiten"], g["coarse_log_norm"])
+    of = o.gauss_whitened(g["fine_mean"], g["fine_whiten"], float(g["fine_log_norm"]))
+    oc = o.gauss_whitened(g["coarse_mean"], g["coarse_whiten"], float(g["coarse_log_norm"]))
+    prob = lowering.make_problem(ctx, ffi.METHOD_MLDA2, fine, g["sigma"], surrogate=coarse, sub_chain_length=S)
+    K = 200
+    x0 = np.tile([-8.0, -7.0], (K, 1)) + np.random.default_rng(S).standard_normal((K, 2))
+    for moments in (True, False):
+        flags = ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT | (ffi.RECORD_MOMENTS if moments else 0)
+        lengths = [1, 2, 3, 1, 8, 5, 4]
+        run = ffi.Run(prob, 11, K, x0, sum(lengths), flags, chain_offset=1000)
+        for n in lengths:
+            run.advance(n)
+        e = o.Ensemble(of, g["sigma"], x0, 11, chain0=1000, surrogate=oc, sub_chain_length=S)
+        out = e.advance(sum(lengths))
+        assert np.array_equal(run.trajectory(), out["traj"]) and np.array_equal(run.accept(), out["acc"])
+        s, (x, lp) = run.summary(), run.state()
+        assert np.array_equal(x, e.x) and np.array_equal(lp, e.lp) and np.array_equal(s["accepted"], e.acc_count)
+        if moments:
+            assert np.array_equal(s["wf_mean"], e.wf_mean) and np.array_equal(s["wf_m2"], e.wf_m2)
+    if S == 6:   # the live reference's chains (fixture F5) through the compile-time kernel
+        n = int(g["n_states"])
+        run = ffi.Run(prob, int(g["seed"]), g["x0"].shape[0], g["x0"], n - 1, ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT)
+        run.advance(n - 1)
+        assert np.array_equal(run.accept(), g["acc"]) and np.array_equal(run.trajectory(), g["traj"][1:])
+
+
+@pytest.mark.parametrize("kind", ["linear", "lv", "gauss1"])
+def test_two_level_compile_time_other_densities(ffi, ctx, kind):
+    from yagremcmc_amd import lowering
+    rng = np.random.default_rng(12)
+    K, S, T = 96, 3, 11
+    if kind == "linear":
+        d, m, nd = 2, 3, 4
+        def mk(seed):
+            r = np.random.default_rng(seed)
+            gg = dict(data=r.standard_normal((nd, m)), noise_precision=r.uniform(0.5, 2, m), prior_mean=r.standard_normal(d),
+                      prior_precision=r.uniform(0.2, 1, d))
+            A, b = r.standard_normal((m, d)), r.standard_normal(m)
+            return (_posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, gg, fwd_matrix=A, fwd_shift=b),
+                    o.posterior_linear(A, b, gg["data"], gg["noise_precision"], gg["prior_mean"], gg["prior_precision"]))
+        (lf, pf), (lc, pc) = mk(1), mk(2)
+        sigma, x0 = np.array([0.3, 0.5]), rng.standard_normal((K, 2))
+    elif kind == "lv":
+        design = rng.uniform(0.5, 1.5, size=(4, 2))
+        base = dict(noise_precision=np.array([25.0, 20.0]), prior_mean=np.zeros(2), prior_precision=np.array([0.7, 0.9]))
+        data = rng.uniform(0.2, 2.0, size=(4, 2))
+        def mk(steps):
+            return (_posterior_low(ffi, ffi.POSTERIOR_LV, 2, dict(base, data=data), design=design, t_final=5.0, alpha=0.8,
+                                   gamma=0.4, rk4_steps=steps),
+                    o.posterior_lv(design, 5.0, 0.8, 0.4, steps, data, **base))
+        (lf, pf), (lc, pc) = mk(40), mk(9)
+        sigma, x0 = np.array([0.2, 0.2]), np.tile([[-0.6, -0.3]], (K, 1))
+    else:
+        d = 1
+        def mk(mean, whiten):
+            low = _gauss_low(ffi, np.array([mean]), np.array([[whiten]]), 1.0)
+            return low, o.gauss_whitened(np.array([mean]), np.array([[whiten]]), 1.0)
+        (lf, pf), (lc, pc) = mk(0.5, 1.2), mk(0.3, 0.8)
+        sigma, x0 = np.array([0.9]), rng.standard_normal((K, 1))
+    prob = lowering.make_problem(ctx, ffi.METHOD_MLDA2, lf, sigma, surrogate=lc, sub_chain_length=S)
+    run = ffi.Run(prob, 5, K, x0, T, ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT | ffi.RECORD_MOMENTS, chain_offset=3)
+    run.advance(4)
+    run.advance(7)
+    e = o.Ensemble(pf, sigma, x0, 5, chain0=3, surrogate=pc, sub_chain_length=S)
+    out = e.advance(T)
+    assert np.array_equal(run.trajectory(), out["traj"]) and np.array_equal(run.accept(), out["acc"])
+    s = run.summary()
+    assert np.array_equal(s["wf_mean"], e.wf_mean) and np.array_equal(s["status"], e.status)
+
+
+@pytest.mark.parametrize("split", ["0", "1"])
+@pytest.mark.parametrize("d", [1, 2])
+def test_random_walk_with_helper_waves_for_the_draws(ffi, ctx, golden, monkeypatch, split, d):
+    """mrw_split_kernel (draws made by three helper waves per chain wave, handed over through LDS) against the
+    one-lane-per-chain kernel and the oracle: ragged ensemble (300 chains: a partly filled workgroup and
+    wave), launches of every length modulo the block of six, odd and even first transitions."""
+    from yagremcmc_amd import lowering
+    monkeypatch.setenv("YMC_SPLIT", split)
+    g = golden("f2_mrw_2d.npz")
+    if d == 2:
+        low = _gauss_low(ffi, g["mean"], g["whiten"], g["log_norm"])
+        p, sigma = o.gauss_whitened(g["mean"], g["whiten"], float(g["log_norm"])), g["sigma"]
+        x0 = np.tile([-8.0, -7.0], (300, 1)) + np.random.default_rng(1).standard_normal((300, 2))
+    else:
+        low = lowering.Lowered(ffi.GAUSS_ISO1D, 1)
+        low.set_array("mean", np.array([1.5]))
+        low.desc.variance = 1.5
+        p, sigma = o.gauss_iso1d(1.5, 1.5), np.array([1.3])
+        x0 = np.random.default_rng(2).standard_normal((300, 1)) - 3.0
+    prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, sigma)
+    for moments in (True, False):
+        flags = ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT | (ffi.RECORD_MOMENTS if moments else 0)
+        lengths = [1, 5, 6, 7, 12, 13, 2, 25]
+        run = ffi.Run(prob, 31, 300, x0, sum(lengths), flags, chain_offset=77)
+        for n in lengths:
+            run.advance(n)
+        e = o.Ensemble(p, sigma, x0, 31, chain0=77)
+        out = e.advance(sum(lengths))
+        assert np.array_equal(run.trajectory(), out["traj"]) and np.array_equal(run.accept(), out["acc"])
+        s, (x, lp) = run.summary(), run.state()
+        assert np.array_equal(x, e.x) and np.array_equal(lp, e.lp) and np.array_equal(s["accepted"], e.acc_count)
+        if moments:
+            assert np.array_equal(s["wf_mean"], e.wf_mean) and np.array_equal(s["wf_m2"], e.wf_m2)
+    # the reference's own chains (fixture F2, 64 chains x 2000 states) through the same kernel
+    if d == 2:
+        run = ffi.Run(prob, int(g["seed"]), g["x0"].shape[0], g["x0"], int(g["n_states"]) - 1,
+                      ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT | ffi.RECORD_MOMENTS)
+        run.advance(int(g["n_states"]) - 1)
+        assert np.array_equal(run.trajectory(), g["traj"][1:]) and np.array_equal(run.accept(), g["acc"])
+        assert np.array_equal(run.summary()["wf_mean"], g["wf_mean"])
+
+
 @pytest.mark.parametrize("rows", ["0", "1"])
 def test_lotka_volterra_row_parallel_variant(ffi, ctx, golden, monkeypatch, rows):
     """One lane per chain vs one lane per (chain, design row): a speed choice, same bits."""

@@ -142,6 +142,194 @@ __global__ __launch_bounds__(64 * (NP + 1)) void split(const Args a)
     a.acc_count[k] = accepted;
 }
 
+
+// SIMD-balanced variant: one 1024-thread workgroup = 16 waves = 4 per SIMD (wave w runs on SIMD w % 4) for
+// 256 chains.  Chain group g = w & 3 (64 chains) lives on SIMD g: wave g is its consumer, waves 4+g, 8+g,
+// 12+g its three producers, so every SIMD carries 1 consumer + 3 producers (in `split` the consumers of
+// four workgroups pile up on SIMD 0).
+template <int R, int PRIO, int LIGHT>
+__global__ __launch_bounds__(1024) void split16(const Args a)
+{
+    ymc_stage_tables();
+    constexpr int NP = 3;
+    constexpr int B = 2 * NP * R;
+    __shared__ double ring[4][2][B][D + 1][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = w & 3, role = w >> 2;
+    const uint64_t k = (uint64_t)blockIdx.x * 256 + g * 64 + lane;
+    const uint32_t chain = (uint32_t)k;
+    const uint32_t nb = a.nsteps / B;
+    if (role != 0) {
+        const int p = role - 1;
+        const double s0 = a.sigma[0], s1 = a.sigma[1];
+        auto fill = [&](uint32_t b) {
+#pragma unroll 1
+            for (int r = 0; r < R; ++r) {
+                const int q = 2 * (NP * r + p);
+                const uint64_t t = a.t0 + b * B + q;
+                const ymc_u32x4 ub = ymc_uniform_block(a.seed, chain, t);
+                ring[g][b & 1][q][D][lane] = ymc_u01_co(ub.v[0], ub.v[1]);
+                ring[g][b & 1][q + 1][D][lane] = ymc_u01_co(ub.v[2], ub.v[3]);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    double z0, z1;
+                    ymc_draw_normal_pair(a.seed, chain, t + h, 0, &z0, &z1);
+                    ring[g][b & 1][q + h][0][lane] = s0 * z0;
+                    ring[g][b & 1][q + h][1][lane] = s1 * z1;
+                }
+            }
+        };
+        fill(0);
+        __syncthreads();
+        for (uint32_t b = 0; b < nb; ++b) {
+            if (b + 1 < nb) fill(b + 1);
+            __syncthreads();
+        }
+        return;
+    }
+    if (PRIO) __builtin_amdgcn_s_setprio(3);
+    double x[D], wmean[D], wm2[D];
+    ymc_load_row<D>(a.x, k, x);
+    ymc_load_row<D>(a.wmean, k, wmean);
+    ymc_load_row<D>(a.wm2, k, wm2);
+    double lp = a.lp[k];
+    uint64_t accepted = a.acc_count[k];
+    __syncthreads();
+    for (uint32_t b = 0; b < nb; ++b) {
+        double dl[B][D], u[B];
+#pragma unroll
+        for (int s = 0; s < B; ++s) {
+            dl[s][0] = ring[g][b & 1][s][0][lane];
+            dl[s][1] = ring[g][b & 1][s][1][lane];
+            u[s] = ring[g][b & 1][s][D][lane];
+        }
+#pragma unroll
+        for (int s = 0; s < B; ++s) tail(a, k, b * B + s, x, lp, accepted, wmean, wm2, dl[s], u[s]);
+        __syncthreads();
+    }
+    ymc_store_row<D>(a.x, k, x);
+    ymc_store_row<D>(a.wmean, k, wmean);
+    ymc_store_row<D>(a.wm2, k, wm2);
+    a.lp[k] = lp;
+    a.acc_count[k] = accepted;
+}
+
+
+// Four roles per SIMD ("quad"): 1024-thread workgroup, 256 chains, chain group g = w & 3 on SIMD g.
+//   role 0  C  consumer: y = x + delta, density, accept, select; writes x', acc to the out ring
+//   role 1  R  recorder: Welford + global stores of the buffer before last, and the uniforms of the next
+//   role 2  PA normals (delta = sigma z) of the even transitions of the next buffer
+//   role 3  PB normals of the odd transitions
+// One barrier per B transitions; per transition the four waves carry ~50 / ~52 / ~56 / ~56 VALU instructions.
+__device__ __forceinline__ void ctail(const Args& a, double (&x)[D], double& lp, uint64_t& accepted, const double (&delta)[D],
+                                      double u, bool& acc_out)
+{
+    double y[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) y[j] = x[j] + delta[j];
+    uint32_t st = 0;
+    const bool moved = !ymc_states_equal<D>(y, x, 0);
+    const double lpy = Dens::eval(a.tgt, y, st);
+    const bool acc = ymc_accept(lpy - lp, moved, ymc_finite(lpy), u, st);
+#pragma unroll
+    for (int j = 0; j < D; ++j) x[j] = acc ? y[j] : x[j];
+    lp = acc ? lpy : lp;
+    accepted += acc ? 1u : 0u;
+    acc_out = acc;
+}
+
+template <int B, int PRIO>
+__global__ __launch_bounds__(1024) void quad(const Args a)
+{
+    ymc_stage_tables();
+    __shared__ double draws[4][2][B][D + 1][64];
+    __shared__ double outs[4][2][B][D][64];
+    __shared__ uint8_t oacc[4][2][B][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = w & 3, role = w >> 2;
+    const uint64_t k = (uint64_t)blockIdx.x * 256 + g * 64 + lane;
+    const uint32_t chain = (uint32_t)k;
+    const uint32_t nb = a.nsteps / B;  // harness: nsteps multiple of B, B even, t0 even
+    if (role >= 2) {
+        const int par = role - 2;
+        const double s0 = a.sigma[0], s1 = a.sigma[1];
+        for (uint32_t i = 0; i < nb + 2; ++i) {
+            if (i < nb) {
+#pragma unroll
+                for (int s = par; s < B; s += 2) {
+                    double z0, z1;
+                    ymc_draw_normal_pair(a.seed, chain, a.t0 + (uint64_t)i * B + s, 0, &z0, &z1);
+                    draws[g][i & 1][s][0][lane] = s0 * z0;
+                    draws[g][i & 1][s][1][lane] = s1 * z1;
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    if (role == 1) {
+        double xp[D], wmean[D], wm2[D];
+        ymc_load_row<D>(a.x, k, xp);
+        ymc_load_row<D>(a.wmean, k, wmean);
+        ymc_load_row<D>(a.wm2, k, wm2);
+        for (uint32_t i = 0; i < nb + 2; ++i) {
+            if (i < nb) {
+#pragma unroll
+                for (int s = 0; s < B; s += 2) {
+                    const ymc_u32x4 ub = ymc_uniform_block(a.seed, chain, a.t0 + (uint64_t)i * B + s);
+                    draws[g][i & 1][s][D][lane] = ymc_u01_co(ub.v[0], ub.v[1]);
+                    draws[g][i & 1][s + 1][D][lane] = ymc_u01_co(ub.v[2], ub.v[3]);
+                }
+            }
+            if (i >= 2) {
+                const uint32_t b = i - 2;
+#pragma unroll
+                for (int s = 0; s < B; ++s) {
+                    const uint32_t n = b * B + s;
+                    double xn[D] = {outs[g][b & 1][s][0][lane], outs[g][b & 1][s][1][lane]};
+                    const uint8_t ac = oacc[g][b & 1][s][lane];
+                    ymc_welford<D>(xp, (double)(a.t0 + n + 1), a.recip[n], wmean, wm2);
+                    ymc_store_row<D>(a.traj + (uint64_t)n * a.K * D, k, xn);
+                    a.acc[(uint64_t)n * a.K + k] = ac;
+                    xp[0] = xn[0];
+                    xp[1] = xn[1];
+                }
+            }
+            __syncthreads();
+        }
+        ymc_store_row<D>(a.wmean, k, wmean);
+        ymc_store_row<D>(a.wm2, k, wm2);
+        return;
+    }
+    if (PRIO) __builtin_amdgcn_s_setprio(3);
+    double x[D];
+    ymc_load_row<D>(a.x, k, x);
+    double lp = a.lp[k];
+    uint64_t accepted = a.acc_count[k];
+    for (uint32_t i = 0; i < nb + 2; ++i) {
+        if (i >= 1 && i <= nb) {
+            const uint32_t b = i - 1;
+            double dl[B][D], u[B];
+#pragma unroll
+            for (int s = 0; s < B; ++s) {
+                dl[s][0] = draws[g][b & 1][s][0][lane];
+                dl[s][1] = draws[g][b & 1][s][1][lane];
+                u[s] = draws[g][b & 1][s][D][lane];
+            }
+#pragma unroll
+            for (int s = 0; s < B; ++s) {
+                bool ac;
+                ctail(a, x, lp, accepted, dl[s], u[s], ac);
+                outs[g][b & 1][s][0][lane] = x[0];
+                outs[g][b & 1][s][1][lane] = x[1];
+                oacc[g][b & 1][s][lane] = ac ? 1 : 0;
+            }
+        }
+        __syncthreads();
+    }
+    ymc_store_row<D>(a.x, k, x);
+    a.lp[k] = lp;
+    a.acc_count[k] = accepted;
+}
+
 // Phase-locked variant: ONE workgroup of NW waves per CU-sized slice of NW/4*... chains.  All NW waves
 // first PRODUCE the draws of B transitions of the workgroup's CW*64 chains into LDS (high occupancy,
 // no serial work), barrier, then the first CW waves CONSUME them (one lane = one chain) while the
@@ -223,7 +411,7 @@ struct Bufs {
 int main(int argc, char** argv)
 {
     const uint64_t K = argc > 1 ? atoll(argv[1]) : 65536;
-    const uint32_t T = 960;
+    const uint32_t T = 960;  // multiple of 4, 6, 12, 16, 24, 32
     Args a;
     memset(&a, 0, sizeof a);
     a.tgt.mean[0] = 1.0; a.tgt.mean[1] = 1.5;
@@ -260,6 +448,13 @@ int main(int argc, char** argv)
         {"split NP3 R1 prio", [](const Args& a, uint64_t K) { hipLaunchKernelGGL((split<3, 1, 1>), dim3(K / 64), dim3(256), 0, 0, a); }},
         {"split NP4 R1 prio", [](const Args& a, uint64_t K) { hipLaunchKernelGGL((split<4, 1, 1>), dim3(K / 64), dim3(320), 0, 0, a); }},
         {"split NP5 R1 prio", [](const Args& a, uint64_t K) { hipLaunchKernelGGL((split<5, 1, 1>), dim3(K / 64), dim3(384), 0, 0, a); }},
+        {"split16 R1", [](const Args& a, uint64_t K) { hipLaunchKernelGGL((split16<1, 0, 0>), dim3(K / 256), dim3(1024), 0, 0, a); }},
+        {"split16 R1 prio", [](const Args& a, uint64_t K) { hipLaunchKernelGGL((split16<1, 1, 0>), dim3(K / 256), dim3(1024), 0, 0, a); }},
+        {"split16 R2 prio", [](const Args& a, uint64_t K) { hipLaunchKernelGGL((split16<2, 1, 0>), dim3(K / 256), dim3(1024), 0, 0, a); }},
+        {"quad B4", [](const Args& a, uint64_t K) { hipLaunchKernelGGL((quad<4, 0>), dim3(K / 256), dim3(1024), 0, 0, a); }},
+        {"quad B6", [](const Args& a, uint64_t K) { hipLaunchKernelGGL((quad<6, 0>), dim3(K / 256), dim3(1024), 0, 0, a); }},
+        {"quad B6 prio", [](const Args& a, uint64_t K) { hipLaunchKernelGGL((quad<6, 1>), dim3(K / 256), dim3(1024), 0, 0, a); }},
+        {"quad B2", [](const Args& a, uint64_t K) { hipLaunchKernelGGL((quad<2, 0>), dim3(K / 256), dim3(1024), 0, 0, a); }},
         {"split NP4 R1", [](const Args& a, uint64_t K) { hipLaunchKernelGGL((split<4, 1, 0>), dim3(K / 64), dim3(320), 0, 0, a); }},
         {"phased NW16 CW4 B16", [](const Args& a, uint64_t K) { launch_phased<16, 4, 16>(a, K); }},
         {"phased NW16 CW4 B24", [](const Args& a, uint64_t K) { launch_phased<16, 4, 24>(a, K); }},

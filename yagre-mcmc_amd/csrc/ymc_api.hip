@@ -331,6 +331,17 @@ int choose_lv_rows(const ymc_run *r)
     return (r->K + 63) / 64 < simds; /* measured: 2.5x at 16 384 chains, break-even near 65 536 */
 }
 
+/* Random walk with at most one 1024-thread workgroup (256 chains) per CU, i.e. at most one wave of chains
+ * per SIMD: let helper waves make the draws (mrw_split_kernel, ymc_kernels.hip).  Identical results;
+ * YMC_SPLIT=0|1 overrides the choice (tests run both). */
+int choose_split(const ymc_run *r)
+{
+    const ymc_problem *p = r->problem;
+    if (p->method != YMC_METHOD_MRW || p->D > 2 || p->kind == YMC_DENSITY_POSTERIOR_LV || p->chol.p) return 0;
+    if (const char *env = std::getenv("YMC_SPLIT")) return env[0] == '1';
+    return (r->K + 255) / 256 <= (uint64_t)r->ctx->prop.multiProcessorCount;
+}
+
 template <int D>
 int launch_advance(ymc_run *r, uint64_t nsteps)
 {
@@ -352,6 +363,7 @@ int launch_advance(ymc_run *r, uint64_t nsteps)
     a.eq_mode = p->eq_mode;
     a.S = p->S;
     a.lv_rows = choose_lv_rows(r);
+    a.split = choose_split(r);
     a.chol = p->chol.as<double>();
     a.x = r->x.as<double>();
     a.lp = r->lp.as<double>();

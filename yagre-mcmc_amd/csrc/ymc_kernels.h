@@ -17,7 +17,8 @@ struct ChainArgs {
     uint64_t wf_n0;      /* Welford count before this launch */
     uint32_t nsteps, flags;
     int32_t eq_mode, S;
-    int32_t lv_rows, pad_; /* Lotka-Volterra: spread a chain over n_data lanes (a speed choice, same results) */
+    int32_t lv_rows;     /* Lotka-Volterra: spread a chain over n_data lanes (a speed choice, same results) */
+    int32_t split;       /* random walk, at most one wave of chains per SIMD: draws made by helper waves (same results) */
     /* carried per-chain state */
     double *x, *lp, *lpc;
     uint64_t *acc_count;
@@ -34,6 +35,9 @@ struct ChainArgs {
 
 template <int D>
 hipError_t ymc_launch_chain(int kind, int method, const ChainArgs<D> &a, hipStream_t s);
+/* ymc_mlda2.hip: two-level kernels with a compile-time sub-chain length; false = not covered */
+template <int D>
+bool ymc_launch_mlda2_static(int kind, unsigned rec, const ChainArgs<D> &a, hipStream_t s);
 template <int D>
 hipError_t ymc_launch_logdensity(int kind, const DensityDev<D> &p, uint64_t n, const double *x, double *out,
                                  uint32_t *status, hipStream_t s);

@@ -148,6 +148,144 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 2))) 
     mrw_body<KIND, D, REC, EQ, kPropDiag>(a);
 }
 
+/*
+ * The random walk for ensembles of AT MOST one wave of chains per SIMD (BASELINE configs[1]: 65 536 chains =
+ * 1024 waves on 1024 SIMDs).  A single wave issues one vector instruction every ~5.3 cycles whatever the
+ * instruction (tools/probe_issue.hip), so with one lane per chain and nothing else on the SIMD the kernel
+ * runs at the ISSUE rate of one wave.  Here a 1024-thread workgroup (16 waves: wave w runs on SIMD w % 4)
+ * serves 256 chains; chain group g = w & 3 (64 chains) lives on SIMD g:
+ *   wave g          the chain itself: y = x + delta, density, accept / reject, moments, record
+ *                   (everything that depends on the state: ~75 instructions per transition)
+ *   waves 4+g, 8+g, 12+g   the draws, which depend on (chain id, transition) only: producer p makes
+ *                   delta = sigma * z and u for transitions 2p, 2p+1 of every block of six (~47 each)
+ * handed over through an LDS ring of two blocks, one barrier per six transitions.  Every lane does the
+ * arithmetic of mrw_body in the same order: same bits.  Measured +20 % at 65 536 chains (1.43e11 against
+ * 1.18e11 transitions/s); what bounds it then is the chip's power limit (the clock drops from 2.39 to
+ * ~2.0 GHz), the same wall the one-lane-per-chain kernel meets at 1 M chains.  The
+ * consumers of four 256-thread workgroups would all land on SIMD 0 -- hence one big workgroup.
+ */
+constexpr int kSplitBlock = 1024, kSplitChains = 256, kSplitProducers = 3, kSplitB = 2 * kSplitProducers;
+
+template <int KIND, int D, unsigned REC, int EQ>
+__global__ __launch_bounds__(kSplitBlock) void mrw_split_kernel(const ChainArgs<D> a)
+{
+    static_assert(REC != kRuntimeRec, "the split kernel serves the specialised record configurations");
+    ymc_stage_tables();
+    constexpr int B = kSplitB;
+    __shared__ double ring[4][2][B][D + 1][64];
+    using R = Rec<REC>;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = w & 3, role = w >> 2;
+    const uint64_t k = (uint64_t)blockIdx.x * kSplitChains + (uint64_t)g * 64 + lane;
+    const bool live = k < a.K;
+    const uint64_t kk = live ? k : 0;  /* lanes past the ensemble shadow chain 0 and never store */
+    const uint32_t chain = (uint32_t)(a.chain0 + kk);
+    const uint32_t nb = (a.nsteps + B - 1) / B;
+
+    if (role != 0) {
+        /* producer p: transitions 2p and 2p + 1 of every block (draws past nsteps are made and never read) */
+        const int p = role - 1;
+        double sigma[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) sigma[j] = a.sigma[j];
+        const bool aligned = (a.t0 & 1u) == 0; /* block starts are even offsets: (2p, 2p+1) share a uniform block */
+        auto fill = [&](uint32_t b) {
+            const int q = 2 * p;
+            const uint64_t t = a.t0 + (uint64_t)b * B + q;
+            double u0, u1;
+            if (aligned) {
+                const ymc_u32x4 ub = ymc_uniform_block(a.seed, chain, t);
+                u0 = ymc_u01_co(ub.v[0], ub.v[1]);
+                u1 = ymc_u01_co(ub.v[2], ub.v[3]);
+            } else {
+                u0 = ymc_draw_uniform(a.seed, chain, t);
+                u1 = ymc_draw_uniform(a.seed, chain, t + 1);
+            }
+            ring[g][b & 1][q][D][lane] = u0;
+            ring[g][b & 1][q + 1][D][lane] = u1;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int j = 0; 2 * j < D; ++j) {
+                    double z0, z1;
+                    ymc_draw_normal_pair(a.seed, chain, t + h, (uint32_t)j, &z0, &z1);
+                    ring[g][b & 1][q + h][2 * j][lane] = sigma[2 * j] * z0;                      /* covariance.py:51-52 */
+                    if (2 * j + 1 < D) ring[g][b & 1][q + h][2 * j + 1][lane] = sigma[2 * j + 1] * z1;
+                }
+            }
+        };
+        if (nb > 0) fill(0);
+        __syncthreads();
+#pragma unroll 1
+        for (uint32_t b = 0; b < nb; ++b) {
+            if (b + 1 < nb) fill(b + 1);
+            __syncthreads();
+        }
+        return;
+    }
+
+    double x[D], wmean[D], wm2[D];
+    ymc_load_row<D>(a.x, kk, x);
+    double lp = a.lp[kk];
+    uint64_t accepted = a.acc_count[kk];
+    uint32_t st = a.status[kk];
+    constexpr bool moments = (REC & YMC_RECORD_MOMENTS) != 0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) wmean[j] = wm2[j] = 0.0;
+    if (moments) {
+        ymc_load_row<D>(a.wf_mean, kk, wmean);
+        ymc_load_row<D>(a.wf_m2, kk, wm2);
+    }
+    /* one transition (metropolisHastings.py:114-120) given its proposal increment and accept uniform */
+    auto transition = [&](uint32_t n, const double (&delta)[D], double u) {
+        double y[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) y[j] = x[j] + delta[j];                         /* :116-117, gaussian.py:66 */
+        const bool moved = !states_equal<D, EQ>(y, x, a.eq_mode);                   /* :60-61 */
+        const double lpy = Density<KIND, D>::eval(a.tgt, y, st);
+        const bool acc = ymc_accept(lpy - lp, moved, ymc_finite(lpy), u, st);       /* mrw.py:51-57, :68-70 */
+        if (moments) ymc_welford<D>(x, (double)(a.wf_n0 + n + 1), ymc_recip_at(a.recip, n), wmean, wm2);
+#pragma unroll
+        for (int j = 0; j < D; ++j) x[j] = acc ? y[j] : x[j];                       /* :79-92 */
+        lp = acc ? lpy : lp;
+        accepted += acc ? 1u : 0u;
+        if (live) {
+            if (R::traj(a)) ymc_store_row<D>(a.traj + (uint64_t)n * a.K * D, k, x); /* :75-76 */
+            if (R::acc(a)) a.acc[(uint64_t)n * a.K + k] = acc ? 1 : 0;              /* diagnostics.py:48-54 */
+        }
+    };
+    __syncthreads();
+    /* the increments and the uniform of transition s of the current block, read where they are used (the
+     * scheduler lifts the reads as far ahead as the register budget of four waves per SIMD allows) */
+    auto step = [&](uint32_t b, int s) {
+        double delta[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) delta[j] = ring[g][b & 1][s][j][lane];
+        transition(b * B + s, delta, ring[g][b & 1][s][D][lane]);
+    };
+#pragma unroll 1
+    for (uint32_t b = 0; b < nb; ++b) {
+        if (b * B + B <= a.nsteps) {
+#pragma unroll
+            for (int s = 0; s < B; ++s) step(b, s);
+        } else {
+#pragma unroll
+            for (int s = 0; s < B; ++s)
+                if (b * B + s < a.nsteps) step(b, s);
+        }
+        __syncthreads();
+    }
+    if (live) {
+        ymc_store_row<D>(a.x, k, x);
+        a.lp[k] = lp;
+        a.acc_count[k] = accepted;
+        a.status[k] = st;
+        if (moments) {
+            ymc_store_row<D>(a.wf_mean, k, wmean);
+            ymc_store_row<D>(a.wf_m2, k, wm2);
+        }
+    }
+}
+
 template <int KIND, int D, unsigned REC, int EQ>
 __device__ __forceinline__ void mlda2_body(const ChainArgs<D> &a)
 {
@@ -489,12 +627,22 @@ void launch_one(int method, const ChainArgs<D> &a, hipStream_t s)
         if constexpr (REC == kRuntimeRec)
             hipLaunchKernelGGL((mrw_kernel<KIND, D, REC, EQ, kPropDense>), dim3(grid_for(a.K)), dim3(kBlock), 0, s, a);
     } else if (method == YMC_METHOD_MRW) {
-        if constexpr (REC != kRuntimeRec)
+        if constexpr (REC != kRuntimeRec) {
+            if constexpr (D <= 2 && KIND != YMC_DENSITY_POSTERIOR_LV) { /* beyond d = 2 the consumer no longer fits four waves per SIMD without spilling */
+                if (a.split) {
+                    hipLaunchKernelGGL((mrw_split_kernel<KIND, D, REC, EQ>),
+                                       dim3((unsigned)((a.K + kSplitChains - 1) / kSplitChains)), dim3(kSplitBlock), 0, s, a);
+                    return;
+                }
+            }
             hipLaunchKernelGGL((mrw_kernel_two_waves<KIND, D, REC, EQ>), dim3(grid_for(a.K)), dim3(kBlock), 0, s, a);
-        else
+        } else
             hipLaunchKernelGGL((mrw_kernel<KIND, D, REC, EQ>), dim3(grid_for(a.K)), dim3(kBlock), 0, s, a);
-    } else
+    } else {
+        if constexpr (REC != kRuntimeRec)
+            if (ymc_launch_mlda2_static<D>(KIND, REC, a, s)) return;
         hipLaunchKernelGGL((mlda2_kernel<KIND, D, REC, EQ>), dim3(grid_for(a.K)), dim3(kBlock), 0, s, a);
+    }
 }
 
 /* the specialised kernels cover what the builders produce by default (trajectory
