@@ -238,6 +238,27 @@ int ymc_run_fetch_state(ymc_run *run, double *state, double *logpost);
 int ymc_run_fetch_summary(ymc_run *run, uint64_t *accepted, uint64_t *wf_n, double *wf_mean,
                           double *wf_m2, uint32_t *status);
 
+/* ---- egress: the record on its way to the host -----------------------------------------------------
+ * ymc_run_fetch_* synchronise, then copy into pageable caller memory (~10 GB/s) while the GPU idles.  The
+ * egress calls stage rows through two page-locked buffers owned by the run, on a copy stream of their own:
+ * _begin returns at once; the copy starts when the launches issued so far have finished and runs BESIDE
+ * the launches issued afterwards; _wait blocks until the slot's copy is done and hands out pointers into
+ * the page-locked buffer (valid until the next _begin on that slot or ymc_run_destroy).  A later
+ * ymc_run_advance that would overwrite record rows still being copied waits for that copy ON THE DEVICE,
+ * so the natural loop is: record capacity 2 n; advance n (rows [0, n)), begin(0, 0, n); advance n (rows
+ * [n, 2n)), begin(1, n, n); wait(0); rewind; advance n; begin(0, 0, n); wait(1); ...
+ * `what`: any of YMC_RECORD_TRAJECTORY | _ACCEPT | _LOGPOST the run records.  Rows are record rows
+ * (thinned rows under record_stride).  The trajectory arrives as [n][n_chains][d], like ymc_run_fetch_trajectory. */
+typedef struct ymc_egress_view {
+    const double *trajectory;  /* [rows][n_chains][d] or NULL */
+    const uint8_t *accept;     /* [rows][n_chains] or NULL */
+    const double *logpost;     /* [rows][n_chains] or NULL */
+    uint64_t first, rows;
+} ymc_egress_view;
+#define YMC_EGRESS_SLOTS 2
+int ymc_run_egress_begin(ymc_run *run, int slot, uint64_t first, uint64_t n, uint32_t what);
+int ymc_run_egress_wait(ymc_run *run, int slot, ymc_egress_view *out);
+
 /* the packed per-chain summary records of this run (the payload of the multi-GPU gather below,
  * written by the same kernel): dst[n_chains][ymc_summary_words] */
 int ymc_run_fetch_packed_summary(ymc_run *run, uint64_t *dst, size_t dst_bytes);

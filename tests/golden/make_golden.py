@@ -735,8 +735,54 @@ def fixture_f13():
     print("F13", acc.mean())
 
 
+def fixture_f14():
+    """Two-level delayed acceptance over a model hierarchy at d = 128 (the matrix-core kernel's size): two
+    C3-shaped linear models (mlda.py:315-335, modelHierarchy.py:6-53), the coarse one a perturbation of the
+    fine one; 8 chains x 200 fine steps, sub-chain length 5; decisions of both levels."""
+    from yagremcmc.statistics.modelHierarchy import BayesianRegressionModelHierarchy
+    from yagremcmc.utility.hierarchy import Hierarchy, SharedComponent
+    d, n_data, seed, K, n, S = 128, 5, 20250114, 8, 201, 5
+    A_f, b_f, data, noise_var = linear_problem(d, n_data, 7)
+    z, _ = oracle.rng_fill(99, 0, d + 1, 0, 1, d, uniforms=False)
+    A_c = A_f + 0.02 * z[0][:d] / np.sqrt(d)          # a surrogate close enough to be useful, different enough to reject
+    b_c = b_f + 0.05 * z[0][d]
+    prior_mean, prior_var, prop_var = np.zeros(d), 5.0, 1.1e-3
+    prior = Gaussian(ParameterVector(prior_mean.copy()), IIDCovarianceMatrix(d, prior_var))
+    noise = CentredGaussianNoise(IIDCovarianceMatrix(d, noise_var))
+    lik_c = AdditiveGaussianNoiseLikelihood(Data(data), ForwardModel(ExampleLinearModelSolver(A_c, b_c)), noise)
+    lik_f = AdditiveGaussianNoiseLikelihood(Data(data), ForwardModel(ExampleLinearModelSolver(A_f, b_f)), noise)
+    model = BayesianRegressionModelHierarchy(Hierarchy([lik_c, lik_f]), SharedComponent(prior, 2))
+    cov = IIDCovarianceMatrix(d, prop_var)
+    traj = np.empty((n, K, d))
+    acc = np.empty((n - 1, K), dtype=np.uint8)
+    sub = np.empty((n - 1, S, K), dtype=np.uint8)
+    lp = np.empty((n, K))
+    for k in range(K):
+        b = MLDABuilder()
+        b.baseProposalCovariance = cov
+        b.subChainLengths = [S]
+        b.bayesModel = model
+        b.surrogateDiagnostics = [AcceptanceRateDiagnostics()]
+        mc = b.build_method()
+        rp = Replay(seed, k, d, (n - 1) * (S + 1), sub_chain_length=S)
+        rp.install()
+        mark_fine_level(mc, rp)
+        mc.run(n, ParameterVector(np.zeros(d)), verbose=False)
+        traj[:, k, :] = np.array(mc.chain.trajectory)
+        acc[:, k] = mc.diagnostics._decisions
+        sub[:, :, k] = np.array(mc.surrogate(0).diagnostics._decisions, dtype=np.uint8).reshape(n - 1, S)
+        lp[:, k] = eval_log_along(mc.target, traj[:, k, :], lambda s_: ParameterVector(np.array(s_)))
+    np.savez_compressed(
+        os.path.join(HERE, "f14_mlda2_linear_d128.npz"), seed=seed, n_states=n, S=S, A_fine=A_f, b_fine=b_f,
+        A_coarse=A_c, b_coarse=b_c, data=data, noise_precision=np.reciprocal(np.full(d, noise_var)),
+        prior_mean=prior_mean, prior_precision=np.reciprocal(np.full(d, prior_var)), sigma=sigma_of(cov),
+        x0=np.zeros((K, d)), traj_head=traj[:, :2, :], traj_sha256=sha(traj), acc=acc, sub_acc=sub, logpost=lp)
+    print("F14", acc.mean(), sub.mean())
+
+
 def main():
-    which = sys.argv[1:] or ["f1", "f2", "f2b", "f3", "f3b", "f4", "f5", "f7", "f8", "f9", "f10", "f11", "f12", "f13"]
+    which = sys.argv[1:] or ["f1", "f2", "f2b", "f3", "f3b", "f4", "f5", "f7", "f8", "f9", "f10", "f11", "f12", "f13",
+                             "f14"]
     if "f1" in which:
         fixture_f1()
     if "f2" in which:
@@ -766,6 +812,8 @@ def main():
         fixture_f11()
     if "f13" in which:
         fixture_f13()
+    if "f14" in which:
+        fixture_f14()
     if "f12" in which:
         fixture_f12()
         fixture_f12("f12b_aem_linear_noheuristic.npz", use_heuristic=False, seed=20250113, min_data=5, K=12,

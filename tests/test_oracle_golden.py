@@ -248,6 +248,25 @@ def test_f7_two_level_over_a_model_hierarchy(golden):
     assert np.array_equal(out["sub_acc"], g["sub_acc"])
 
 
+def test_f14_two_level_over_a_model_hierarchy_d128(golden):
+    """mlda.py:315-335 with two d = 128 linear models (the matrix-core kernel's size): the reference's
+    decisions at both levels, its chains (sha256 of all 201 x 8 x 128 states) and log-posteriors"""
+    g = golden("f14_mlda2_linear_d128.npz")
+    n, S = int(g["n_states"]), int(g["S"])
+    common = (g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+    fine = o.posterior_linear(g["A_fine"], g["b_fine"], *common)
+    coarse = o.posterior_linear(g["A_coarse"], g["b_coarse"], *common)
+    e = o.Ensemble(fine, g["sigma"], g["x0"], int(g["seed"]), surrogate=coarse, sub_chain_length=S)
+    out = e.advance(n - 1, want_sub=True)
+    assert np.array_equal(out["acc"], g["acc"]) and np.array_equal(out["sub_acc"], g["sub_acc"])
+    full = np.concatenate([g["x0"][None], out["traj"]])
+    assert np.array_equal(full[:, :2, :], g["traj_head"])
+    assert hashlib.sha256(np.ascontiguousarray(full).tobytes()).hexdigest() == str(g["traj_sha256"])
+    want = g["logpost"][1:]
+    assert np.abs(out["logpost"] - want).max() <= LP_RTOL * np.abs(want).max()
+    assert 0.5 < g["acc"].mean() < 0.95 and 0.2 < g["sub_acc"].mean() < 0.8   # both levels decide both ways
+
+
 def test_f8_preconditioned_crank_nicolson(golden):
     """pcn.py:9-57 on the Lotka-Volterra likelihood with a centred Gaussian prior"""
     g = golden("f8_pcn_lotka_volterra.npz")

@@ -76,6 +76,11 @@ class RunDesc(C.Structure):
     ]
 
 
+class EgressView(C.Structure):
+    _fields_ = [("trajectory", _dp), ("accept", C.POINTER(C.c_uint8)), ("logpost", _dp),
+                ("first", C.c_uint64), ("rows", C.c_uint64)]
+
+
 class DeviceInfo(C.Structure):
     _fields_ = [("name", C.c_char * 128), ("arch", C.c_char * 64), ("compute_units", C.c_int32),
                 ("clock_mhz", C.c_int32), ("hbm_bytes", C.c_uint64)]
@@ -110,6 +115,8 @@ _PROTOTYPES = {
     "ymc_run_fetch_state": (C.c_int, [_vp, _vp, _vp]),
     "ymc_run_fetch_summary": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "ymc_run_fetch_packed_summary": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "ymc_run_egress_begin": (C.c_int, [_vp, C.c_int, _u64, _u64, C.c_uint32]),
+    "ymc_run_egress_wait": (C.c_int, [_vp, C.c_int, C.POINTER(EgressView)]),
     "ymc_logdensity_eval": (C.c_int, [_vp, _vp, C.c_int, _u64, _vp, _vp, _vp]),
     "ymc_forward_eval": (C.c_int, [_vp, _vp, C.c_int, _u64, _vp, _vp]),
     "ymc_run_iat": (C.c_int, [_vp, _u64, _u64, C.c_int, C.c_double, _vp]),
@@ -404,6 +411,27 @@ class Run(Handle):
         out = np.empty(self.K, dtype=np.int32)
         check(lib().ymc_run_iat(self.raw, first, n, method, float(sokal_const), vptr(out)))
         return checked_iat(out, allow_undefined)
+
+    def egress_begin(self, slot, first, n, what=RECORD_TRAJECTORY):
+        """Start copying record rows [first, first + n) to the run's page-locked staging slot 0 | 1 on the copy
+        stream; returns at once and the copy runs beside later launches (include/ymc.h, egress)."""
+        check(lib().ymc_run_egress_begin(self.raw, int(slot), int(first), int(n), int(what)))
+
+    def egress_wait(self, slot):
+        """Block until the slot's copy is done; -> dict of NumPy VIEWS into the page-locked staging memory
+        (trajectory (n, K, d), accept (n, K), logpost (n, K) as requested; `first`), valid until the next
+        egress_begin on that slot."""
+        v = EgressView()
+        check(lib().ymc_run_egress_wait(self.raw, int(slot), C.byref(v)))
+        n = int(v.rows)
+        out = dict(first=int(v.first))
+        if v.trajectory:
+            out["trajectory"] = np.ctypeslib.as_array(v.trajectory, shape=(n, self.K, self.d))
+        if v.accept:
+            out["accept"] = np.ctypeslib.as_array(v.accept, shape=(n, self.K))
+        if v.logpost:
+            out["logpost"] = np.ctypeslib.as_array(v.logpost, shape=(n, self.K))
+        return out
 
     def packed_summary(self):
         """(K, 3d+5) u64: the records pack_summary_kernel writes (the payload of the multi-GPU gather)."""

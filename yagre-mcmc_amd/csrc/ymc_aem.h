@@ -13,6 +13,7 @@ struct AemArgs {
     uint64_t seed, chain0, K;
     uint64_t t0, wf_n0;
     uint32_t nsteps, flags;
+    uint32_t rec_stride, rec_since; /* thinned record (RecordClock) */
     int32_t eq_mode, S, min_data, use_heuristic;
     /* carried per chain */
     double *x, *lp;

@@ -209,6 +209,7 @@ __global__ __launch_bounds__(kBlock) void aem2_kernel(const AemArgs<D> a)
     uc.valid = false;
     uc.pair = 0;
 
+    RecordClock clk(a.rec_stride, a.rec_since);
 #pragma unroll 1
     for (uint32_t n = 0; n < a.nsteps; ++n) {
         const uint64_t tbase = (a.t0 + n) * (uint64_t)(S + 1);
@@ -251,9 +252,12 @@ __global__ __launch_bounds__(kBlock) void aem2_kernel(const AemArgs<D> a)
             lpf = lpfy;
             accepted += 1u;
         }
-        if (a.traj) ymc_store_row<D>(a.traj + (uint64_t)n * a.K * D, k, x);
         if (a.acc) a.acc[(uint64_t)n * a.K + k] = acc ? 1 : 0;
-        if (a.lp_out) a.lp_out[(uint64_t)n * a.K + k] = lpf;
+        if (clk.due()) {
+            if (a.traj) ymc_store_row<D>(a.traj + (uint64_t)clk.row * a.K * D, k, x);
+            if (a.lp_out) a.lp_out[(uint64_t)clk.row * a.K + k] = lpf;
+            clk.wrote();
+        }
     }
 
     ymc_store_row<D>(a.x, k, x);

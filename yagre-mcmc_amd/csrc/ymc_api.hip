@@ -50,6 +50,20 @@ int fail(int code, const char *fmt, ...)
         if (rc_ != YMC_OK) return rc_; \
     } while (0)
 
+/* page-locked host memory, grown on demand */
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    ~PinnedBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    int reserve(size_t n);
+};
+
 struct DeviceBuf {
     void *p = nullptr;
     size_t bytes = 0;
@@ -71,6 +85,15 @@ struct DeviceBuf {
     template <class T>
     T *as() const { return static_cast<T *>(p); }
 };
+
+int PinnedBuf::reserve(size_t n)
+{
+    if (n <= bytes) return YMC_OK;
+    release();
+    YMC_HIP(hipHostMalloc(&p, n, hipHostMallocDefault));
+    bytes = n;
+    return YMC_OK;
+}
 
 /* host copy of one lowered density + its device-resident arrays */
 struct DensityHost {
@@ -130,9 +153,21 @@ struct ymc_run {
     uint64_t seed = 0, chain0 = 0, K = 0;
     uint32_t flags = 0;
     uint64_t capacity = 0, recorded = 0, steps_done = 0;
+    uint32_t stride = 1; /* record_stride: rows hold the states after transitions stride, 2 stride, ... of the run */
     DeviceBuf x, lp, lpc, acc_count, wf_mean, wf_m2, status, traj, acc, lp_out, sub_acc, summary, x_before, recip;
     DeviceBuf level_acc; /* MLDA_NESTED: [E-1][K] */
     DeviceBuf err_n, err_mean, err_m2, aem_prec, aem_flags, cache_key, cache_val; /* AEM2 */
+    /* egress (ymc_run_egress_*): a copy stream, two slots of page-locked staging */
+    struct EgressSlot {
+        PinnedBuf traj, acc, lp;
+        DeviceBuf untiled;          /* tile-kernel record: rows untiled on the device before they travel */
+        hipEvent_t ready = nullptr; /* compute stream: everything issued before _begin */
+        hipEvent_t done = nullptr;  /* copy stream: the slot's copies */
+        bool pending = false;
+        uint64_t first = 0, rows = 0;
+        uint32_t what = 0;
+    } egress[YMC_EGRESS_SLOTS];
+    hipStream_t copy_stream = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timed;  /* launches since the last query */
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
 };
@@ -363,6 +398,8 @@ int launch_advance(ymc_run *r, uint64_t nsteps)
     a.eq_mode = p->eq_mode;
     a.S = p->S;
     a.lv_rows = choose_lv_rows(r);
+    a.rec_stride = r->stride;
+    a.rec_since = (uint32_t)(r->steps_done % r->stride);
     a.split = choose_split(r);
     a.chol = p->chol.as<double>();
     a.x = r->x.as<double>();
@@ -421,6 +458,8 @@ int launch_advance_aem(ymc_run *r, uint64_t nsteps)
     a.flags = r->flags;
     a.eq_mode = p->eq_mode;
     a.S = p->S;
+    a.rec_stride = r->stride;
+    a.rec_since = (uint32_t)(r->steps_done % r->stride);
     a.min_data = p->aem_min_data;
     a.use_heuristic = p->aem_heuristic;
     a.x = r->x.as<double>();
@@ -501,6 +540,8 @@ int launch_advance_nested(ymc_run *r, uint64_t nsteps)
     a.K = r->K;
     a.t0 = r->steps_done;
     a.cost_top = p->lvl_cost[p->E - 1];
+    a.rec_stride = r->stride;
+    a.rec_since = (uint32_t)(r->steps_done % r->stride);
     a.wf_n0 = r->steps_done;
     a.nsteps = (uint32_t)nsteps;
     a.flags = r->flags;
@@ -593,6 +634,8 @@ int launch_advance_tile(ymc_run *r, uint64_t nsteps)
     a.t0 = r->steps_done;
     a.nsteps = (uint32_t)nsteps;
     a.flags = r->flags;
+    a.rec_stride = r->stride;
+    a.rec_since = (uint32_t)(r->steps_done % r->stride);
     a.pcn = p->method == YMC_METHOD_PCN;
     a.pcn_c1 = p->pcn_c1;
     a.pcn_c2 = p->pcn_c2;
@@ -926,8 +969,13 @@ int ymc_run_create(ymc_ctx *ctx, const ymc_problem *problem, const ymc_run_desc 
         return fail(YMC_ERR_INVALID, "initial_state must have 1 or n_chains rows");
     if (records_anything(desc->record_flags) && desc->record_capacity == 0)
         return fail(YMC_ERR_INVALID, "record_capacity must be positive when something is recorded");
-    if (desc->record_stride > 1)
-        return fail(YMC_ERR_UNSUPPORTED, "thinned records are not available yet");
+    if (desc->record_stride > 1 && (desc->record_flags & (YMC_RECORD_ACCEPT | YMC_RECORD_SUB_ACCEPT)))
+        return fail(YMC_ERR_INVALID, "record_stride %u thins the trajectory; the per-transition decision records "
+                                     "(YMC_RECORD_ACCEPT / _SUB_ACCEPT) are full-rate data and cannot be combined with it",
+                    desc->record_stride);
+    if (desc->record_stride > 1 && problem->tile && (desc->record_flags & YMC_RECORD_MOMENTS))
+        return fail(YMC_ERR_UNSUPPORTED, "at this dimension the Welford moments are replayed from the FULL record: "
+                                         "record_stride must be 1 with YMC_RECORD_MOMENTS");
     if (problem->tile && (desc->record_flags & YMC_RECORD_MOMENTS) && !(desc->record_flags & YMC_RECORD_TRAJECTORY))
         return fail(YMC_ERR_UNSUPPORTED,
                     "at this dimension the Welford moments are replayed from the record: record the trajectory too");
@@ -940,6 +988,7 @@ int ymc_run_create(ymc_ctx *ctx, const ymc_problem *problem, const ymc_run_desc 
     r->chain0 = desc->chain_offset;
     r->K = desc->n_chains;
     r->flags = desc->record_flags;
+    r->stride = desc->record_stride > 1 ? desc->record_stride : 1;
     r->capacity = records_anything(r->flags) ? desc->record_capacity : 0;
     const uint64_t K = r->K;
     const int D = problem->D;
@@ -1013,6 +1062,14 @@ int ymc_run_destroy(ymc_run *run)
     if (!run) return YMC_OK;
     (void)hipSetDevice(run->ctx->device);
     (void)hipStreamSynchronize(run->ctx->stream);
+    if (run->copy_stream) {
+        (void)hipStreamSynchronize(run->copy_stream);
+        (void)hipStreamDestroy(run->copy_stream);
+    }
+    for (auto &slot : run->egress) {
+        if (slot.ready) (void)hipEventDestroy(slot.ready);
+        if (slot.done) (void)hipEventDestroy(slot.done);
+    }
     for (auto &v : {run->timed, run->pool})
         for (auto &ev : v) {
             (void)hipEventDestroy(ev.first);
@@ -1028,11 +1085,17 @@ int ymc_run_advance(ymc_run *run, uint64_t nsteps)
 {
     if (!run) return fail(YMC_ERR_INVALID, "null argument");
     if (nsteps == 0) return YMC_OK;
-    if (records_anything(run->flags) && run->recorded + nsteps > run->capacity)
+    /* rows this call adds: the transitions t (0-based, counted over the run) with (t + 1) % stride == 0 */
+    const uint64_t new_rows = (run->steps_done + nsteps) / run->stride - run->steps_done / run->stride;
+    if (records_anything(run->flags) && run->recorded + new_rows > run->capacity)
         return fail(YMC_ERR_CAPACITY, "record holds %llu of %llu rows; %llu more do not fit",
                     (unsigned long long)run->recorded, (unsigned long long)run->capacity,
-                    (unsigned long long)nsteps);
+                    (unsigned long long)new_rows);
     YMC_HIP(hipSetDevice(run->ctx->device));
+    /* rows about to be written must not be on their way to the host any more */
+    for (auto &slot : run->egress)
+        if (slot.pending && run->recorded < slot.first + slot.rows && slot.first < run->recorded + new_rows)
+            YMC_HIP(hipStreamWaitEvent(run->ctx->stream, slot.done, 0));
     const uint64_t chunk_max = 1u << 24;
     while (nsteps) {
         const uint64_t chunk = nsteps < chunk_max ? nsteps : chunk_max;
@@ -1045,8 +1108,9 @@ int ymc_run_advance(ymc_run *run, uint64_t nsteps)
         } else {
             YMC_DISPATCH_D(run->problem->D, YMC_TRY(launch_advance<DD>(run, chunk)));
         }
+        if (records_anything(run->flags))
+            run->recorded += (run->steps_done + chunk) / run->stride - run->steps_done / run->stride;
         run->steps_done += chunk;
-        if (records_anything(run->flags)) run->recorded += chunk;
         nsteps -= chunk;
     }
     return YMC_OK;
@@ -1210,6 +1274,75 @@ int ymc_run_fetch_summary(ymc_run *run, uint64_t *accepted, uint64_t *wf_n, doub
     if (wf_mean) YMC_HIP(hipMemcpy(wf_mean, run->wf_mean.p, run->wf_mean.bytes, hipMemcpyDeviceToHost));
     if (wf_m2) YMC_HIP(hipMemcpy(wf_m2, run->wf_m2.p, run->wf_m2.bytes, hipMemcpyDeviceToHost));
     if (status) YMC_HIP(hipMemcpy(status, run->status.p, run->status.bytes, hipMemcpyDeviceToHost));
+    return YMC_OK;
+}
+
+int ymc_run_egress_begin(ymc_run *run, int slot_index, uint64_t first, uint64_t n, uint32_t what)
+{
+    if (!run) return fail(YMC_ERR_INVALID, "null argument");
+    if (slot_index < 0 || slot_index >= YMC_EGRESS_SLOTS)
+        return fail(YMC_ERR_INVALID, "egress slot %d out of range (0 .. %d)", slot_index, YMC_EGRESS_SLOTS - 1);
+    const uint32_t known = YMC_RECORD_TRAJECTORY | YMC_RECORD_ACCEPT | YMC_RECORD_LOGPOST;
+    if (what == 0 || (what & ~known)) return fail(YMC_ERR_INVALID, "egress of record kinds 0x%x is not possible", what);
+    if (what & ~run->flags) return fail(YMC_ERR_INVALID, "the run does not record what was asked for (0x%x of 0x%x)", what, run->flags);
+    if (n == 0 || first + n > run->recorded)
+        return fail(YMC_ERR_INVALID, "rows [%llu, %llu) requested but only %llu recorded", (unsigned long long)first,
+                    (unsigned long long)(first + n), (unsigned long long)run->recorded);
+    YMC_HIP(hipSetDevice(run->ctx->device));
+    ymc_run::EgressSlot &slot = run->egress[slot_index];
+    if (!run->copy_stream) YMC_HIP(hipStreamCreateWithFlags(&run->copy_stream, hipStreamNonBlocking));
+    if (!slot.ready) YMC_HIP(hipEventCreateWithFlags(&slot.ready, hipEventDisableTiming));
+    if (!slot.done) YMC_HIP(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+    if (slot.pending) YMC_HIP(hipEventSynchronize(slot.done)); /* the buffers are about to be reused */
+    const uint64_t K = run->K;
+    const int D = run->problem->D;
+    const size_t traj_row = K * (size_t)D * sizeof(double);
+    if (what & YMC_RECORD_TRAJECTORY) YMC_TRY(slot.traj.reserve(n * traj_row));
+    if (what & YMC_RECORD_ACCEPT) YMC_TRY(slot.acc.reserve(n * K));
+    if (what & YMC_RECORD_LOGPOST) YMC_TRY(slot.lp.reserve(n * K * sizeof(double)));
+    const double *traj_src = nullptr;
+    if (what & YMC_RECORD_TRAJECTORY) {
+        if (run->problem->tile) {
+            if (slot.untiled.bytes < n * traj_row) YMC_TRY(slot.untiled.alloc(n * traj_row));
+            YMC_HIP(ymc_launch_untile(run->traj.as<double>(), first, n, K, D, run->problem->tgt.KS,
+                                      slot.untiled.as<double>(), run->ctx->stream));
+            traj_src = slot.untiled.as<double>();
+        } else {
+            traj_src = run->traj.as<double>() + first * K * D;
+        }
+    }
+    YMC_HIP(hipEventRecord(slot.ready, run->ctx->stream));
+    YMC_HIP(hipStreamWaitEvent(run->copy_stream, slot.ready, 0));
+    if (what & YMC_RECORD_TRAJECTORY)
+        YMC_HIP(hipMemcpyAsync(slot.traj.p, traj_src, n * traj_row, hipMemcpyDeviceToHost, run->copy_stream));
+    if (what & YMC_RECORD_ACCEPT)
+        YMC_HIP(hipMemcpyAsync(slot.acc.p, run->acc.as<uint8_t>() + first * K, n * K, hipMemcpyDeviceToHost, run->copy_stream));
+    if (what & YMC_RECORD_LOGPOST)
+        YMC_HIP(hipMemcpyAsync(slot.lp.p, run->lp_out.as<double>() + first * K, n * K * sizeof(double),
+                               hipMemcpyDeviceToHost, run->copy_stream));
+    YMC_HIP(hipEventRecord(slot.done, run->copy_stream));
+    slot.pending = true;
+    slot.first = first;
+    slot.rows = n;
+    slot.what = what;
+    return YMC_OK;
+}
+
+int ymc_run_egress_wait(ymc_run *run, int slot_index, ymc_egress_view *out)
+{
+    if (!run || !out) return fail(YMC_ERR_INVALID, "null argument");
+    if (slot_index < 0 || slot_index >= YMC_EGRESS_SLOTS)
+        return fail(YMC_ERR_INVALID, "egress slot %d out of range (0 .. %d)", slot_index, YMC_EGRESS_SLOTS - 1);
+    ymc_run::EgressSlot &slot = run->egress[slot_index];
+    if (!slot.done || slot.rows == 0) return fail(YMC_ERR_INVALID, "nothing was begun on egress slot %d", slot_index);
+    YMC_HIP(hipSetDevice(run->ctx->device));
+    YMC_HIP(hipEventSynchronize(slot.done));
+    slot.pending = false;
+    out->trajectory = (slot.what & YMC_RECORD_TRAJECTORY) ? static_cast<const double *>(slot.traj.p) : nullptr;
+    out->accept = (slot.what & YMC_RECORD_ACCEPT) ? static_cast<const uint8_t *>(slot.acc.p) : nullptr;
+    out->logpost = (slot.what & YMC_RECORD_LOGPOST) ? static_cast<const double *>(slot.lp.p) : nullptr;
+    out->first = slot.first;
+    out->rows = slot.rows;
     return YMC_OK;
 }
 

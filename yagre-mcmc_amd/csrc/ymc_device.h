@@ -299,6 +299,28 @@ __device__ __forceinline__ void ymc_welford(const double (&x)[D], double dn, dou
     }
 }
 
+/* Thinned record (ymc_run_desc.record_stride): of the transitions of a run only every stride-th one is
+ * written to the trajectory / log-density record.  `since` counts the transitions made after the last
+ * recorded one (carried from launch to launch by the host), `row` the rows this launch has written.
+ * Wave-uniform: scalar registers and scalar branches only. */
+struct RecordClock {
+    uint32_t stride, since, row;
+    __device__ __forceinline__ RecordClock(uint32_t stride_, uint32_t since_)
+        : stride(stride_ ? stride_ : 1u), since(since_), row(0u)
+    {
+    }
+    /* called once per transition: is this one recorded?  (the caller writes row `row`, then calls wrote()) */
+    __device__ __forceinline__ bool due()
+    {
+        if (++since >= stride) {
+            since = 0u;
+            return true;
+        }
+        return false;
+    }
+    __device__ __forceinline__ void wrote() { ++row; }
+};
+
 template <int D>
 __device__ __forceinline__ void ymc_load_row(const double *__restrict__ base, uint64_t k, double (&v)[D])
 {

@@ -19,6 +19,7 @@ struct ChainArgs {
     int32_t eq_mode, S;
     int32_t lv_rows;     /* Lotka-Volterra: spread a chain over n_data lanes (a speed choice, same results) */
     int32_t split;       /* random walk, at most one wave of chains per SIMD: draws made by helper waves (same results) */
+    uint32_t rec_stride, rec_since; /* thinned record (RecordClock): stride, transitions since the last recorded one */
     /* carried per-chain state */
     double *x, *lp, *lpc;
     uint64_t *acc_count;

@@ -82,6 +82,7 @@ __device__ __forceinline__ void mrw_body(const ChainArgs<D> &a)
         ymc_load_row<D>(a.wf_m2, k, wm2);
     }
 
+    RecordClock clk(R::rt ? a.rec_stride : 1u, a.rec_since); /* the specialised records are never thinned */
     /* one transition (metropolisHastings.py:114-120) given its accept uniform */
     auto transition = [&](uint32_t n, double u) {
         const uint64_t t = a.t0 + n;
@@ -100,9 +101,17 @@ __device__ __forceinline__ void mrw_body(const ChainArgs<D> &a)
         for (int j = 0; j < D; ++j) x[j] = acc ? y[j] : x[j];                   /* :79-92 */
         lp = acc ? lpy : lp;
         accepted += acc ? 1u : 0u;
-        if (R::traj(a)) ymc_store_row<D>(a.traj + (uint64_t)n * a.K * D, k, x); /* :75-76 */
         if (R::acc(a)) a.acc[(uint64_t)n * a.K + k] = acc ? 1 : 0;              /* diagnostics.py:48-54 */
-        if (R::lp(a)) a.lp_out[(uint64_t)n * a.K + k] = lp;
+        if constexpr (R::rt) {
+            if (clk.due()) {
+                if (R::traj(a)) ymc_store_row<D>(a.traj + (uint64_t)clk.row * a.K * D, k, x);
+                if (R::lp(a)) a.lp_out[(uint64_t)clk.row * a.K + k] = lp;
+                clk.wrote();
+            }
+        } else {
+            if (R::traj(a)) ymc_store_row<D>(a.traj + (uint64_t)n * a.K * D, k, x); /* :75-76 */
+            if (R::lp(a)) a.lp_out[(uint64_t)n * a.K + k] = lp;
+        }
     };
 
     /* transitions 2p and 2p+1 share one Philox block of uniforms: walk in aligned pairs */
@@ -312,6 +321,7 @@ __device__ __forceinline__ void mlda2_body(const ChainArgs<D> &a)
     UniformCache uc;
     uc.valid = false;
     uc.pair = 0;
+    RecordClock clk(R::rt ? a.rec_stride : 1u, a.rec_since);
 
 #pragma unroll 1
     for (uint32_t n = 0; n < a.nsteps; ++n) {
@@ -348,9 +358,12 @@ __device__ __forceinline__ void mlda2_body(const ChainArgs<D> &a)
         lpf = acc ? lpfy : lpf;
         lpc = acc ? lpcz : lpc;
         accepted += acc ? 1u : 0u;
-        if (R::traj(a)) ymc_store_row<D>(a.traj + (uint64_t)n * a.K * D, k, x);
         if (R::acc(a)) a.acc[(uint64_t)n * a.K + k] = acc ? 1 : 0;
-        if (R::lp(a)) a.lp_out[(uint64_t)n * a.K + k] = lpf;
+        if (clk.due()) {
+            if (R::traj(a)) ymc_store_row<D>(a.traj + (uint64_t)clk.row * a.K * D, k, x);
+            if (R::lp(a)) a.lp_out[(uint64_t)clk.row * a.K + k] = lpf;
+            clk.wrote();
+        }
     }
 
     ymc_store_row<D>(a.x, k, x);
@@ -416,6 +429,7 @@ __global__ __launch_bounds__(kBlock) void mrw_lv_rows_kernel(const ChainArgs<2> 
     UniformCache uc;
     uc.valid = false;
     uc.pair = 0;
+    RecordClock clk(a.rec_stride, a.rec_since);
 
 #pragma unroll 1
     for (uint32_t n = 0; n < a.nsteps; ++n) {
@@ -454,11 +468,13 @@ __global__ __launch_bounds__(kBlock) void mrw_lv_rows_kernel(const ChainArgs<2> 
         for (int j = 0; j < D; ++j) x[j] = acc ? y[j] : x[j];
         lp = acc ? lpy : lp;
         accepted += acc ? 1u : 0u;
+        const bool rec = clk.due();
         if (live && row == 0) {
-            if (R::traj(a)) ymc_store_row<D>(a.traj + (uint64_t)n * a.K * D, k, x);
             if (R::acc(a)) a.acc[(uint64_t)n * a.K + k] = acc ? 1 : 0;
-            if (R::lp(a)) a.lp_out[(uint64_t)n * a.K + k] = lp;
+            if (rec && R::traj(a)) ymc_store_row<D>(a.traj + (uint64_t)clk.row * a.K * D, k, x);
+            if (rec && R::lp(a)) a.lp_out[(uint64_t)clk.row * a.K + k] = lp;
         }
+        if (rec) clk.wrote();
     }
     if (live && row == 0) {
         ymc_store_row<D>(a.x, k, x);
@@ -654,7 +670,7 @@ hipError_t launch_chain(int method, const ChainArgs<D> &a, hipStream_t s)
     const unsigned rec = (a.traj ? YMC_RECORD_TRAJECTORY : 0u) | (a.acc ? YMC_RECORD_ACCEPT : 0u) |
                          (a.lp_out ? YMC_RECORD_LOGPOST : 0u) | (a.sub_acc ? YMC_RECORD_SUB_ACCEPT : 0u) |
                          (a.flags & YMC_RECORD_MOMENTS);
-    if (method == YMC_METHOD_PCN || a.chol)
+    if (method == YMC_METHOD_PCN || a.chol || a.rec_stride > 1)
         launch_one<KIND, D, kRuntimeRec, -1>(method, a, s);
     else if (a.eq_mode == YMC_EQ_EXACT && rec == kTA)
         launch_one<KIND, D, kTA, YMC_EQ_EXACT>(method, a, s);

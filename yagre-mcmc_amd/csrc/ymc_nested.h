@@ -18,6 +18,7 @@ struct NestedArgs {
     uint64_t cost_top;  /* transitions one top-level step spans (c_{E-1}) */
     uint64_t wf_n0;
     uint32_t nsteps, flags;
+    uint32_t rec_stride, rec_since; /* thinned record (RecordClock) */
     /* carried per-chain state: x, P_top(x), Q_top(x) */
     double *x, *lp, *lpq;
     uint64_t *acc_count;

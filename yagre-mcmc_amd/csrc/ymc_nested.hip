@@ -118,6 +118,7 @@ __global__ __launch_bounds__(kBlock) void mlda_nested_kernel(const NestedArgs<D>
         ymc_load_row<D>(a.wf_m2, k, wm2);
     }
 
+    RecordClock clk(a.rec_stride, a.rec_since);
 #pragma unroll 1
     for (uint32_t n = 0; n < a.nsteps; ++n) {
         w.t = (a.t0 + n) * a.cost_top;
@@ -128,9 +129,12 @@ __global__ __launch_bounds__(kBlock) void mlda_nested_kernel(const NestedArgs<D>
         if (moments) ymc_welford<D>(x, (double)(a.wf_n0 + n + 1), ymc_recip_at(a.recip, n), wmean, wm2);
         const bool acc = w.decide(a.P[E - 1], a.Q[E - 1], x, y, lpP, lpQ);            /* mlda.py:146-154 */
         accepted += acc ? 1u : 0u;
-        if (a.traj) ymc_store_row<D>(a.traj + (uint64_t)n * a.K * D, k, x);
         if (a.acc) a.acc[(uint64_t)n * a.K + k] = acc ? 1 : 0;
-        if (a.lp_out) a.lp_out[(uint64_t)n * a.K + k] = lpP;
+        if (clk.due()) {
+            if (a.traj) ymc_store_row<D>(a.traj + (uint64_t)clk.row * a.K * D, k, x);
+            if (a.lp_out) a.lp_out[(uint64_t)clk.row * a.K + k] = lpP;
+            clk.wrote();
+        }
     }
 
     ymc_store_row<D>(a.x, k, x);

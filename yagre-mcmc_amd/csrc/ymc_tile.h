@@ -21,6 +21,7 @@ struct TileArgs {
     uint64_t seed, chain0, K, t0;
     uint32_t nsteps, flags;
     int32_t pcn, pad_;      /* 1: preconditioned Crank-Nicolson (pcn.py:9-57): sigma is the PRIOR's, lp the log-likelihood */
+    uint32_t rec_stride, rec_since; /* thinned record (RecordClock) */
     double pcn_c1, pcn_c2;  /* sqrt(1 - 2h), sqrt(2h) */
     double *x, *lp;
     uint64_t *acc_count;

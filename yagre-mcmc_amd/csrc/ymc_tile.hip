@@ -96,6 +96,7 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
     UniformCache uc;
     uc.valid = false;
     uc.pair = 0;
+    RecordClock clk(a.rec_stride, a.rec_since);
 
 #pragma unroll 1
     for (uint32_t n = 0; n < a.nsteps; ++n) {
@@ -176,15 +177,17 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
         lp = acc ? lpy : lp;
         accepted += acc ? 1u : 0u;
 
-        if (a.traj) {
-            double *row = a.traj + (((uint64_t)n * nct + tile) * KS) * 64 + lane;
+        const bool rec = clk.due();
+        if (rec && a.traj) {
+            double *row = a.traj + (((uint64_t)clk.row * nct + tile) * KS) * 64 + lane;
 #pragma unroll
             for (int s = 0; s < KS; ++s) row[s * 64] = x[s];
         }
         if (live && g == 0) {
             if (a.acc) a.acc[(uint64_t)n * a.K + k] = acc ? 1 : 0;
-            if (a.lp_out) a.lp_out[(uint64_t)n * a.K + k] = lp;
+            if (rec && a.lp_out) a.lp_out[(uint64_t)clk.row * a.K + k] = lp;
         }
+        if (rec) clk.wrote();
     }
 
     if (live) {

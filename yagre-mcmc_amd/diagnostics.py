@@ -91,6 +91,8 @@ class AcceptanceRateDiagnostics:
         if self._steps < self._lag:
             raise RuntimeError("Insufficient data for rolling acceptance rate.")
         m = self._matrix
+        if m is None:
+            raise RuntimeError("The per-transition decisions were not recorded (thinned record).")
         return np.sum(m[-self._lag:]) / (self._lag * m.shape[1])
 
     def global_acceptance_rate(self):

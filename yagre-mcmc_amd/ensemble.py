@@ -115,8 +115,8 @@ class MetropolisHastingsEnsemble:
         ctx = _ffi.default_context(self.device)
         self._problem = self._make_problem(ctx, state_eq)
         nsteps = chainLength - 1
-        run = _ffi.Run(self._problem, self.seed, self.nChains, x0, max(nsteps, 1), self._record_flags(),
-                       self.chainOffset)
+        run = _ffi.Run(self._problem, self.seed, self.nChains, x0, max(nsteps // self.recordStride, 1),
+                       self._record_flags(), self.chainOffset, record_stride=self.recordStride)
         self._run = run
         self._chain._attach(np.broadcast_to(x0, (self.nChains, x0.shape[1])).copy(), run)
         if verbose and nsteps > 0:
@@ -138,6 +138,9 @@ class MetropolisHastingsEnsemble:
 
     @property
     def accept_decisions(self):
+        if not (self._run.flags & _ffi.RECORD_ACCEPT):
+            raise RuntimeError("the per-transition decisions are not recorded with recordStride > 1 "
+                               "(accept counts and rates are)")
         return self._run.accept()
 
     @property
@@ -188,7 +191,10 @@ class MetropolisHastingsEnsemble:
         return x0, _ffi.EQ_EXACT
 
     def _record_flags(self):
-        flags = _ffi.RECORD_ACCEPT
+        """recordStride = s > 1 (a thinned record: the states after transitions s, 2s, ... -- what the
+        reference's examples keep after thinning by the IAT, example_mcmc_2d_singleLevel.py:71-79): the
+        per-transition decision record is dropped, accept counts and moments still see every transition."""
+        flags = _ffi.RECORD_ACCEPT if self.recordStride == 1 else 0
         if self.recordTrajectory:
             flags |= _ffi.RECORD_TRAJECTORY
         if self.recordLogPosterior:
@@ -202,7 +208,8 @@ class MetropolisHastingsEnsemble:
 
     def _ingest(self):
         run = self._run
-        self._diagnostics._ingest(run.accept, run.summary(), run.steps_done()[0])
+        fetch = run.accept if (run.flags & _ffi.RECORD_ACCEPT) else None
+        self._diagnostics._ingest(fetch, run.summary(), run.steps_done()[0])
 
     def _advance_verbosely(self, run, nsteps, chainLength):
         """VerbosityController (utility/verbosity.py:11-52): every
@@ -308,6 +315,8 @@ class MLDA(MetropolisHastingsEnsemble):
         self.recordSubChain = bool(recordSubChain)
         if self.recordSubChain and len(self._surrogates) != 1:
             raise lowering.UnsupportedPlugin("sub-chain decisions are recorded for one surrogate only")
+        if self.recordSubChain and self.recordStride > 1:
+            raise ValueError("sub-chain decisions are a per-transition record: recordStride must be 1")
 
     @property
     def nSurrogates(self):
