@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "c4", "iat"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "c4", "iat", "c3m"])
     ap.add_argument("--chains", type=int, default=0, help="chains per GPU (default: the workload's)")
     ap.add_argument("--transitions", type=int, default=0, help="MH transitions per chain per launch")
     ap.add_argument("--launches-per-step", type=int, default=0, help="kernel launches per bench step")
@@ -108,7 +108,7 @@ def make_workload(name, ffi, ctx, lowering):
         return dict(problem=prob, x0=x0, K=131072, T=1000, L=20, d=2,
                     desc="C5: two-level delayed acceptance (example_mcmc_2d_twoLevel.py), S=6",
                     spec=dict(target=s_fine, sigma=sigma, surrogate=s_coarse, S=6))
-    if name == "c3":
+    if name in ("c3", "c3m"):
         # linear forward model, d = m = 128, nData = 5
         d = 128
         rng = np.random.default_rng(7)
@@ -124,6 +124,22 @@ def make_workload(name, ffi, ctx, lowering):
                      ("prior_precision", prior_prec), ("fwd_matrix", A), ("fwd_shift", b)):
             low.set_array(k, v)
         sigma = np.sqrt(np.reciprocal(np.reciprocal(np.full(d, 1.1e-3))))
+        if name == "c3m":
+            # two-level delayed acceptance over a model hierarchy at C3's size (configs[2] is named after
+            # example_inference_linearModel_twoLevel.py): the coarse model is a perturbation of the fine one
+            A_c, b_c = A + 0.02 * rng.standard_normal((d, d)) / np.sqrt(d), b + 0.05 * rng.standard_normal(d)
+            coarse = lowering.Lowered(ffi.POSTERIOR_LINEAR, d)
+            coarse.desc.n_data, coarse.desc.data_dim = data.shape[0], d
+            for k, v in (("data", data), ("noise_precision", noise_prec), ("prior_mean", prior_mean),
+                         ("prior_precision", prior_prec), ("fwd_matrix", A_c), ("fwd_shift", b_c)):
+                coarse.set_array(k, v)
+            prob = lowering.make_problem(ctx, ffi.METHOD_MLDA2, low, sigma, surrogate=coarse, sub_chain_length=5)
+            lin = lambda A_, b_: dict(kind="linear", A=A_, b=b_, data=data, noise_prec=noise_prec,  # noqa: E731
+                                      prior_mean=prior_mean, prior_prec=prior_prec)
+            return dict(problem=prob, x0=np.zeros((1, d)), K=262144, T=20, L=5, d=d,
+                        desc="C3 two-level: delayed acceptance over two linear models, d = m = 128, nData = 5, S = 5 "
+                             "(fp64 MFMA tile kernel; steps = FINE steps, each with 5 coarse transitions)",
+                        spec=dict(target=lin(A, b), surrogate=lin(A_c, b_c), S=5, sigma=sigma))
         prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, sigma)
         return dict(problem=prob, x0=np.zeros((1, d)), K=262144, T=100, L=5, d=d,
                     desc="C3: linear forward model posterior d = m = 128, nData = 5 (fp64 MFMA tile kernel)",
@@ -220,18 +236,24 @@ def roofline_block(args, wl, K, T, kernel_ms, launches, clock_mhz, info):
     sq = rec.get("sq_per_launch") or {}
     valu = None
     if sq.get("SQ_INSTS_VALU") and clock_mhz and ksec > 0:
-        waves = rec.get("waves_per_launch") or math.ceil(K / 64)
+        waves = math.ceil(K / (16 if args.workload in ("c3", "c3m") else 64))   # waves' worth of chains
         simds = 4 * info["compute_units"]
         avail = ksec * clock_mhz * 1e6 * simds          # SIMD issue cycles in one launch
-        ipt = sq["SQ_INSTS_VALU"] / (waves * T)
+        mfma = sq.get("SQ_INSTS_MFMA", 0.0)
+        ipt = (sq["SQ_INSTS_VALU"] - mfma) / (waves * T)
+        busy = 4.0 * (sq["SQ_INSTS_VALU"] - mfma) + sq.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
         valu = {"instr_per_transition": ipt, "salu_instr_per_transition": sq.get("SQ_INSTS_SALU", 0.0) / (waves * T),
-                "cycles_per_transition": avail / (waves * T), "frac": 4.0 * sq["SQ_INSTS_VALU"] / avail,
-                "clock_mhz": clock_mhz, "waves_per_simd": waves / simds,
-                "note": "frac = 4 cycles x wave-level VALU instructions per launch / (kernel time x sustained clock x "
-                        "SIMDs); instruction counts per wave and transition",
+                "mfma_instr_per_transition": mfma / (waves * T) if mfma else None,
+                "mfma_coexec_cycles": sq.get("SQ_VALU_MFMA_COEXEC_CYCLES"),
+                "cycles_per_transition": avail / (waves * T), "frac": busy / avail,
+                "clock_mhz": clock_mhz, "chain_waves_per_simd": waves / simds,
+                "note": "frac = (4 cycles x wave-level VALU instructions + matrix-pipe busy cycles) per launch / (kernel "
+                        "time x sustained clock x SIMDs): the share of the SIMDs' fp64 datapath time in use (an f64 MFMA "
+                        "and a VALU instruction never execute together on gfx950: SQ_VALU_MFMA_COEXEC_CYCLES = 0); "
+                        "instruction counts per wave of chains and transition",
                 "source": {"instr": rec.get("source"), "kernel_time_and_clock": "this run"}}
-    if args.workload == "c3":
-        flops = 2.0 * d * d * K * T
+    if args.workload in ("c3", "c3m"):
+        flops = 2.0 * d * d * K * T * (6 if args.workload == "c3m" else 1)   # c3m: 5 coarse + 1 fine map per fine step
         tf = flops / ksec / 1e12 if ksec > 0 else 0.0
         return dict(common, bound="mfma", achieved=tf, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / FP64_PEAK_TFLOPS,
                     algorithmic_flops_per_launch=flops, valu=valu,
@@ -307,7 +329,7 @@ def main():
     T = args.transitions or wl["T"]
     L = args.launches_per_step or wl["L"]
     d, x0 = wl["d"], wl["x0"]
-    if args.workload == "c3":
+    if args.workload in ("c3", "c3m"):
         args.no_moments = True   # the reference's default diagnostics; the tile kernel keeps no Welford state
     flags = ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT | (0 if args.no_moments else ffi.RECORD_MOMENTS)
     run = ffi.Run(wl["problem"], 20250103, K, x0, T, flags, chain_offset=rank * K)

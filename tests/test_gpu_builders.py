@@ -600,6 +600,42 @@ def test_two_level_lotka_volterra_model_hierarchy_vs_oracle():
     assert 0.05 < out["acc"].mean() < 0.999 and not np.array_equal(out["acc"], out["sub_acc"][:, -1, :])
 
 
+def test_two_level_over_a_model_hierarchy_d128_f14(golden):
+    """MLDABuilder.bayesModel = BayesianRegressionModelHierarchy of two d = 128 linear models (mlda.py:315-335):
+    through the builders the chains are the live reference's (fixture F14), on the matrix-core kernel."""
+    import hashlib
+    from yagremcmc_amd.chain.diagnostics import AcceptanceRateDiagnostics
+    from yagremcmc_amd.chain.method.mlda import MLDABuilder
+    from yagremcmc_amd.exampleSetup import ExampleLinearModelSolver
+    from yagremcmc_amd.model.forwardModel import ForwardModel
+    from yagremcmc_amd.parameter.vector import ParameterVector
+    from yagremcmc_amd.statistics.covariance import IIDCovarianceMatrix
+    from yagremcmc_amd.statistics.data import Data
+    from yagremcmc_amd.statistics.gaussian import Gaussian
+    from yagremcmc_amd.statistics.likelihood import AdditiveGaussianNoiseLikelihood
+    from yagremcmc_amd.statistics.modelHierarchy import BayesianRegressionModelHierarchy
+    from yagremcmc_amd.statistics.noise import CentredGaussianNoise
+    from yagremcmc_amd.utility.hierarchy import Hierarchy, SharedComponent
+    g = golden("f14_mlda2_linear_d128.npz")
+    d, n, S, K = 128, int(g["n_states"]), int(g["S"]), g["x0"].shape[0]
+    prior = Gaussian(ParameterVector(np.array(g["prior_mean"])), IIDCovarianceMatrix(d, 5.0))
+    noise = CentredGaussianNoise(IIDCovarianceMatrix(d, 0.3))
+    liks = [AdditiveGaussianNoiseLikelihood(Data(g["data"]), ForwardModel(ExampleLinearModelSolver(g[f"A_{lv}"], g[f"b_{lv}"])), noise)
+            for lv in ("coarse", "fine")]
+    b = MLDABuilder()
+    b.bayesModel = BayesianRegressionModelHierarchy(Hierarchy(liks), SharedComponent(prior, 2))
+    b.baseProposalCovariance = IIDCovarianceMatrix(d, 1.1e-3)
+    b.subChainLengths = [S]
+    b.surrogateDiagnostics = [AcceptanceRateDiagnostics()]
+    b.nChains, b.seed, b.recordSubChain = K, int(g["seed"]), True
+    mc = b.build_method()
+    mc.run(n, ParameterVector(np.zeros(d)), verbose=False)
+    assert np.array_equal(mc.accept_decisions, g["acc"]) and np.array_equal(mc.sub_chain_decisions, g["sub_acc"])
+    traj = mc.chain.ensemble_trajectory
+    assert hashlib.sha256(np.ascontiguousarray(traj).tobytes()).hexdigest() == str(g["traj_sha256"])
+    assert abs(mc.diagnostics.global_acceptance_rate() - g["acc"].mean()) < 1e-15
+
+
 def test_iat_of_a_stuck_chain_is_reported_not_invented():
     """A chain that never moves (or was flagged non-finite and froze) has a constant series: c0 = 0 and the
     autocorrelation is 0 / 0.  The device reports IAT_UNDEFINED for it; the Python layer raises unless asked."""

@@ -643,6 +643,56 @@ def test_tile_kernel_preconditioned_crank_nicolson(ffi, ctx, d, m, nd, K, h):
     _same_as_oracle(dev, e, out)
 
 
+def test_f14_two_level_d128_matrix_cores(ffi, ctx, golden):
+    """Two-level delayed acceptance over two d = 128 linear models (linear_tile_mlda2_kernel): the LIVE
+    reference's decisions at both levels, its chains (sha256 of all states) and log-posteriors; == oracle."""
+    import hashlib
+    g = golden("f14_mlda2_linear_d128.npz")
+    n, S, d = int(g["n_states"]), int(g["S"]), 128
+    common = dict(data=g["data"], noise_precision=g["noise_precision"], prior_mean=g["prior_mean"],
+                  prior_precision=g["prior_precision"])
+    fine = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, common, fwd_matrix=g["A_fine"], fwd_shift=g["b_fine"])
+    coarse = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, common, fwd_matrix=g["A_coarse"], fwd_shift=g["b_coarse"])
+    dev = _device_run(ffi, ctx, fine, g["sigma"], g["x0"], int(g["seed"]), n - 1, method=ffi.METHOD_MLDA2, sur=coarse, S=S,
+                      splits=3)
+    assert np.array_equal(dev["acc"], g["acc"]) and np.array_equal(dev["sub_acc"], g["sub_acc"])
+    full = np.concatenate([g["x0"][None], dev["traj"]])
+    assert np.array_equal(full[:, :2, :], g["traj_head"])
+    assert hashlib.sha256(np.ascontiguousarray(full).tobytes()).hexdigest() == str(g["traj_sha256"])
+    want = g["logpost"][1:]
+    assert np.abs(dev["logpost"] - want).max() <= 1e-12 * np.abs(want).max()
+    of = o.posterior_linear(g["A_fine"], g["b_fine"], *common.values())
+    oc = o.posterior_linear(g["A_coarse"], g["b_coarse"], *common.values())
+    e = o.Ensemble(of, g["sigma"], g["x0"], int(g["seed"]), surrogate=oc, sub_chain_length=S)
+    out = e.advance(n - 1, want_sub=True)
+    _same_as_oracle(dev, e, out)
+    assert np.array_equal(dev["sub_acc"], out["sub_acc"])
+
+
+@pytest.mark.parametrize("d,mf,mc,nd,K,S", [(128, 128, 128, 5, 70, 5), (9, 3, 3, 2, 33, 2), (16, 40, 12, 1, 64, 3),
+                                              (40, 70, 70, 8, 50, 4), (100, 20, 36, 4, 129, 1), (5, 30, 6, 5, 40, 6)])
+def test_tile_kernel_two_level_other_shapes(ffi, ctx, d, mf, mc, nd, K, S):
+    """Ragged shapes: dimensions that are not multiples of the MFMA tile, levels with different numbers of
+    outputs (each with its own data), a level that alone would fit the lane kernels, a partly filled last wave."""
+    rng = np.random.default_rng(500 + d + mf + mc)
+
+    def level(m, scale):
+        g = dict(data=rng.normal(size=(nd, m)), noise_precision=rng.uniform(0.5, 3, size=m), prior_mean=rng.normal(size=d) * 0.1,
+                 prior_precision=rng.uniform(0.1, 2, size=d))
+        A, b = scale * rng.normal(size=(m, d)) / np.sqrt(d), rng.normal(size=m)
+        return (_posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, g, fwd_matrix=A, fwd_shift=b),
+                o.posterior_linear(A, b, g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"]))
+
+    (lf, pf), (lc, pc) = level(mf, 1.0), level(mc, 0.9)
+    sigma = rng.uniform(0.02, 0.08, size=d)
+    x0 = rng.normal(size=(K, d))
+    dev = _device_run(ffi, ctx, lf, sigma, x0, 4712, 40, method=ffi.METHOD_MLDA2, sur=lc, S=S, chain0=2000, splits=3)
+    e = o.Ensemble(pf, sigma, x0, 4712, chain0=2000, surrogate=pc, sub_chain_length=S)
+    out = e.advance(40, want_sub=True)
+    _same_as_oracle(dev, e, out)   # incl. the Welford moments replayed from the record
+    assert np.array_equal(dev["sub_acc"], out["sub_acc"])
+
+
 def test_tile_kernel_limits(ffi, ctx):
     from yagremcmc_amd import lowering
     rng = np.random.default_rng(1)

@@ -16,21 +16,24 @@ PROF = os.path.join(ROOT, "profiles")
 
 
 def one(pattern):
-    hits = sorted(glob.glob(pattern, recursive=True))
-    if len(hits) != 1:
-        raise SystemExit(f"expected one file for {pattern}, found {hits}")
-    return hits[0]
+    """the newest match (gpurun merges every call's output into the same local directory)"""
+    hits = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+    if not hits:
+        raise SystemExit(f"no file for {pattern}")
+    return hits[-1]
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-    traffic = {}
-    for wl in ("c2", "c3", "c5", "c4"):
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    wls = sys.argv[2:] or ["c2", "c3", "c5", "c4"]
+    tpath = os.path.join(PROF, "pmc_traffic.json")
+    traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    for wl in wls:
         sdir = os.path.join(OUT, f"prof_{wl}_stats")
         if not os.path.isdir(sdir):
             continue
         line = json.loads(open(os.path.join(OUT, f"prof_{wl}_stats.json")).read().strip().splitlines()[-1])
-        K, T = line["config"]["chains_per_gpu"], line["config"]["transitions_per_step"]
+        K, T = line["config"]["chains_per_gpu"], line["config"].get("transitions_per_launch", line["config"]["transitions_per_step"])
         stem = os.path.join(PROF, f"{tag}_{wl}_K{K}_T{T}")
         rows = list(csv.DictReader(open(one(os.path.join(sdir, "**", "*_kernel_stats.csv")))))
         with open(stem + "_kernel_stats.csv", "w", newline="") as f:
@@ -40,7 +43,8 @@ def main():
         dominant = rows[0]["Name"]
         json.dump(line, open(stem + "_bench_under_rocprof.json", "w"))
         pmc_rows, sums = [], {}
-        for ctr in ("WRITE_SIZE", "FETCH_SIZE", "SQ"):
+        grid = None
+        for ctr in ("WRITE_SIZE", "FETCH_SIZE", "SQ", "SQW", "GRBM"):
             cdir = os.path.join(OUT, f"prof_{wl}_{ctr}")
             if not os.path.isdir(cdir):
                 continue
@@ -55,6 +59,7 @@ def main():
                                                    "SGPR_Count", "Counter_Name", "Counter_Value")}
                                 | {"Duration_ns": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})
                 sums.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+                grid, wg = int(r["Grid_Size"]), int(r["Workgroup_Size"])
         if pmc_rows:
             with open(stem + "_pmc.csv", "w", newline="") as f:
                 w = csv.DictWriter(f, fieldnames=list(pmc_rows[0].keys()))
@@ -71,12 +76,13 @@ def main():
                               "kernel's 8-B/lane stores)",
                 "algorithmic_bytes_per_launch": K * T * (8 * d + 1),
                 "dominant_kernel": dominant,
-                "sq_per_launch": {k: v for k, v in med.items() if k.startswith("SQ_")},
+                "sq_per_launch": {k: v for k, v in med.items() if k.startswith("SQ_") or k.startswith("GRBM_")},
+                "waves_per_launch": (grid // 64) if grid else None, "workgroup_size": wg if grid else None,
                 "source": f"profiles/{os.path.basename(stem)}_pmc.csv (rocprofv3 --pmc, separate passes of the same "
                           "bench command; median over launches)"}
         print(wl, dominant[:60], {k: round(v, 1) for k, v in med.items()})
     if traffic:
-        json.dump(traffic, open(os.path.join(PROF, "pmc_traffic.json"), "w"), indent=1)
+        json.dump(traffic, open(tpath, "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -156,6 +156,7 @@ struct ymc_run {
     uint32_t stride = 1; /* record_stride: rows hold the states after transitions stride, 2 stride, ... of the run */
     DeviceBuf x, lp, lpc, acc_count, wf_mean, wf_m2, status, traj, acc, lp_out, sub_acc, summary, x_before, recip;
     DeviceBuf level_acc; /* MLDA_NESTED: [E-1][K] */
+    DeviceBuf x_tiled;   /* two-level tile kernel: the carried state in the record's tiled layout */
     DeviceBuf err_n, err_mean, err_m2, aem_prec, aem_flags, cache_key, cache_val; /* AEM2 */
     /* egress (ymc_run_egress_*): a copy stream, two slots of page-locked staging */
     struct EgressSlot {
@@ -187,7 +188,14 @@ int copy_array(std::vector<double> &dst, const double *src, size_t n, const char
     return YMC_OK;
 }
 
-int lower_density(ymc_ctx *ctx, const ymc_density_desc &in, DensityHost &out, int expect_dim)
+bool needs_tile(const ymc_density_desc &in)
+{
+    return in.kind == YMC_DENSITY_POSTERIOR_LINEAR && (in.dim > YMC_LANE_DMAX || in.data_dim > YMC_LANE_MMAX);
+}
+
+/* force_tile: lower a linear posterior for the matrix-core path even if it would fit the lane kernels (the
+ * levels of a two-level sampler run in ONE kernel: both on the same path) */
+int lower_density(ymc_ctx *ctx, const ymc_density_desc &in, DensityHost &out, int expect_dim, bool force_tile = false)
 {
     (void)ctx;
     out.d = in;
@@ -195,7 +203,7 @@ int lower_density(ymc_ctx *ctx, const ymc_density_desc &in, DensityHost &out, in
     if (d < 1) return fail(YMC_ERR_INVALID, "parameter dimension must be positive, got %d", d);
     if (expect_dim > 0 && d != expect_dim)
         return fail(YMC_ERR_INVALID, "surrogate dimension %d differs from target dimension %d", d, expect_dim);
-    const bool big = in.kind == YMC_DENSITY_POSTERIOR_LINEAR && (d > YMC_LANE_DMAX || in.data_dim > YMC_LANE_MMAX);
+    const bool big = needs_tile(in) || (force_tile && in.kind == YMC_DENSITY_POSTERIOR_LINEAR);
     if (d > YMC_LANE_DMAX && !big)
         return fail(YMC_ERR_UNSUPPORTED, "parameter dimension %d exceeds the lane-per-chain limit %d", d,
                     YMC_LANE_DMAX);
@@ -583,9 +591,8 @@ int launch_advance_nested(ymc_run *r, uint64_t nsteps)
 }
 
 /* A in MFMA A-operand fragment order + the padded constant arrays, one block */
-int build_tile_blob(ymc_problem *p)
+int build_tile_blob(ymc_problem *p, DensityHost &h)
 {
-    DensityHost &h = p->tgt;
     const int KS = h.KS, MT = h.MT, d = h.d.dim, m = h.d.data_dim;
     const size_t m_pad = 16 * (size_t)MT, d_pad = 4 * (size_t)KS;
     std::vector<double> blob((size_t)MT * KS * 64 + m_pad * 3 + 3 * d_pad, 0.0);
@@ -621,13 +628,24 @@ uint64_t tiled_row_doubles(const ymc_run *r)
 int launch_advance_tile(ymc_run *r, uint64_t nsteps)
 {
     const ymc_problem *p = r->problem;
-    const DensityHost &h = p->tgt;
+    const bool mlda2 = p->method == YMC_METHOD_MLDA2;
+    const DensityHost &h = mlda2 ? p->sur : p->tgt; /* the level staged in LDS */
     TileArgs a{};
     a.blob = h.tile_blob.as<double>();
     a.lik_const = h.lik_const;
     a.d = p->D;
     a.m = h.d.data_dim;
     a.MT = h.MT;
+    if (mlda2) {
+        a.blob_f = p->tgt.tile_blob.as<double>();
+        a.lik_const_f = p->tgt.lik_const;
+        a.m_f = p->tgt.d.data_dim;
+        a.MT_f = p->tgt.MT;
+        a.S = p->S;
+        a.lpc = r->lpc.as<double>();
+        a.x_tiled = r->x_tiled.as<double>();
+        if (r->flags & YMC_RECORD_SUB_ACCEPT) a.sub_acc = r->sub_acc.as<uint8_t>() + r->recorded * (uint64_t)p->S * r->K;
+    }
     a.seed = r->seed;
     a.chain0 = r->chain0;
     a.K = r->K;
@@ -661,7 +679,8 @@ int launch_advance_tile(ymc_run *r, uint64_t nsteps)
         YMC_HIP(hipEventCreate(&ev.second));
     }
     YMC_HIP(hipEventRecord(ev.first, r->ctx->stream));
-    hipError_t e = ymc_launch_linear_tile(h.KS, a, r->ctx->stream);
+    hipError_t e = mlda2 ? ymc_launch_linear_tile_mlda2(h.KS, a, r->ctx->stream)
+                         : ymc_launch_linear_tile(h.KS, a, r->ctx->stream);
     if (e == hipSuccess && moments)
         e = ymc_launch_welford_replay(a.traj, r->x_before.as<double>(), nsteps, r->K, p->D, h.KS, r->steps_done,
                                       r->wf_mean.as<double>(), r->wf_m2.as<double>(), r->ctx->stream);
@@ -816,7 +835,10 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
     p->ctx = ctx;
     p->method = desc->method;
     p->eq_mode = desc->state_eq;
-    int rc = lower_density(ctx, desc->target, p->tgt, 0);
+    const bool two_level = desc->method == YMC_METHOD_MLDA2 || desc->method == YMC_METHOD_AEM2;
+    const bool joint_tile = two_level && desc->surrogate.kind == desc->target.kind &&
+                            (needs_tile(desc->target) || needs_tile(desc->surrogate));
+    int rc = lower_density(ctx, desc->target, p->tgt, 0, joint_tile);
     if (rc == YMC_OK) {
         p->D = desc->target.dim;
         p->kind = desc->target.kind;
@@ -846,13 +868,16 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
         if (rc == YMC_OK && desc->surrogate.kind != desc->target.kind)
             rc = fail(YMC_ERR_UNSUPPORTED, "surrogate density kind %d differs from target kind %d",
                       desc->surrogate.kind, desc->target.kind);
-        if (rc == YMC_OK) rc = lower_density(ctx, desc->surrogate, p->sur, p->D);
-        /* the lane kernels hold at most YMC_LANE_MMAX forward outputs per level: a surrogate that needs
-         * the tile path under a lane-path target would be evaluated truncated */
-        if (rc == YMC_OK && p->sur.tile && !p->tgt.tile)
-            rc = fail(YMC_ERR_UNSUPPORTED, "the surrogate's forward map has %d outputs; with a target of %d "
-                                           "parameters and %d outputs both levels must fit the lane kernels (<= %d)",
-                      desc->surrogate.data_dim, p->D, desc->target.data_dim, YMC_LANE_MMAX);
+        if (rc == YMC_OK) rc = lower_density(ctx, desc->surrogate, p->sur, p->D, joint_tile);
+        /* both levels run in one kernel: on the lane path each holds at most YMC_LANE_MMAX forward outputs, on
+         * the matrix-core path the coarse matrix and both levels' constants share the LDS */
+        if (rc == YMC_OK && p->sur.tile != p->tgt.tile)
+            rc = fail(YMC_ERR_UNSUPPORTED, "the two levels do not fit one kernel (target %d x %d, surrogate %d x %d)",
+                      desc->target.data_dim, p->D, desc->surrogate.data_dim, p->D);
+        if (rc == YMC_OK && p->tgt.tile && desc->method == YMC_METHOD_MLDA2 &&
+            ymc_tile_mlda2_lds_bytes(p->sur.KS, p->sur.MT, p->tgt.MT) > kTileLdsLimit)
+            rc = fail(YMC_ERR_UNSUPPORTED, "the coarse forward map %d x %d plus both levels' constants do not fit the "
+                                           "160 KB LDS", desc->surrogate.data_dim, p->D);
         p->S = desc->sub_chain_length;
     }
     if (rc == YMC_OK && desc->method == YMC_METHOD_MLDA_NESTED) {
@@ -916,9 +941,10 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
         }
     }
     if (rc == YMC_OK && p->tgt.tile) {
-        if (p->method != YMC_METHOD_MRW && p->method != YMC_METHOD_PCN)
-            rc = fail(YMC_ERR_UNSUPPORTED, "only the random-walk and pCN samplers are available at this dimension");
-        if (rc == YMC_OK) rc = build_tile_blob(p);
+        if (p->method != YMC_METHOD_MRW && p->method != YMC_METHOD_PCN && p->method != YMC_METHOD_MLDA2)
+            rc = fail(YMC_ERR_UNSUPPORTED, "the random-walk, pCN and two-level samplers are available at this dimension");
+        if (rc == YMC_OK) rc = build_tile_blob(p, p->tgt);
+        if (rc == YMC_OK && p->method == YMC_METHOD_MLDA2) rc = build_tile_blob(p, p->sur);
         p->tile = true;
     }
     if (rc == YMC_OK && p->method == YMC_METHOD_MLDA_NESTED) {
@@ -1022,6 +1048,8 @@ int ymc_run_create(ymc_ctx *ctx, const ymc_problem *problem, const ymc_run_desc 
         if ((r->flags & YMC_RECORD_SUB_ACCEPT) &&
             (problem->method == YMC_METHOD_MLDA2 || problem->method == YMC_METHOD_AEM2))
             YMC_TRY(r->sub_acc.alloc(r->capacity * (uint64_t)S * K));
+        if (problem->tile && problem->method == YMC_METHOD_MLDA2)
+            YMC_TRY(r->x_tiled.alloc(tiled_row_doubles(r) * sizeof(double)));
         if (problem->method == YMC_METHOD_AEM2) {
             const uint64_t m = (uint64_t)problem->sur.d.data_dim;
             DeviceBuf *bufs[] = {&r->err_n, &r->err_mean, &r->err_m2, &r->aem_prec, &r->aem_flags, &r->cache_key,

@@ -29,6 +29,15 @@ struct TileArgs {
     double *traj; /* tiled layout [rows][ceil(K/16)][KS][64] */
     uint8_t *acc;
     double *lp_out;
+    /* two-level delayed acceptance (mlda.py:100-110,146-154): `blob` is the COARSE level (staged in LDS, it is
+     * evaluated S times per fine step), blob_f the FINE level in the same layout (its A fragments are read
+     * from global memory / L2, its constants are staged) */
+    const double *blob_f;
+    double lik_const_f;
+    int32_t m_f, MT_f, S, pad1_;
+    double *lpc;      /* coarse log-density of the carried (fine) state */
+    double *x_tiled;  /* the carried state in the record's tiled layout [ceil(K/16)][KS][64] (scratch) */
+    uint8_t *sub_acc; /* [rows][S][K] or null */
 };
 
 struct BigLinearArgs {
@@ -38,7 +47,9 @@ struct BigLinearArgs {
 };
 
 size_t ymc_tile_lds_bytes(int KS, int MT);
+size_t ymc_tile_mlda2_lds_bytes(int KS, int MT_coarse, int MT_fine);
 hipError_t ymc_launch_linear_tile(int KS, const TileArgs &a, hipStream_t s);
+hipError_t ymc_launch_linear_tile_mlda2(int KS, const TileArgs &a, hipStream_t s);
 hipError_t ymc_launch_untile(const double *tiled, uint64_t row0, uint64_t rows, uint64_t K, int d, int KS,
                              double *out, hipStream_t s);
 hipError_t ymc_launch_welford_replay(const double *tiled, const double *x_before, uint64_t rows, uint64_t K, int d,

@@ -204,6 +204,199 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
     }
 }
 
+/*
+ * Two-level delayed acceptance over two linear models at large dimension (MLDABuilder.bayesModel = a
+ * BayesianRegressionModelHierarchy, mlda.py:315-335; example_inference_linearModel_twoLevel.py at C3's size).
+ * Same mapping as linear_tile_kernel.  The COARSE model is evaluated S times per fine step, so its matrix is
+ * the one staged in LDS; the FINE model's fragments are read straight from global memory (128 KB, resident
+ * in every XCD's L2) -- two matrices do not fit the 160 KB of LDS.  Registers hold the sub-chain state z and
+ * the proposal y (as x and y there); the fine state x lives in `x_tiled` (the record's coalesced layout)
+ * and is read back once per fine step for the `proposal == state` test and the rejected lanes.
+ * Draw addressing as mlda2_kernel: fine step n owns transitions t = n (S + 1) + s.
+ */
+template <int KS>
+__global__ __launch_bounds__(kTileThreads) void linear_tile_mlda2_kernel(const TileArgs a)
+{
+    ymc_stage_tables();
+    extern __shared__ double lds[];
+    const int MTc = a.MT, MTf = a.MT_f, m_pad_c = 16 * MTc, m_pad_f = 16 * MTf, d_pad = 4 * KS;
+    /* coarse level: A fragments | bias | n * noise_prec | row mean | prior mean | prior prec | sigma */
+    double *Ac = lds;
+    double *bias_c = Ac + (size_t)MTc * KS * 64;
+    double *nprec_c = bias_c + m_pad_c;
+    double *dbar_c = nprec_c + m_pad_c;
+    double *pmean_c = dbar_c + m_pad_c;
+    double *pprec_c = pmean_c + d_pad;
+    double *sigma = pprec_c + d_pad;
+    const size_t blob_c = (size_t)MTc * KS * 64 + (size_t)m_pad_c * 3 + 3 * (size_t)d_pad;
+    /* fine level: the constants only */
+    double *bias_f = lds + blob_c;
+    double *nprec_f = bias_f + m_pad_f;
+    double *dbar_f = nprec_f + m_pad_f;
+    double *pmean_f = dbar_f + m_pad_f;
+    double *pprec_f = pmean_f + d_pad;
+    const size_t consts_f = (size_t)m_pad_f * 3 + 2 * (size_t)d_pad;
+    const double *Af = a.blob_f;
+
+    const int tid = threadIdx.x;
+    for (size_t i = tid; i < blob_c / 2; i += kTileThreads)
+        reinterpret_cast<double2 *>(lds)[i] = reinterpret_cast<const double2 *>(a.blob)[i];
+    for (size_t i = tid; i < consts_f; i += kTileThreads) bias_f[i] = a.blob_f[(size_t)MTf * KS * 64 + i];
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+    const uint64_t nct = (a.K + 15) / 16;
+    const uint64_t tile = (uint64_t)blockIdx.x * kTileWaves + wave;
+    if (tile >= nct) return;
+    const uint64_t k = tile * 16 + c;
+    const bool live = k < a.K;
+    const uint32_t chain = (uint32_t)(a.chain0 + k);
+    const int d = a.d, S = a.S;
+    const bool odd = (g & 1) != 0;
+    const uint32_t pair_of_g = (g == 0) ? 0u : (g == 1) ? 2u : (g == 2) ? 1u : 3u;
+    double *xt = a.x_tiled + (tile * KS) * 64 + lane; /* this lane's column of the carried fine state */
+
+    double z[KS], y[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int j = 4 * s + g;
+        z[s] = (live && j < d) ? a.x[k * d + j] : 0.0;
+        xt[s * 64] = z[s];
+    }
+    double lpf = live ? a.lp[k] : 0.0;
+    double lpc = live ? a.lpc[k] : 0.0;
+    uint64_t accepted = live ? a.acc_count[k] : 0;
+    uint32_t st = live ? a.status[k] : 0;
+    UniformCache uc;
+    uc.valid = false;
+    uc.pair = 0;
+    RecordClock clk(a.rec_stride, a.rec_since);
+
+    /* Gaussian-noise likelihood of the forward value A v + b through the row-mean identity, the forward map
+     * on the matrix cores (as linear_tile_kernel); A's fragments come from LDS or from global memory */
+    auto loglik = [&](const double *A, int MT, const double *bias, const double *nprec, const double *dbar,
+                      double lik_const, const double (&v)[KS]) {
+        double Ssum = 0.0;
+#pragma unroll 1
+        for (int mt = 0; mt < MT; mt += 2) {
+            d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+            const double *Af0 = A + (size_t)mt * KS * 64 + lane;
+            const double *Af1 = Af0 + (size_t)KS * 64;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Af0[s * 64], v[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Af1[s * 64], v[s], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 16 * (mt + h) + 4 * r + g;
+                    const double F = (h ? acc1[r] : acc0[r]) + bias[m];
+                    const double res = F - dbar[m];
+                    const double px = nprec[m] * res;
+                    Ssum = Ssum + res * px;
+                }
+            }
+        }
+        return -0.5 * (combine4(Ssum) + lik_const);
+    };
+    /* Gaussian prior (gaussian.py:19-24) */
+    auto logprior = [&](const double *pmean, const double *pprec, const double (&v)[KS]) {
+        double P = 0.0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int j = 4 * s + g;
+            const double dx = v[s] - pmean[j];
+            const double px = pprec[j] * dx;
+            P = P + dx * px;
+        }
+        return -0.5 * combine4(P);
+    };
+    auto any_differs = [&](const double (&p)[KS], const double (&q)[KS]) {
+        bool dl = false;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) dl = dl || !(p[s] == q[s]);
+        int mv = dl ? 1 : 0;
+        mv |= __shfl_xor(mv, 16, 64);
+        mv |= __shfl_xor(mv, 32, 64);
+        return mv != 0;
+    };
+
+#pragma unroll 1
+    for (uint32_t n = 0; n < a.nsteps; ++n) {
+        const uint64_t tbase = (a.t0 + n) * (uint64_t)(S + 1);
+        double lpcz = lpc;
+        /* surrogate.run(S + 1, state): S random-walk transitions on the coarse posterior */
+#pragma unroll 1
+        for (int sub = 0; sub < S; ++sub) {
+            const uint64_t t = tbase + (uint64_t)sub;
+#pragma unroll
+            for (int q = 0; q < KS / 2; ++q) {
+                double z0, z1;
+                ymc_draw_normal_pair(a.seed, chain, t, 4u * (uint32_t)q + pair_of_g, &z0, &z1);
+                const double keep = odd ? z1 : z0;
+                const double give = odd ? z0 : z1;
+                const double recv = shfl_xor_f64(give, 16);
+                const double xi0 = odd ? recv : keep;
+                const double xi1 = odd ? keep : recv;
+                y[2 * q] = z[2 * q] + sigma[8 * q + g] * xi0;
+                y[2 * q + 1] = z[2 * q + 1] + sigma[8 * q + 4 + g] * xi1;
+            }
+            const bool moved = any_differs(y, z);
+            const double lpcy = loglik(Ac, MTc, bias_c, nprec_c, dbar_c, a.lik_const, y) + logprior(pmean_c, pprec_c, y);
+            const double u = ymc_uniform_cached(uc, a.seed, chain, t);
+            const bool acc = ymc_accept(lpcy - lpcz, moved, ymc_finite(lpcy), u, st);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) z[s] = acc ? y[s] : z[s];
+            lpcz = acc ? lpcy : lpcz;
+            if (a.sub_acc && live && g == 0) a.sub_acc[((uint64_t)n * S + sub) * a.K + k] = acc ? 1 : 0;
+        }
+        /* fine accept / reject (mlda.py:146-154); y <- the fine state x */
+#pragma unroll
+        for (int s = 0; s < KS; ++s) y[s] = xt[s * 64];
+        const bool moved = any_differs(z, y);
+        const double lpfy = loglik(Af, MTf, bias_f, nprec_f, dbar_f, a.lik_const_f, z) + logprior(pmean_f, pprec_f, z);
+        const double log_ratio = ((lpfy + lpc) - lpcz) - lpf;
+        const double u = ymc_uniform_cached(uc, a.seed, chain, tbase + (uint64_t)S);
+        const bool acc = ymc_accept(log_ratio, moved, ymc_finite(lpfy) && ymc_finite(lpcz), u, st);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            z[s] = acc ? z[s] : y[s];
+            xt[s * 64] = z[s];
+        }
+        lpf = acc ? lpfy : lpf;
+        lpc = acc ? lpcz : lpc;
+        accepted += acc ? 1u : 0u;
+
+        const bool rec = clk.due();
+        if (rec && a.traj) {
+            double *row = a.traj + (((uint64_t)clk.row * nct + tile) * KS) * 64 + lane;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) row[s * 64] = z[s];
+        }
+        if (live && g == 0) {
+            if (a.acc) a.acc[(uint64_t)n * a.K + k] = acc ? 1 : 0;
+            if (rec && a.lp_out) a.lp_out[(uint64_t)clk.row * a.K + k] = lpf;
+        }
+        if (rec) clk.wrote();
+    }
+
+    if (live) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int j = 4 * s + g;
+            if (j < d) a.x[k * d + j] = z[s];
+        }
+        if (g == 0) {
+            a.lp[k] = lpf;
+            a.lpc[k] = lpc;
+            a.acc_count[k] = accepted;
+            a.status[k] = st;
+        }
+    }
+}
+
 /* record in tiled layout -> out[rows][K][d] */
 __global__ __launch_bounds__(256) void untile_kernel(const double *__restrict__ tiled, uint64_t row0, uint64_t rows,
                                                      uint64_t K, int d, int KS, double *__restrict__ out)
@@ -312,6 +505,35 @@ static hipError_t launch_tile_as(const TileArgs &a, hipStream_t s)
     const unsigned grid = (unsigned)((nct + kTileWaves - 1) / kTileWaves);
     hipLaunchKernelGGL((linear_tile_kernel<KS, PCN>), dim3(grid), dim3(kTileThreads), lds, s, a);
     return hipGetLastError();
+}
+
+size_t ymc_tile_mlda2_lds_bytes(int KS, int MT_coarse, int MT_fine)
+{
+    return ymc_tile_lds_bytes(KS, MT_coarse) + (16 * (size_t)MT_fine * 3 + 2 * 4 * (size_t)KS) * sizeof(double);
+}
+
+template <int KS>
+static hipError_t launch_tile_mlda2(const TileArgs &a, hipStream_t s)
+{
+    const size_t lds = ymc_tile_mlda2_lds_bytes(KS, a.MT, a.MT_f);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_tile_mlda2_kernel<KS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const uint64_t nct = (a.K + 15) / 16;
+    const unsigned grid = (unsigned)((nct + kTileWaves - 1) / kTileWaves);
+    hipLaunchKernelGGL((linear_tile_mlda2_kernel<KS>), dim3(grid), dim3(kTileThreads), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t ymc_launch_linear_tile_mlda2(int KS, const TileArgs &a, hipStream_t s)
+{
+    switch (KS) {
+    case 4: return launch_tile_mlda2<4>(a, s);
+    case 8: return launch_tile_mlda2<8>(a, s);
+    case 16: return launch_tile_mlda2<16>(a, s);
+    case 32: return launch_tile_mlda2<32>(a, s);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 template <int KS>

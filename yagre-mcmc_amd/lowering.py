@@ -243,8 +243,9 @@ def warn_if_degenerate(target_low, surrogate_lows, what="surrogate"):
     for i, sur in enumerate(surrogate_lows):
         if same_lowering(target_low, sur):
             warnings.warn(f"{what} {i} lowers to exactly the target density: delayed acceptance degenerates (every "
-                          "fine step repeats the coarse decision). For Lotka-Volterra levels give each solver its own "
-                          "'rk4Steps' (or distinct 'rtol').", RuntimeWarning, stacklevel=3)
+                          "fine step repeats the coarse decision). If the levels were meant to differ in a solver "
+                          "setting, give it a device counterpart (Lotka-Volterra: each level its own 'rk4Steps' or "
+                          "'rtol').", RuntimeWarning, stacklevel=3)
 
 
 def state_eq_of(state):
