@@ -278,7 +278,7 @@ int ymc_forward_eval(ymc_ctx *ctx, const ymc_problem *problem, int which, uint64
  * (IAT of the per-state mean over the components), 1 = 'max' (largest IAT over
  * the components); sokal_const as :92.  iat[n_chains]; YMC_IAT_UNDEFINED for a chain whose series is
  * constant (zero variance: the autocorrelation is 0 / 0, the reference fails on it). */
-#define YMC_IAT_UNDEFINED (-1)
+#define YMC_IAT_UNDEFINED (-2147483647 - 1) /* INT32_MIN: a short anti-correlated series can have a genuine IAT of -1 */
 int ymc_run_iat(ymc_run *run, uint64_t first, uint64_t n, int method, double sokal_const, int32_t *iat);
 /* the same for states held by the caller: states[n][n_chains][d] (the shape of
  * ymc_run_fetch_trajectory's output; n_chains = 1 is the reference's (n, d) array) */

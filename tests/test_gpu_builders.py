@@ -672,6 +672,28 @@ def _reference_iat(series, c=5.0):
     return 1
 
 
+@pytest.mark.parametrize("kernel", ["wave", "block"])
+@pytest.mark.parametrize("N", [2, 9, 77, 513, 1500, 4100])
+def test_iat_kernels_on_ragged_series(monkeypatch, kernel, N):
+    """The wave-per-series kernel (register-blocked lags, LDS tiles of 512) and the workgroup-per-series one
+    against the NumPy restatement of autocorrelation.py: lengths around the tile and lag-block sizes, slowly
+    and quickly decorrelating series (windows that close in the first block and after several)."""
+    from yagremcmc_amd import _ffi
+    monkeypatch.setenv("YMC_IAT_KERNEL", kernel)
+    rng = np.random.default_rng(N)
+    S = 70
+    phi = rng.uniform(0.0, 0.97, size=S)
+    x = np.zeros((S, N))
+    e = rng.standard_normal((S, N))
+    for t in range(1, N):
+        x[:, t] = phi * x[:, t - 1] + e[:, t]
+    x[:, 0] = e[:, 0]
+    x += rng.normal(size=(S, 1)) * 50.0                   # a large mean: centring matters
+    got, _ = _ffi.default_context(0).iat_series(x)
+    want = np.array([_reference_iat(x[s]) for s in range(S)])
+    assert np.array_equal(got, want), (got - want)[got != want]
+
+
 @pytest.mark.parametrize("d", [8, 24, 128])
 def test_integrated_autocorrelation_from_the_tiled_record_and_numpy_mean_order(d):
     """'mean' IAT at d >= 8: the per-state mean is formed in NumPy's pairwise order (bit-identical to

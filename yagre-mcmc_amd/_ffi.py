@@ -26,7 +26,7 @@ EQ_EXACT, EQ_ISCLOSE = 0, 1
 # record flags
 RECORD_TRAJECTORY, RECORD_ACCEPT, RECORD_LOGPOST, RECORD_SUB_ACCEPT, RECORD_MOMENTS = 1, 2, 4, 8, 16
 CHAIN_NONFINITE = 1
-IAT_UNDEFINED = -1
+IAT_UNDEFINED = -2147483648
 UNIQUE_ID_BYTES = 128
 
 LANE_DMAX = 8
@@ -174,7 +174,7 @@ def checked_iat(iat, allow_undefined=False):
     bad = int((iat == IAT_UNDEFINED).sum())
     if bad and not allow_undefined:
         raise ValueError(f"{bad} of {iat.size} series are constant (zero variance): their integrated autocorrelation "
-                         "time is undefined. Pass allowUndefined=True to get -1 for them.")
+                         "time is undefined. Pass allowUndefined=True to get IAT_UNDEFINED (INT32_MIN) for them.")
     return iat
 
 

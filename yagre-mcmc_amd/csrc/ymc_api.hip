@@ -126,6 +126,9 @@ struct ymc_ctx {
     hipStream_t probe_stream = nullptr;
     uint64_t *probe_out = nullptr;
     bool probe_pending = false;
+    /* post-processing scratch (series-major copy of the record, results), kept between calls: allocating
+     * 10 GB per ymc_run_iat call cost more than the kernels */
+    DeviceBuf post_series, post_out;
 };
 
 struct ymc_problem {
@@ -1451,9 +1454,9 @@ int iat_from_device_states(ymc_ctx *ctx, const double *traj, uint64_t first, uin
     if (!(sokal_const > 0.0)) return fail(YMC_ERR_INVALID, "the Sokal constant must be positive");
     if (n < 2) return fail(YMC_ERR_INVALID, "a series needs at least two entries");
     const uint64_t per_chain = method == 0 ? 1 : (uint64_t)d, S = K * per_chain;
-    DeviceBuf series, out;
-    YMC_TRY(series.alloc(S * n * sizeof(double)));
-    YMC_TRY(out.alloc(S * sizeof(int32_t)));
+    DeviceBuf &series = ctx->post_series, &out = ctx->post_out;
+    if (series.bytes < S * n * sizeof(double)) YMC_TRY(series.alloc(S * n * sizeof(double)));
+    if (out.bytes < S * sizeof(int32_t)) YMC_TRY(out.alloc(S * sizeof(int32_t)));
     hipStream_t st = ctx->stream;
     YMC_HIP(ymc_launch_series_from_record(traj, first, n, K, d, tile_KS, method == 0, series.as<double>(), st));
     YMC_HIP(ymc_launch_iat(series.as<double>(), S, n, sokal_const, out.as<int32_t>(), nullptr, st));

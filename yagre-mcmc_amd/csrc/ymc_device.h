@@ -155,9 +155,14 @@ struct Density<YMC_DENSITY_POSTERIOR_LV, D> {
         bool bad = false;
         for (int n = 0; n < p.n_data; ++n) {
             double x = p.design[2 * n], y = p.design[2 * n + 1];
-            for (int s = 0; s < p.rk4_steps; ++s) {
-                ymc_lv_rk4_step(&x, &y, alpha, beta, gamma, delta, h, h2, h6);
+            int s = 0;
+#pragma unroll 1
+            for (; s + 5 <= p.rk4_steps; s += 5) { /* five steps per iteration: the loop branch is a visible bubble */
+#pragma unroll
+                for (int r = 0; r < 5; ++r) ymc_lv_rk4_step(&x, &y, alpha, beta, gamma, delta, h, h2, h6);
             }
+#pragma unroll 1
+            for (; s < p.rk4_steps; ++s) ymc_lv_rk4_step(&x, &y, alpha, beta, gamma, delta, h, h2, h6);
             bad = bad || !ymc_finite(x) || !ymc_finite(y);
             double r[2] = {x - p.data[2 * n], y - p.data[2 * n + 1]};
             total = total + ymc_diag_norm_sq<2>(r, p.noise_prec, 2);

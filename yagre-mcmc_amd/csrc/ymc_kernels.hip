@@ -441,9 +441,16 @@ __global__ __launch_bounds__(kBlock) void mrw_lv_rows_kernel(const ChainArgs<2> 
         /* this lane's ODE solve (Density<POSTERIOR_LV>::eval, one design row) */
         const double beta = ymc_exp(y[0]), delta = ymc_exp(y[1]);
         double sx = dx0, sy = dy0;
-        for (int s = 0; s < p.rk4_steps; ++s) {
-            ymc_lv_rk4_step(&sx, &sy, alpha, beta, gamma, delta, h, h2, h6);
+        /* five steps per loop iteration: at ~2.7 waves per SIMD the loop branch of a 30-instruction body is a
+         * visible bubble (north_star's 50 steps divide evenly; any other count finishes in the remainder loop) */
+        int s = 0;
+#pragma unroll 1
+        for (; s + 5 <= p.rk4_steps; s += 5) {
+#pragma unroll
+            for (int r = 0; r < 5; ++r) ymc_lv_rk4_step(&sx, &sy, alpha, beta, gamma, delta, h, h2, h6);
         }
+#pragma unroll 1
+        for (; s < p.rk4_steps; ++s) ymc_lv_rk4_step(&sx, &sy, alpha, beta, gamma, delta, h, h2, h6);
         const int bad_l = (!ymc_finite(sx) || !ymc_finite(sy)) ? 1 : 0;
         const double res[2] = {sx - obs0, sy - obs1};
         const double term = ymc_diag_norm_sq<2>(res, p.noise_prec, 2);

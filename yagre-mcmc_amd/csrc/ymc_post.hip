@@ -23,6 +23,8 @@
  * series); here they are direct sums in a fixed order, so values agree to
  * rounding (~1e-13) and the integer IAT agrees except at exact ties.
  */
+#include <cstdlib>
+
 #include "ymc_kernels.h"
 #include "ymc_post.h"
 
@@ -113,6 +115,120 @@ __global__ __launch_bounds__(256) void series_from_record_kernel(const RecordVie
     }
 }
 
+/*
+ * IAT of many series at once: ONE WAVE per series, lags in register blocks of 32.
+ *
+ * iat_kernel (below, kept for the ACF of single long series) gives a series a whole workgroup, keeps it in
+ * LDS and forms every lag sum with two LDS reads per product: with 10^5 series of 10^4 states
+ * (BASELINE configs[1] right after run()) that is LDS-bandwidth bound and leaves most of the chip idle
+ * (measured 51 ms per 65 536 series).  Here the lags l = 32 b .. 32 b + 31 of block b are 32 accumulators
+ * per lane; the centred series streams through a small wave-private LDS tile (coalesced global loads), lane
+ * i takes 8 consecutive elements a_j of the tile and slides a register window over the elements they pair
+ * with, so a product costs one fma and 1/32 LDS read.  After each block the 32 lag sums are reduced over
+ * the wave and Sokal's window test (autocorrelation.py:51-59) runs on them; most series close their window
+ * inside the third block.  Lag sums are formed in a different order than iat_kernel's: values agree to
+ * rounding, the integer IAT except at exact ties (as against the reference's FFT-based sums).
+ */
+constexpr int kIatLags = 32;   /* lags per register block */
+constexpr int kIatPer = 8;     /* consecutive elements per lane and tile */
+constexpr int kIatTile = 64 * kIatPer;
+constexpr int kIatNear = 96;   /* lag blocks starting at l0 <= kIatNear take both factors from one staged tile */
+
+__device__ __forceinline__ int iat_pad(int t) { return t + (t >> 3); } /* one spare double per 8: lane bases 9 apart */
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const uint64_t b = ymc_bits(v);
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)b, m, 64);
+        const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(b >> 32), m, 64);
+        v = v + ymc_from_bits(((uint64_t)hi << 32) | lo);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(64) void iat_wave_kernel(const double *__restrict__ series, uint64_t n_series, uint64_t N,
+                                                      double sokal, int32_t *__restrict__ iat_out,
+                                                      int32_t *__restrict__ lag_out)
+{
+    constexpr int L = kIatLags, P = kIatPer, TB = kIatTile;
+    /* x[T0 .. T0 + TB + kIatNear + L) - mean, 0 past the end: for the first lag blocks (l0 <= kIatNear, where almost
+     * every series closes its window) both factors of a product come from this one tile, so a block reads the
+     * series once; later blocks stage the shifted factors separately */
+    __shared__ double tileA[TB + kIatNear + L + (TB + kIatNear + L) / 8 + 8];
+    __shared__ double tileB[TB + L + (TB + L) / 8 + 8];  /* x[T0 + l0 .. T0 + l0 + TB + L) - mean (far blocks only) */
+    const uint64_t sidx = blockIdx.x;
+    if (sidx >= n_series) return;
+    const double *x = series + sidx * N;
+    const int lane = threadIdx.x;
+
+    double part = 0.0;
+    for (uint64_t t = lane; t < N; t += 64) part = part + x[t];
+    const double mean = wave_sum(part) / (double)N;
+
+    double c0 = 0.0, cum = 1.0, iat_at = 1.0;
+    int64_t stop = 0;
+    bool found = false;
+    for (uint64_t l0 = 0; l0 < N && !found; l0 += L) {
+        double acc[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) acc[l] = 0.0;
+        const bool near = l0 <= (uint64_t)kIatNear;
+        const double *Bt = near ? tileA : tileB;        /* the shifted factors: Bt[iat_pad(bo + q)] = x[T0 + l0 + q] */
+        const int bo = near ? (int)l0 : 0;
+        for (uint64_t T0 = 0; T0 + l0 < N; T0 += TB) { /* tiles whose elements still have a partner at lag l0 */
+            __syncthreads();
+            const int na = near ? TB + (int)l0 + L : TB;
+            for (int q = lane; q < na; q += 64) {
+                const uint64_t t = T0 + q;
+                tileA[iat_pad(q)] = t < N ? x[t] - mean : 0.0;
+            }
+            if (!near)
+                for (int q = lane; q < TB + L; q += 64) {
+                    const uint64_t t = T0 + l0 + q;
+                    tileB[iat_pad(q)] = t < N ? x[t] - mean : 0.0;
+                }
+            __syncthreads();
+            double a[P], w[L];
+#pragma unroll
+            for (int j = 0; j < P; ++j) a[j] = tileA[iat_pad(P * lane + j)];
+#pragma unroll
+            for (int l = 0; l < L; ++l) w[l] = Bt[iat_pad(bo + P * lane + l)];
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                /* w[(j + l) % L] holds x[T0 + l0 + P lane + j + l] for l = 0 .. L-1 */
+#pragma unroll
+                for (int l = 0; l < L; ++l) acc[l] = ymc_fma(a[j], w[(j + l) % L], acc[l]);
+                if (j + 1 < P) w[j % L] = Bt[iat_pad(bo + P * lane + j + L)];
+            }
+        }
+        /* reduce the block's lag sums over the wave and run the window test on them */
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const double c = wave_sum(acc[l]);
+            const uint64_t lag = l0 + (uint64_t)l;
+            if (lag == 0) {
+                c0 = c;
+            } else if (!found && lag < N) {
+                cum = cum + c / c0;
+                const double iat_l = 2.0 * cum - 1.0;
+                if (!((double)lag < sokal * iat_l)) {
+                    found = true;
+                    stop = (int64_t)lag;
+                    iat_at = iat_l;
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        const double value = found ? iat_at : 1.0;
+        const bool defined = c0 > 0.0 && __builtin_fabs(value) < 2147483647.0;
+        iat_out[sidx] = defined ? (int32_t)__builtin_rint(value) : YMC_IAT_UNDEFINED;
+        if (lag_out) lag_out[sidx] = (int32_t)stop;
+    }
+}
+
 __global__ __launch_bounds__(kPostThreads) void iat_kernel(const double *__restrict__ series, uint64_t N, double sokal,
                                                            int32_t *__restrict__ iat_out, int32_t *__restrict__ lag_out)
 {
@@ -160,7 +276,7 @@ __global__ __launch_bounds__(kPostThreads) void iat_kernel(const double *__restr
          * converting a NaN to an integer */
         const double value = found ? iat_at : 1.0;
         const bool defined = c0 > 0.0 && __builtin_fabs(value) < 2147483647.0;
-        iat_out[blockIdx.x] = defined ? (int32_t)__builtin_rint(value) : -1;
+        iat_out[blockIdx.x] = defined ? (int32_t)__builtin_rint(value) : YMC_IAT_UNDEFINED;
         if (lag_out) lag_out[blockIdx.x] = (int32_t)stop;
     }
 }
@@ -207,6 +323,14 @@ hipError_t ymc_launch_series_from_record(const double *traj, uint64_t row0, uint
 hipError_t ymc_launch_iat(const double *series, uint64_t S, uint64_t N, double sokal, int32_t *iat, int32_t *lag,
                           hipStream_t s)
 {
+    /* many series: a wave each (register-blocked lags); a few long ones: a workgroup each with the series in LDS.
+     * YMC_IAT_KERNEL=wave|block overrides (tests run both) */
+    bool wave = S >= 64;
+    if (const char *env = std::getenv("YMC_IAT_KERNEL")) wave = env[0] == 'w';
+    if (wave) {
+        hipLaunchKernelGGL(iat_wave_kernel, dim3((unsigned)S), dim3(64), 0, s, series, S, N, sokal, iat, lag);
+        return hipGetLastError();
+    }
     const size_t lds = lds_for(N);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&iat_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsDoubles * sizeof(double)));

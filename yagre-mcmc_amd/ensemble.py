@@ -165,7 +165,7 @@ class MetropolisHastingsEnsemble:
         """postprocessing/autocorrelation.py:92-140 for every chain, computed on the device from the
         record: the equivalent of `ac.integrated_autocorrelation(states[burnin:], method)` per chain.
         Returns an int for one chain, an array of nChains ints otherwise.  A chain that never moved has no
-        autocorrelation: ValueError, or -1 in its place with allowUndefined."""
+        autocorrelation: ValueError, or IAT_UNDEFINED (INT32_MIN) in its place with allowUndefined."""
         methods = {"mean": 0, "max": 1}
         if method not in methods:
             raise ValueError(f"Invalid IAT - Type: {method}. Options are 'mean' and 'max'.")

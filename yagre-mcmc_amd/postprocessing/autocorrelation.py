@@ -20,7 +20,7 @@ def estimate_autocorrelation_function_1d(sequence, device=0):
 def integrated_autocorrelation(seq, method='mean', sokalConst=5., device=0, allowUndefined=False):
     """autocorrelation.py:92-140.  `seq`: (n, d) states of one chain -> int, or
     (n, K, d) states of K chains -> array of K ints.  A constant series has no autocorrelation:
-    ValueError (the reference fails on 0 / 0 too), or -1 in its place with allowUndefined."""
+    ValueError (the reference fails on 0 / 0 too), or IAT_UNDEFINED (INT32_MIN) in its place with allowUndefined."""
     if method not in _METHODS:
         raise ValueError(f"Invalid IAT - Type: {method}. Options are 'mean' and 'max'.")
     arr = np.asarray(seq, dtype=np.float64)
