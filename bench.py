@@ -202,10 +202,14 @@ def cpu_baseline(spec, x0):
     n16 = min(16, visible)
     rate16 = timed(per_thread * n16, T, n16, 4.0)[0] if n16 != visible else rate_all
     rate1 = timed(per_thread, T, 1, 4.0)[0]
-    return {"value": rate_all, "unit": "steps/s", "cores": visible, "kind": "port",
-            "sample": f"{per_thread * visible} chains x {T} transitions x {reps} passes of the same workload "
-                      f"(trajectory, mask, log-density and moments recorded, record buffers resident), "
-                      f"{visible} OpenMP threads, {dt:.1f} s",
+    # the GPU box gives a one-GPU job a share of the host's CPU time: every visible hardware thread at once can
+    # be SLOWER than 16 threads.  The headline is the better of the two, with the thread count that produced it.
+    best, cores = (rate_all, visible) if rate_all >= rate16 else (rate16, n16)
+    return {"value": best, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"{per_thread} chains per thread x {T} transitions of the same workload (trajectory, mask, "
+                      f"log-density and moments recorded, record buffers resident), passes repeated for 8 s "
+                      f"({visible} threads), 4 s (16 threads) and 4 s (1 thread)",
+            "host_threads_visible": visible, "all_visible_threads_steps_per_s": rate_all,
             "threads_16_steps_per_s": rate16, "single_thread_steps_per_s": rate1,
             "reference_single_core_steps_per_s_survey_container": 2.2e4}
 
