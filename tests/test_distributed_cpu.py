@@ -151,6 +151,25 @@ def test_tcp_store_allgather_and_broadcast():
         assert nonce == res[0][3] and p == res[0][4] and p != port
 
 
+def test_tcp_store_eight_ranks():
+    """The size of the 8-GPU launch: unique-id broadcast, outcome agreement, max-over-ranks, gather of
+    per-rank payloads of the C5 summary size (131 072 chains x 11 words), in rank order."""
+    import struct
+    port = _free_port()
+
+    def body(st):
+        uid = st.broadcast(bytes(range(128)) if st.rank == 0 else b"")
+        ok = st.allgather(b"ok")
+        tmax = max(struct.unpack("<d", p)[0] for p in st.allgather(struct.pack("<d", 1.0 + st.rank)))
+        mine = np.full(131072 * 11, st.rank, dtype=np.uint64)
+        parts = st.allgather(mine.tobytes())
+        return uid, ok, tmax, [int(np.frombuffer(p, dtype=np.uint64)[-1]) for p in parts], len(parts[3])
+    res = _store_ranks(8, port, body, timeout=60)
+    for uid, ok, tmax, last, nbytes in res:
+        assert uid == bytes(range(128)) and ok == [b"ok"] * 8 and tmax == 8.0
+        assert last == list(range(8)) and nbytes == 131072 * 11 * 8
+
+
 def test_tcp_store_back_to_back_same_key():
     """Two launches with the same MASTER_PORT and run id, one after the other (a torchrun restart, a
     second launch from the same shell): nothing of the first is visible to the second."""

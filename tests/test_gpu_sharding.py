@@ -125,6 +125,41 @@ def test_c5_total_1048576_chains_one_run_equals_8_shards(ffi, ctx):
     assert pooled["flagged"] == 0 and 0.2 < pooled["acceptance_rate"] < 0.95
 
 
+def _launch_bench(world, port, extra_env, *args):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, YMC_BENCH_ALLOW_SHARED_GPU="1", **extra_env)
+    env.pop("YMC_COMM", None) if "YMC_COMM" not in extra_env else None
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world),
+           "--steps", "2", "--warmup", "1", "--chains", "8192", "--transitions", "200", "--launches-per-step", "2", *args]
+    return subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+
+
+def test_bench_under_the_drivers_launcher_two_ranks(ffi):
+    """bench.py exactly as the driver starts it for N > 1 (`python -m torch.distributed.run ...`), two ranks on
+    this box's one GPU.  With the explicit rehearsal transport the ranks meet over the TCP store (next to the
+    launcher's own store on MASTER_PORT), shard by global chain id and gather; WITHOUT it RCCL is mandatory,
+    RCCL refuses two ranks on one device, and every rank exits non-zero with the reason -- no line is printed."""
+    import json
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    r = _launch_bench(2, port, {"YMC_COMM": "tcp"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["collective"] == "tcp" and line["nranks_seen"] == 2
+    assert line["config"]["chains_total"] == 16384 and line["value"] > 0 and line["scaling"] == "weak"
+    assert 0.3 < line["acceptance_rate"] < 0.8 and line["chains_flagged_nonfinite"] == 0
+    r = _launch_bench(2, port + 40, {"YMC_COMM_TIMEOUT": "60"})
+    assert r.returncode != 0
+    assert "RCCL is required for more than one rank" in r.stderr and "ncclCommInitRank" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
 def test_clock_probe_reports_a_plausible_shader_clock(ffi, ctx):
     ctx.clock_probe_start(30.0)
     mhz, ms = ctx.clock_probe_read()

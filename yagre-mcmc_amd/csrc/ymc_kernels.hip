@@ -388,9 +388,14 @@ __global__ __launch_bounds__(kBlock) void mlda2_kernel(const ChainArgs<D> a)
  * chains per GPU = a quarter of a wave per SIMD with one lane per chain).  The
  * likelihood is n_data independent ODE solves (testSetup.py:118-141), so a chain
  * is spread over G = n_data lanes: lane r integrates design row r, the row
- * norms are gathered in row order (the canonical sequential sum), and every
- * lane of the group repeats the cheap rest (draws, prior, accept) so that no
- * broadcast is needed.  64 / G chains per wave.  Same bits as mrw_kernel.
+ * norms are gathered in row order (the canonical sequential sum).  The draws do
+ * not depend on the state, so they are not repeated by the G lanes of a chain:
+ * once per round of G transitions lane r makes the proposal increment and the
+ * accept uniform of transition (round start + r) and leaves them in a
+ * wave-private LDS slot; at every transition the group reads its slot (one
+ * broadcast read).  What the lanes still repeat is the cheap state-dependent
+ * rest (prior, exp, accept, moments).  64 / G chains per wave.  Same bits as
+ * mrw_kernel.
  */
 template <unsigned REC>
 __global__ __launch_bounds__(kBlock) void mrw_lv_rows_kernel(const ChainArgs<2> a)
@@ -426,17 +431,30 @@ __global__ __launch_bounds__(kBlock) void mrw_lv_rows_kernel(const ChainArgs<2> 
     const int myrow = (slot < cpw) ? row : 0;
     const double dx0 = p.design[2 * myrow], dy0 = p.design[2 * myrow + 1];
     const double obs0 = p.data[2 * myrow], obs1 = p.data[2 * myrow + 1];
-    UniformCache uc;
-    uc.valid = false;
-    uc.pair = 0;
     RecordClock clk(a.rec_stride, a.rec_since);
+    __shared__ double draw_slots[kBlock / 64][64][3]; /* per wave and lane: sigma_0 z_0, sigma_1 z_1, u */
+    double (*slots)[3] = draw_slots[threadIdx.x >> 6];
+    int in_round = 0;                                   /* transition index within the round of G */
 
 #pragma unroll 1
     for (uint32_t n = 0; n < a.nsteps; ++n) {
-        const uint64_t t = a.t0 + n;
+        if (in_round == 0) { /* wave-uniform: lane r of every group makes the draws of transition n + r */
+            const uint64_t tr = a.t0 + n + (uint64_t)row;
+            double z0, z1;
+            ymc_draw_normal_pair(a.seed, chain, tr, 0u, &z0, &z1);
+            const double ur = ymc_draw_uniform(a.seed, chain, tr);
+            __builtin_amdgcn_wave_barrier();
+            slots[lane][0] = sigma[0] * z0;             /* covariance.py:51-52 */
+            slots[lane][1] = sigma[1] * z1;
+            slots[lane][2] = ur;
+            __builtin_amdgcn_wave_barrier();
+        }
+        const int src = (base + in_round) & 63;
         double y[D];
-        ymc_propose<D>(x, sigma, a.seed, chain, t, y);
-        const double u = ymc_uniform_cached(uc, a.seed, chain, t);
+        y[0] = x[0] + slots[src][0];                     /* mrw.py:32-38 -> gaussian.py:66 */
+        y[1] = x[1] + slots[src][1];
+        const double u = slots[src][2];
+        in_round = (in_round + 1 == G) ? 0 : in_round + 1;
         const bool moved = !ymc_states_equal<D>(y, x, YMC_EQ_EXACT);
         /* this lane's ODE solve (Density<POSTERIOR_LV>::eval, one design row) */
         const double beta = ymc_exp(y[0]), delta = ymc_exp(y[1]);
