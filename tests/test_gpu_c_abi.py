@@ -152,3 +152,15 @@ def test_invalid_descriptions_are_refused_with_messages():
         run.sub_accept()
     with pytest.raises(_ffi.YmcError, match="4 of 4 rows"):
         run.advance(1)
+    # a burn-in beyond the record: a negative row count must not wrap around into a huge allocation
+    full = _ffi.Run(prob, 1, 8, np.zeros((1, 2)), 6, _ffi.RECORD_TRAJECTORY | _ffi.RECORD_ACCEPT)
+    full.advance(6)
+    with pytest.raises(ValueError, match="burn-in"):
+        full.iat(first=10)
+    with pytest.raises(ValueError, match="recorded"):
+        full.trajectory(first=10)
+    out = np.zeros(8, dtype=np.int32)
+    rc = _ffi.lib().ymc_run_iat(full.raw, 10, (1 << 64) - 4, 0, 5.0, _ffi.vptr(out))   # what -4 looks like through the ABI
+    assert rc == _ffi.ERR_INVALID and b"burn-in" in _ffi.lib().ymc_last_error()
+    buf = np.zeros((2, 8, 2))
+    assert _ffi.lib().ymc_run_fetch_trajectory(full.raw, 5, (1 << 64) - 3, _ffi.vptr(buf), buf.nbytes) == _ffi.ERR_INVALID

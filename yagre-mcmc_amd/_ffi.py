@@ -356,6 +356,8 @@ class Run(Handle):
     def _fetch(self, fn, first, n, shape, dtype):
         if n is None:
             n = self.steps_done()[1] - first
+        if first < 0 or n < 0:
+            raise ValueError(f"rows [{first}, {first} + {n}) requested; {self.steps_done()[1]} are recorded")
         out = np.empty((n,) + shape, dtype=dtype)
         check(getattr(lib(), fn)(self.raw, first, n, vptr(out), out.nbytes))
         return out
@@ -408,6 +410,8 @@ class Run(Handle):
         """Integrated autocorrelation time of every chain from record rows [first, first+n)."""
         if n is None:
             n = self.steps_done()[1] - first
+        if first < 0 or n < 2:
+            raise ValueError(f"the burn-in leaves {n} of {self.steps_done()[1]} recorded states: at least 2 are needed")
         out = np.empty(self.K, dtype=np.int32)
         check(lib().ymc_run_iat(self.raw, first, n, method, float(sokal_const), vptr(out)))
         return checked_iat(out, allow_undefined)

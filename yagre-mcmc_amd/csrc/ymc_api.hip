@@ -384,8 +384,10 @@ int choose_split(const ymc_run *r)
 {
     const ymc_problem *p = r->problem;
     if (p->method != YMC_METHOD_MRW || p->D > 2 || p->kind == YMC_DENSITY_POSTERIOR_LV || p->chol.p) return 0;
-    if (const char *env = std::getenv("YMC_SPLIT")) return env[0] == '1';
-    return (r->K + 255) / 256 <= (uint64_t)r->ctx->prop.multiProcessorCount;
+    int np = 3; /* producer waves per chain wave */
+    if (const char *env = std::getenv("YMC_SPLIT_NP")) np = env[0] == '2' ? 2 : 3;
+    if (const char *env = std::getenv("YMC_SPLIT")) return env[0] == '1' ? np : 0;
+    return (r->K + 255) / 256 <= (uint64_t)r->ctx->prop.multiProcessorCount ? np : 0;
 }
 
 template <int D>
@@ -706,7 +708,7 @@ int fetch_rows(ymc_run *r, const DeviceBuf &buf, uint32_t need_flag, const char 
 {
     if (!r || !dst) return fail(YMC_ERR_INVALID, "null argument");
     if (!(r->flags & need_flag)) return fail(YMC_ERR_INVALID, "the run does not record %s", what);
-    if (first + n > r->recorded)
+    if (first > r->recorded || n > r->recorded - first) /* overflow-safe: a negative count arrives as a huge one */
         return fail(YMC_ERR_INVALID, "rows [%llu, %llu) requested but only %llu recorded", (unsigned long long)first,
                     (unsigned long long)(first + n), (unsigned long long)r->recorded);
     if (dst_bytes < n * row_bytes) return fail(YMC_ERR_INVALID, "destination too small for %s", what);
@@ -1196,7 +1198,8 @@ int ymc_run_fetch_trajectory(ymc_run *run, uint64_t first, uint64_t n, double *d
         /* the record is in the kernel's tiled layout: untile on the device, chunk by chunk */
         if (!dst) return fail(YMC_ERR_INVALID, "null argument");
         if (!(run->flags & YMC_RECORD_TRAJECTORY)) return fail(YMC_ERR_INVALID, "the run does not record the trajectory");
-        if (first + n > run->recorded) return fail(YMC_ERR_INVALID, "rows beyond the record requested");
+        if (first > run->recorded || n > run->recorded - first)
+            return fail(YMC_ERR_INVALID, "rows beyond the record requested");
         const uint64_t row_doubles = run->K * (uint64_t)run->problem->D;
         if (dst_bytes < n * row_doubles * sizeof(double)) return fail(YMC_ERR_INVALID, "destination too small");
         YMC_HIP(hipSetDevice(run->ctx->device));
@@ -1316,7 +1319,7 @@ int ymc_run_egress_begin(ymc_run *run, int slot_index, uint64_t first, uint64_t 
     const uint32_t known = YMC_RECORD_TRAJECTORY | YMC_RECORD_ACCEPT | YMC_RECORD_LOGPOST;
     if (what == 0 || (what & ~known)) return fail(YMC_ERR_INVALID, "egress of record kinds 0x%x is not possible", what);
     if (what & ~run->flags) return fail(YMC_ERR_INVALID, "the run does not record what was asked for (0x%x of 0x%x)", what, run->flags);
-    if (n == 0 || first + n > run->recorded)
+    if (n == 0 || first > run->recorded || n > run->recorded - first)
         return fail(YMC_ERR_INVALID, "rows [%llu, %llu) requested but only %llu recorded", (unsigned long long)first,
                     (unsigned long long)(first + n), (unsigned long long)run->recorded);
     YMC_HIP(hipSetDevice(run->ctx->device));
@@ -1483,7 +1486,10 @@ int ymc_run_iat(ymc_run *run, uint64_t first, uint64_t n, int method, double sok
 {
     if (!run || !iat) return fail(YMC_ERR_INVALID, "null argument");
     if (!(run->flags & YMC_RECORD_TRAJECTORY)) return fail(YMC_ERR_INVALID, "the run does not record the trajectory");
-    if (first + n > run->recorded) return fail(YMC_ERR_INVALID, "rows beyond the record requested");
+    if (first > run->recorded || n > run->recorded - first)
+        return fail(YMC_ERR_INVALID, "rows [%llu, %llu + %llu) requested but %llu are recorded (burn-in beyond the record?)",
+                    (unsigned long long)first, (unsigned long long)first, (unsigned long long)n,
+                    (unsigned long long)run->recorded);
     YMC_HIP(hipSetDevice(run->ctx->device));
     return iat_from_device_states(run->ctx, run->traj.as<double>(), first, n, run->K, run->problem->D, method,
                                   sokal_const, iat, run->problem->tile ? run->problem->tgt.KS : 0);

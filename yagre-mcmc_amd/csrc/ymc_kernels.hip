@@ -173,14 +173,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 2))) 
  * ~2.0 GHz), the same wall the one-lane-per-chain kernel meets at 1 M chains.  The
  * consumers of four 256-thread workgroups would all land on SIMD 0 -- hence one big workgroup.
  */
-constexpr int kSplitBlock = 1024, kSplitChains = 256, kSplitProducers = 3, kSplitB = 2 * kSplitProducers;
+constexpr int kSplitChains = 256;
 
-template <int KIND, int D, unsigned REC, int EQ>
-__global__ __launch_bounds__(kSplitBlock) void mrw_split_kernel(const ChainArgs<D> a)
+template <int KIND, int D, unsigned REC, int EQ, int NP>
+__global__ __launch_bounds__(256 * (NP + 1)) void mrw_split_kernel(const ChainArgs<D> a)
 {
     static_assert(REC != kRuntimeRec, "the split kernel serves the specialised record configurations");
     ymc_stage_tables();
-    constexpr int B = kSplitB;
+    constexpr int B = 2 * NP;
     __shared__ double ring[4][2][B][D + 1][64];
     using R = Rec<REC>;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = w & 3, role = w >> 2;
@@ -671,8 +671,11 @@ void launch_one(int method, const ChainArgs<D> &a, hipStream_t s)
         if constexpr (REC != kRuntimeRec) {
             if constexpr (D <= 2 && KIND != YMC_DENSITY_POSTERIOR_LV) { /* beyond d = 2 the consumer no longer fits four waves per SIMD without spilling */
                 if (a.split) {
-                    hipLaunchKernelGGL((mrw_split_kernel<KIND, D, REC, EQ>),
-                                       dim3((unsigned)((a.K + kSplitChains - 1) / kSplitChains)), dim3(kSplitBlock), 0, s, a);
+                    const dim3 grid((unsigned)((a.K + kSplitChains - 1) / kSplitChains));
+                    if (a.split == 2)
+                        hipLaunchKernelGGL((mrw_split_kernel<KIND, D, REC, EQ, 2>), grid, dim3(768), 0, s, a);
+                    else
+                        hipLaunchKernelGGL((mrw_split_kernel<KIND, D, REC, EQ, 3>), grid, dim3(1024), 0, s, a);
                     return;
                 }
             }
