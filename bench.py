@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--launches-per-step", type=int, default=0, help="kernel launches per bench step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-moments", action="store_true")
+    ap.add_argument("--record-stride", type=int, default=1,
+                    help="thinned record: keep every s-th state (drops the per-transition decision record)")
     return ap.parse_args()
 
 
@@ -228,7 +230,7 @@ def profiled(workload, K, T):
 def roofline_block(args, wl, K, T, kernel_ms, launches, clock_mhz, info):
     d = wl["d"]
     ksec = kernel_ms * 1e-3
-    bytes_launch = K * T * (8 * d + 1)
+    bytes_launch = K * T * (8 * d + 1) if args.record_stride <= 1 else K * (T // args.record_stride) * 8 * d
     hbm = bytes_launch / ksec / 1e9 if ksec > 0 else 0.0
     rec = profiled(args.workload, K, T)
     traffic = rec.get("hbm_bytes_per_launch")
@@ -335,8 +337,10 @@ def main():
     d, x0 = wl["d"], wl["x0"]
     if args.workload in ("c3", "c3m"):
         args.no_moments = True   # the reference's default diagnostics; the tile kernel keeps no Welford state
-    flags = ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT | (0 if args.no_moments else ffi.RECORD_MOMENTS)
-    run = ffi.Run(wl["problem"], 20250103, K, x0, T, flags, chain_offset=rank * K)
+    stride = max(args.record_stride, 1)
+    flags = ffi.RECORD_TRAJECTORY | (ffi.RECORD_ACCEPT if stride == 1 else 0) | (0 if args.no_moments else ffi.RECORD_MOMENTS)
+    # rows per launch: T // stride, or one more when the launch boundaries do not fall on multiples of the stride
+    run = ffi.Run(wl["problem"], 20250103, K, x0, T // stride + 1, flags, chain_offset=rank * K, record_stride=stride)
 
     # YMC_BENCH_FORCE_COMM=1 exercises the RCCL path with a single rank (1-GPU rehearsal of the N > 1 flow)
     use_comm = world > 1 or os.environ.get("YMC_BENCH_FORCE_COMM") == "1"
@@ -415,6 +419,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": wl["desc"], "chains_per_gpu": K, "chains_total": world * K,
                    "transitions_per_launch": T, "launches_per_step": L, "transitions_per_step": T * L,
+                   "record_stride": stride,
                    "record": "trajectory f64 [T][K][d] + accept u8 [T][K]"
                    + ("" if args.no_moments else " + Welford moments") + ", refilled by every launch",
                    "parallelism": f"chains sharded over {world} GPU(s)",

@@ -89,6 +89,29 @@ def test_thinned_record_is_every_sth_row_of_the_full_record(ffi, ctx, golden, st
             thin.advance(stride)                                                # the thinned record is full
 
 
+@pytest.mark.parametrize("split", ["0", "1"])
+@pytest.mark.parametrize("stride", [2, 5])
+def test_thinned_record_specialised_random_walk_kernels(ffi, ctx, golden, monkeypatch, split, stride):
+    """The builders' thinned default (trajectory, with or without moments, no decision record) runs compile-time
+    record masks in the one-lane-per-chain kernel and in the helper-wave kernel: same rows as the full record."""
+    monkeypatch.setenv("YMC_SPLIT", split)
+    _, prob, x0, _ = _problems(ffi, ctx, golden)[0]
+    K, T = x0.shape[0], 53
+    full = ffi.Run(prob, 9, K, x0, T, ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT | ffi.RECORD_MOMENTS)
+    full.advance(T)
+    for flags in (ffi.RECORD_TRAJECTORY, ffi.RECORD_TRAJECTORY | ffi.RECORD_MOMENTS):
+        thin = ffi.Run(prob, 9, K, x0, T // stride, flags, record_stride=stride)
+        for n in (1, 6, 7, 12, 2):
+            thin.advance(n)
+        thin.advance(T - thin.steps_done()[0])
+        assert thin.steps_done() == (T, T // stride)
+        assert np.array_equal(thin.trajectory(), full.trajectory()[stride - 1::stride])
+        sf, st = full.summary(), thin.summary()
+        assert np.array_equal(sf["accepted"], st["accepted"]) and np.array_equal(full.state()[0], thin.state()[0])
+        if flags & ffi.RECORD_MOMENTS:
+            assert np.array_equal(sf["wf_mean"], st["wf_mean"]) and np.array_equal(sf["wf_m2"], st["wf_m2"])
+
+
 def test_thinned_record_misuse_is_refused(ffi, ctx, golden):
     name, prob, x0, _ = _problems(ffi, ctx, golden)[0]
     with pytest.raises(ffi.YmcError, match="full-rate"):

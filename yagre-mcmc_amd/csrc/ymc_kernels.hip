@@ -32,10 +32,15 @@ inline unsigned grid_for(uint64_t n) { return (unsigned)((n + kBlock - 1) / kBlo
  * the run-time form that serves every other flag combination. */
 constexpr unsigned kRuntimeRec = ~0u;
 constexpr unsigned kTA = YMC_RECORD_TRAJECTORY | YMC_RECORD_ACCEPT;
+/* a compile-time record mask with this bit is THINNED (ymc_run_desc.record_stride > 1): rows are written when
+ * the launch's RecordClock says so; the thinned masks are trajectory and trajectory + moments */
+constexpr unsigned kThin = 0x100u;
+constexpr unsigned kT = YMC_RECORD_TRAJECTORY;
 
 template <unsigned REC>
 struct Rec {
     static constexpr bool rt = REC == kRuntimeRec;
+    static constexpr bool thin = rt || (REC & kThin) != 0; /* rows follow the RecordClock */
     template <int D>
     static __device__ __forceinline__ bool traj(const ChainArgs<D> &a) { return rt ? a.traj != nullptr : (REC & YMC_RECORD_TRAJECTORY) != 0; }
     template <int D>
@@ -82,7 +87,7 @@ __device__ __forceinline__ void mrw_body(const ChainArgs<D> &a)
         ymc_load_row<D>(a.wf_m2, k, wm2);
     }
 
-    RecordClock clk(R::rt ? a.rec_stride : 1u, a.rec_since); /* the specialised records are never thinned */
+    RecordClock clk(R::thin ? a.rec_stride : 1u, a.rec_since);
     /* one transition (metropolisHastings.py:114-120) given its accept uniform */
     auto transition = [&](uint32_t n, double u) {
         const uint64_t t = a.t0 + n;
@@ -102,7 +107,7 @@ __device__ __forceinline__ void mrw_body(const ChainArgs<D> &a)
         lp = acc ? lpy : lp;
         accepted += acc ? 1u : 0u;
         if (R::acc(a)) a.acc[(uint64_t)n * a.K + k] = acc ? 1 : 0;              /* diagnostics.py:48-54 */
-        if constexpr (R::rt) {
+        if constexpr (R::thin) {
             if (clk.due()) {
                 if (R::traj(a)) ymc_store_row<D>(a.traj + (uint64_t)clk.row * a.K * D, k, x);
                 if (R::lp(a)) a.lp_out[(uint64_t)clk.row * a.K + k] = lp;
@@ -244,6 +249,7 @@ __global__ __launch_bounds__(256 * (NP + 1)) void mrw_split_kernel(const ChainAr
         ymc_load_row<D>(a.wf_mean, kk, wmean);
         ymc_load_row<D>(a.wf_m2, kk, wm2);
     }
+    RecordClock clk(R::thin ? a.rec_stride : 1u, a.rec_since);
     /* one transition (metropolisHastings.py:114-120) given its proposal increment and accept uniform */
     auto transition = [&](uint32_t n, const double (&delta)[D], double u) {
         double y[D];
@@ -257,7 +263,12 @@ __global__ __launch_bounds__(256 * (NP + 1)) void mrw_split_kernel(const ChainAr
         for (int j = 0; j < D; ++j) x[j] = acc ? y[j] : x[j];                       /* :79-92 */
         lp = acc ? lpy : lp;
         accepted += acc ? 1u : 0u;
-        if (live) {
+        if constexpr (R::thin) {
+            if (clk.due()) {
+                if (live && R::traj(a)) ymc_store_row<D>(a.traj + (uint64_t)clk.row * a.K * D, k, x);
+                clk.wrote();
+            }
+        } else if (live) {
             if (R::traj(a)) ymc_store_row<D>(a.traj + (uint64_t)n * a.K * D, k, x); /* :75-76 */
             if (R::acc(a)) a.acc[(uint64_t)n * a.K + k] = acc ? 1 : 0;              /* diagnostics.py:48-54 */
         }
@@ -682,7 +693,7 @@ void launch_one(int method, const ChainArgs<D> &a, hipStream_t s)
             hipLaunchKernelGGL((mrw_kernel_two_waves<KIND, D, REC, EQ>), dim3(grid_for(a.K)), dim3(kBlock), 0, s, a);
         } else
             hipLaunchKernelGGL((mrw_kernel<KIND, D, REC, EQ>), dim3(grid_for(a.K)), dim3(kBlock), 0, s, a);
-    } else {
+    } else if constexpr (REC == kRuntimeRec || (REC & kThin) == 0) { /* the thinned masks are the random walk's */
         if constexpr (REC != kRuntimeRec)
             if (ymc_launch_mlda2_static<D>(KIND, REC, a, s)) return;
         hipLaunchKernelGGL((mlda2_kernel<KIND, D, REC, EQ>), dim3(grid_for(a.K)), dim3(kBlock), 0, s, a);
@@ -698,12 +709,17 @@ hipError_t launch_chain(int method, const ChainArgs<D> &a, hipStream_t s)
     const unsigned rec = (a.traj ? YMC_RECORD_TRAJECTORY : 0u) | (a.acc ? YMC_RECORD_ACCEPT : 0u) |
                          (a.lp_out ? YMC_RECORD_LOGPOST : 0u) | (a.sub_acc ? YMC_RECORD_SUB_ACCEPT : 0u) |
                          (a.flags & YMC_RECORD_MOMENTS);
-    if (method == YMC_METHOD_PCN || a.chol || a.rec_stride > 1)
+    const bool thin = a.rec_stride > 1, exact = a.eq_mode == YMC_EQ_EXACT;
+    if (method == YMC_METHOD_PCN || a.chol)
         launch_one<KIND, D, kRuntimeRec, -1>(method, a, s);
-    else if (a.eq_mode == YMC_EQ_EXACT && rec == kTA)
+    else if (exact && !thin && rec == kTA)
         launch_one<KIND, D, kTA, YMC_EQ_EXACT>(method, a, s);
-    else if (a.eq_mode == YMC_EQ_EXACT && rec == (kTA | YMC_RECORD_MOMENTS))
+    else if (exact && !thin && rec == (kTA | YMC_RECORD_MOMENTS))
         launch_one<KIND, D, kTA | YMC_RECORD_MOMENTS, YMC_EQ_EXACT>(method, a, s);
+    else if (exact && thin && rec == kT && method == YMC_METHOD_MRW)
+        launch_one<KIND, D, kThin | kT, YMC_EQ_EXACT>(method, a, s);
+    else if (exact && thin && rec == (kT | YMC_RECORD_MOMENTS) && method == YMC_METHOD_MRW)
+        launch_one<KIND, D, kThin | kT | YMC_RECORD_MOMENTS, YMC_EQ_EXACT>(method, a, s);
     else
         launch_one<KIND, D, kRuntimeRec, -1>(method, a, s);
     return hipGetLastError();

@@ -46,6 +46,19 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask)
     return ymc_from_bits(((uint64_t)hi << 32) | lo);
 }
 
+/* The 2 x 2 transpose between the lane rows (16 lanes each) g = 0 | 1 and g = 2 | 3: afterwards `a` holds
+ * (own a, partner's a) and `b` (partner's b, own b) for (even, odd) rows -- i.e. a's odd rows and b's even
+ * rows are swapped.  gfx950's v_permlane16_swap_b32 does exactly this per dword, so a normal pair changes
+ * hands in two instructions (it replaced four 64-bit selects and a 64-bit ds_bpermute per pair). */
+__device__ __forceinline__ void swap_odd_even_rows(double &a, double &b)
+{
+    const uint64_t ba = ymc_bits(a), bb = ymc_bits(b);
+    const auto lo = __builtin_amdgcn_permlane16_swap((uint32_t)ba, (uint32_t)bb, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((uint32_t)(ba >> 32), (uint32_t)(bb >> 32), false, false);
+    a = ymc_from_bits(((uint64_t)hi[0] << 32) | lo[0]);
+    b = ymc_from_bits(((uint64_t)hi[1] << 32) | lo[1]);
+}
+
 /* (S0 + S1) + (S2 + S3) over the four lanes (g = 0..3) that share a chain */
 __device__ __forceinline__ double combine4(double s)
 {
@@ -81,7 +94,6 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
     const bool live = k < a.K;
     const uint32_t chain = (uint32_t)(a.chain0 + k);
     const int d = a.d;
-    const bool odd = (g & 1) != 0;
     const uint32_t pair_of_g = (g == 0) ? 0u : (g == 1) ? 2u : (g == 2) ? 1u : 3u;
 
     double x[KS], y[KS];
@@ -105,13 +117,12 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
         bool moved_l = false;
 #pragma unroll
         for (int q = 0; q < KS / 2; ++q) {
-            double z0, z1;
-            ymc_draw_normal_pair(a.seed, chain, t, 4u * (uint32_t)q + pair_of_g, &z0, &z1);
-            const double keep = odd ? z1 : z0;
-            const double give = odd ? z0 : z1;
-            const double recv = shfl_xor_f64(give, 16);
-            const double xi0 = odd ? recv : keep; /* component 8 q + g     (s = 2 q)     */
-            const double xi1 = odd ? keep : recv; /* component 8 q + 4 + g (s = 2 q + 1) */
+            /* even rows (g = 0, 2) drew the pair of components (8 q + g, 8 q + g + 1), odd rows that of
+             * (8 q + 3 + g, 8 q + 4 + g): an even row keeps its first normal and takes its partner's first,
+             * an odd row takes its partner's second and keeps its own second */
+            double xi0, xi1; /* components 8 q + g (s = 2 q) and 8 q + 4 + g (s = 2 q + 1) */
+            ymc_draw_normal_pair(a.seed, chain, t, 4u * (uint32_t)q + pair_of_g, &xi0, &xi1);
+            swap_odd_even_rows(xi0, xi1);
             if constexpr (PCN) { /* pcn.py:27-36: xi ~ prior, y = sqrt(1 - 2h) x + sqrt(2h) xi */
                 const double p0 = pmean[8 * q + g] + sigma[8 * q + g] * xi0;
                 const double p1 = pmean[8 * q + 4 + g] + sigma[8 * q + 4 + g] * xi1;
@@ -252,7 +263,6 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_mlda2_kernel(const T
     const bool live = k < a.K;
     const uint32_t chain = (uint32_t)(a.chain0 + k);
     const int d = a.d, S = a.S;
-    const bool odd = (g & 1) != 0;
     const uint32_t pair_of_g = (g == 0) ? 0u : (g == 1) ? 2u : (g == 2) ? 1u : 3u;
     double *xt = a.x_tiled + (tile * KS) * 64 + lane; /* this lane's column of the carried fine state */
 
@@ -333,13 +343,9 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_mlda2_kernel(const T
             const uint64_t t = tbase + (uint64_t)sub;
 #pragma unroll
             for (int q = 0; q < KS / 2; ++q) {
-                double z0, z1;
-                ymc_draw_normal_pair(a.seed, chain, t, 4u * (uint32_t)q + pair_of_g, &z0, &z1);
-                const double keep = odd ? z1 : z0;
-                const double give = odd ? z0 : z1;
-                const double recv = shfl_xor_f64(give, 16);
-                const double xi0 = odd ? recv : keep;
-                const double xi1 = odd ? keep : recv;
+                double xi0, xi1;
+                ymc_draw_normal_pair(a.seed, chain, t, 4u * (uint32_t)q + pair_of_g, &xi0, &xi1);
+                swap_odd_even_rows(xi0, xi1);
                 y[2 * q] = z[2 * q] + sigma[8 * q + g] * xi0;
                 y[2 * q + 1] = z[2 * q + 1] + sigma[8 * q + 4 + g] * xi1;
             }
