@@ -782,6 +782,43 @@ def test_c3_full_size_linear_d128(ffi, ctx):
     assert np.array_equal(part.trajectory(), traj[:, 3 * K // 4:])
 
 
+def test_c3_full_size_two_level_d128(ffi, ctx):
+    """BASELINE configs[2] is named after example_inference_linearModel_twoLevel.py: 262 144 chains, two d = m =
+    128 linear models, S = 5 on the matrix-core kernel; slices of the ensemble against the oracle, the
+    delayed-acceptance invariants on all of it, sharding invariance on the last quarter."""
+    from yagremcmc_amd import lowering
+    d, K, T, S = 128, 262144, 3, 5
+    rng = np.random.default_rng(7)
+    A = rng.standard_normal((d, d)) / np.sqrt(d)
+    b = rng.standard_normal(d)
+    theta = rng.standard_normal(d)
+    common = dict(data=np.array([A @ theta + b + np.sqrt(0.3) * rng.standard_normal(d) for _ in range(5)]),
+                  noise_precision=np.reciprocal(np.full(d, 0.3)), prior_mean=np.zeros(d),
+                  prior_precision=np.reciprocal(np.full(d, 5.0)))
+    A_c, b_c = A + 0.02 * rng.standard_normal((d, d)) / np.sqrt(d), b + 0.05 * rng.standard_normal(d)
+    fine = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, common, fwd_matrix=A, fwd_shift=b)
+    coarse = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, common, fwd_matrix=A_c, fwd_shift=b_c)
+    sigma = np.sqrt(np.reciprocal(np.reciprocal(np.full(d, 1.1e-3))))
+    prob = lowering.make_problem(ctx, ffi.METHOD_MLDA2, fine, sigma, surrogate=coarse, sub_chain_length=S)
+    x0 = np.zeros((1, d))
+    flags = ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT | ffi.RECORD_SUB_ACCEPT
+    run = ffi.Run(prob, 20250103, K, x0, T, flags)
+    run.advance(T)
+    traj, acc, sub = run.trajectory(), run.accept(), run.sub_accept()
+    of = o.posterior_linear(A, b, *common.values())
+    oc = o.posterior_linear(A_c, b_c, *common.values())
+    _slices_match_oracle(ffi, traj, acc, lambda c0, w: o.Ensemble(of, sigma, np.zeros((w, d)), 20250103, chain0=c0,
+                                                                  surrogate=oc, sub_chain_length=S), K, T)
+    assert not (acc.astype(bool) & ~sub.any(axis=1)).any()          # a fine step is accepted only if a sub-step moved
+    prev = np.concatenate([np.broadcast_to(x0, (1, K, d)), traj[:-1]])
+    assert np.array_equal((traj == prev).all(axis=2), acc == 0)
+    assert np.array_equal(run.summary()["accepted"], acc.sum(axis=0).astype(np.uint64))
+    assert 0.3 < acc.mean() < 0.98 and 0.2 < sub.mean() < 0.8
+    part = ffi.Run(prob, 20250103, K // 4, x0, T, flags, 3 * K // 4)
+    part.advance(T)
+    assert np.array_equal(part.trajectory(), traj[:, 3 * K // 4:]) and np.array_equal(part.sub_accept(), sub[:, :, 3 * K // 4:])
+
+
 def test_c5_full_size_two_level(ffi, ctx, golden):
     """131 072 chains per GPU of the two-level sampler, S = 6 (BASELINE configs[4] per-GPU share)."""
     from yagremcmc_amd import lowering
