@@ -38,8 +38,13 @@ __device__ __forceinline__ void static_for(F &&f)
 constexpr int kBlock = 256;
 constexpr unsigned kTA = YMC_RECORD_TRAJECTORY | YMC_RECORD_ACCEPT;
 
+#if defined(YMC_MLDA2_TWO_WAVES)
+#define YMC_MLDA2_ATTR __attribute__((amdgpu_waves_per_eu(1, 2)))
+#else
+#define YMC_MLDA2_ATTR
+#endif
 template <int KIND, int D, unsigned REC, int S>
-__global__ __launch_bounds__(kBlock) void mlda2_static_kernel(const ChainArgs<D> a)
+__global__ __launch_bounds__(kBlock) YMC_MLDA2_ATTR void mlda2_static_kernel(const ChainArgs<D> a)
 {
     ymc_stage_tables();
     const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
