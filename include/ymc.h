@@ -75,6 +75,14 @@ typedef struct ymc_density_desc {
     double gamma;
     int32_t rk4_steps;
     int32_t likelihood_only;       /* POSTERIOR_*: 1 = the likelihood alone (the target of pCN, pcn.py:77-78) */
+    /* DenseCovarianceMatrix (covariance.py:69-94) as the NOISE covariance (noise.py:21-22) or the PRIOR covariance
+     * (gaussian.py:19-24): the INVERSE of its lower Cholesky factor, [data_dim][data_dim] / [d][d] row-major
+     * (entries above the diagonal are ignored), so that |r|^2 in the covariance's norm is |L^-1 r|^2.  NULL = the
+     * diagonal covariance of noise_precision / prior_precision.  Lane-kernel sizes only (d, data_dim <= 8);
+     * not with YMC_METHOD_PCN (its proposal draws from a diagonal prior) or YMC_METHOD_AEM2 (the reference's
+     * AEMNoise refuses non-diagonal noise, noise.py:30-33). */
+    const double *noise_chol_inv;
+    const double *prior_chol_inv;
 } ymc_density_desc;
 
 typedef enum ymc_method {

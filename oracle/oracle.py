@@ -36,6 +36,7 @@ class _Density(C.Structure):
         ("design", _dp), ("t_final", C.c_double), ("alpha", C.c_double), ("gamma", C.c_double),
         ("rk4_steps", C.c_int32), ("likelihood_only", C.c_int32),
         ("lin_dbar", _dp), ("lin_nprec", _dp), ("lin_const", C.c_double),
+        ("noise_linv", _dp), ("prior_linv", _dp),
     ]
 
 
@@ -107,6 +108,18 @@ def _posterior_common(kind, dim, data, noise_precision, prior_mean, prior_precis
                 prior_precision=_f64(prior_precision).reshape(-1))
 
 
+def dense_covariances(p, noise_cov=None, prior_cov=None):
+    """Replace the diagonal noise / prior covariance of a posterior by a dense one (DenseCovarianceMatrix,
+    covariance.py:69-94): the inverse of its lower Cholesky factor (ymc_whitened_norm_sq)."""
+    p = dict(p)
+    for key, cov in (("noise_linv", noise_cov), ("prior_linv", prior_cov)):
+        if cov is not None:
+            L = np.linalg.cholesky(_f64(cov))
+            from scipy.linalg import solve_triangular
+            p[key] = np.tril(solve_triangular(L, np.eye(L.shape[0]), lower=True))
+    return p
+
+
 def posterior_linear(A, b, data, noise_precision, prior_mean, prior_precision):
     A = _f64(A)
     p = _posterior_common(POST_LINEAR, A.shape[1], data, noise_precision, prior_mean, prior_precision)
@@ -131,7 +144,7 @@ def _lower(p):
     d.kind, d.dim = p["kind"], p["dim"]
     keep = []
     for name in ("mean", "whiten", "data", "noise_precision", "prior_mean", "prior_precision",
-                 "fwd_matrix", "fwd_shift", "design"):
+                 "fwd_matrix", "fwd_shift", "design", "noise_linv", "prior_linv"):
         if name in p:
             arr = _f64(p[name])
             keep.append(arr)

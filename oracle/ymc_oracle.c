@@ -76,6 +76,9 @@ typedef struct ymo_density {
     /* POST_LINEAR: ymc_linear_data_summary of (data, noise_precision), filled by ymo_linear_summary */
     const double *lin_dbar, *lin_nprec;
     double lin_const;
+    /* dense noise / prior covariance (DenseCovarianceMatrix, covariance.py:69-94): the inverse of its lower
+     * Cholesky factor, or NULL for the diagonal covariance above (ymc_whitened_norm_sq, ymc_numerics.h) */
+    const double *noise_linv, *prior_linv;
 } ymo_density;
 
 /* ---------------------------------------------------------------------- */
@@ -165,6 +168,7 @@ static double ymo_gaussian_prior_log(const ymo_density *p, const double *theta)
 {
     double x[YMO_DMAX];
     for (int32_t j = 0; j < p->dim; ++j) x[j] = theta[j] - p->prior_mean[j];
+    if (p->prior_linv) return -0.5 * ymc_whitened_norm_sq(p->prior_linv, x, p->dim);
     return -0.5 * ymo_diag_norm_sq(x, p->prior_precision, p->dim);
 }
 
@@ -219,7 +223,7 @@ static int ymo_forward_lv(const ymo_density *p, const double *theta, double *F)
  * data row) and (n_data, data_dim) for Lotka-Volterra (row i pairs with D_i). */
 static double ymo_log_likelihood(const ymo_density *p, const double *F, int per_row_eval)
 {
-    if (!per_row_eval) {
+    if (!per_row_eval && !p->noise_linv) {
         /* one forward value for all rows: |F - Dbar|^2_{nP} + sum_i |D_i - Dbar|^2_P (ymc_numerics.h) */
         double r0[YMO_MMAX];
         for (int32_t j = 0; j < p->data_dim; ++j) r0[j] = F[j] - p->lin_dbar[j];
@@ -231,7 +235,8 @@ static double ymo_log_likelihood(const ymo_density *p, const double *F, int per_
         const double *Fi = per_row_eval ? F + (int64_t)i * p->data_dim : F;
         const double *Di = p->data + (int64_t)i * p->data_dim;
         for (int32_t j = 0; j < p->data_dim; ++j) r[j] = Fi[j] - Di[j];
-        total = total + ymo_diag_norm_sq(r, p->noise_precision, p->data_dim);
+        total = total + (p->noise_linv ? ymc_whitened_norm_sq(p->noise_linv, r, p->data_dim)
+                                       : ymo_diag_norm_sq(r, p->noise_precision, p->data_dim));
     }
     return -0.5 * total;
 }

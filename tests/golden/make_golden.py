@@ -780,9 +780,61 @@ def fixture_f14():
     print("F14", acc.mean(), sub.mean())
 
 
+def fixture_f15():
+    """Dense covariances as NOISE and PRIOR models (CentredGaussianNoise / Gaussian over DenseCovarianceMatrix,
+    covariance.py:69-94, noise.py:21-22, gaussian.py:19-24): (a) a linear model d = 3, 4 outputs, 5 data rows,
+    dense 4 x 4 noise and dense 3 x 3 prior covariance; (b) Lotka-Volterra with a dense 2 x 2 noise covariance
+    (reference loop over the RK4 plug-in).  The reference solves two triangular systems per norm with LAPACK;
+    the fixture pins decisions, chains and log-posteriors (the latter to rounding)."""
+    z, _ = oracle.rng_fill(1515, 0, 40, 0, 1, 4, uniforms=False)
+    z = z[0]
+    d, m, nd = 3, 4, 5
+    A, b = z[:4, :3] * 0.8, z[4, :4]
+    theta_true = z[5, :3]
+    Bn = z[6:10, :4] * 0.4
+    noise_cov = Bn @ Bn.T + 0.3 * np.eye(m)
+    Bp = z[10:13, :3] * 0.7
+    prior_cov = Bp @ Bp.T + 1.5 * np.eye(d)
+    Ln = np.linalg.cholesky(noise_cov)
+    data = np.array([A @ theta_true + b + Ln @ z[13 + i, :4] for i in range(nd)])
+    prior_mean = z[20, :3] * 0.3
+    like = AdditiveGaussianNoiseLikelihood(Data(data), ForwardModel(ExampleLinearModelSolver(A, b)),
+                                           CentredGaussianNoise(DenseCovarianceMatrix(noise_cov)))
+    prior = Gaussian(ParameterVector(prior_mean.copy()), DenseCovarianceMatrix(prior_cov))
+    model = BayesianRegressionModel(like, prior)
+    seed, K, n = 20250115, 16, 400
+    prop_cov = DiagonalCovarianceMatrix(np.array([0.12, 0.2, 0.15]))
+    traj, acc, lp = run_mrw_model(model, seed, K, n, prop_cov, np.zeros(d))
+    out = dict(seed=seed, n_states=n, A=A, b=b, data=data, noise_cov=noise_cov, prior_cov=prior_cov, prior_mean=prior_mean,
+               sigma=sigma_of(prop_cov), x0=np.zeros((K, d)), traj=traj, acc=acc, logpost=lp)
+    # (b) Lotka-Volterra, dense 2 x 2 noise
+    cfg = {'T': 6., 'alpha': 0.8, 'gamma': 0.4, 'nData': 5, 'dataDim': 2}
+    design = np.array([[0.1, 0.9], [0.5, 0.5], [1., 0.5], [0.5, 1.], [2.5, 1.5]])
+    lv_noise_cov = np.array([[0.05, 0.02], [0.02, 0.08]])
+    pv, pm = 0.02, np.zeros(2)
+    base = oracle.posterior_lv(design, cfg['T'], cfg['alpha'], cfg['gamma'], 50, np.zeros((5, 2)), np.ones(2), pm,
+                               np.reciprocal(np.full(2, pv)))
+    clean = oracle.forward(base, np.log(np.array([0.4, 0.6]))).reshape(5, 2)
+    lv_data = clean + (np.linalg.cholesky(lv_noise_cov) @ z[21:26, :2].T).T
+    problem = dict(base, data=lv_data)
+    lv_like = AdditiveGaussianNoiseLikelihood(Data(lv_data), ForwardModel(RK4LotkaVolterraSolver(problem)),
+                                              CentredGaussianNoise(DenseCovarianceMatrix(lv_noise_cov)))
+    lv_prior = Gaussian(LotkaVolterraParameter.from_coefficient(pm.copy()), IIDCovarianceMatrix(2, pv))
+    lv_prop = DiagonalCovarianceMatrix(np.array([0.02, 0.01]))
+    Kl, nl = 8, 250
+    ltraj, lacc, llp = run_mrw_model(BayesianRegressionModel(lv_like, lv_prior), seed + 1, Kl, nl, lv_prop,
+                                     np.array([-0.6, -0.3]), make_param=LotkaVolterraParameter.from_coefficient)
+    out.update(lv_seed=seed + 1, lv_n_states=nl, lv_design=design, lv_t_final=cfg['T'], lv_alpha=cfg['alpha'],
+               lv_gamma=cfg['gamma'], lv_rk4_steps=50, lv_data=lv_data, lv_noise_cov=lv_noise_cov, lv_prior_mean=pm,
+               lv_prior_precision=np.reciprocal(np.full(2, pv)), lv_sigma=sigma_of(lv_prop),
+               lv_x0=np.tile([-0.6, -0.3], (Kl, 1)), lv_traj=ltraj, lv_acc=lacc, lv_logpost=llp)
+    np.savez_compressed(os.path.join(HERE, "f15_dense_noise_prior.npz"), **out)
+    print("F15", acc.mean(), lacc.mean())
+
+
 def main():
     which = sys.argv[1:] or ["f1", "f2", "f2b", "f3", "f3b", "f4", "f5", "f7", "f8", "f9", "f10", "f11", "f12", "f13",
-                             "f14"]
+                             "f14", "f15"]
     if "f1" in which:
         fixture_f1()
     if "f2" in which:
@@ -814,6 +866,8 @@ def main():
         fixture_f13()
     if "f14" in which:
         fixture_f14()
+    if "f15" in which:
+        fixture_f15()
     if "f12" in which:
         fixture_f12()
         fixture_f12("f12b_aem_linear_noheuristic.npz", use_heuristic=False, seed=20250113, min_data=5, K=12,

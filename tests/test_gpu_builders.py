@@ -636,6 +636,36 @@ def test_two_level_over_a_model_hierarchy_d128_f14(golden):
     assert abs(mc.diagnostics.global_acceptance_rate() - g["acc"].mean()) < 1e-15
 
 
+def test_dense_noise_and_prior_through_the_builders_f15(golden):
+    """MRWBuilder.bayesModel with CentredGaussianNoise(DenseCovarianceMatrix) and a Gaussian prior over a
+    DenseCovarianceMatrix: the chains of the live reference (fixture F15a)."""
+    from yagremcmc_amd.chain.method.mrw import MRWBuilder
+    from yagremcmc_amd.exampleSetup import ExampleLinearModelSolver
+    from yagremcmc_amd.model.forwardModel import ForwardModel
+    from yagremcmc_amd.parameter.vector import ParameterVector
+    from yagremcmc_amd.statistics.bayesModel import BayesianRegressionModel
+    from yagremcmc_amd.statistics.covariance import DenseCovarianceMatrix, DiagonalCovarianceMatrix
+    from yagremcmc_amd.statistics.data import Data
+    from yagremcmc_amd.statistics.gaussian import Gaussian
+    from yagremcmc_amd.statistics.likelihood import AdditiveGaussianNoiseLikelihood
+    from yagremcmc_amd.statistics.noise import CentredGaussianNoise
+    g = golden("f15_dense_noise_prior.npz")
+    like = AdditiveGaussianNoiseLikelihood(Data(g["data"]), ForwardModel(ExampleLinearModelSolver(g["A"], g["b"])),
+                                           CentredGaussianNoise(DenseCovarianceMatrix(g["noise_cov"])))
+    prior = Gaussian(ParameterVector(np.array(g["prior_mean"])), DenseCovarianceMatrix(g["prior_cov"]))
+    b = MRWBuilder()
+    b.bayesModel = BayesianRegressionModel(like, prior)
+    b.proposalCovariance = DiagonalCovarianceMatrix(np.array([0.12, 0.2, 0.15]))
+    b.nChains, b.seed, b.recordLogPosterior = g["x0"].shape[0], int(g["seed"]), True
+    mc = b.build_method()
+    mc.run(int(g["n_states"]), ParameterVector(np.zeros(3)), verbose=False)
+    assert np.array_equal(mc.accept_decisions, g["acc"]) and np.array_equal(mc.chain.ensemble_trajectory, g["traj"])
+    assert np.abs(mc.log_posterior - g["logpost"]).max() <= 1e-12 * np.abs(g["logpost"]).max()
+    # evaluate_log of the posterior object itself goes through the same lowering
+    k, n = 3, 200
+    assert mc.target.evaluate_log(ParameterVector(mc.chain.ensemble_trajectory[n, k].copy())) == mc.log_posterior[n, k]
+
+
 def test_iat_of_a_stuck_chain_is_reported_not_invented():
     """A chain that never moves (or was flagged non-finite and froze) has a constant series: c0 = 0 and the
     autocorrelation is 0 / 0.  The device reports IAT_UNDEFINED for it; the Python layer raises unless asked."""

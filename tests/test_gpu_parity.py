@@ -643,6 +643,79 @@ def test_tile_kernel_preconditioned_crank_nicolson(ffi, ctx, d, m, nd, K, h):
     _same_as_oracle(dev, e, out)
 
 
+def _dense_low(ffi, kind, dim, g, noise_cov=None, prior_cov=None, **extra):
+    from scipy.linalg import solve_triangular
+    low = _posterior_low(ffi, kind, dim, g, **extra)
+    for field, cov in (("noise_chol_inv", noise_cov), ("prior_chol_inv", prior_cov)):
+        if cov is not None:
+            L = np.linalg.cholesky(np.asarray(cov, dtype=float))
+            low.set_array(field, np.tril(solve_triangular(L, np.eye(L.shape[0]), lower=True)))
+    return low
+
+
+def test_f15_dense_noise_and_prior_covariances(ffi, ctx, golden):
+    """DenseCovarianceMatrix as noise and prior model (noise.py:21-22, gaussian.py:19-24 over covariance.py:69-94):
+    device == oracle bit for bit; decisions and chains == the live reference's, log-posteriors to rounding."""
+    g = golden("f15_dense_noise_prior.npz")
+    lin = o.dense_covariances(o.posterior_linear(g["A"], g["b"], g["data"], np.ones(4), g["prior_mean"], np.ones(3)),
+                              noise_cov=g["noise_cov"], prior_cov=g["prior_cov"])
+    lv = o.dense_covariances(
+        o.posterior_lv(g["lv_design"], float(g["lv_t_final"]), float(g["lv_alpha"]), float(g["lv_gamma"]),
+                       int(g["lv_rk4_steps"]), g["lv_data"], np.ones(2), g["lv_prior_mean"], g["lv_prior_precision"]),
+        noise_cov=g["lv_noise_cov"])
+    common = dict(data=g["data"], noise_precision=np.ones(4), prior_mean=g["prior_mean"], prior_precision=np.ones(3))
+    low = _dense_low(ffi, ffi.POSTERIOR_LINEAR, 3, common, g["noise_cov"], g["prior_cov"], fwd_matrix=g["A"], fwd_shift=g["b"])
+    n = int(g["n_states"])
+    dev = _device_run(ffi, ctx, low, g["sigma"], g["x0"], int(g["seed"]), n - 1, splits=2)
+    e = o.Ensemble(lin, g["sigma"], g["x0"], int(g["seed"]))
+    _same_as_oracle(dev, e, e.advance(n - 1))
+    _same_as_reference(dev, g)
+    lvc = dict(data=g["lv_data"], noise_precision=np.ones(2), prior_mean=g["lv_prior_mean"], prior_precision=g["lv_prior_precision"])
+    for rows in ("0", "1"):       # one lane per chain, and one lane per (chain, design row)
+        import os
+        os.environ["YMC_LV_ROWS"] = rows
+        try:
+            low = _dense_low(ffi, ffi.POSTERIOR_LV, 2, lvc, g["lv_noise_cov"], None, design=np.asarray(g["lv_design"]),
+                             t_final=float(g["lv_t_final"]), alpha=float(g["lv_alpha"]), gamma=float(g["lv_gamma"]),
+                             rk4_steps=int(g["lv_rk4_steps"]))
+            nl = int(g["lv_n_states"])
+            dev = _device_run(ffi, ctx, low, g["lv_sigma"], g["lv_x0"], int(g["lv_seed"]), nl - 1)
+        finally:
+            del os.environ["YMC_LV_ROWS"]
+        e = o.Ensemble(lv, g["lv_sigma"], g["lv_x0"], int(g["lv_seed"]))
+        _same_as_oracle(dev, e, e.advance(nl - 1))
+        _same_as_reference(dev, dict(acc=g["lv_acc"], traj=g["lv_traj"], logpost=g["lv_logpost"]))
+
+
+@pytest.mark.parametrize("d,m,nd,method", [(1, 1, 3, "mrw"), (5, 8, 2, "mrw"), (8, 3, 4, "mlda2"), (2, 6, 5, "mlda2")])
+def test_dense_covariances_other_shapes_vs_oracle(ffi, ctx, d, m, nd, method):
+    rng = np.random.default_rng(1000 + 10 * d + m)
+
+    def spd(n):
+        B = rng.normal(size=(n, n))
+        return B @ B.T + n * 0.2 * np.eye(n)
+
+    def level(scale):
+        g = dict(data=rng.normal(size=(nd, m)), noise_precision=np.ones(m), prior_mean=rng.normal(size=d) * 0.2,
+                 prior_precision=np.ones(d))
+        A, b, nc, pc = scale * rng.normal(size=(m, d)), rng.normal(size=m), spd(m), spd(d)
+        return (_dense_low(ffi, ffi.POSTERIOR_LINEAR, d, g, nc, pc, fwd_matrix=A, fwd_shift=b),
+                o.dense_covariances(o.posterior_linear(A, b, g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"]),
+                                    noise_cov=nc, prior_cov=pc))
+
+    (lf, pf), (lc, pc_) = level(1.0), level(0.8)
+    sigma, x0 = rng.uniform(0.1, 0.4, size=d), rng.normal(size=(45, d))
+    if method == "mrw":
+        dev = _device_run(ffi, ctx, lf, sigma, x0, 77, 40, chain0=5, splits=2)
+        e = o.Ensemble(pf, sigma, x0, 77, chain0=5)
+        _same_as_oracle(dev, e, e.advance(40))
+    else:
+        dev = _device_run(ffi, ctx, lf, sigma, x0, 77, 30, method=ffi.METHOD_MLDA2, sur=lc, S=3, chain0=5)
+        e = o.Ensemble(pf, sigma, x0, 77, chain0=5, surrogate=pc_, sub_chain_length=3)
+        out = e.advance(30, want_sub=True)
+        _same_as_oracle(dev, e, out)
+
+
 def test_f14_two_level_d128_matrix_cores(ffi, ctx, golden):
     """Two-level delayed acceptance over two d = 128 linear models (linear_tile_mlda2_kernel): the LIVE
     reference's decisions at both levels, its chains (sha256 of all states) and log-posteriors; == oracle."""

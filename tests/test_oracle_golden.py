@@ -267,6 +267,40 @@ def test_f14_two_level_over_a_model_hierarchy_d128(golden):
     assert 0.5 < g["acc"].mean() < 0.95 and 0.2 < g["sub_acc"].mean() < 0.8   # both levels decide both ways
 
 
+def _f15_problems(g):
+    lin = o.dense_covariances(
+        o.posterior_linear(g["A"], g["b"], g["data"], np.ones(4), g["prior_mean"], np.ones(3)),
+        noise_cov=g["noise_cov"], prior_cov=g["prior_cov"])
+    lv = o.dense_covariances(
+        o.posterior_lv(g["lv_design"], float(g["lv_t_final"]), float(g["lv_alpha"]), float(g["lv_gamma"]),
+                       int(g["lv_rk4_steps"]), g["lv_data"], np.ones(2), g["lv_prior_mean"], g["lv_prior_precision"]),
+        noise_cov=g["lv_noise_cov"])
+    return lin, lv
+
+
+def test_f15_dense_noise_and_prior_covariances(golden):
+    """CentredGaussianNoise / Gaussian over DenseCovarianceMatrix (covariance.py:69-94): the reference solves
+    two triangular systems per norm with LAPACK (unspecified order), the ensemble forms |L^-1 r|^2 in its own
+    order: every decision and every state equal, log-posteriors to rounding (measured 3e-15, bar 1e-12)."""
+    g = golden("f15_dense_noise_prior.npz")
+    lin, lv = _f15_problems(g)
+    n = int(g["n_states"])
+    e = o.Ensemble(lin, g["sigma"], g["x0"], int(g["seed"]))
+    out = e.advance(n - 1)
+    _check(out, g, n)
+    nl = int(g["lv_n_states"])
+    e = o.Ensemble(lv, g["lv_sigma"], g["lv_x0"], int(g["lv_seed"]))
+    out = e.advance(nl - 1)
+    _check(out, dict(acc=g["lv_acc"], traj=g["lv_traj"], logpost=g["lv_logpost"]), nl)
+    # against NumPy on random residuals: |r|^2_Sigma = r . Sigma^-1 r
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((50, 3))
+    want = np.array([-0.5 * (xi - g["prior_mean"]) @ np.linalg.solve(g["prior_cov"], xi - g["prior_mean"]) for xi in x])
+    only_prior = dict(lin, data=np.zeros((1, 4)), n_data=1, fwd_matrix=np.zeros((4, 3)), fwd_shift=np.zeros(4))
+    got, _ = o.logdensity(only_prior, x)
+    assert np.allclose(got, want, rtol=1e-12, atol=0)
+
+
 def test_f8_preconditioned_crank_nicolson(golden):
     """pcn.py:9-57 on the Lotka-Volterra likelihood with a centred Gaussian prior"""
     g = golden("f8_pcn_lotka_volterra.npz")

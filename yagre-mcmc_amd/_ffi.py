@@ -52,6 +52,7 @@ class DensityDesc(C.Structure):
         ("fwd_matrix", _dp), ("fwd_shift", _dp), ("design", _dp),
         ("t_final", C.c_double), ("alpha", C.c_double), ("gamma", C.c_double),
         ("rk4_steps", C.c_int32), ("likelihood_only", C.c_int32),
+        ("noise_chol_inv", _dp), ("prior_chol_inv", _dp),
     ]
 
 

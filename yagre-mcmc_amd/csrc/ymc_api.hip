@@ -100,6 +100,8 @@ struct DensityHost {
     ymc_density_desc d{};
     std::vector<double> mean, whiten, data, noise_prec, prior_mean, prior_prec, A, b, design;
     std::vector<double> dbar, nprec; /* POSTERIOR_LINEAR: ymc_linear_data_summary */
+    std::vector<double> noise_linv, prior_linv; /* dense covariances: inverse Cholesky factors (empty: diagonal) */
+    size_t off_nlinv = 0, off_plinv = 0;
     double lik_const = 0.0;
     DeviceBuf dev;  /* one allocation: data | noise_prec | prior_mean | prior_prec | A | b | design | dbar | nprec */
     size_t off_data = 0, off_noise = 0, off_pmean = 0, off_pprec = 0, off_A = 0, off_b = 0, off_design = 0,
@@ -231,6 +233,20 @@ int lower_density(ymc_ctx *ctx, const ymc_density_desc &in, DensityHost &out, in
         YMC_TRY(copy_array(out.noise_prec, in.noise_precision, m, "noise_precision"));
         YMC_TRY(copy_array(out.prior_mean, in.prior_mean, d, "prior_mean"));
         YMC_TRY(copy_array(out.prior_prec, in.prior_precision, d, "prior_precision"));
+        if (in.noise_chol_inv || in.prior_chol_inv) {
+            if (big) return fail(YMC_ERR_UNSUPPORTED, "dense noise / prior covariances are lowered for the lane kernels "
+                                                      "(parameter and data dimension <= %d)", YMC_LANE_DMAX);
+            auto lower_tri = [&](std::vector<double> &dst, const double *src, size_t n, const char *what) -> int {
+                YMC_TRY(copy_array(dst, src, n * n, what));
+                for (size_t i = 0; i < n; ++i) {
+                    for (size_t j = i + 1; j < n; ++j) dst[i * n + j] = 0.0;
+                    if (!(dst[i * n + i] > 0.0)) return fail(YMC_ERR_INVALID, "%s: the diagonal of an inverse Cholesky factor is positive", what);
+                }
+                return YMC_OK;
+            };
+            if (in.noise_chol_inv) YMC_TRY(lower_tri(out.noise_linv, in.noise_chol_inv, m, "noise_chol_inv"));
+            if (in.prior_chol_inv) YMC_TRY(lower_tri(out.prior_linv, in.prior_chol_inv, (size_t)d, "prior_chol_inv"));
+        }
         if (in.kind == YMC_DENSITY_POSTERIOR_LINEAR) {
             if (big) {
                 /* the matrix-core tile kernel: A staged in LDS, d <= 128 */
@@ -271,6 +287,8 @@ int lower_density(ymc_ctx *ctx, const ymc_density_desc &in, DensityHost &out, in
         put(out.design, out.off_design);
         put(out.dbar, out.off_dbar);
         put(out.nprec, out.off_nprec);
+        put(out.noise_linv, out.off_nlinv);
+        put(out.prior_linv, out.off_plinv);
         YMC_TRY(out.dev.alloc(blob.size() * sizeof(double)));
         YMC_HIP(hipMemcpy(out.dev.p, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice));
         break;
@@ -305,6 +323,8 @@ DensityDev<D> device_view(const DensityHost &h)
         v.design = base + h.off_design;
         v.dbar = base + h.off_dbar;
         v.nprec = base + h.off_nprec;
+        if (!h.noise_linv.empty()) v.noise_linv = base + h.off_nlinv;
+        if (!h.prior_linv.empty()) v.prior_linv = base + h.off_plinv;
     }
     v.lik_const = h.lik_const;
     v.t_final = h.d.t_final;
@@ -864,6 +884,8 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
         else if (desc->surrogate.data_dim != desc->target.data_dim)
             rc = fail(YMC_ERR_INVALID, "the model error needs forward maps of equal output dimension (%d vs %d)",
                       desc->target.data_dim, desc->surrogate.data_dim);
+        if (rc == YMC_OK && (desc->target.noise_chol_inv || desc->surrogate.noise_chol_inv))
+            rc = fail(YMC_ERR_UNSUPPORTED, "Currently, AEM is only implemented for independent measurement noise.");
         p->aem_min_data = desc->aem_min_data_size;
         p->aem_heuristic = desc->aem_use_noise_heuristic != 0;
     }
@@ -937,6 +959,8 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
         /* PreconditionedCrankNicolson.__init__, pcn.py:40-49; PCNBuilder, pcn.py:77-83 */
         if (p->kind != YMC_DENSITY_POSTERIOR_LINEAR && p->kind != YMC_DENSITY_POSTERIOR_LV)
             rc = fail(YMC_ERR_INVALID, "PCN is only defined in relation to a Bayesian model");
+        else if (desc->target.prior_chol_inv)
+            rc = fail(YMC_ERR_UNSUPPORTED, "the pCN proposal draws from a diagonal prior covariance");
         else if (!(desc->pcn_step_size > 0.0 && desc->pcn_step_size <= 0.5))
             rc = fail(YMC_ERR_INVALID, "PCN step size must be in (0, 0.5], got %g", desc->pcn_step_size);
         else {

@@ -38,7 +38,26 @@ struct DensityDev {
     /* POSTERIOR_LINEAR: ymc_linear_data_summary of (data, noise_prec) */
     const double *dbar, *nprec;
     double lik_const;
+    /* dense noise / prior covariance: inverse Cholesky factors (null: diagonal), ymc_whitened_norm_sq */
+    const double *noise_linv, *prior_linv;
 };
+
+/* ymc_whitened_norm_sq for a register-resident residual (same operations in the same order) */
+template <int N>
+__device__ __forceinline__ double ymc_whitened_norm_sq_reg(const double *__restrict__ linv, const double (&r)[N], int n)
+{
+    double S[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if (i < n) {
+            double w = linv[i * n] * r[0];
+#pragma unroll
+            for (int j = 1; j <= i; ++j) w = ymc_fma(linv[i * n + j], r[j], w);
+            S[i & 3] = S[i & 3] + w * w;
+        }
+    }
+    return (S[0] + S[1]) + (S[2] + S[3]);
+}
 
 __device__ __forceinline__ bool ymc_finite(double v) { return __builtin_fabs(v) <= YMC_DBL_MAX; }
 
@@ -65,6 +84,7 @@ __device__ __forceinline__ double ymc_prior_log(const DensityDev<D> &p, const do
     double x[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) x[j] = theta[j] - p.prior_mean[j];
+    if (p.prior_linv) return -0.5 * ymc_whitened_norm_sq_reg<D>(p.prior_linv, x, D); /* wave-uniform */
     return -0.5 * ymc_diag_norm_sq<D>(x, p.prior_prec, D);
 }
 
@@ -128,6 +148,17 @@ struct Density<YMC_DENSITY_POSTERIOR_LINEAR, D> {
         (void)st;
         double F[YMC_LANE_MMAX];
         forward(p, x, F);
+        if (p.noise_linv) { /* dense noise covariance: row by row (likelihood.py:33-39,80) */
+            double total = 0.0;
+            for (int i = 0; i < p.n_data; ++i) {
+                double ri[YMC_LANE_MMAX];
+#pragma unroll
+                for (int j = 0; j < YMC_LANE_MMAX; ++j) ri[j] = (j < p.data_dim) ? F[j] - p.data[i * p.data_dim + j] : 0.0;
+                total = total + ymc_whitened_norm_sq_reg<YMC_LANE_MMAX>(p.noise_linv, ri, p.data_dim);
+            }
+            const double logl_dense = -0.5 * total;
+            return p.likelihood_only ? logl_dense : logl_dense + ymc_prior_log<D>(p, x);
+        }
         /* likelihood.py:74-84, :33-39 through the row-mean identity (ymc_linear_data_summary) */
         double r[YMC_LANE_MMAX];
 #pragma unroll
@@ -165,7 +196,8 @@ struct Density<YMC_DENSITY_POSTERIOR_LV, D> {
             for (; s < p.rk4_steps; ++s) ymc_lv_rk4_step(&x, &y, alpha, beta, gamma, delta, h, h2, h6);
             bad = bad || !ymc_finite(x) || !ymc_finite(y);
             double r[2] = {x - p.data[2 * n], y - p.data[2 * n + 1]};
-            total = total + ymc_diag_norm_sq<2>(r, p.noise_prec, 2);
+            total = total + (p.noise_linv ? ymc_whitened_norm_sq_reg<2>(p.noise_linv, r, 2)
+                                          : ymc_diag_norm_sq<2>(r, p.noise_prec, 2));
         }
         double lp = p.likelihood_only ? -0.5 * total : -0.5 * total + ymc_prior_log<D>(p, th);
         if (bad) {

@@ -482,7 +482,8 @@ __global__ __launch_bounds__(kBlock) void mrw_lv_rows_kernel(const ChainArgs<2> 
         for (; s < p.rk4_steps; ++s) ymc_lv_rk4_step(&sx, &sy, alpha, beta, gamma, delta, h, h2, h6);
         const int bad_l = (!ymc_finite(sx) || !ymc_finite(sy)) ? 1 : 0;
         const double res[2] = {sx - obs0, sy - obs1};
-        const double term = ymc_diag_norm_sq<2>(res, p.noise_prec, 2);
+        const double term = p.noise_linv ? ymc_whitened_norm_sq_reg<2>(p.noise_linv, res, 2)
+                                         : ymc_diag_norm_sq<2>(res, p.noise_prec, 2);
         /* gather the rows in order: total = ((t_0) + t_1) + ... (likelihood.py:80) */
         double total = 0.0;
         int bad = 0;

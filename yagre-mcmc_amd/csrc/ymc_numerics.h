@@ -509,6 +509,27 @@ YMC_FN void ymc_linear_data_summary(const double *data, const double *prec, int3
 }
 
 /* ------------------------------------------------------------------------ */
+/* |r|^2 in the norm of a DENSE covariance Sigma = L L^T                     */
+/* (CovarianceMatrix.induced_norm_squared over DenseCovarianceMatrix,        */
+/* covariance.py:19-22,69-94) from Linv = L^-1 (lower triangular, row-major  */
+/* n x n, formed once on the host):  w = Linv r,  |r|^2 = |w|^2.  The        */
+/* reference solves two triangular systems with LAPACK and takes a BLAS dot  */
+/* product -- orders that are not specified; the ensemble's order is: row i  */
+/* of Linv r as a left-to-right fma chain, the squares as the canonical four */
+/* interleaved partial sums.  Values agree with the reference to rounding.   */
+/* ------------------------------------------------------------------------ */
+YMC_FN double ymc_whitened_norm_sq(const double *linv, const double *r, int32_t n)
+{
+    double S[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int32_t i = 0; i < n; ++i) {
+        double w = linv[(int64_t)i * n] * r[0];
+        for (int32_t j = 1; j <= i; ++j) w = ymc_fma(linv[(int64_t)i * n + j], r[j], w);
+        S[i & 3] = S[i & 3] + w * w;
+    }
+    return (S[0] + S[1]) + (S[2] + S[3]);
+}
+
+/* ------------------------------------------------------------------------ */
 /* Lotka-Volterra flow (testSetup.py:96-99) and one step of classical RK4,  */
 /* the ensemble's integrator (the reference integrates adaptively with      */
 /* scipy's solve_ivp; agreement of the forward map is checked to 1e-3, so   */

@@ -83,6 +83,25 @@ def _diag_precision(cov, n, what):
     return prec
 
 
+def _set_covariance(low, cov, n, what, prec_field, linv_field):
+    """A noise / prior covariance on the descriptor: Diagonal / IID as its precision vector; a
+    DenseCovarianceMatrix (covariance.py:69-94, recognised by its lower Cholesky factor `cholFactor_`) as the
+    inverse of that factor, so that the device forms |L^-1 r|^2 (ymc_whitened_norm_sq)."""
+    L = getattr(cov, "cholFactor_", None)
+    if L is None:
+        low.set_array(prec_field, _diag_precision(cov, n, what))
+        return
+    _require_stock(cov, f"{what} covariance", "apply_inverse", "induced_norm_squared", "apply_chol_factor")
+    L = np.tril(np.asarray(L, dtype=np.float64))
+    if L.shape != (n, n):
+        raise ValueError(f"{what} covariance has dimension {L.shape[0]}, expected {n}")
+    if n > _ffi.LANE_DMAX:
+        raise UnsupportedPlugin(f"a dense {what} covariance is lowered up to dimension {_ffi.LANE_DMAX}, got {n}")
+    from scipy.linalg import solve_triangular
+    low.set_array(linv_field, np.tril(solve_triangular(L, np.eye(n), lower=True)))
+    low.set_array(prec_field, np.reciprocal(np.diag(L @ L.T)))   # unused by the dense path; keeps the field valid
+
+
 class Lowered:
     """A ymc_density_desc plus the arrays it points into."""
 
@@ -190,12 +209,12 @@ def lower_posterior(likelihood, prior, rk4_steps=None):
     noise = likelihood._noiseModel
     if _name(noise) == "AEMNoise":  # noise.py:25-39: the measurement noise it wraps is the initial model
         noise = noise._dataNoise
-    low.set_array("noise_precision", _diag_precision(noise.covariance, data_dim, "noise"))
+    _set_covariance(low, noise.covariance, data_dim, "noise", "noise_precision", "noise_chol_inv")
     pm = np.asarray(prior.mean.coefficient, dtype=np.float64).reshape(-1)
     if pm.size != dim:
         raise ValueError(f"prior mean has dimension {pm.size}, the forward map takes {dim}")
     low.set_array("prior_mean", pm)
-    low.set_array("prior_precision", _diag_precision(prior.covariance, dim, "prior"))
+    _set_covariance(low, prior.covariance, dim, "prior", "prior_precision", "prior_chol_inv")
     return low
 
 

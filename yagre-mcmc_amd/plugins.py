@@ -140,9 +140,9 @@ class IIDCovarianceMatrix(DiagonalCovarianceMatrix):
 
 
 class DenseCovarianceMatrix(CovarianceMatrix):
-    """covariance.py:69-94: a dense covariance through its lower Cholesky factor.  As a random-walk
-    proposal covariance it is lowered to the device (y = x + L xi); the host methods mirror the
-    reference's."""
+    """covariance.py:69-94: a dense covariance through its lower Cholesky factor.  Lowered to the device as
+    a random-walk proposal covariance (y = x + L xi) and as a noise or prior covariance (|L^-1 r|^2), all up to
+    dimension 8; the host methods mirror the reference's."""
 
     def __init__(self, denseCovMat):
         from scipy.linalg import cholesky
