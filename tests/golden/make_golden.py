@@ -780,6 +780,69 @@ def fixture_f14():
     print("F14", acc.mean(), sub.mean())
 
 
+def fixture_f16(name="f16_aem_linear_d128.npz", use_heuristic=True, seed=20250116, min_data=6, K=8, n=161, S=4):
+    """The adaptive error model over two d = 128 linear models (the matrix-core kernel's size): AEMBuilder
+    (aem.py:61-82) with AEMLikelihoods on both levels, fresh likelihood objects per chain; chains, decisions of
+    both levels, and what every chain's coarse likelihood learned (error count, mean, variance, inflated
+    precision)."""
+    from yagremcmc.chain.method.aem import AEMBuilder
+    from yagremcmc.chain.target import UnnormalisedPosterior
+    from yagremcmc.statistics.likelihood import AEMLikelihood
+    from yagremcmc.statistics.modelHierarchy import BayesianRegressionModelHierarchy
+    from yagremcmc.utility.hierarchy import Hierarchy, SharedComponent
+    d, n_data = 128, 5
+    A_f, b_f, data, noise_var = linear_problem(d, n_data, 7)
+    z, _ = oracle.rng_fill(99, 0, d + 1, 0, 1, d, uniforms=False)
+    A_c = A_f + 0.02 * z[0][:d] / np.sqrt(d)
+    b_c = b_f + 0.05 * z[0][d]
+    prior_mean, prior_var, prop_var = np.zeros(d), 5.0, 1.1e-3
+    cov = IIDCovarianceMatrix(d, prop_var)
+    traj = np.empty((n, K, d))
+    acc = np.empty((n - 1, K), dtype=np.uint8)
+    sub_acc = np.empty((n - 1, S, K), dtype=np.uint8)
+    lp = np.empty((n, K))
+    err_n = np.zeros(K, dtype=np.uint64)
+    err_mean, err_mvar, aem_prec = np.zeros((K, d)), np.zeros((K, d)), np.zeros((K, d))
+    hits = np.zeros(K, dtype=np.int64)
+    for k in range(K):
+        prior = Gaussian(ParameterVector(prior_mean.copy()), IIDCovarianceMatrix(d, prior_var))
+        noise = CentredGaussianNoise(IIDCovarianceMatrix(d, noise_var))
+        lik_c = AEMLikelihood(Data(data), ForwardModel(ExampleLinearModelSolver(A_c, b_c)), noise, min_data, use_heuristic)
+        lik_f = AEMLikelihood(Data(data), ForwardModel(ExampleLinearModelSolver(A_f, b_f)), noise, min_data, use_heuristic)
+        model = BayesianRegressionModelHierarchy(Hierarchy([lik_c, lik_f]), SharedComponent(prior, 2))
+        b = AEMBuilder()
+        b.baseProposalCovariance = cov
+        b.subChainLengths = [S]
+        b.bayesModel = model
+        b.surrogateDiagnostics = [AcceptanceRateDiagnostics()]
+        mc = b.build_method()
+        rp = Replay(seed, k, d, (n - 1) * (S + 1), sub_chain_length=S)
+        rp.install()
+        mark_fine_level(mc, rp)
+        mc.run(n, ParameterVector(np.zeros(d)), verbose=False)
+        traj[:, k, :] = np.array(mc.chain.trajectory)
+        acc[:, k] = mc.diagnostics._decisions
+        sub_acc[:, :, k] = np.array(mc.surrogate(0).diagnostics._decisions, dtype=np.uint8).reshape(n - 1, S)
+        plain = AdditiveGaussianNoiseLikelihood(Data(data), ForwardModel(ExampleLinearModelSolver(A_f, b_f)), noise)
+        lp[:, k] = eval_log_along(UnnormalisedPosterior(plain, prior), traj[:, k, :], lambda s_: ParameterVector(np.array(s_)))
+        err_n[k] = lik_c.accumulator.nData
+        assert lik_f.accumulator.nData == 0
+        if err_n[k] >= 1:
+            err_mean[k] = lik_c.accumulator.mean()
+        if err_n[k] >= 2:
+            err_mvar[k] = lik_c.accumulator.marginal_variance()
+        if lik_c._noiseModel._aemNoise is not None:
+            aem_prec[k] = lik_c._noiseModel._aemNoise.covariance._precision
+        hits[k] = lik_c._cache.hits
+    np.savez_compressed(
+        os.path.join(HERE, name), seed=seed, n_states=n, S=S, min_data_size=min_data, use_noise_heuristic=int(use_heuristic),
+        A_fine=A_f, b_fine=b_f, A_coarse=A_c, b_coarse=b_c, data=data, noise_precision=np.reciprocal(np.full(d, noise_var)),
+        prior_mean=prior_mean, prior_precision=np.reciprocal(np.full(d, prior_var)), sigma=sigma_of(cov), x0=np.zeros((K, d)),
+        traj_head=traj[:, :2, :], traj_sha256=sha(traj), acc=acc, sub_acc=sub_acc, logpost=lp, err_n=err_n, err_mean=err_mean,
+        err_mvar=err_mvar, aem_prec=aem_prec)
+    print(name, acc.mean(), sub_acc.mean(), "accepted per chain", err_n.min(), err_n.max(), "cache hits", hits.mean())
+
+
 def fixture_f15():
     """Dense covariances as NOISE and PRIOR models (CentredGaussianNoise / Gaussian over DenseCovarianceMatrix,
     covariance.py:69-94, noise.py:21-22, gaussian.py:19-24): (a) a linear model d = 3, 4 outputs, 5 data rows,
@@ -834,7 +897,7 @@ def fixture_f15():
 
 def main():
     which = sys.argv[1:] or ["f1", "f2", "f2b", "f3", "f3b", "f4", "f5", "f7", "f8", "f9", "f10", "f11", "f12", "f13",
-                             "f14", "f15"]
+                             "f14", "f15", "f16"]
     if "f1" in which:
         fixture_f1()
     if "f2" in which:
@@ -868,6 +931,8 @@ def main():
         fixture_f14()
     if "f15" in which:
         fixture_f15()
+    if "f16" in which:
+        fixture_f16()
     if "f12" in which:
         fixture_f12()
         fixture_f12("f12b_aem_linear_noheuristic.npz", use_heuristic=False, seed=20250113, min_data=5, K=12,

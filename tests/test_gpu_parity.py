@@ -407,6 +407,56 @@ def test_aem_other_shapes_vs_oracle(ffi, ctx, d, m, nd):
     assert dev["err"]["has_precision"].mean() > 0.5
 
 
+def test_f16_adaptive_error_model_d128_matrix_cores(ffi, ctx, golden):
+    """The adaptive error model on the matrix-core kernel (linear_tile_aem2_kernel: per-output error-model
+    arrays in the tiled layout, cache keyed by the identity of the points): the live reference's chains at
+    d = 128 (sha256), decisions of both levels, what every chain learned; == oracle bit for bit."""
+    import hashlib
+    g = golden("f16_aem_linear_d128.npz")
+    n, S = int(g["n_states"]), int(g["S"])
+    common = dict(data=g["data"], noise_precision=g["noise_precision"], prior_mean=g["prior_mean"],
+                  prior_precision=g["prior_precision"])
+    dev = _aem_device_run(ffi, ctx, g, dict(common, A=g["A_fine"], b=g["b_fine"]), dict(common, A=g["A_coarse"], b=g["b_coarse"]),
+                          g["sigma"], g["x0"], int(g["seed"]), n - 1, S, int(g["min_data_size"]),
+                          int(g["use_noise_heuristic"]), splits=3)
+    e = o.AemEnsemble(o.posterior_linear(g["A_fine"], g["b_fine"], **common),
+                      o.posterior_linear(g["A_coarse"], g["b_coarse"], **common), g["sigma"], g["x0"],
+                      int(g["seed"]), S, int(g["min_data_size"]), int(g["use_noise_heuristic"]))
+    out = e.advance(n - 1, want_sub=True)
+    _same_as_oracle(dev, e, out)
+    assert np.array_equal(dev["sub_acc"], out["sub_acc"])
+    _same_error_model(dev, e)
+    assert np.array_equal(dev["acc"], g["acc"]) and np.array_equal(dev["sub_acc"], g["sub_acc"])
+    full = np.concatenate([g["x0"][None], dev["traj"]])
+    assert hashlib.sha256(np.ascontiguousarray(full).tobytes()).hexdigest() == str(g["traj_sha256"])
+    assert np.array_equal(dev["err"]["n"], g["err_n"])
+    assert np.allclose(dev["err"]["precision"], g["aem_prec"], rtol=1e-11, atol=0)
+
+
+@pytest.mark.parametrize("d,m,nd,K", [(128, 128, 5, 70), (9, 3, 2, 33), (16, 40, 1, 64), (40, 70, 8, 50), (5, 30, 6, 40)])
+def test_tile_kernel_adaptive_error_model_other_shapes(ffi, ctx, d, m, nd, K):
+    rng = np.random.default_rng(40 + d + m)
+    A = rng.normal(size=(m, d)) / np.sqrt(d)
+    b = rng.normal(size=m) * 0.3
+    As, bs = A + 0.05 * rng.normal(size=(m, d)), b + 0.1 * rng.normal(size=m)
+    theta = rng.normal(size=d)
+    data = np.array([A @ theta + b + 0.5 * rng.normal(size=m) for _ in range(nd)])
+    common = dict(data=data, noise_precision=np.full(m, 4.0) * rng.uniform(0.8, 1.2, size=m),
+                  prior_mean=np.zeros(d), prior_precision=np.full(d, 0.25))
+    sigma = np.full(d, 0.5 / np.sqrt(d))
+    x0 = rng.normal(size=(K, d)) * 0.3
+    for heur in (1, 0):
+        dev = _aem_device_run(ffi, ctx, None, dict(common, A=A, b=b), dict(common, A=As, b=bs), sigma, x0, 31338, 60, 3,
+                              4, heur, splits=2, chain0=91)
+        e = o.AemEnsemble(o.posterior_linear(A, b, **common), o.posterior_linear(As, bs, **common), sigma, x0, 31338, 3,
+                          4, heur, chain0=91)
+        out = e.advance(60, want_sub=True)
+        _same_as_oracle(dev, e, out)
+        assert np.array_equal(dev["sub_acc"], out["sub_acc"])
+        _same_error_model(dev, e)
+    assert dev["err"]["n"].max() > 4
+
+
 def test_aem_full_size_invariants(ffi, ctx, golden):
     """65 536 chains: the error model has seen exactly the accepted fine proposals of its chain
     (aem.py:26-56), the inflated precision exists iff nData > minDataSize and is below the data

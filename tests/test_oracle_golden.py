@@ -190,6 +190,24 @@ def test_f12_adaptive_error_model(golden, name):
     assert np.array_equal(e2.aem_mean, e.aem_mean) and np.array_equal(e2.cache_val, e.cache_val)
 
 
+def test_f16_adaptive_error_model_d128(golden):
+    """aem.py over two d = 128 linear models (the matrix-core kernel's size): chains (sha256 of all states),
+    decisions at both levels and the learned error model == the live reference's."""
+    g = golden("f16_aem_linear_d128.npz")
+    n = int(g["n_states"])
+    e = _aem_from_fixture(g)
+    out = e.advance(n - 1, want_sub=True)
+    assert np.array_equal(out["acc"], g["acc"]) and np.array_equal(out["sub_acc"], g["sub_acc"])
+    full = np.concatenate([g["x0"][None], out["traj"]])
+    assert hashlib.sha256(np.ascontiguousarray(full).tobytes()).hexdigest() == str(g["traj_sha256"])
+    want = g["logpost"][1:]
+    assert np.abs(out["logpost"] - want).max() <= LP_RTOL * np.abs(want).max()
+    assert np.array_equal(e.aem_n, g["err_n"]) and e.aem_n.min() > int(g["min_data_size"])
+    assert np.allclose(e.aem_mean, g["err_mean"], rtol=1e-11, atol=1e-14)
+    assert np.allclose(e.aem_m2 / (e.aem_n[:, None] - 1.0), g["err_mvar"], rtol=1e-10, atol=0)
+    assert np.allclose(e.aem_prec, g["aem_prec"], rtol=1e-11, atol=0)
+
+
 def test_f13_dense_proposal_covariance(golden):
     """DenseCovarianceMatrix proposal (covariance.py:69-94): the reference sums L @ xi in BLAS' order,
     the ensemble row-wise left to right -- every decision equals the reference's, states agree to

@@ -110,6 +110,7 @@ struct DensityHost {
     bool tile = false;
     int KS = 0, MT = 0;
     DeviceBuf tile_blob;
+    DeviceBuf aem_rows; /* tile adaptive error model: noise precision [m_pad] | data rows [n_data][m_pad] */
 };
 
 }  // namespace
@@ -645,6 +646,19 @@ int build_tile_blob(ymc_problem *p, DensityHost &h)
     return YMC_OK;
 }
 
+/* the coarse level's raw noise precision and data rows, padded to the tile kernel's output count */
+int build_aem_rows(DensityHost &h)
+{
+    const size_t m = h.d.data_dim, m_pad = 16 * (size_t)h.MT, nd = h.d.n_data;
+    std::vector<double> rows(m_pad * (1 + nd), 0.0);
+    for (size_t j = 0; j < m; ++j) rows[j] = h.noise_prec[j];
+    for (size_t i = 0; i < nd; ++i)
+        for (size_t j = 0; j < m; ++j) rows[m_pad * (1 + i) + j] = h.data[i * m + j];
+    YMC_TRY(h.aem_rows.alloc(rows.size() * sizeof(double)));
+    YMC_HIP(hipMemcpy(h.aem_rows.p, rows.data(), rows.size() * sizeof(double), hipMemcpyHostToDevice));
+    return YMC_OK;
+}
+
 uint64_t tiled_row_doubles(const ymc_run *r)
 {
     return ((r->K + 15) / 16) * (uint64_t)r->problem->tgt.KS * 64;
@@ -653,7 +667,8 @@ uint64_t tiled_row_doubles(const ymc_run *r)
 int launch_advance_tile(ymc_run *r, uint64_t nsteps)
 {
     const ymc_problem *p = r->problem;
-    const bool mlda2 = p->method == YMC_METHOD_MLDA2;
+    const bool aem2 = p->method == YMC_METHOD_AEM2;
+    const bool mlda2 = p->method == YMC_METHOD_MLDA2 || aem2;
     const DensityHost &h = mlda2 ? p->sur : p->tgt; /* the level staged in LDS */
     TileArgs a{};
     a.blob = h.tile_blob.as<double>();
@@ -670,6 +685,19 @@ int launch_advance_tile(ymc_run *r, uint64_t nsteps)
         a.lpc = r->lpc.as<double>();
         a.x_tiled = r->x_tiled.as<double>();
         if (r->flags & YMC_RECORD_SUB_ACCEPT) a.sub_acc = r->sub_acc.as<uint8_t>() + r->recorded * (uint64_t)p->S * r->K;
+    }
+    if (aem2) {
+        a.n_data = h.d.n_data;
+        a.min_data = p->aem_min_data;
+        a.use_heuristic = p->aem_heuristic;
+        a.aem_rows = h.aem_rows.as<double>();
+        a.err_n = r->err_n.as<uint64_t>();
+        a.err_mean_t = r->err_mean.as<double>();
+        a.err_m2_t = r->err_m2.as<double>();
+        a.prec_t = r->aem_prec.as<double>();
+        a.aem_flags = r->aem_flags.as<int32_t>();
+        a.cache_id = r->cache_key.as<uint64_t>();
+        a.cache_val = r->cache_val.as<double>();
     }
     a.seed = r->seed;
     a.chain0 = r->chain0;
@@ -704,8 +732,9 @@ int launch_advance_tile(ymc_run *r, uint64_t nsteps)
         YMC_HIP(hipEventCreate(&ev.second));
     }
     YMC_HIP(hipEventRecord(ev.first, r->ctx->stream));
-    hipError_t e = mlda2 ? ymc_launch_linear_tile_mlda2(h.KS, a, r->ctx->stream)
-                         : ymc_launch_linear_tile(h.KS, a, r->ctx->stream);
+    hipError_t e = aem2    ? ymc_launch_linear_tile_aem2(h.KS, a, r->ctx->stream)
+                   : mlda2 ? ymc_launch_linear_tile_mlda2(h.KS, a, r->ctx->stream)
+                           : ymc_launch_linear_tile(h.KS, a, r->ctx->stream);
     if (e == hipSuccess && moments)
         e = ymc_launch_welford_replay(a.traj, r->x_before.as<double>(), nsteps, r->K, p->D, h.KS, r->steps_done,
                                       r->wf_mean.as<double>(), r->wf_m2.as<double>(), r->ctx->stream);
@@ -875,8 +904,9 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
         if (desc->target.kind != YMC_DENSITY_POSTERIOR_LINEAR || desc->surrogate.kind != YMC_DENSITY_POSTERIOR_LINEAR)
             rc = fail(YMC_ERR_INVALID, "Adaptive error correction only makes sense if the target emerges from a "
                                        "Bayesian model.");
-        else if (p->tgt.tile)
-            rc = fail(YMC_ERR_UNSUPPORTED, "only the random-walk sampler is available at this dimension");
+        else if (p->tgt.tile && desc->target.n_data > ymc_tile_aem2_max_rows())
+            rc = fail(YMC_ERR_UNSUPPORTED, "at this dimension the adaptive error model handles up to %d data rows, got %d",
+                      ymc_tile_aem2_max_rows(), desc->target.n_data);
         else if (desc->aem_min_data_size < 2)
             rc = fail(YMC_ERR_INVALID, "Smallest senisible data size for AEM is 2.");
         else if (desc->target.likelihood_only || desc->surrogate.likelihood_only)
@@ -901,6 +931,10 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
         if (rc == YMC_OK && p->sur.tile != p->tgt.tile)
             rc = fail(YMC_ERR_UNSUPPORTED, "the two levels do not fit one kernel (target %d x %d, surrogate %d x %d)",
                       desc->target.data_dim, p->D, desc->surrogate.data_dim, p->D);
+        if (rc == YMC_OK && p->tgt.tile && desc->method == YMC_METHOD_AEM2 &&
+            ymc_tile_aem2_lds_bytes(p->sur.KS, p->sur.MT, desc->surrogate.n_data) > kTileLdsLimit)
+            rc = fail(YMC_ERR_UNSUPPORTED, "the coarse forward map %d x %d, both levels' constants and the data rows do "
+                                           "not fit the 160 KB LDS", desc->surrogate.data_dim, p->D);
         if (rc == YMC_OK && p->tgt.tile && desc->method == YMC_METHOD_MLDA2 &&
             ymc_tile_mlda2_lds_bytes(p->sur.KS, p->sur.MT, p->tgt.MT) > kTileLdsLimit)
             rc = fail(YMC_ERR_UNSUPPORTED, "the coarse forward map %d x %d plus both levels' constants do not fit the "
@@ -970,10 +1004,13 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
         }
     }
     if (rc == YMC_OK && p->tgt.tile) {
-        if (p->method != YMC_METHOD_MRW && p->method != YMC_METHOD_PCN && p->method != YMC_METHOD_MLDA2)
-            rc = fail(YMC_ERR_UNSUPPORTED, "the random-walk, pCN and two-level samplers are available at this dimension");
+        if (p->method == YMC_METHOD_MLDA_NESTED)
+            rc = fail(YMC_ERR_UNSUPPORTED, "the random-walk, pCN, two-level and adaptive-error-model samplers are "
+                                           "available at this dimension");
+        const bool two = p->method == YMC_METHOD_MLDA2 || p->method == YMC_METHOD_AEM2;
         if (rc == YMC_OK) rc = build_tile_blob(p, p->tgt);
-        if (rc == YMC_OK && p->method == YMC_METHOD_MLDA2) rc = build_tile_blob(p, p->sur);
+        if (rc == YMC_OK && two) rc = build_tile_blob(p, p->sur);
+        if (rc == YMC_OK && p->method == YMC_METHOD_AEM2) rc = build_aem_rows(p->sur);
         p->tile = true;
     }
     if (rc == YMC_OK && p->method == YMC_METHOD_MLDA_NESTED) {
@@ -1077,9 +1114,21 @@ int ymc_run_create(ymc_ctx *ctx, const ymc_problem *problem, const ymc_run_desc 
         if ((r->flags & YMC_RECORD_SUB_ACCEPT) &&
             (problem->method == YMC_METHOD_MLDA2 || problem->method == YMC_METHOD_AEM2))
             YMC_TRY(r->sub_acc.alloc(r->capacity * (uint64_t)S * K));
-        if (problem->tile && problem->method == YMC_METHOD_MLDA2)
+        if (problem->tile && (problem->method == YMC_METHOD_MLDA2 || problem->method == YMC_METHOD_AEM2))
             YMC_TRY(r->x_tiled.alloc(tiled_row_doubles(r) * sizeof(double)));
-        if (problem->method == YMC_METHOD_AEM2) {
+        if (problem->method == YMC_METHOD_AEM2 && problem->tile) {
+            /* per-output arrays in the kernel's tiled layout [ceil(K/16)][4 MT][64]; ids of the cached points */
+            const uint64_t per_out = ((K + 15) / 16) * 4ull * (uint64_t)problem->sur.MT * 64ull;
+            DeviceBuf *bufs[] = {&r->err_n, &r->err_mean, &r->err_m2, &r->aem_prec, &r->aem_flags, &r->cache_key,
+                                 &r->cache_val};
+            const size_t sizes[] = {K * sizeof(uint64_t), per_out * sizeof(double), per_out * sizeof(double),
+                                    per_out * sizeof(double), K * 2 * sizeof(int32_t), K * 4 * sizeof(uint64_t),
+                                    K * YMC_AEM_CACHE * sizeof(double)};
+            for (int i = 0; i < 7; ++i) {
+                YMC_TRY(bufs[i]->alloc(sizes[i]));
+                YMC_HIP(hipMemsetAsync(bufs[i]->p, 0, sizes[i], ctx->stream));
+            }
+        } else if (problem->method == YMC_METHOD_AEM2) {
             const uint64_t m = (uint64_t)problem->sur.d.data_dim;
             DeviceBuf *bufs[] = {&r->err_n, &r->err_mean, &r->err_m2, &r->aem_prec, &r->aem_flags, &r->cache_key,
                                  &r->cache_val};
@@ -1274,9 +1323,28 @@ int ymc_run_fetch_error_model(ymc_run *run, uint64_t *n, double *mean, double *m
     YMC_HIP(hipSetDevice(run->ctx->device));
     YMC_HIP(hipStreamSynchronize(run->ctx->stream));
     if (n) YMC_HIP(hipMemcpy(n, run->err_n.p, run->err_n.bytes, hipMemcpyDeviceToHost));
-    if (mean) YMC_HIP(hipMemcpy(mean, run->err_mean.p, run->err_mean.bytes, hipMemcpyDeviceToHost));
-    if (m2) YMC_HIP(hipMemcpy(m2, run->err_m2.p, run->err_m2.bytes, hipMemcpyDeviceToHost));
-    if (precision) YMC_HIP(hipMemcpy(precision, run->aem_prec.p, run->aem_prec.bytes, hipMemcpyDeviceToHost));
+    if (run->problem->tile) {
+        /* the matrix-core kernel keeps the per-output arrays in its own layout [tile][4 MT][64] */
+        const uint64_t K = run->K, m = (uint64_t)run->problem->sur.d.data_dim, Q = 4ull * run->problem->sur.MT;
+        std::vector<double> tiled(run->err_mean.bytes / sizeof(double));
+        auto untile = [&](const DeviceBuf &src, double *dst) -> int {
+            if (!dst) return YMC_OK;
+            YMC_HIP(hipMemcpy(tiled.data(), src.p, src.bytes, hipMemcpyDeviceToHost));
+            for (uint64_t k = 0; k < K; ++k)
+                for (uint64_t j = 0; j < m; ++j) {
+                    const uint64_t q = 4 * (j / 16) + (j % 16) / 4, lane = 16 * (j % 4) + k % 16;
+                    dst[k * m + j] = tiled[((k / 16) * Q + q) * 64 + lane];
+                }
+            return YMC_OK;
+        };
+        YMC_TRY(untile(run->err_mean, mean));
+        YMC_TRY(untile(run->err_m2, m2));
+        YMC_TRY(untile(run->aem_prec, precision));
+    } else {
+        if (mean) YMC_HIP(hipMemcpy(mean, run->err_mean.p, run->err_mean.bytes, hipMemcpyDeviceToHost));
+        if (m2) YMC_HIP(hipMemcpy(m2, run->err_m2.p, run->err_m2.bytes, hipMemcpyDeviceToHost));
+        if (precision) YMC_HIP(hipMemcpy(precision, run->aem_prec.p, run->aem_prec.bytes, hipMemcpyDeviceToHost));
+    }
     if (has_precision) {
         std::vector<int32_t> flags(2 * run->K);
         YMC_HIP(hipMemcpy(flags.data(), run->aem_flags.p, run->aem_flags.bytes, hipMemcpyDeviceToHost));

@@ -38,6 +38,16 @@ struct TileArgs {
     double *lpc;      /* coarse log-density of the carried (fine) state */
     double *x_tiled;  /* the carried state in the record's tiled layout [ceil(K/16)][KS][64] (scratch) */
     uint8_t *sub_acc; /* [rows][S][K] or null */
+    /* adaptive error model (ymc_tile_aem.hip; both levels have m outputs): the coarse likelihood's state per
+     * chain.  Per-output arrays are laid out like the record, [ceil(K/16)][4 MT][64]: slot 4 mt + r of lane
+     * (g, c) belongs to output 16 mt + 4 r + g of chain c */
+    int32_t n_data, min_data, use_heuristic, pad2_;
+    const double *aem_rows;  /* noise precision [m_pad] | data rows [n_data][m_pad] of the coarse level */
+    uint64_t *err_n;         /* [K] accepted fine proposals */
+    double *err_mean_t, *err_m2_t, *prec_t;
+    int32_t *aem_flags;      /* [K][2] {precision set, cache fill} */
+    uint64_t *cache_id;      /* [K][4]: the three cached points' ids (oldest first) and the carried state's id */
+    double *cache_val;       /* [K][3] */
 };
 
 struct BigLinearArgs {
@@ -50,6 +60,9 @@ size_t ymc_tile_lds_bytes(int KS, int MT);
 size_t ymc_tile_mlda2_lds_bytes(int KS, int MT_coarse, int MT_fine);
 hipError_t ymc_launch_linear_tile(int KS, const TileArgs &a, hipStream_t s);
 hipError_t ymc_launch_linear_tile_mlda2(int KS, const TileArgs &a, hipStream_t s);
+size_t ymc_tile_aem2_lds_bytes(int KS, int MT, int n_data);
+int ymc_tile_aem2_max_rows(void);
+hipError_t ymc_launch_linear_tile_aem2(int KS, const TileArgs &a, hipStream_t s);
 hipError_t ymc_launch_untile(const double *tiled, uint64_t row0, uint64_t rows, uint64_t K, int d, int KS,
                              double *out, hipStream_t s);
 hipError_t ymc_launch_welford_replay(const double *tiled, const double *x_before, uint64_t rows, uint64_t K, int d,

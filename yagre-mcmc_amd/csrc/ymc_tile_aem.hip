@@ -1,0 +1,462 @@
+/*
+ * ymc_tile_aem.hip -- two-level delayed acceptance with the ADAPTIVE ERROR MODEL over two linear models at
+ * large dimension (d, data_dim <= 128): the matrix-core counterpart of ymc_aem.hip
+ * (chain/method/aem.py:6-58; statistics/likelihood.py:90-155; noise.py:25-61; utility/memoisation.py:76-149).
+ *
+ * Mapping of linear_tile_mlda2_kernel (one wave = 16 chains, lane (g, c) owns chain c and the components /
+ * outputs congruent g mod 4; coarse matrix in LDS, fine matrix fragments from L2).  What a chain's coarse
+ * AEMLikelihood object holds lives with its four lanes:
+ *   - the Welford accumulator of the model error F_fine(y) - F_coarse(y) over the ACCEPTED fine proposals,
+ *     the residual shift and the inflated noise precision: one value per output, so lane (g, c) keeps the
+ *     entries of ITS outputs in arrays laid out like the record ([tile][slot][lane], coalesced), read at every
+ *     coarse evaluation and rewritten when the chain accepts;
+ *   - the three-entry AEMCache of log-likelihood values, most recently used last (a hit returns the value
+ *     stored when the entry was made, possibly under an older error model -- the reference's chains depend on
+ *     that).  Its keys are parameter vectors; comparing 128-component keys at every query would cost more
+ *     than the likelihood, so a key is the IDENTITY of the point: every proposal is a new point (id = its
+ *     transition index + 1, the initial state has id 0), accepting hands the id on.  Two ids are equal iff
+ *     the vectors are the same point of the walk; distinct proposals that coincide in all d components have
+ *     probability zero, and a proposal equal to its state is rejected before any query (as in the reference).
+ * A miss needs the likelihood under the CURRENT error model: it is evaluated for the whole wave whenever
+ * any of its chains misses (a ballot), and only the chains that missed take the value.
+ * Same draws and the same arithmetic in the same order as ymo_aem_advance / aem2_kernel: bit-identical.
+ */
+#define YMC_COEFF_IN_SGPR 1
+#include "ymc_kernels.h"
+#include "ymc_tile.h"
+#include "ymc_tile_dev.h"
+
+namespace {
+
+constexpr int kAemRows = 8; /* data rows whose partial sums a lane keeps in registers */
+/* four waves per workgroup = one per SIMD: sub-chain state, proposal, the row sums and the cache take more
+ * than the 256 registers a wave has at two per SIMD (345 spills at d = 128) */
+constexpr int kAemWaves = 4, kAemThreads = 64 * kAemWaves;
+
+struct AemCache {
+    int32_t nkeys;
+    uint64_t key[3];
+    double val[3];
+
+    __device__ __forceinline__ int find(uint64_t id) const
+    {
+        if (nkeys > 0 && key[0] == id) return 0;
+        if (nkeys > 1 && key[1] == id) return 1;
+        if (nkeys > 2 && key[2] == id) return 2;
+        return -1;
+    }
+    __device__ __forceinline__ void put(int slot, uint64_t id, double v)
+    {
+        key[slot] = id;
+        val[slot] = v;
+    }
+    __device__ __forceinline__ void copy(int dst, int src)
+    {
+        key[dst] = key[src];
+        val[dst] = val[src];
+    }
+    /* AEMLikelihood.query_log_likelihood + update_cache (likelihood.py:121-126,135-141) given where the key
+     * was found (-1: not) and, for a miss, the likelihood under the current error model */
+    __device__ __forceinline__ double take(uint64_t id, int hit, double fresh)
+    {
+        if (hit == 0) { /* retrieve: the entry moves to the back (memoisation.py:98-103) */
+            const double v = val[0];
+            if (nkeys == 2) {
+                copy(0, 1);
+                put(1, id, v);
+            } else if (nkeys == 3) {
+                copy(0, 1);
+                copy(1, 2);
+                put(2, id, v);
+            }
+            return v;
+        }
+        if (hit == 1) {
+            const double v = val[1];
+            if (nkeys == 3) {
+                copy(1, 2);
+                put(2, id, v);
+            }
+            return v;
+        }
+        if (hit == 2) return val[2];
+        if (nkeys == 3) { /* evict the oldest (memoisation.py:92-96) */
+            copy(0, 1);
+            copy(1, 2);
+            put(2, id, fresh);
+        } else {
+            put(nkeys, id, fresh);
+            nkeys += 1;
+        }
+        return fresh;
+    }
+};
+
+template <int KS>
+__global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const TileArgs a)
+{
+    ymc_stage_tables();
+    extern __shared__ double lds[];
+    const int MT = a.MT, m_pad = 16 * MT, d_pad = 4 * KS, Q = 4 * MT; /* both levels have a.m outputs */
+    /* coarse level: A fragments | bias | (n * noise_prec, unused) | (row mean, unused) | prior mean | prior prec | sigma */
+    double *Ac = lds;
+    double *bias_c = Ac + (size_t)MT * KS * 64;
+    double *pmean_c = bias_c + 3 * m_pad;
+    double *pprec_c = pmean_c + d_pad;
+    double *sigma = pprec_c + d_pad;
+    const size_t blob_c = (size_t)MT * KS * 64 + (size_t)m_pad * 3 + 3 * (size_t)d_pad;
+    /* fine level constants: bias | n * noise_prec | row mean | prior mean | prior prec */
+    double *bias_f = lds + blob_c;
+    double *nprec_f = bias_f + m_pad;
+    double *dbar_f = nprec_f + m_pad;
+    double *pmean_f = dbar_f + m_pad;
+    double *pprec_f = pmean_f + d_pad;
+    const size_t consts_f = (size_t)m_pad * 3 + 2 * (size_t)d_pad;
+    /* the coarse likelihood row by row: noise precision | data rows [n_data][m_pad] */
+    double *nprec_c = bias_f + consts_f;
+    double *data_c = nprec_c + m_pad;
+    const size_t rows_c = (size_t)m_pad * (1 + (size_t)a.n_data);
+    const double *Af = a.blob_f;
+
+    const int tid = threadIdx.x;
+    for (size_t i = tid; i < blob_c / 2; i += kAemThreads)
+        reinterpret_cast<double2 *>(lds)[i] = reinterpret_cast<const double2 *>(a.blob)[i];
+    for (size_t i = tid; i < consts_f; i += kAemThreads) bias_f[i] = a.blob_f[(size_t)MT * KS * 64 + i];
+    for (size_t i = tid; i < rows_c; i += kAemThreads) nprec_c[i] = a.aem_rows[i];
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+    const uint64_t nct = (a.K + 15) / 16;
+    const uint64_t tile = (uint64_t)blockIdx.x * kAemWaves + wave;
+    if (tile >= nct) return;
+    const uint64_t k = tile * 16 + c;
+    const bool live = k < a.K;
+    const uint64_t kk = live ? k : 0;
+    const uint32_t chain = (uint32_t)(a.chain0 + kk);
+    const int d = a.d, S = a.S, m_real = a.m, n_data = a.n_data;
+    const uint32_t pair_of_g = (g == 0) ? 0u : (g == 1) ? 2u : (g == 2) ? 1u : 3u;
+    double *xt = a.x_tiled + (tile * KS) * 64 + lane;
+    /* this lane's column of the per-output error-model arrays: slot q = 4 mt + r <-> output 16 mt + 4 r + g */
+    double *em = a.err_mean_t + (tile * Q) * 64 + lane;
+    double *e2 = a.err_m2_t + (tile * Q) * 64 + lane;
+    double *ep = a.prec_t + (tile * Q) * 64 + lane;
+
+    double z[KS], y[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int j = 4 * s + g;
+        z[s] = (live && j < d) ? a.x[k * d + j] : 0.0;
+        xt[s * 64] = z[s];
+    }
+    double lpf = live ? a.lp[k] : 0.0;
+    uint64_t accepted = live ? a.acc_count[k] : 0;
+    uint32_t st = live ? a.status[k] : 0;
+    uint64_t n_err = a.err_n[kk];
+    bool has_prec = a.aem_flags[2 * kk] != 0;
+    AemCache cache;
+    cache.nkeys = a.aem_flags[2 * kk + 1];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        cache.key[i] = a.cache_id[kk * 4 + i];
+        cache.val[i] = a.cache_val[kk * 3 + i];
+    }
+    uint64_t x_id = a.cache_id[kk * 4 + 3];
+    UniformCache uc;
+    uc.valid = false;
+    uc.pair = 0;
+    RecordClock clk(a.rec_stride, a.rec_since);
+
+    /* AEMLikelihood.compute_log_likelihood under the CURRENT error model of every chain (likelihood.py:77-84,
+     * 128-133): residual F - D_i (+ error mean once n >= minDataSize), norm in the (inflated) noise precision,
+     * row by row; every row's terms in the canonical four partial sums */
+    auto now = [&](const double (&v)[KS]) {
+        const bool shift = n_err >= (uint64_t)a.min_data;
+        double Srow[kAemRows];
+#pragma unroll
+        for (int i = 0; i < kAemRows; ++i) Srow[i] = 0.0;
+#pragma unroll 1
+        for (int mt = 0; mt < MT; mt += 2) {
+            d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+            const double *A0 = Ac + (size_t)mt * KS * 64 + lane;
+            const double *A1 = A0 + (size_t)KS * 64;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[s * 64], v[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1[s * 64], v[s], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 16 * (mt + h) + 4 * r + g, q = 4 * (mt + h) + r;
+                    const double F = (h ? acc1[r] : acc0[r]) + bias_c[m];
+                    const double mean = em[q * 64];
+                    const double pe = has_prec ? ep[q * 64] : nprec_c[m];
+#pragma unroll
+                    for (int i = 0; i < kAemRows; ++i) {
+                        if (i < n_data) {
+                            double res = F - data_c[i * m_pad + m];
+                            res = shift ? res + mean : res;
+                            const double px = pe * res;
+                            Srow[i] = Srow[i] + res * px;
+                        }
+                    }
+                }
+            }
+        }
+        double total = 0.0;
+#pragma unroll
+        for (int i = 0; i < kAemRows; ++i)
+            if (i < n_data) total = total + combine4(Srow[i]);
+        return -0.5 * total;
+    };
+    /* the fine model's plain likelihood through the row-mean identity, matrix fragments from global memory */
+    auto loglik_fine = [&](const double (&v)[KS]) {
+        double Ssum = 0.0;
+#pragma unroll 1
+        for (int mt = 0; mt < MT; mt += 2) {
+            d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+            const double *A0 = Af + (size_t)mt * KS * 64 + lane;
+            const double *A1 = A0 + (size_t)KS * 64;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[s * 64], v[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1[s * 64], v[s], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 16 * (mt + h) + 4 * r + g;
+                    const double F = (h ? acc1[r] : acc0[r]) + bias_f[m];
+                    const double res = F - dbar_f[m];
+                    const double px = nprec_f[m] * res;
+                    Ssum = Ssum + res * px;
+                }
+            }
+        }
+        return -0.5 * (combine4(Ssum) + a.lik_const_f);
+    };
+    auto logprior = [&](const double *pmean, const double *pprec, const double (&v)[KS]) {
+        double P = 0.0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int j = 4 * s + g;
+            const double dx = v[s] - pmean[j];
+            const double px = pprec[j] * dx;
+            P = P + dx * px;
+        }
+        return -0.5 * combine4(P);
+    };
+    auto any_differs = [&](const double (&p)[KS], const double (&q)[KS]) {
+        bool dl = false;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) dl = dl || !(p[s] == q[s]);
+        int mv = dl ? 1 : 0;
+        mv |= __shfl_xor(mv, 16, 64);
+        mv |= __shfl_xor(mv, 32, 64);
+        return mv != 0;
+    };
+    /* one cache query of every chain of the wave (`active` lanes only): the current-model likelihood is
+     * evaluated for the wave iff some active chain misses */
+    auto query = [&](uint64_t id, const double (&v)[KS], bool active) {
+        const int hit = cache.find(id);
+        const bool miss = active && hit < 0;
+        double fresh = 0.0;
+        if (__builtin_amdgcn_ballot_w64(miss) != 0) fresh = now(v);
+        return active ? cache.take(id, hit, fresh) : 0.0;
+    };
+    /* update_error_estimate(F_fine(v) - F_coarse(v)) for the chains with `mine` (aem.py:44-56,
+     * likelihood.py:142-150, noise.py:41-54) */
+    auto update = [&](const double (&v)[KS], bool mine) {
+        const uint64_t n_new = n_err + 1;
+        const double dn = (double)n_new, nm1 = (double)(n_new - 1);
+        const bool inflate = n_new > (uint64_t)a.min_data;
+        double lo = 0.0, hi = 0.0;
+        bool first = true;
+#pragma unroll 1
+        for (int mt = 0; mt < MT; mt += 2) {
+            d4 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0}, f0 = {0.0, 0.0, 0.0, 0.0}, f1 = {0.0, 0.0, 0.0, 0.0};
+            const double *C0 = Ac + (size_t)mt * KS * 64 + lane, *C1 = C0 + (size_t)KS * 64;
+            const double *F0 = Af + (size_t)mt * KS * 64 + lane, *F1 = F0 + (size_t)KS * 64;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(C0[s * 64], v[s], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(C1[s * 64], v[s], c1, 0, 0, 0);
+                f0 = __builtin_amdgcn_mfma_f64_16x16x4f64(F0[s * 64], v[s], f0, 0, 0, 0);
+                f1 = __builtin_amdgcn_mfma_f64_16x16x4f64(F1[s * 64], v[s], f1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 16 * (mt + h) + 4 * r + g, q = 4 * (mt + h) + r;
+                    const double Ff = (h ? f1[r] : f0[r]) + bias_f[m];
+                    const double Fc = (h ? c1[r] : c0[r]) + bias_c[m];
+                    const double e = Ff - Fc;
+                    double mean = em[q * 64], m2 = e2[q * 64];
+                    const double delta = e - mean; /* estimation.py:36-53 */
+                    mean = mean + delta / dn;
+                    const double delta2 = e - mean;
+                    m2 = m2 + delta * delta2;
+                    if (mine && m < m_real) {
+                        em[q * 64] = mean;
+                        e2[q * 64] = m2;
+                        const double mvar = m2 / nm1;
+                        lo = (first || mvar < lo) ? mvar : lo;
+                        hi = (first || mvar > hi) ? mvar : hi;
+                        first = false;
+                    }
+                }
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(mine && inflate) != 0) {
+            /* min / max of the marginal variances over ALL outputs of the chain: the four lanes' ranges joined
+             * (a lane without a real output holds none) */
+#pragma unroll
+            for (int mask = 16; mask <= 32; mask <<= 1) {
+                const double olo = shfl_xor_f64(lo, mask), ohi = shfl_xor_f64(hi, mask);
+                const int ofirst = __shfl_xor(first ? 1 : 0, mask, 64);
+                if (!ofirst) {
+                    lo = (first || olo < lo) ? olo : lo;
+                    hi = (first || ohi > hi) ? ohi : hi;
+                    first = false;
+                }
+            }
+            double scaling = 1.0;
+            if (a.use_heuristic) { /* noise.py:41-46 */
+                const double minval = lo > 1e-6 ? lo : 1e-6;
+                scaling = 2.0 * hi / minval;
+                scaling = scaling < 100.0 ? scaling : 100.0;
+            }
+            if (mine && inflate) {
+#pragma unroll 1
+                for (int q = 0; q < Q; ++q) {
+                    const int m = 16 * (q >> 2) + 4 * (q & 3) + g;
+                    if (m < m_real) {
+                        const double mvar = e2[q * 64] / nm1;
+                        ep[q * 64] = 1.0 / (scaling * mvar + 1.0 / nprec_c[m]); /* noise.py:51-53, covariance.py:36-41 */
+                    }
+                }
+                has_prec = true;
+            }
+        }
+        if (mine) n_err = n_new;
+    };
+
+#pragma unroll 1
+    for (uint32_t n = 0; n < a.nsteps; ++n) {
+        const uint64_t tbase = (a.t0 + n) * (uint64_t)(S + 1);
+        uint64_t z_id = x_id;
+        /* surrogate.run(S + 1, state), mlda.py:102-110 */
+#pragma unroll 1
+        for (int sub = 0; sub < S; ++sub) {
+            const uint64_t t = tbase + (uint64_t)sub;
+#pragma unroll
+            for (int q = 0; q < KS / 2; ++q) {
+                double xi0, xi1;
+                ymc_draw_normal_pair(a.seed, chain, t, 4u * (uint32_t)q + pair_of_g, &xi0, &xi1);
+                swap_odd_even_rows(xi0, xi1);
+                y[2 * q] = z[2 * q] + sigma[8 * q + g] * xi0;
+                y[2 * q + 1] = z[2 * q + 1] + sigma[8 * q + 4 + g] * xi1;
+            }
+            const double u = ymc_uniform_cached(uc, a.seed, chain, t);
+            const bool moved = any_differs(y, z);
+            /* mrw.py:51-57: evaluate_log(proposal), then evaluate_log(state) */
+            const uint64_t y_id = t + 1;
+            const double ly = query(y_id, y, moved) + logprior(pmean_c, pprec_c, y);
+            const double lz = query(z_id, z, moved) + logprior(pmean_c, pprec_c, z);
+            const bool acc = moved && ymc_accept(ly - lz, true, ymc_finite(ly), u, st);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) z[s] = acc ? y[s] : z[s];
+            z_id = acc ? y_id : z_id;
+            if (a.sub_acc && live && g == 0) a.sub_acc[((uint64_t)n * S + sub) * a.K + k] = acc ? 1 : 0;
+        }
+        /* fine accept / reject, mlda.py:146-154: tgt(y), finest(x), finest(y), tgt(x); y <- the fine state x */
+#pragma unroll
+        for (int s = 0; s < KS; ++s) y[s] = xt[s * 64];
+        const double u = ymc_uniform_cached(uc, a.seed, chain, tbase + (uint64_t)S);
+        const bool moved = any_differs(z, y);
+        const double lpfy = loglik_fine(z) + logprior(pmean_f, pprec_f, z);
+        const double cx = query(x_id, y, moved) + logprior(pmean_c, pprec_c, y);
+        const double cy = query(z_id, z, moved) + logprior(pmean_c, pprec_c, z);
+        const double log_ratio = ((lpfy + cx) - cy) - lpf;
+        const bool acc = moved && ymc_accept(log_ratio, true, ymc_finite(lpfy) && ymc_finite(cy), u, st);
+        if (__builtin_amdgcn_ballot_w64(acc) != 0) update(z, acc); /* aem.py:26-56, before the chain moves */
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            z[s] = acc ? z[s] : y[s];
+            xt[s * 64] = z[s];
+        }
+        lpf = acc ? lpfy : lpf;
+        x_id = acc ? z_id : x_id;
+        accepted += acc ? 1u : 0u;
+
+        const bool rec = clk.due();
+        if (rec && a.traj) {
+            double *row = a.traj + (((uint64_t)clk.row * nct + tile) * KS) * 64 + lane;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) row[s * 64] = z[s];
+        }
+        if (live && g == 0) {
+            if (a.acc) a.acc[(uint64_t)n * a.K + k] = acc ? 1 : 0;
+            if (rec && a.lp_out) a.lp_out[(uint64_t)clk.row * a.K + k] = lpf;
+        }
+        if (rec) clk.wrote();
+    }
+
+    if (live) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int j = 4 * s + g;
+            if (j < d) a.x[k * d + j] = z[s];
+        }
+        if (g == 0) {
+            a.lp[k] = lpf;
+            a.acc_count[k] = accepted;
+            a.status[k] = st;
+            a.err_n[k] = n_err;
+            a.aem_flags[2 * k] = has_prec ? 1 : 0;
+            a.aem_flags[2 * k + 1] = cache.nkeys;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                a.cache_id[k * 4 + i] = cache.key[i];
+                a.cache_val[k * 3 + i] = cache.val[i];
+            }
+            a.cache_id[k * 4 + 3] = x_id;
+        }
+    }
+}
+
+template <int KS>
+hipError_t launch_as(const TileArgs &a, hipStream_t s)
+{
+    const size_t lds = ymc_tile_aem2_lds_bytes(KS, a.MT, a.n_data);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_tile_aem2_kernel<KS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const uint64_t nct = (a.K + 15) / 16;
+    const unsigned grid = (unsigned)((nct + kAemWaves - 1) / kAemWaves);
+    hipLaunchKernelGGL((linear_tile_aem2_kernel<KS>), dim3(grid), dim3(kAemThreads), lds, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+size_t ymc_tile_aem2_lds_bytes(int KS, int MT, int n_data)
+{
+    return ymc_tile_mlda2_lds_bytes(KS, MT, MT) + 16 * (size_t)MT * (1 + (size_t)n_data) * sizeof(double);
+}
+
+int ymc_tile_aem2_max_rows(void) { return kAemRows; }
+
+hipError_t ymc_launch_linear_tile_aem2(int KS, const TileArgs &a, hipStream_t s)
+{
+    switch (KS) {
+    case 4: return launch_as<4>(a, s);
+    case 8: return launch_as<8>(a, s);
+    case 16: return launch_as<16>(a, s);
+    case 32: return launch_as<32>(a, s);
+    default: return hipErrorInvalidValue;
+    }
+}
