@@ -112,6 +112,25 @@ def test_thinned_record_specialised_random_walk_kernels(ffi, ctx, golden, monkey
             assert np.array_equal(sf["wf_mean"], st["wf_mean"]) and np.array_equal(sf["wf_m2"], st["wf_m2"])
 
 
+@pytest.mark.parametrize("stride", [2, 5])
+def test_thinned_record_specialised_two_level_kernels(ffi, ctx, golden, stride):
+    """Two-level with a compile-time sub-chain length (S = 4) and the thinned default record."""
+    _, prob, x0, _ = _problems(ffi, ctx, golden)[1]
+    K, T = x0.shape[0], 37
+    full = ffi.Run(prob, 9, K, x0, T, ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT | ffi.RECORD_MOMENTS)
+    full.advance(T)
+    for flags in (ffi.RECORD_TRAJECTORY, ffi.RECORD_TRAJECTORY | ffi.RECORD_MOMENTS):
+        thin = ffi.Run(prob, 9, K, x0, T // stride, flags, record_stride=stride)
+        for n in (1, 2, 3, 8):
+            thin.advance(n)
+        thin.advance(T - thin.steps_done()[0])
+        assert np.array_equal(thin.trajectory(), full.trajectory()[stride - 1::stride])
+        sf, st = full.summary(), thin.summary()
+        assert np.array_equal(sf["accepted"], st["accepted"]) and np.array_equal(full.state()[1], thin.state()[1])
+        if flags & ffi.RECORD_MOMENTS:
+            assert np.array_equal(sf["wf_mean"], st["wf_mean"])
+
+
 def test_thinned_record_misuse_is_refused(ffi, ctx, golden):
     name, prob, x0, _ = _problems(ffi, ctx, golden)[0]
     with pytest.raises(ffi.YmcError, match="full-rate"):

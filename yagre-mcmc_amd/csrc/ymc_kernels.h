@@ -38,7 +38,14 @@ template <int D>
 hipError_t ymc_launch_chain(int kind, int method, const ChainArgs<D> &a, hipStream_t s);
 /* ymc_mlda2.hip: two-level kernels with a compile-time sub-chain length; false = not covered */
 template <int D>
-bool ymc_launch_mlda2_static(int kind, unsigned rec, const ChainArgs<D> &a, hipStream_t s);
+bool ymc_launch_mlda2_static_full(int kind, unsigned rec, const ChainArgs<D> &a, hipStream_t s); /* full-rate record masks */
+template <int D>
+bool ymc_launch_mlda2_static_thin(int kind, unsigned rec, const ChainArgs<D> &a, hipStream_t s); /* thinned record masks */
+template <int D>
+inline bool ymc_launch_mlda2_static(int kind, unsigned rec, const ChainArgs<D> &a, hipStream_t s)
+{
+    return a.rec_stride > 1 ? ymc_launch_mlda2_static_thin<D>(kind, rec, a, s) : ymc_launch_mlda2_static_full<D>(kind, rec, a, s);
+}
 template <int D>
 hipError_t ymc_launch_logdensity(int kind, const DensityDev<D> &p, uint64_t n, const double *x, double *out,
                                  uint32_t *status, hipStream_t s);

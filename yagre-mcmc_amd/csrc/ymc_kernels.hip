@@ -721,6 +721,9 @@ hipError_t launch_chain(int method, const ChainArgs<D> &a, hipStream_t s)
         launch_one<KIND, D, kThin | kT, YMC_EQ_EXACT>(method, a, s);
     else if (exact && thin && rec == (kT | YMC_RECORD_MOMENTS) && method == YMC_METHOD_MRW)
         launch_one<KIND, D, kThin | kT | YMC_RECORD_MOMENTS, YMC_EQ_EXACT>(method, a, s);
+    else if (exact && thin && method == YMC_METHOD_MLDA2 && (rec == kT || rec == (kT | YMC_RECORD_MOMENTS)) &&
+             ymc_launch_mlda2_static<D>(KIND, rec, a, s))
+        ; /* two-level with a compile-time sub-chain length and a thinned record (ymc_mlda2.hip) */
     else
         launch_one<KIND, D, kRuntimeRec, -1>(method, a, s);
     return hipGetLastError();

@@ -36,7 +36,9 @@ __device__ __forceinline__ void static_for(F &&f)
 }
 
 constexpr int kBlock = 256;
-constexpr unsigned kTA = YMC_RECORD_TRAJECTORY | YMC_RECORD_ACCEPT;
+[[maybe_unused]] constexpr unsigned kTA = YMC_RECORD_TRAJECTORY | YMC_RECORD_ACCEPT;
+/* thinned record masks (ymc_run_desc.record_stride > 1): trajectory, trajectory + moments, rows by RecordClock */
+[[maybe_unused]] constexpr unsigned kThin = 0x100u, kT = YMC_RECORD_TRAJECTORY;
 
 #if defined(YMC_MLDA2_TWO_WAVES)
 #define YMC_MLDA2_ATTR __attribute__((amdgpu_waves_per_eu(1, 2)))
@@ -53,6 +55,8 @@ __global__ __launch_bounds__(kBlock) YMC_MLDA2_ATTR void mlda2_static_kernel(con
     constexpr int C = S + 1;               /* transitions per fine step */
     constexpr int FS = (C & 1) ? 2 : 1;    /* fine steps per unit */
     constexpr bool moments = (REC & YMC_RECORD_MOMENTS) != 0;
+    constexpr bool thin = (REC & kThin) != 0;
+    RecordClock clk(thin ? a.rec_stride : 1u, a.rec_since);
 
     double x[D], wmean[D], wm2[D], sigma[D];
     ymc_load_row<D>(a.x, k, x);
@@ -93,8 +97,15 @@ __global__ __launch_bounds__(kBlock) YMC_MLDA2_ATTR void mlda2_static_kernel(con
         lpf = acc ? lpfy : lpf;
         lpc = acc ? lpcz : lpc;
         accepted += acc ? 1u : 0u;
-        ymc_store_row<D>(a.traj + (uint64_t)n * a.K * D, k, x);
-        a.acc[(uint64_t)n * a.K + k] = acc ? 1 : 0;
+        if constexpr (thin) {
+            if (clk.due()) {
+                ymc_store_row<D>(a.traj + (uint64_t)clk.row * a.K * D, k, x);
+                clk.wrote();
+            }
+        } else {
+            ymc_store_row<D>(a.traj + (uint64_t)n * a.K * D, k, x);
+            a.acc[(uint64_t)n * a.K + k] = acc ? 1 : 0;
+        }
     };
     /* one fine step with per-transition uniforms (unit boundaries of a launch) */
     auto single = [&](uint32_t n) {
@@ -162,19 +173,32 @@ bool launch_s(const ChainArgs<D> &a, hipStream_t s)
     }
 }
 
+/* This file is compiled twice (Makefile): once for the full-rate record masks, once with -DYMC_MLDA2_THIN for
+ * the thinned ones -- 120 unrolled kernels in one translation unit take over three minutes to build. */
 template <int KIND, int D>
 bool launch_rec(unsigned rec, const ChainArgs<D> &a, hipStream_t s)
 {
+#if defined(YMC_MLDA2_THIN)
+    if (rec == kT) return launch_s<KIND, D, kThin | kT>(a, s);
+    if (rec == (kT | YMC_RECORD_MOMENTS)) return launch_s<KIND, D, kThin | kT | YMC_RECORD_MOMENTS>(a, s);
+#else
     if (rec == kTA) return launch_s<KIND, D, kTA>(a, s);
     if (rec == (kTA | YMC_RECORD_MOMENTS)) return launch_s<KIND, D, kTA | YMC_RECORD_MOMENTS>(a, s);
+#endif
     return false;
 }
 
 }  // namespace
 
+#if defined(YMC_MLDA2_THIN)
+#define YMC_MLDA2_ENTRY ymc_launch_mlda2_static_thin
+#else
+#define YMC_MLDA2_ENTRY ymc_launch_mlda2_static_full
+#endif
+
 /* true: a compile-time-S kernel was launched; false: the caller launches mlda2_kernel */
 template <int D>
-bool ymc_launch_mlda2_static(int kind, unsigned rec, const ChainArgs<D> &a, hipStream_t s)
+bool YMC_MLDA2_ENTRY(int kind, unsigned rec, const ChainArgs<D> &a, hipStream_t s)
 {
     if constexpr (D > 2) {
         return false;
@@ -191,6 +215,6 @@ bool ymc_launch_mlda2_static(int kind, unsigned rec, const ChainArgs<D> &a, hipS
     }
 }
 
-#define YMC_INSTANTIATE(D) template bool ymc_launch_mlda2_static<D>(int, unsigned, const ChainArgs<D> &, hipStream_t);
+#define YMC_INSTANTIATE(D) template bool YMC_MLDA2_ENTRY<D>(int, unsigned, const ChainArgs<D> &, hipStream_t);
 YMC_INSTANTIATE(1) YMC_INSTANTIATE(2) YMC_INSTANTIATE(3) YMC_INSTANTIATE(4)
 YMC_INSTANTIATE(5) YMC_INSTANTIATE(6) YMC_INSTANTIATE(7) YMC_INSTANTIATE(8)
