@@ -421,7 +421,10 @@ static void ymo_propose_dense(const double *x, const double *chol, uint64_t seed
     for (int32_t j = 0; 2 * j < d; ++j) ymc_draw_normal_pair(seed, chain, t, (uint32_t)j, &z[2 * j], &z[2 * j + 1]);
     for (int32_t i = 0; i < d; ++i) {
         double acc = chol[(int64_t)i * d] * z[0];
-        for (int32_t j = 1; j <= i; ++j) acc = acc + chol[(int64_t)i * d + j] * z[j];
+        if (d > 8) /* the matrix-core kernel's order: row i of L xi as one k-ordered fma chain (v_mfma_f64) */
+            for (int32_t j = 1; j <= i; ++j) acc = ymc_fma(chol[(int64_t)i * d + j], z[j], acc);
+        else       /* the lane kernels' order: separate multiplies and adds, left to right */
+            for (int32_t j = 1; j <= i; ++j) acc = acc + chol[(int64_t)i * d + j] * z[j];
         y[i] = x[i] + acc;
     }
 }

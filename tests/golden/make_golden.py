@@ -843,6 +843,27 @@ def fixture_f16(name="f16_aem_linear_d128.npz", use_heuristic=True, seed=2025011
     print(name, acc.mean(), sub_acc.mean(), "accepted per chain", err_n.min(), err_n.max(), "cache hits", hits.mean())
 
 
+def fixture_f17():
+    """Random walk with a DENSE proposal covariance at d = 16 (the matrix-core kernel's path): the reference forms
+    L @ xi with BLAS' dgemv (unspecified order), the ensemble as k-ordered fma chains: decisions equal, states to
+    rounding."""
+    d, n_data, seed, K, n = 16, 3, 20250117, 8, 300
+    A, b, data, noise_var = linear_problem(d, n_data, 17)
+    prior_mean, prior_var = np.zeros(d), 5.0
+    model = build_linear_reference(A, b, data, noise_var, prior_mean, prior_var)
+    z, _ = oracle.rng_fill(1717, 0, d, 0, 1, d, uniforms=False)
+    B = z[0] * 0.05
+    prop = B @ B.T + 0.02 * np.eye(d)
+    cov = DenseCovarianceMatrix(prop.copy())
+    traj, acc, lp = run_mrw_model(model, seed, K, n, cov, np.zeros(d))
+    np.savez_compressed(
+        os.path.join(HERE, "f17_mrw_dense_proposal_d16.npz"), seed=seed, n_states=n, A=A, b=b, data=data,
+        noise_precision=np.reciprocal(np.full(d, noise_var)), prior_mean=prior_mean,
+        prior_precision=np.reciprocal(np.full(d, prior_var)), proposal_cov=prop, chol=np.array(cov.cholFactor_),
+        x0=np.zeros((K, d)), traj=traj, acc=acc, logpost=lp)
+    print("F17", acc.mean())
+
+
 def fixture_f15():
     """Dense covariances as NOISE and PRIOR models (CentredGaussianNoise / Gaussian over DenseCovarianceMatrix,
     covariance.py:69-94, noise.py:21-22, gaussian.py:19-24): (a) a linear model d = 3, 4 outputs, 5 data rows,
@@ -897,7 +918,7 @@ def fixture_f15():
 
 def main():
     which = sys.argv[1:] or ["f1", "f2", "f2b", "f3", "f3b", "f4", "f5", "f7", "f8", "f9", "f10", "f11", "f12", "f13",
-                             "f14", "f15", "f16"]
+                             "f14", "f15", "f16", "f17"]
     if "f1" in which:
         fixture_f1()
     if "f2" in which:
@@ -933,6 +954,8 @@ def main():
         fixture_f15()
     if "f16" in which:
         fixture_f16()
+    if "f17" in which:
+        fixture_f17()
     if "f12" in which:
         fixture_f12()
         fixture_f12("f12b_aem_linear_noheuristic.npz", use_heuristic=False, seed=20250113, min_data=5, K=12,

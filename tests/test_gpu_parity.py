@@ -766,6 +766,49 @@ def test_dense_covariances_other_shapes_vs_oracle(ffi, ctx, d, m, nd, method):
         _same_as_oracle(dev, e, out)
 
 
+def _dense_tile_run(ffi, ctx, low, L, x0, seed, nsteps, chain0=0, splits=2):
+    from yagremcmc_amd import lowering
+    d = x0.shape[1]
+    prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, np.ones(d), chol=np.tril(L))
+    run = ffi.Run(prob, seed, x0.shape[0], x0, nsteps, _flags(ffi, True), chain0)
+    base, rem = divmod(nsteps, splits)
+    for i in range(splits):
+        run.advance(base + (1 if i < rem else 0))
+    return dict(traj=run.trajectory(), acc=run.accept(), logpost=run.logpost(), summary=run.summary(), state=run.state())
+
+
+def test_f17_dense_proposal_d16_matrix_cores(ffi, ctx, golden):
+    """y = x + L xi on the matrix cores (L's fragments from L2, rows of L xi as MFMA fma chains): == oracle bit for
+    bit; against the live reference (BLAS' dgemv order) every decision equal, states within 1e-12."""
+    g = golden("f17_mrw_dense_proposal_d16.npz")
+    n = int(g["n_states"])
+    common = dict(data=g["data"], noise_precision=g["noise_precision"], prior_mean=g["prior_mean"], prior_precision=g["prior_precision"])
+    low = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, 16, common, fwd_matrix=g["A"], fwd_shift=g["b"])
+    dev = _dense_tile_run(ffi, ctx, low, g["chol"], g["x0"], int(g["seed"]), n - 1)
+    p = o.posterior_linear(g["A"], g["b"], g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+    e = o.Ensemble(p, np.ones(16), g["x0"], int(g["seed"]), chol=g["chol"])
+    _same_as_oracle(dev, e, e.advance(n - 1))
+    assert np.array_equal(dev["acc"], g["acc"]) and np.abs(dev["traj"] - g["traj"][1:]).max() <= 1e-12
+
+
+@pytest.mark.parametrize("d,m,nd,K", [(128, 128, 2, 40), (9, 3, 2, 33), (20, 40, 1, 64), (100, 20, 4, 129)])
+def test_tile_kernel_dense_proposal_other_shapes(ffi, ctx, d, m, nd, K):
+    rng = np.random.default_rng(600 + d + m)
+    g = dict(A=rng.normal(size=(m, d)) / np.sqrt(d), b=rng.normal(size=m), data=rng.normal(size=(nd, m)),
+             noise_precision=rng.uniform(0.5, 3, size=m), prior_mean=rng.normal(size=d) * 0.1,
+             prior_precision=rng.uniform(0.1, 2, size=d))
+    low = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, g, fwd_matrix=g["A"], fwd_shift=g["b"])
+    B = rng.normal(size=(d, d)) * 0.02 / np.sqrt(d)
+    L = np.linalg.cholesky(B @ B.T + 0.002 * np.eye(d))
+    x0 = rng.normal(size=(K, d))
+    dev = _dense_tile_run(ffi, ctx, low, L, x0, 4713, 40, chain0=3000, splits=3)
+    p = o.posterior_linear(g["A"], g["b"], g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+    e = o.Ensemble(p, np.ones(d), x0, 4713, chain0=3000, chol=L)
+    out = e.advance(40)
+    assert 0.02 < out["acc"].mean() < 0.98
+    _same_as_oracle(dev, e, out)
+
+
 def test_f14_two_level_d128_matrix_cores(ffi, ctx, golden):
     """Two-level delayed acceptance over two d = 128 linear models (linear_tile_mlda2_kernel): the LIVE
     reference's decisions at both levels, its chains (sha256 of all states) and log-posteriors; == oracle."""

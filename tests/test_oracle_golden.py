@@ -190,6 +190,20 @@ def test_f12_adaptive_error_model(golden, name):
     assert np.array_equal(e2.aem_mean, e.aem_mean) and np.array_equal(e2.cache_val, e.cache_val)
 
 
+def test_f17_dense_proposal_covariance_d16(golden):
+    """DenseCovarianceMatrix proposal beyond the lane kernels' dimension: rows of L xi as k-ordered fma chains
+    (the matrix-core order) against BLAS' dgemv in the reference: decisions equal, states to rounding."""
+    g = golden("f17_mrw_dense_proposal_d16.npz")
+    n = int(g["n_states"])
+    p = o.posterior_linear(g["A"], g["b"], g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+    e = o.Ensemble(p, np.ones(16), g["x0"], int(g["seed"]), chol=g["chol"])
+    out = e.advance(n - 1)
+    assert np.array_equal(out["acc"], g["acc"])
+    assert np.abs(out["traj"] - g["traj"][1:]).max() <= 1e-12
+    want = g["logpost"][1:]
+    assert np.abs(out["logpost"] - want).max() <= 1e-12 * np.abs(want).max()
+
+
 def test_f16_adaptive_error_model_d128(golden):
     """aem.py over two d = 128 linear models (the matrix-core kernel's size): chains (sha256 of all states),
     decisions at both levels and the learned error model == the live reference's."""

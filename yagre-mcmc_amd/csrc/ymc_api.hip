@@ -145,6 +145,8 @@ struct ymc_problem {
     DensityHost tgt, sur;
     std::vector<double> sigma;
     DeviceBuf chol; /* dense proposal covariance: lower Cholesky factor [D][D] */
+    DeviceBuf chol_frag; /* the same as MFMA A-operand fragments [MT_L][KS][64] (matrix-core kernel) */
+    int MT_L = 0;
     /* MLDA_NESTED: P of levels 0..E-2 (level E-1's is tgt), Q of levels 1..E-1 (index 0 unused) */
     int E = 0;
     DensityHost lvlP[YMC_MAX_LEVELS], lvlQ[YMC_MAX_LEVELS];
@@ -163,6 +165,7 @@ struct ymc_run {
     DeviceBuf x, lp, lpc, acc_count, wf_mean, wf_m2, status, traj, acc, lp_out, sub_acc, summary, x_before, recip;
     DeviceBuf level_acc; /* MLDA_NESTED: [E-1][K] */
     DeviceBuf x_tiled;   /* two-level tile kernel: the carried state in the record's tiled layout */
+    DeviceBuf w_tiled;   /* dense proposal on the tile kernel: L xi in the record's tiled layout */
     DeviceBuf err_n, err_mean, err_m2, aem_prec, aem_flags, cache_key, cache_val; /* AEM2 */
     /* egress (ymc_run_egress_*): a copy stream, two slots of page-locked staging */
     struct EgressSlot {
@@ -686,6 +689,11 @@ int launch_advance_tile(ymc_run *r, uint64_t nsteps)
         a.x_tiled = r->x_tiled.as<double>();
         if (r->flags & YMC_RECORD_SUB_ACCEPT) a.sub_acc = r->sub_acc.as<uint8_t>() + r->recorded * (uint64_t)p->S * r->K;
     }
+    if (p->chol_frag.p) {
+        a.chol_frag = p->chol_frag.as<double>();
+        a.w_tiled = r->w_tiled.as<double>();
+        a.MT_L = p->MT_L;
+    }
     if (aem2) {
         a.n_data = h.d.n_data;
         a.min_data = p->aem_min_data;
@@ -970,9 +978,8 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
         if (rc == YMC_OK) rc = copy_array(p->sigma, desc->proposal_sigma, p->D, "proposal_sigma");
     }
     if (rc == YMC_OK && desc->proposal_chol) {
-        if (desc->method != YMC_METHOD_MRW || p->tgt.tile)
-            rc = fail(YMC_ERR_UNSUPPORTED, "a dense proposal covariance is available for the random walk at d <= %d",
-                      YMC_LANE_DMAX);
+        if (desc->method != YMC_METHOD_MRW)
+            rc = fail(YMC_ERR_UNSUPPORTED, "a dense proposal covariance is available for the random walk");
         else {
             std::vector<double> L((size_t)p->D * p->D, 0.0);
             for (int i = 0; rc == YMC_OK && i < p->D; ++i)
@@ -984,6 +991,20 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
             auto up = [&]() -> int {
                 YMC_TRY(p->chol.alloc(L.size() * sizeof(double)));
                 YMC_HIP(hipMemcpy(p->chol.p, L.data(), p->chol.bytes, hipMemcpyHostToDevice));
+                if (p->tgt.tile) { /* fragments for the matrix cores: rows = components, padded to whole tile pairs */
+                    const int KS = p->tgt.KS, d = p->D;
+                    p->MT_L = (d + 15) / 16;
+                    p->MT_L += p->MT_L & 1;
+                    std::vector<double> frag((size_t)p->MT_L * KS * 64, 0.0);
+                    for (int mt = 0; mt < p->MT_L; ++mt)
+                        for (int s = 0; s < KS; ++s)
+                            for (int l = 0; l < 64; ++l) {
+                                const int row = 16 * mt + (l & 15), col = 4 * s + (l >> 4);
+                                if (row < d && col < d) frag[((size_t)mt * KS + s) * 64 + l] = L[(size_t)row * d + col];
+                            }
+                    YMC_TRY(p->chol_frag.alloc(frag.size() * sizeof(double)));
+                    YMC_HIP(hipMemcpy(p->chol_frag.p, frag.data(), p->chol_frag.bytes, hipMemcpyHostToDevice));
+                }
                 return YMC_OK;
             };
             if (rc == YMC_OK) rc = up();
@@ -1116,6 +1137,7 @@ int ymc_run_create(ymc_ctx *ctx, const ymc_problem *problem, const ymc_run_desc 
             YMC_TRY(r->sub_acc.alloc(r->capacity * (uint64_t)S * K));
         if (problem->tile && (problem->method == YMC_METHOD_MLDA2 || problem->method == YMC_METHOD_AEM2))
             YMC_TRY(r->x_tiled.alloc(tiled_row_doubles(r) * sizeof(double)));
+        if (problem->tile && problem->chol_frag.p) YMC_TRY(r->w_tiled.alloc(tiled_row_doubles(r) * sizeof(double)));
         if (problem->method == YMC_METHOD_AEM2 && problem->tile) {
             /* per-output arrays in the kernel's tiled layout [ceil(K/16)][4 MT][64]; ids of the cached points */
             const uint64_t per_out = ((K + 15) / 16) * 4ull * (uint64_t)problem->sur.MT * 64ull;

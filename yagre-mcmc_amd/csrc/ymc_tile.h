@@ -38,6 +38,12 @@ struct TileArgs {
     double *lpc;      /* coarse log-density of the carried (fine) state */
     double *x_tiled;  /* the carried state in the record's tiled layout [ceil(K/16)][KS][64] (scratch) */
     uint8_t *sub_acc; /* [rows][S][K] or null */
+    /* random walk with a DENSE proposal covariance (covariance.py:69-94): its lower Cholesky factor as MFMA
+     * A-operand fragments [MT_L][KS][64] in global memory (rows = components), and a scratch in the record's
+     * tiled layout for L xi; null = the diagonal proposal of sigma */
+    const double *chol_frag;
+    double *w_tiled;
+    int32_t MT_L, pad3_;
     /* adaptive error model (ymc_tile_aem.hip; both levels have m outputs): the coarse likelihood's state per
      * chain.  Per-output arrays are laid out like the record, [ceil(K/16)][4 MT][64]: slot 4 mt + r of lane
      * (g, c) belongs to output 16 mt + 4 r + g of chain c */

@@ -93,7 +93,10 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
             double xi0, xi1; /* components 8 q + g (s = 2 q) and 8 q + 4 + g (s = 2 q + 1) */
             ymc_draw_normal_pair(a.seed, chain, t, 4u * (uint32_t)q + pair_of_g, &xi0, &xi1);
             swap_odd_even_rows(xi0, xi1);
-            if constexpr (PCN) { /* pcn.py:27-36: xi ~ prior, y = sqrt(1 - 2h) x + sqrt(2h) xi */
+            if (a.chol_frag) { /* dense proposal covariance: park xi in y, L xi follows below (wave-uniform) */
+                y[2 * q] = xi0;
+                y[2 * q + 1] = xi1;
+            } else if constexpr (PCN) { /* pcn.py:27-36: xi ~ prior, y = sqrt(1 - 2h) x + sqrt(2h) xi */
                 const double p0 = pmean[8 * q + g] + sigma[8 * q + g] * xi0;
                 const double p1 = pmean[8 * q + 4 + g] + sigma[8 * q + 4 + g] * xi1;
                 y[2 * q] = a.pcn_c1 * x[2 * q] + a.pcn_c2 * p0;
@@ -102,7 +105,36 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
                 y[2 * q] = x[2 * q] + sigma[8 * q + g] * xi0;
                 y[2 * q + 1] = x[2 * q + 1] + sigma[8 * q + 4 + g] * xi1;
             }
-            moved_l = moved_l || !(y[2 * q] == x[2 * q]) || !(y[2 * q + 1] == x[2 * q + 1]);
+            if (!a.chol_frag) moved_l = moved_l || !(y[2 * q] == x[2 * q]) || !(y[2 * q + 1] == x[2 * q + 1]);
+        }
+        if (a.chol_frag) {
+            /* y = x + L xi (covariance.py:91-92, gaussian.py:66): row i of L xi is one k-ordered fma chain on the
+             * matrix cores -- output 16 mt + 4 r + g of the accumulator IS component 4 s + g, s = 4 mt + r, of this
+             * lane.  The rows pass through a scratch in the record's layout, because y holds xi until the last
+             * product (L's fragments come from global memory: 128 KB, L2-resident, as the fine matrix of the
+             * two-level kernel). */
+            double *wt = a.w_tiled + (tile * KS) * 64 + lane;
+#pragma unroll 1
+            for (int mt = 0; mt < a.MT_L; mt += 2) {
+                d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+                const double *L0 = a.chol_frag + (size_t)mt * KS * 64 + lane;
+                const double *L1 = L0 + (size_t)KS * 64;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(L0[s * 64], y[s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(L1[s * 64], y[s], acc1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (4 * mt + r < KS) wt[(4 * mt + r) * 64] = acc0[r];
+                    if (4 * (mt + 1) + r < KS) wt[(4 * (mt + 1) + r) * 64] = acc1[r];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                y[s] = x[s] + wt[s * 64];
+                moved_l = moved_l || !(y[s] == x[s]);
+            }
         }
         int mv = moved_l ? 1 : 0;
         mv |= __shfl_xor(mv, 16, 64);
