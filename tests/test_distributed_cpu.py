@@ -192,10 +192,10 @@ def test_tcp_store_is_not_fooled_by_an_echo():
     ephemeral source port can equal the port it probes) -- is not a store."""
     import threading
     from yagremcmc_amd import distributed
-    port = _free_port()
     srv = socket.socket()
     srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-    srv.bind(("127.0.0.1", port + 1))
+    srv.bind(("127.0.0.1", 0))          # the echo sits on the FIRST candidate port of the store (MASTER_PORT + 1)
+    port = srv.getsockname()[1] - 1
     srv.listen(4)
     srv.settimeout(0.2)
     stop = threading.Event()
