@@ -113,6 +113,81 @@ def test_random_configuration_matches_oracle(case, monkeypatch):
         assert (s["wf_n"] == T).all()
 
 
+@pytest.mark.parametrize("case", range(40))
+def test_random_round2_features_match_oracle(case, monkeypatch):
+    """This round's paths, fuzzed against the oracle: thinned records (compile-time and run-time masks), the
+    helper-wave random-walk kernel on / off, two-level kernels with compile-time and run-time sub-chain lengths,
+    dense noise / prior covariances, the rows leaving through the egress buffers."""
+    from scipy.linalg import solve_triangular
+    from yagremcmc_amd import _ffi as ffi, lowering
+    ctx = ffi.default_context(0)
+    rng = np.random.default_rng(7000 + case)
+    kind = ["gauss", "linear", "gauss", "lv", "linear"][case % 5]
+    d = 2 if kind == "lv" else int(rng.choice([1, 2, 2, 3, 5]))
+    low, p = _lowered(ffi, kind, d, rng)
+    if kind == "linear" and case % 2:       # dense noise and prior covariances
+        m = int(low.desc.data_dim)
+
+        def spd(n):
+            B = rng.normal(size=(n, n))
+            return B @ B.T + 0.3 * n * np.eye(n)
+        nc, pc = spd(m), spd(d)
+        for field, cov in (("noise_chol_inv", nc), ("prior_chol_inv", pc)):
+            L = np.linalg.cholesky(cov)
+            low.set_array(field, np.tril(solve_triangular(L, np.eye(L.shape[0]), lower=True)))
+        p = o.dense_covariances(p, noise_cov=nc, prior_cov=pc)
+    monkeypatch.setenv("YMC_SPLIT", str(case % 2))
+    if kind == "lv":
+        monkeypatch.setenv("YMC_LV_ROWS", str((case // 5) % 2))
+    method = "mlda" if case % 3 == 0 else "mrw"
+    K = int(rng.choice([5, 64, 130, 300]))
+    stride = int(rng.choice([1, 1, 2, 3, 7]))
+    T = int(rng.integers(stride, 70))
+    chain0 = int(rng.choice([0, 11, 2**31 + 5]))
+    seed = int(rng.integers(0, 2**63))
+    flags = ffi.RECORD_TRAJECTORY | int(rng.choice([0, ffi.RECORD_MOMENTS])) | int(rng.choice([0, 0, ffi.RECORD_LOGPOST]))
+    if stride == 1:
+        flags |= ffi.RECORD_ACCEPT
+    sigma = rng.uniform(0.05, 0.6, size=d)
+    x0 = rng.normal(size=(K, d)) * 0.3 - (np.array([0.6, 0.3]) if kind == "lv" else 0.0)
+    kwargs = {}
+    if method == "mlda":
+        S = int(rng.choice([1, 2, 3, 4, 6, 7]))        # 2, 3, 4, 6 have compile-time kernels at d <= 2
+        low2, p2 = _lowered(ffi, kind, d, np.random.default_rng(9500 + case)) if kind == "gauss" else (low, p)
+        with np.errstate(all="ignore"):
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)
+                prob = lowering.make_problem(ctx, ffi.METHOD_MLDA2, low, sigma, surrogate=low2, sub_chain_length=S)
+        e = o.Ensemble(p, sigma, x0, seed, chain0=chain0, surrogate=p2, sub_chain_length=S)
+    else:
+        prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, sigma)
+        e = o.Ensemble(p, sigma, x0, seed, chain0=chain0)
+    run = ffi.Run(prob, seed, K, x0, max(T // stride, 1), flags, chain0, record_stride=stride)
+    cut = int(rng.integers(0, T + 1))
+    run.advance(cut)
+    run.advance(T - cut)
+    out = e.advance(T, **kwargs)
+    rows = T // stride
+    want_traj, want_lp = out["traj"][stride - 1::stride][:rows], out["logpost"][stride - 1::stride][:rows]
+    assert run.steps_done() == (T, rows)
+    if rows:
+        assert np.array_equal(run.trajectory(), want_traj)
+        if flags & ffi.RECORD_LOGPOST:
+            assert np.array_equal(run.logpost(), want_lp, equal_nan=True)
+        first = int(rng.integers(0, rows))                       # the same rows through the egress buffers
+        run.egress_begin(case % 2, first, rows - first, ffi.RECORD_TRAJECTORY)
+        assert np.array_equal(run.egress_wait(case % 2)["trajectory"], want_traj[first:])
+    if flags & ffi.RECORD_ACCEPT:
+        assert np.array_equal(run.accept(), out["acc"])
+    x, lp = run.state()
+    assert np.array_equal(x, e.x) and np.array_equal(lp, e.lp, equal_nan=True)
+    s = run.summary()
+    assert np.array_equal(s["accepted"], e.acc_count) and np.array_equal(s["status"], e.status)
+    if flags & ffi.RECORD_MOMENTS:
+        assert np.array_equal(s["wf_mean"], e.wf_mean) and np.array_equal(s["wf_m2"], e.wf_m2)
+
+
 class _Pre:
     """a density that is already lowered (lets the lowering layer pass it through)"""
 
