@@ -276,12 +276,14 @@ def _tcp_comm_worker(rank, world, port, total, steps, q):
         q.put((packed, tmax))
 
 
-def test_tcp_communicator_two_ranks():
-    """YMC_COMM=tcp (explicit only): the rehearsal communicator gives the device layout's gather."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_tcp_communicator_processes(world):
+    """YMC_COMM=tcp (explicit only): the rehearsal communicator gives the device layout's gather; with 8
+    processes it is the shape of the 8-GPU launch (rendezvous, barrier, max-reduction, gather, goodbye)."""
     import multiprocessing as mp
     from oracle import oracle as o
     from yagremcmc_amd import distributed
-    total, steps, world = 64, 100, 2
+    total, steps = 64, 100
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -292,7 +294,7 @@ def test_tcp_communicator_two_ranks():
     for p_ in procs:
         p_.join(timeout=60)
         assert p_.exitcode == 0
-    assert tmax == 2.0 and packed.shape == (2, 32, 11)
+    assert tmax == float(world) and packed.shape == (world, total // world, 11)
     g = np.load(os.path.join(ROOT, "tests", "golden", "f2_mrw_2d.npz"))
     p = o.gauss_whitened(g["mean"], g["whiten"], float(g["log_norm"]))
     e = o.Ensemble(p, g["sigma"], np.tile([-8.0, -7.0], (total, 1)), 4242)
