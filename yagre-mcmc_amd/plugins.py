@@ -16,6 +16,12 @@ from enum import Enum, unique
 import numpy as np
 
 
+def _view(attribute, doc=None):
+    """A read-only property over a private attribute: the value objects below expose their constructor
+    arguments under the reference's property names and nothing more."""
+    return property(lambda self: getattr(self, attribute), doc=doc)
+
+
 # --------------------------------------------------------------------------
 # parameters (yagremcmc/parameter/{interface,scalar,vector}.py)
 # --------------------------------------------------------------------------
@@ -105,28 +111,25 @@ class CovarianceMatrix:
 
 
 class DiagonalCovarianceMatrix(CovarianceMatrix):
-    """covariance.py:25-55: stores the reciprocals of the marginal variances;
-    the proposal's standard deviations are sqrt(reciprocal(precision)) -- formed
-    exactly like that in lowering.proposal_sigma so that x + sigma*xi rounds as
-    in the reference."""
+    """covariance.py:25-55: held as `_precision`, the reciprocals of the marginal variances; every other
+    quantity is derived from it on demand.  The proposal's standard deviations are
+    sqrt(reciprocal(precision)) -- formed exactly like that in lowering.proposal_sigma so that
+    x + sigma*xi rounds as in the reference."""
 
     def __init__(self, marginalVariances):
-        self._precision = np.reciprocal(np.asarray(marginalVariances, dtype=float))
+        self.marginalVariance = marginalVariances
 
-    @property
-    def marginalVariance(self):
+    def _get_variance(self):
         return np.reciprocal(self._precision)
 
-    @marginalVariance.setter
-    def marginalVariance(self, mVar):
+    def _set_variance(self, mVar):
         self._precision = np.reciprocal(np.asarray(mVar, dtype=float))
 
-    @property
-    def dimension(self):
-        return self._precision.size
+    marginalVariance = property(_get_variance, _set_variance)
+    dimension = property(lambda self: self._precision.size)
 
     def apply_chol_factor(self, x):
-        return np.sqrt(np.reciprocal(self._precision)) * x
+        return np.sqrt(self._get_variance()) * x
 
     def apply_inverse(self, x):
         return self._precision * x
@@ -146,26 +149,22 @@ class DenseCovarianceMatrix(CovarianceMatrix):
 
     def __init__(self, denseCovMat):
         from scipy.linalg import cholesky
-        denseCovMat = np.asarray(denseCovMat, dtype=float)
-        s = denseCovMat.shape
-        assert s[0] == s[1]
-        self.dim_ = s[0]
-        self.cholFactor_ = cholesky(denseCovMat, lower=True)
+        C = np.asarray(denseCovMat, dtype=float)
+        assert C.ndim == 2 and C.shape[0] == C.shape[1]
+        self.dim_, self.cholFactor_ = C.shape[0], cholesky(C, lower=True)
 
-    @property
-    def dimension(self):
-        return self.dim_
+    dimension = _view("dim_")
 
     def apply_chol_factor(self, x):
         return self.cholFactor_ @ x
 
     def apply_inverse(self, x):
         from scipy.linalg import solve_triangular
-        y = solve_triangular(self.cholFactor_, x, lower=True)
-        return solve_triangular(self.cholFactor_.T, y, lower=False)
+        L = self.cholFactor_
+        return solve_triangular(L.T, solve_triangular(L, x, lower=True), lower=False)
 
     def dense(self):
-        return np.matmul(self.cholFactor_, self.cholFactor_.T)
+        return self.cholFactor_ @ self.cholFactor_.T
 
 
 # --------------------------------------------------------------------------
@@ -196,33 +195,19 @@ class GaussianDensity(_DeviceDensity):
     """gaussian.py:8-24: -0.5 |x - mean|^2 in the precision norm, no constant."""
 
     def __init__(self, meanVector, covariance):
-        self._mean = meanVector
-        self._cov = covariance
+        self._mean, self._cov = meanVector, covariance
 
-    @property
-    def covariance(self):
-        return self._cov
+    covariance = _view("_cov")
 
 
 class Gaussian:
     """gaussian.py:27-66 (the prior law / the proposal law)."""
 
     def __init__(self, mean, covariance):
-        self._mean = mean
-        self._cov = covariance
-        self._density = GaussianDensity(self._mean.coefficient, self._cov)
+        self._mean, self._cov = mean, covariance
+        self._density = GaussianDensity(mean.coefficient, covariance)
 
-    @property
-    def mean(self):
-        return self._mean
-
-    @property
-    def covariance(self):
-        return self._cov
-
-    @property
-    def density(self):
-        return self._density
+    mean, covariance, density = _view("_mean"), _view("_cov"), _view("_density")
 
 
 class CentredGaussianNoise:
@@ -234,9 +219,7 @@ class CentredGaussianNoise:
                              f"with CovarianceMatrix. Got: {type(covariance)}")
         self._cov = covariance
 
-    @property
-    def covariance(self):
-        return self._cov
+    covariance = _view("_cov")
 
     def induced_norm_squared(self, vector):
         return self._cov.induced_norm_squared(vector)
@@ -247,19 +230,9 @@ class Data:
 
     def __init__(self, dataArray):
         self.array_ = np.array(dataArray)
-        self.size_, self.dim_ = dataArray.shape[0], dataArray.shape[1]
+        self.size_, self.dim_ = dataArray.shape[:2]
 
-    @property
-    def size(self):
-        return self.size_
-
-    @property
-    def dim(self):
-        return self.dim_
-
-    @property
-    def array(self):
-        return self.array_
+    size, dim, array = _view("size_", "number of observations"), _view("dim_"), _view("array_")
 
 
 # --------------------------------------------------------------------------
@@ -512,34 +485,29 @@ class BayesianRegressionModel:
     """bayesModel.py:5-29 (non-hierarchical components only)."""
 
     def __init__(self, likelihood, prior):
-        self._likelihood = likelihood
-        self._prior = prior
+        self._likelihood, self._prior = likelihood, prior
 
-    @property
-    def prior(self):
-        return self._prior
-
-    @property
-    def likelihood(self):
-        return self._likelihood
+    prior, likelihood = _view("_prior"), _view("_likelihood")
 
 
 class HierarchyBase:
-    """utility/hierarchy.py:5-31"""
+    """utility/hierarchy.py:5-31: levels 0 .. size-1, coarsest first; -1 addresses the finest."""
 
     def __init__(self, nLevels):
         if nLevels < 1:
             raise ValueError(f"Trying to set up hierarchy with {nLevels} levels.")
         self._nLevels = nLevels
 
-    @property
-    def size(self):
-        return self._nLevels
+    size = _view("_nLevels")
 
     def validate_level_index(self, idx):
-        if idx < -1 or self._nLevels <= idx:
+        if not -1 <= idx < self._nLevels:
             raise ValueError(f"invalid level index. Trying to access level {idx} in a hierarchy of "
                              f"{self._nLevels} levels.")
+
+    def level(self, lvlIdx):
+        self.validate_level_index(lvlIdx)
+        return self._component(lvlIdx)
 
 
 class SharedComponent(HierarchyBase):
@@ -549,8 +517,7 @@ class SharedComponent(HierarchyBase):
         super().__init__(nLevels)
         self._sharedComponent = sharedComponent
 
-    def level(self, lvlIdx):
-        self.validate_level_index(lvlIdx)
+    def _component(self, lvlIdx):
         return self._sharedComponent
 
 
@@ -561,8 +528,7 @@ class Hierarchy(HierarchyBase):
         super().__init__(len(hierarchy))
         self._hierarchy = list(hierarchy)
 
-    def level(self, lvlIdx):
-        self.validate_level_index(lvlIdx)
+    def _component(self, lvlIdx):
         return self._hierarchy[lvlIdx]
 
 
@@ -585,16 +551,9 @@ class UnnormalisedPosterior(_DeviceDensity):
     """chain/target.py:4-22: log-likelihood + log prior density."""
 
     def __init__(self, likelihood, prior):
-        self._likelihood = likelihood
-        self._prior = prior
+        self._likelihood, self._prior = likelihood, prior
 
-    @property
-    def likelihood(self):
-        return self._likelihood
-
-    @property
-    def prior(self):
-        return self._prior
+    likelihood, prior = _view("_likelihood"), _view("_prior")
 
 
 # --------------------------------------------------------------------------
