@@ -36,9 +36,15 @@
 
 namespace {
 
-template <int KS, bool PCN>
+/* PROP: the proposal of the kernel -- diagonal random walk, pCN, or random walk with a dense covariance.  A
+ * compile-time choice: the dense branch as a run-time test cost the diagonal kernel 20 VGPRs (8 spilled at
+ * KS = 32) and 20 % of its speed. */
+enum { kPropDiag = 0, kPropPcn = 1, kPropDense = 2 };
+
+template <int KS, int PROP>
 __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArgs a)
 {
+    constexpr bool PCN = PROP == kPropPcn, DENSE = PROP == kPropDense;
     ymc_stage_tables();
     extern __shared__ double lds[];
     const int MT = a.MT, m_pad = 16 * MT, d_pad = 4 * KS;
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
             double xi0, xi1; /* components 8 q + g (s = 2 q) and 8 q + 4 + g (s = 2 q + 1) */
             ymc_draw_normal_pair(a.seed, chain, t, 4u * (uint32_t)q + pair_of_g, &xi0, &xi1);
             swap_odd_even_rows(xi0, xi1);
-            if (a.chol_frag) { /* dense proposal covariance: park xi in y, L xi follows below (wave-uniform) */
+            if constexpr (DENSE) { /* dense proposal covariance: park xi in y, L xi follows below */
                 y[2 * q] = xi0;
                 y[2 * q + 1] = xi1;
             } else if constexpr (PCN) { /* pcn.py:27-36: xi ~ prior, y = sqrt(1 - 2h) x + sqrt(2h) xi */
@@ -105,9 +111,9 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
                 y[2 * q] = x[2 * q] + sigma[8 * q + g] * xi0;
                 y[2 * q + 1] = x[2 * q + 1] + sigma[8 * q + 4 + g] * xi1;
             }
-            if (!a.chol_frag) moved_l = moved_l || !(y[2 * q] == x[2 * q]) || !(y[2 * q + 1] == x[2 * q + 1]);
+            if constexpr (!DENSE) moved_l = moved_l || !(y[2 * q] == x[2 * q]) || !(y[2 * q + 1] == x[2 * q + 1]);
         }
-        if (a.chol_frag) {
+        if constexpr (DENSE) {
             /* y = x + L xi (covariance.py:91-92, gaussian.py:66): row i of L xi is one k-ordered fma chain on the
              * matrix cores -- output 16 mt + 4 r + g of the accumulator IS component 4 s + g, s = 4 mt + r, of this
              * lane.  The rows pass through a scratch in the record's layout, because y holds xi until the last
@@ -502,16 +508,16 @@ size_t ymc_tile_lds_bytes(int KS, int MT)
     return ((size_t)MT * KS * 64 + m_pad * 3 + 3 * d_pad) * sizeof(double);  /* + 2 KB static (log table) */
 }
 
-template <int KS, bool PCN>
+template <int KS, int PROP>
 static hipError_t launch_tile_as(const TileArgs &a, hipStream_t s)
 {
     const size_t lds = ymc_tile_lds_bytes(KS, a.MT);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_tile_kernel<KS, PCN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_tile_kernel<KS, PROP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const uint64_t nct = (a.K + 15) / 16;
     const unsigned grid = (unsigned)((nct + kTileWaves - 1) / kTileWaves);
-    hipLaunchKernelGGL((linear_tile_kernel<KS, PCN>), dim3(grid), dim3(kTileThreads), lds, s, a);
+    hipLaunchKernelGGL((linear_tile_kernel<KS, PROP>), dim3(grid), dim3(kTileThreads), lds, s, a);
     return hipGetLastError();
 }
 
@@ -547,7 +553,8 @@ hipError_t ymc_launch_linear_tile_mlda2(int KS, const TileArgs &a, hipStream_t s
 template <int KS>
 static hipError_t launch_tile(const TileArgs &a, hipStream_t s)
 {
-    return a.pcn ? launch_tile_as<KS, true>(a, s) : launch_tile_as<KS, false>(a, s);
+    if (a.chol_frag) return a.pcn ? hipErrorInvalidValue : launch_tile_as<KS, kPropDense>(a, s);
+    return a.pcn ? launch_tile_as<KS, kPropPcn>(a, s) : launch_tile_as<KS, kPropDiag>(a, s);
 }
 
 hipError_t ymc_launch_linear_tile(int KS, const TileArgs &a, hipStream_t s)
