@@ -1,6 +1,6 @@
 #!/bin/bash
 # Registers, spills, LDS and scratch of the gfx950 kernels in one object file:
-#   tools/kernel_resources.sh yagre-mcmc_amd/csrc/ymc_kernels.o [name-regex]
+#   tools/kernel_resources.sh yagre-mcmc_amd/csrc/ymc_kernels_p1.o [name-regex]
 set -e
 OBJ=$(readlink -f "$1"); PAT=${2:-.}
 TMP=$(mktemp -d); trap 'rm -rf $TMP' EXIT

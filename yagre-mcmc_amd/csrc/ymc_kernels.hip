@@ -18,6 +18,21 @@
 #define YMC_COEFF_HOISTED 1
 #include "ymc_kernels.h"
 
+/* This file is compiled four times (Makefile, -DYMC_KERNELS_PART=0..3): the dimensions are independent
+ * instantiations and one translation unit with all of them takes two minutes to build.  Part 0 also holds the
+ * kernels that are not templates on the dimension. */
+#ifndef YMC_KERNELS_PART
+#error "compile with -DYMC_KERNELS_PART=0..3 (see the Makefile)"
+#elif YMC_KERNELS_PART == 0
+#define YMC_FOR_EACH_D(X) X(1)
+#elif YMC_KERNELS_PART == 1
+#define YMC_FOR_EACH_D(X) X(2)
+#elif YMC_KERNELS_PART == 2
+#define YMC_FOR_EACH_D(X) X(3) X(4) X(5)
+#else
+#define YMC_FOR_EACH_D(X) X(6) X(7) X(8)
+#endif
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -557,6 +572,7 @@ __global__ __launch_bounds__(kBlock) void forward_linear_kernel(const DensityDev
         if (m < p.data_dim) out[i * p.data_dim + m] = F[m];
 }
 
+template <int UNUSED = 0> /* a template only so that the parts without d = 2 do not emit it */
 __global__ __launch_bounds__(kBlock) void forward_lv_kernel(const DensityDev<2> p, uint64_t n,
                                                             const double *__restrict__ xin,
                                                             double *__restrict__ out)
@@ -575,6 +591,7 @@ __global__ __launch_bounds__(kBlock) void forward_lv_kernel(const DensityDev<2> 
     }
 }
 
+#if YMC_KERNELS_PART == 0
 /* the draws of chains chain0..chain0+K-1 in transitions t0..t0+nt-1 */
 __global__ __launch_bounds__(kBlock) void rng_fill_kernel(uint64_t seed, uint64_t chain0, uint64_t K,
                                                           uint64_t t0, uint64_t nt, int d,
@@ -670,6 +687,8 @@ __global__ __launch_bounds__(kBlock) void pack_summary_kernel(uint64_t K, int d,
 }
 
 
+#endif /* part 0 */
+
 template <int KIND, int D, unsigned REC, int EQ>
 void launch_one(int method, const ChainArgs<D> &a, hipStream_t s)
 {
@@ -731,7 +750,6 @@ hipError_t launch_chain(int method, const ChainArgs<D> &a, hipStream_t s)
 
 }  // namespace
 
-#define YMC_FOR_EACH_D(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8)
 
 template <int D>
 hipError_t ymc_launch_chain(int kind, int method, const ChainArgs<D> &a, hipStream_t s)
@@ -797,7 +815,7 @@ hipError_t ymc_launch_forward(int kind, const DensityDev<D> &p, uint64_t n, cons
         hipLaunchKernelGGL((forward_linear_kernel<D>), g, b, 0, s, p, n, x, out);
     } else if (kind == YMC_DENSITY_POSTERIOR_LV) {
         if constexpr (D == 2)
-            hipLaunchKernelGGL(forward_lv_kernel, g, b, 0, s, p, n, x, out);
+            hipLaunchKernelGGL(forward_lv_kernel<>, g, b, 0, s, p, n, x, out);
         else
             return hipErrorInvalidValue;
     } else {
@@ -814,6 +832,7 @@ hipError_t ymc_launch_forward(int kind, const DensityDev<D> &p, uint64_t n, cons
                                               double *, hipStream_t);
 YMC_FOR_EACH_D(YMC_INSTANTIATE)
 
+#if YMC_KERNELS_PART == 0
 hipError_t ymc_launch_rng_fill(uint64_t seed, uint64_t chain0, uint64_t K, uint64_t t0, uint64_t nt, int d,
                                double *xi, double *u, hipStream_t s)
 {
@@ -848,3 +867,4 @@ hipError_t ymc_launch_pack_summary(uint64_t K, int d, uint64_t wf_n, const doubl
                        wmean, wm2, status, out);
     return hipGetLastError();
 }
+#endif /* part 0 */

@@ -215,6 +215,14 @@ bool YMC_MLDA2_ENTRY(int kind, unsigned rec, const ChainArgs<D> &a, hipStream_t 
     }
 }
 
+/* ... and each of the two once per dimension with kernels (-DYMC_MLDA2_D=1|2; the d = 1 objects also carry
+ * the "not covered" answers of d = 3..8) */
 #define YMC_INSTANTIATE(D) template bool YMC_MLDA2_ENTRY<D>(int, unsigned, const ChainArgs<D> &, hipStream_t);
-YMC_INSTANTIATE(1) YMC_INSTANTIATE(2) YMC_INSTANTIATE(3) YMC_INSTANTIATE(4)
+#if YMC_MLDA2_D == 1
+YMC_INSTANTIATE(1) YMC_INSTANTIATE(3) YMC_INSTANTIATE(4)
 YMC_INSTANTIATE(5) YMC_INSTANTIATE(6) YMC_INSTANTIATE(7) YMC_INSTANTIATE(8)
+#elif YMC_MLDA2_D == 2
+YMC_INSTANTIATE(2)
+#else
+#error "compile with -DYMC_MLDA2_D=1 or 2 (see the Makefile)"
+#endif
