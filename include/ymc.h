@@ -99,7 +99,8 @@ typedef enum ymc_method {
      *   level e      1 <= e <= E-2: subChainLengths[2e+1] steps, each = one level-(e-1) run accepted
      *                with exp(P(y) + Q(x) - Q(y) - P(x)), P = surrogateTargets[2e], Q = [2e-1]
      *   level E-1    the recorded chain: P = the target, Q = surrogateTargets[n-1]
-     * (An odd n >= 3 raises AttributeError in the reference; the Python layer raises the same.) */
+     * (An odd n >= 3 raises AttributeError in the reference; the Python layer raises the same.)
+     * Lane kernels up to d = 8; hierarchies of POSTERIOR_LINEAR models up to d = 128 on the matrix cores. */
     YMC_METHOD_MLDA_NESTED = 4,
     /* AdaptiveErrorModel with one surrogate (chain/method/aem.py:6-58): MLDA2 whose coarse
      * AEMLikelihood (statistics/likelihood.py:90-155, noise.py:25-61) learns the model error

@@ -916,9 +916,74 @@ def fixture_f15():
     print("F15", acc.mean(), lacc.mean())
 
 
+def fixture_f18(name="f18_mlda_nested2_linear_d128.npz", d=128, n_models=3, seed=20250118, K=6, n=101,
+                sub_lengths=(3, 4), perturb=0.02, prop_var=1.1e-3):
+    """Delayed acceptance over a hierarchy of THREE (and, second fixture, FIVE) linear models at large dimension
+    (mlda.py:12-73,100-116,315-335; modelHierarchy.py:6-53): an even number of surrogates, executed by the
+    reference as a nest of n/2 + 1 effective levels (include/ymc.h, YMC_METHOD_MLDA_NESTED).  The coarser a
+    model, the larger its perturbation of the finest one's matrix and shift."""
+    from yagremcmc.statistics.modelHierarchy import BayesianRegressionModelHierarchy
+    from yagremcmc.utility.hierarchy import Hierarchy, SharedComponent
+    n_data = 5
+    A_f, b_f, data, noise_var = linear_problem(d, n_data, 11)
+    ns = n_models - 1
+    assert ns % 2 == 0 and len(sub_lengths) == ns
+    As, bs = [], []
+    for i in range(ns):
+        z, _ = oracle.rng_fill(1234 + i, 0, d + 1, 0, 1, d, uniforms=False)
+        scale = perturb * (ns - i)
+        As.append(A_f + scale * z[0][:d] / np.sqrt(d))
+        bs.append(b_f + 2.5 * scale * z[0][d])
+    As.append(A_f)
+    bs.append(b_f)
+    prior_mean, prior_var = np.zeros(d), 5.0
+    prior = Gaussian(ParameterVector(prior_mean.copy()), IIDCovarianceMatrix(d, prior_var))
+    noise = CentredGaussianNoise(IIDCovarianceMatrix(d, noise_var))
+    liks = [AdditiveGaussianNoiseLikelihood(Data(data), ForwardModel(ExampleLinearModelSolver(A, b)), noise)
+            for A, b in zip(As, bs)]
+    model = BayesianRegressionModelHierarchy(Hierarchy(liks), SharedComponent(prior, n_models))
+    E = ns // 2 + 1
+    steps = [sub_lengths[2 * e + 1] for e in range(E - 1)]
+    cost = 1
+    for s_ in steps:
+        cost = s_ * cost + 1
+    cov = IIDCovarianceMatrix(d, prop_var)
+    traj = np.empty((n, K, d))
+    acc = np.empty((n - 1, K), dtype=np.uint8)
+    lp = np.empty((n, K))
+    level_acc = np.zeros((E - 1, K), dtype=np.uint64)
+    for k in range(K):
+        b = MLDABuilder()
+        b.baseProposalCovariance = cov
+        b.subChainLengths = list(sub_lengths)
+        b.bayesModel = model
+        b.surrogateDiagnostics = [AcceptanceRateDiagnostics() for _ in range(ns)]
+        mc = b.build_method()
+        rp = SequentialReplay(seed, k, d, (n - 1) * cost)
+        rp.install()
+        rp.watch(mc)
+        for i in range(ns):
+            rp.watch(mc.surrogate(i))
+        mc.run(n, ParameterVector(np.zeros(d)), verbose=False)
+        assert rp.t == (n - 1) * cost, (rp.t, (n - 1) * cost)
+        traj[:, k, :] = np.array(mc.chain.trajectory)
+        acc[:, k] = mc.diagnostics._decisions
+        lp[:, k] = eval_log_along(mc.target, traj[:, k, :], lambda s_: ParameterVector(np.array(s_)))
+        for e in range(E - 1):
+            level_acc[e, k] = int(np.sum(mc.surrogate(2 * e).diagnostics._decisions))
+        for i in range(1, ns, 2):   # the levels whose accept step never runs
+            assert len(mc.surrogate(i).diagnostics._decisions) == 0
+    np.savez_compressed(
+        os.path.join(HERE, name), seed=seed, n_states=n, sub_lengths=np.array(sub_lengths), A=np.array(As), b=np.array(bs),
+        data=data, noise_precision=np.reciprocal(np.full(d, noise_var)), prior_mean=prior_mean,
+        prior_precision=np.reciprocal(np.full(d, prior_var)), sigma=sigma_of(cov), x0=np.zeros((K, d)),
+        traj_head=traj[:, :2, :], traj_sha256=sha(traj), acc=acc, logpost=lp, level_acc=level_acc, cost_top=cost)
+    print(name, acc.mean(), level_acc.sum(axis=1))
+
+
 def main():
     which = sys.argv[1:] or ["f1", "f2", "f2b", "f3", "f3b", "f4", "f5", "f7", "f8", "f9", "f10", "f11", "f12", "f13",
-                             "f14", "f15", "f16", "f17"]
+                             "f14", "f15", "f16", "f17", "f18"]
     if "f1" in which:
         fixture_f1()
     if "f2" in which:
@@ -956,6 +1021,10 @@ def main():
         fixture_f16()
     if "f17" in which:
         fixture_f17()
+    if "f18" in which:
+        fixture_f18()
+        fixture_f18("f18b_mlda_nested4_linear_d24.npz", d=24, n_models=5, seed=20250119, K=6, n=81,
+                    sub_lengths=(2, 3, 2, 2), perturb=0.03, prop_var=6e-3)
     if "f12" in which:
         fixture_f12()
         fixture_f12("f12b_aem_linear_noheuristic.npz", use_heuristic=False, seed=20250113, min_data=5, K=12,

@@ -636,6 +636,48 @@ def test_two_level_over_a_model_hierarchy_d128_f14(golden):
     assert abs(mc.diagnostics.global_acceptance_rate() - g["acc"].mean()) < 1e-15
 
 
+@pytest.mark.parametrize("name,prior_var,noise_var,prop_var", [("f18_mlda_nested2_linear_d128.npz", 5.0, 0.3, 1.1e-3),
+                                                               ("f18b_mlda_nested4_linear_d24.npz", 5.0, 0.3, 6e-3)])
+def test_nested_levels_over_model_hierarchies_f18(golden, name, prior_var, noise_var, prop_var):
+    """MLDABuilder.bayesModel = a hierarchy of three (d = 128) / five (d = 24) linear models, i.e. an even number
+    of surrogates: through the builders the chains are the live reference's (fixtures F18), on the matrix cores."""
+    import hashlib
+    from yagremcmc_amd.chain.diagnostics import AcceptanceRateDiagnostics
+    from yagremcmc_amd.chain.method.mlda import MLDABuilder
+    from yagremcmc_amd.exampleSetup import ExampleLinearModelSolver
+    from yagremcmc_amd.model.forwardModel import ForwardModel
+    from yagremcmc_amd.parameter.vector import ParameterVector
+    from yagremcmc_amd.statistics.covariance import IIDCovarianceMatrix
+    from yagremcmc_amd.statistics.data import Data
+    from yagremcmc_amd.statistics.gaussian import Gaussian
+    from yagremcmc_amd.statistics.likelihood import AdditiveGaussianNoiseLikelihood
+    from yagremcmc_amd.statistics.modelHierarchy import BayesianRegressionModelHierarchy
+    from yagremcmc_amd.statistics.noise import CentredGaussianNoise
+    from yagremcmc_amd.utility.hierarchy import Hierarchy, SharedComponent
+    g = golden(name)
+    n_models, d = g["A"].shape[0], g["A"].shape[2]
+    n, K = int(g["n_states"]), g["x0"].shape[0]
+    prior = Gaussian(ParameterVector(np.array(g["prior_mean"])), IIDCovarianceMatrix(d, prior_var))
+    noise = CentredGaussianNoise(IIDCovarianceMatrix(d, noise_var))
+    liks = [AdditiveGaussianNoiseLikelihood(Data(g["data"]), ForwardModel(ExampleLinearModelSolver(A, b_)), noise)
+            for A, b_ in zip(g["A"], g["b"])]
+    b = MLDABuilder()
+    b.bayesModel = BayesianRegressionModelHierarchy(Hierarchy(liks), SharedComponent(prior, n_models))
+    b.baseProposalCovariance = IIDCovarianceMatrix(d, prop_var)
+    b.subChainLengths = [int(v) for v in g["sub_lengths"]]
+    b.surrogateDiagnostics = [AcceptanceRateDiagnostics() for _ in range(n_models - 1)]
+    b.nChains, b.seed = K, int(g["seed"])
+    mc = b.build_method()
+    mc.run(n, ParameterVector(np.zeros(d)), verbose=False)
+    assert np.array_equal(mc.accept_decisions, g["acc"])
+    traj = mc.chain.ensemble_trajectory
+    assert hashlib.sha256(np.ascontiguousarray(traj).tobytes()).hexdigest() == str(g["traj_sha256"])
+    assert abs(mc.diagnostics.global_acceptance_rate() - g["acc"].mean()) < 1e-15
+    for e in range(g["level_acc"].shape[0]):   # the executed lower levels: surrogates 0, 2, ...
+        made = (n - 1) * int(np.prod([int(g["sub_lengths"][2 * j + 1]) for j in range(e, g["level_acc"].shape[0])]))
+        assert abs(mc.surrogate(2 * e).diagnostics.global_acceptance_rate() - g["level_acc"][e].sum() / (made * K)) < 1e-15
+
+
 def test_dense_noise_and_prior_through_the_builders_f15(golden):
     """MRWBuilder.bayesModel with CentredGaussianNoise(DenseCovarianceMatrix) and a Gaussian prior over a
     DenseCovarianceMatrix: the chains of the live reference (fixture F15a)."""

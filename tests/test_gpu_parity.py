@@ -859,6 +859,66 @@ def test_tile_kernel_two_level_other_shapes(ffi, ctx, d, mf, mc, nd, K, S):
     assert np.array_equal(dev["sub_acc"], out["sub_acc"])
 
 
+@pytest.mark.parametrize("name", ["f18_mlda_nested2_linear_d128.npz", "f18b_mlda_nested4_linear_d24.npz"])
+def test_f18_nested_levels_matrix_cores(ffi, ctx, golden, name):
+    """Hierarchies of three (d = 128) and five (d = 24) linear models (linear_tile_nested_kernel): the LIVE
+    reference's top-level decisions, accepted counts of the lower levels, chains (sha256) and log-posteriors;
+    == oracle."""
+    import hashlib
+    g = golden(name)
+    n, d = int(g["n_states"]), g["A"].shape[2]
+    common = dict(data=g["data"], noise_precision=g["noise_precision"], prior_mean=g["prior_mean"],
+                  prior_precision=g["prior_precision"])
+    lows = [_posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, common, fwd_matrix=A, fwd_shift=b) for A, b in zip(g["A"], g["b"])]
+    subs = [int(v) for v in g["sub_lengths"]]
+    dev = _nested_device_run(ffi, ctx, lows[-1], lows[:-1], subs, g["sigma"], g["x0"], int(g["seed"]), n - 1, splits=3)
+    assert np.array_equal(dev["acc"], g["acc"]) and np.array_equal(dev["level_acc"], g["level_acc"])
+    full = np.concatenate([g["x0"][None], dev["traj"]])
+    assert np.array_equal(full[:, :2, :], g["traj_head"])
+    assert hashlib.sha256(np.ascontiguousarray(full).tobytes()).hexdigest() == str(g["traj_sha256"])
+    want = g["logpost"][1:]
+    assert np.abs(dev["logpost"] - want).max() <= 1e-12 * np.abs(want).max()
+    models = [o.posterior_linear(A, b, *common.values()) for A, b in zip(g["A"], g["b"])]
+    P, Q, steps = o.nested_levels(models[:-1], subs, models[-1])
+    e = o.NestedEnsemble(P, Q, steps, g["sigma"], g["x0"], int(g["seed"]))
+    out = e.advance(n - 1)
+    _same_as_oracle(dev, e, out)
+    assert np.array_equal(dev["level_acc"], e.level_acc)
+
+
+@pytest.mark.parametrize("d,ms,nd,K,E", [(128, (128, 128, 128), 5, 40, 2), (12, (5, 20, 9), 3, 33, 2),
+                                         (24, (16, 40, 8, 30, 12), 2, 70, 3), (64, (64, 30, 64, 10, 48), 4, 17, 3),
+                                         (9, (3, 3, 4, 2, 5, 3, 6), 1, 129, 4), (5, (30, 12, 6), 2, 20, 2)])
+def test_tile_kernel_nested_levels_vs_oracle(ffi, ctx, d, ms, nd, K, E):
+    """Delayed acceptance over an even number of surrogates at large dimension (ymc_tile_nested.hip): a
+    hierarchy of 2 (E - 1) + 1 linear models, each with its own matrix, output count and data; ragged shapes, a
+    partly filled last wave, a hierarchy one of whose models alone would fit the lane kernels.  Everything the
+    lane kernel's test compares: chains, decisions of the recorded level, accepted counts of the lower levels,
+    log-posteriors, Welford moments, carried state -- across three launches."""
+    rng = np.random.default_rng(900 + d + sum(ms))
+    assert len(ms) == 2 * (E - 1) + 1
+
+    def model(m, scale):
+        g = dict(data=rng.normal(size=(nd, m)), noise_precision=rng.uniform(0.5, 3, size=m), prior_mean=rng.normal(size=d) * 0.1,
+                 prior_precision=rng.uniform(0.1, 2, size=d))
+        A, b = scale * rng.normal(size=(m, d)) / np.sqrt(d), rng.normal(size=m)
+        return (_posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, g, fwd_matrix=A, fwd_shift=b),
+                o.posterior_linear(A, b, g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"]))
+
+    models = [model(m, 1.0 - 0.03 * i) for i, m in enumerate(ms)]
+    (lt, pt), surs = models[-1], models[:-1]
+    subs = [int(v) for v in rng.integers(1, 4, size=len(surs))]
+    sigma = rng.uniform(0.02, 0.08, size=d)
+    x0 = rng.normal(size=(K, d))
+    dev = _nested_device_run(ffi, ctx, lt, [l for l, _ in surs], subs, sigma, x0, 777, 24, splits=3, chain0=3000)
+    P, Q, steps = o.nested_levels([p for _, p in surs], subs, pt)
+    e = o.NestedEnsemble(P, Q, steps, sigma, x0, 777, chain0=3000)
+    out = e.advance(24)
+    _same_as_oracle(dev, e, out)
+    assert np.array_equal(dev["level_acc"], e.level_acc)
+    assert 0 < dev["acc"].mean() < 1
+
+
 def test_tile_kernel_limits(ffi, ctx):
     from yagremcmc_amd import lowering
     rng = np.random.default_rng(1)

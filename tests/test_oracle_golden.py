@@ -299,6 +299,29 @@ def test_f14_two_level_over_a_model_hierarchy_d128(golden):
     assert 0.5 < g["acc"].mean() < 0.95 and 0.2 < g["sub_acc"].mean() < 0.8   # both levels decide both ways
 
 
+@pytest.mark.parametrize("name", ["f18_mlda_nested2_linear_d128.npz", "f18b_mlda_nested4_linear_d24.npz"])
+def test_f18_nested_levels_over_model_hierarchies_at_large_dimension(golden, name):
+    """MLDABuilder.bayesModel = a hierarchy of three (d = 128) / five (d = 24) linear models: an even number of
+    surrogates, run by the reference as a nest of effective levels (mlda.py:12-73,100-116,315-335).  The
+    reference's top-level decisions, the accepted counts of the lower levels, its chains (sha256) and
+    log-posteriors."""
+    g = golden(name)
+    n = int(g["n_states"])
+    common = (g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+    models = [o.posterior_linear(A, b, *common) for A, b in zip(g["A"], g["b"])]
+    P, Q, steps = o.nested_levels(models[:-1], [int(v) for v in g["sub_lengths"]], models[-1])
+    e = o.NestedEnsemble(P, Q, steps, g["sigma"], g["x0"], int(g["seed"]))
+    out = e.advance(n - 1)
+    assert e.cost_top == int(g["cost_top"])
+    assert np.array_equal(out["acc"], g["acc"]) and np.array_equal(e.level_acc, g["level_acc"])
+    full = np.concatenate([g["x0"][None], out["traj"]])
+    assert np.array_equal(full[:, :2, :], g["traj_head"])
+    assert hashlib.sha256(np.ascontiguousarray(full).tobytes()).hexdigest() == str(g["traj_sha256"])
+    want = g["logpost"][1:]
+    assert np.abs(out["logpost"] - want).max() <= LP_RTOL * np.abs(want).max()
+    assert 0.3 < g["acc"].mean() < 0.9                                        # the levels decide both ways
+
+
 def _f15_problems(g):
     lin = o.dense_covariances(
         o.posterior_linear(g["A"], g["b"], g["data"], np.ones(4), g["prior_mean"], np.ones(3)),

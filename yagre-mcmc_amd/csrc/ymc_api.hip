@@ -153,6 +153,7 @@ struct ymc_problem {
     int lvl_steps[YMC_MAX_LEVELS] = {0, 0, 0, 0};
     uint64_t lvl_cost[YMC_MAX_LEVELS] = {0, 0, 0, 0}; /* transitions one step of level e spans */
     DeviceBuf lvlP_dev, lvlQ_dev;                     /* DensityDev<D>[E] each */
+    DeviceBuf tile_levels;                            /* matrix-core path: TileLevel[2 E], P / Q of level l at 2 l, 2 l + 1 */
 };
 
 struct ymc_run {
@@ -672,7 +673,8 @@ int launch_advance_tile(ymc_run *r, uint64_t nsteps)
     const ymc_problem *p = r->problem;
     const bool aem2 = p->method == YMC_METHOD_AEM2;
     const bool mlda2 = p->method == YMC_METHOD_MLDA2 || aem2;
-    const DensityHost &h = mlda2 ? p->sur : p->tgt; /* the level staged in LDS */
+    const bool nested = p->method == YMC_METHOD_MLDA_NESTED;
+    const DensityHost &h = mlda2 ? p->sur : nested ? p->lvlP[0] : p->tgt; /* the level staged in LDS */
     TileArgs a{};
     a.blob = h.tile_blob.as<double>();
     a.lik_const = h.lik_const;
@@ -688,6 +690,15 @@ int launch_advance_tile(ymc_run *r, uint64_t nsteps)
         a.lpc = r->lpc.as<double>();
         a.x_tiled = r->x_tiled.as<double>();
         if (r->flags & YMC_RECORD_SUB_ACCEPT) a.sub_acc = r->sub_acc.as<uint8_t>() + r->recorded * (uint64_t)p->S * r->K;
+    }
+    if (nested) {
+        a.levels = p->tile_levels.as<TileLevel>();
+        a.E = p->E;
+        for (int e = 0; e < YMC_MAX_LEVELS; ++e) a.steps[e] = p->lvl_steps[e];
+        a.cost_top = p->lvl_cost[p->E - 1];
+        a.level_acc = r->level_acc.as<uint64_t>();
+        a.lpc = r->lpc.as<double>();
+        a.x_tiled = r->x_tiled.as<double>();
     }
     if (p->chol_frag.p) {
         a.chol_frag = p->chol_frag.as<double>();
@@ -740,9 +751,10 @@ int launch_advance_tile(ymc_run *r, uint64_t nsteps)
         YMC_HIP(hipEventCreate(&ev.second));
     }
     YMC_HIP(hipEventRecord(ev.first, r->ctx->stream));
-    hipError_t e = aem2    ? ymc_launch_linear_tile_aem2(h.KS, a, r->ctx->stream)
-                   : mlda2 ? ymc_launch_linear_tile_mlda2(h.KS, a, r->ctx->stream)
-                           : ymc_launch_linear_tile(h.KS, a, r->ctx->stream);
+    hipError_t e = aem2     ? ymc_launch_linear_tile_aem2(h.KS, a, r->ctx->stream)
+                   : mlda2  ? ymc_launch_linear_tile_mlda2(h.KS, a, r->ctx->stream)
+                   : nested ? ymc_launch_linear_tile_nested(h.KS, a, r->ctx->stream)
+                            : ymc_launch_linear_tile(h.KS, a, r->ctx->stream);
     if (e == hipSuccess && moments)
         e = ymc_launch_welford_replay(a.traj, r->x_before.as<double>(), nsteps, r->K, p->D, h.KS, r->steps_done,
                                       r->wf_mean.as<double>(), r->wf_m2.as<double>(), r->ctx->stream);
@@ -898,8 +910,15 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
     p->method = desc->method;
     p->eq_mode = desc->state_eq;
     const bool two_level = desc->method == YMC_METHOD_MLDA2 || desc->method == YMC_METHOD_AEM2;
-    const bool joint_tile = two_level && desc->surrogate.kind == desc->target.kind &&
-                            (needs_tile(desc->target) || needs_tile(desc->surrogate));
+    bool joint_tile = two_level && desc->surrogate.kind == desc->target.kind &&
+                      (needs_tile(desc->target) || needs_tile(desc->surrogate));
+    if (desc->method == YMC_METHOD_MLDA_NESTED && desc->n_levels >= 2 && desc->n_levels <= YMC_MAX_LEVELS &&
+        desc->level_target && desc->level_correction) {
+        /* all levels run in one kernel: if one posterior needs the matrix-core path, all take it */
+        joint_tile = needs_tile(desc->target);
+        for (int e = 0; e < desc->n_levels - 1; ++e)
+            joint_tile = joint_tile || needs_tile(desc->level_target[e]) || needs_tile(desc->level_correction[e]);
+    }
     int rc = lower_density(ctx, desc->target, p->tgt, 0, joint_tile);
     if (rc == YMC_OK) {
         p->D = desc->target.dim;
@@ -963,10 +982,10 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
             if (rc == YMC_OK && (P.kind != desc->target.kind || Q.kind != desc->target.kind))
                 rc = fail(YMC_ERR_UNSUPPORTED, "surrogate density kinds %d / %d differ from target kind %d", P.kind,
                           Q.kind, desc->target.kind);
-            if (rc == YMC_OK) rc = lower_density(ctx, P, p->lvlP[e], p->D);
-            if (rc == YMC_OK) rc = lower_density(ctx, Q, p->lvlQ[e + 1], p->D);
-            if (rc == YMC_OK && (p->lvlP[e].tile || p->lvlQ[e + 1].tile))
-                rc = fail(YMC_ERR_UNSUPPORTED, "only the random-walk sampler is available at this dimension");
+            if (rc == YMC_OK) rc = lower_density(ctx, P, p->lvlP[e], p->D, joint_tile);
+            if (rc == YMC_OK) rc = lower_density(ctx, Q, p->lvlQ[e + 1], p->D, joint_tile);
+            if (rc == YMC_OK && (p->lvlP[e].tile != p->tgt.tile || p->lvlQ[e + 1].tile != p->tgt.tile))
+                rc = fail(YMC_ERR_UNSUPPORTED, "the levels do not fit one kernel (mixed forward-map sizes)");
             p->lvl_steps[e] = desc->level_steps[e];
             p->lvl_cost[e] = e == 0 ? 1 : (uint64_t)p->lvl_steps[e - 1] * p->lvl_cost[e - 1] + 1;
         }
@@ -1025,16 +1044,33 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
         }
     }
     if (rc == YMC_OK && p->tgt.tile) {
-        if (p->method == YMC_METHOD_MLDA_NESTED)
-            rc = fail(YMC_ERR_UNSUPPORTED, "the random-walk, pCN, two-level and adaptive-error-model samplers are "
-                                           "available at this dimension");
         const bool two = p->method == YMC_METHOD_MLDA2 || p->method == YMC_METHOD_AEM2;
         if (rc == YMC_OK) rc = build_tile_blob(p, p->tgt);
         if (rc == YMC_OK && two) rc = build_tile_blob(p, p->sur);
         if (rc == YMC_OK && p->method == YMC_METHOD_AEM2) rc = build_aem_rows(p->sur);
+        if (rc == YMC_OK && p->method == YMC_METHOD_MLDA_NESTED) {
+            /* level 0's posterior is staged in LDS whole (lower_density checked that it fits); the posteriors of
+             * the levels above are read from global memory through a table of blocks */
+            auto up = [&]() -> int {
+                std::vector<TileLevel> lv(2 * (size_t)p->E, TileLevel{nullptr, 0.0, 0, 0});
+                for (int e = 0; e < p->E; ++e) {
+                    DensityHost &P = e == p->E - 1 ? p->tgt : p->lvlP[e];
+                    if (e < p->E - 1) YMC_TRY(build_tile_blob(p, P));
+                    lv[2 * e] = TileLevel{P.tile_blob.as<double>(), P.lik_const, P.MT, 0};
+                    if (e >= 1) {
+                        YMC_TRY(build_tile_blob(p, p->lvlQ[e]));
+                        lv[2 * e + 1] = TileLevel{p->lvlQ[e].tile_blob.as<double>(), p->lvlQ[e].lik_const, p->lvlQ[e].MT, 0};
+                    }
+                }
+                YMC_TRY(p->tile_levels.alloc(lv.size() * sizeof(TileLevel)));
+                YMC_HIP(hipMemcpy(p->tile_levels.p, lv.data(), p->tile_levels.bytes, hipMemcpyHostToDevice));
+                return YMC_OK;
+            };
+            rc = up();
+        }
         p->tile = true;
     }
-    if (rc == YMC_OK && p->method == YMC_METHOD_MLDA_NESTED) {
+    if (rc == YMC_OK && p->method == YMC_METHOD_MLDA_NESTED && !p->tile) {
         auto up = [&]() -> int {
             YMC_DISPATCH_D(p->D, return upload_levels<DD>(p));
             return YMC_OK;
@@ -1137,6 +1173,8 @@ int ymc_run_create(ymc_ctx *ctx, const ymc_problem *problem, const ymc_run_desc 
             YMC_TRY(r->sub_acc.alloc(r->capacity * (uint64_t)S * K));
         if (problem->tile && (problem->method == YMC_METHOD_MLDA2 || problem->method == YMC_METHOD_AEM2))
             YMC_TRY(r->x_tiled.alloc(tiled_row_doubles(r) * sizeof(double)));
+        if (problem->tile && problem->method == YMC_METHOD_MLDA_NESTED) /* the parked states of levels 1 .. E-1 */
+            YMC_TRY(r->x_tiled.alloc((uint64_t)(problem->E - 1) * tiled_row_doubles(r) * sizeof(double)));
         if (problem->tile && problem->chol_frag.p) YMC_TRY(r->w_tiled.alloc(tiled_row_doubles(r) * sizeof(double)));
         if (problem->method == YMC_METHOD_AEM2 && problem->tile) {
             /* per-output arrays in the kernel's tiled layout [ceil(K/16)][4 MT][64]; ids of the cached points */

@@ -7,9 +7,19 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "../../include/ymc.h"
+
 constexpr int kTileWaves = 8;                 /* waves per workgroup (one per SIMD), 16 chains each */
 constexpr int kTileThreads = 64 * kTileWaves;
 constexpr size_t kTileLdsLimit = 156 * 1024;  /* LDS per CU on gfx950 (160 KB) less the 4 KB of static draw tables */
+
+/* one posterior of a level above the base of the nested sampler (ymc_tile_nested.hip): a block in `blob`'s
+ * layout in global memory */
+struct TileLevel {
+    const double *blob;
+    double lik_const;
+    int32_t MT, pad_;
+};
 
 struct TileArgs {
     /* one device block, staged into LDS by every workgroup:
@@ -54,6 +64,13 @@ struct TileArgs {
     int32_t *aem_flags;      /* [K][2] {precision set, cache fill} */
     uint64_t *cache_id;      /* [K][4]: the three cached points' ids (oldest first) and the carried state's id */
     double *cache_val;       /* [K][3] */
+    /* nested delayed acceptance (ymc_tile_nested.hip, YMC_METHOD_MLDA_NESTED): `blob` is level 0's posterior,
+     * levels[2 l] / levels[2 l + 1] are P / Q of level l >= 1 (device array), lp / lpc the top level's P / Q of
+     * the carried state, x_tiled holds E - 1 parked states */
+    const TileLevel *levels;
+    int32_t E, steps[YMC_MAX_LEVELS], pad4_;
+    uint64_t cost_top;       /* transitions one top-level step spans */
+    uint64_t *level_acc;     /* [E-1][K] accepted transitions of the lower levels */
 };
 
 struct BigLinearArgs {
@@ -69,6 +86,7 @@ hipError_t ymc_launch_linear_tile_mlda2(int KS, const TileArgs &a, hipStream_t s
 size_t ymc_tile_aem2_lds_bytes(int KS, int MT, int n_data);
 int ymc_tile_aem2_max_rows(void);
 hipError_t ymc_launch_linear_tile_aem2(int KS, const TileArgs &a, hipStream_t s);
+hipError_t ymc_launch_linear_tile_nested(int KS, const TileArgs &a, hipStream_t s);
 hipError_t ymc_launch_untile(const double *tiled, uint64_t row0, uint64_t rows, uint64_t K, int d, int KS,
                              double *out, hipStream_t s);
 hipError_t ymc_launch_welford_replay(const double *tiled, const double *x_before, uint64_t rows, uint64_t K, int d,

@@ -1,0 +1,302 @@
+/*
+ * ymc_tile_nested.hip -- delayed acceptance over an even number of surrogates (YMC_METHOD_MLDA_NESTED,
+ * include/ymc.h; chain/method/mlda.py:12-73,100-116) for linear posteriors at large dimension
+ * (MLDABuilder.bayesModel = a BayesianRegressionModelHierarchy of three or more models,
+ * mlda.py:315-335, modelHierarchy.py:6-53), on the matrix cores.
+ *
+ * Same chain-to-lane mapping as linear_tile_kernel (16 chains per wave, component 4 s + g of chain c in
+ * register s of lane (g, c)); what the lane kernel of ymc_nested.hip writes as a recursion over the E
+ * effective levels is an explicit walk here, because the states of the levels do not fit the registers:
+ *
+ *   registers   z  the state being walked at level 0 (and, on the way up, the proposal of each level)
+ *               y  level 0's proposal / the parked state of the deciding level
+ *   x_tiled     the current states of levels 1 .. E-1, parked in the record's coalesced layout
+ *   LDS         level 0's posterior P[0] whole (it is evaluated most often): A fragments + constants
+ *   L2          P[l], Q[l] of the levels above: fragments and constants read from global memory
+ *
+ * A level-l decision (mlda.py:35-43,146-154) compares the state z that came up from below with the parked
+ * x_l, evaluates P[l](z) and Q[l](z) (two GEMVs on the matrix cores) and keeps one of the two; the counters
+ * of the levels are wave-uniform, so the walk is straight-line code for the whole wave.  Decisions take
+ * consecutive transition indices in execution order, exactly as in mlda_nested_kernel and the oracle.
+ */
+#define YMC_COEFF_IN_SGPR 1
+#include "ymc_kernels.h"
+#include "ymc_tile.h"
+#include "ymc_tile_dev.h"
+
+namespace {
+
+/* four waves per workgroup (one per SIMD; the LDS admits one workgroup per CU anyway): at KS = 32 the walk
+ * needs z, y, two accumulator chains and the fragments in flight from L2 -- more than the 256 registers a
+ * wave gets at two waves per SIMD */
+constexpr int kNestWaves = 4;
+constexpr int kNestThreads = 64 * kNestWaves;
+
+/* one value per level, addressed by a run-time (wave-uniform) level: named members and selects, so that the
+ * values stay in registers (an indexed array went to scratch) */
+template <typename T>
+struct PerLevel {
+    T v0, v1, v2, v3;
+    static_assert(YMC_MAX_LEVELS == 4, "PerLevel holds four levels");
+    __device__ __forceinline__ T get(int l) const { return l == 0 ? v0 : l == 1 ? v1 : l == 2 ? v2 : v3; }
+    __device__ __forceinline__ void set(int l, T x)
+    {
+        v0 = l == 0 ? x : v0;
+        v1 = l == 1 ? x : v1;
+        v2 = l == 2 ? x : v2;
+        v3 = l == 3 ? x : v3;
+    }
+};
+
+template <int KS>
+__global__ __launch_bounds__(kNestThreads) void linear_tile_nested_kernel(const TileArgs a)
+{
+    ymc_stage_tables();
+    extern __shared__ double lds[];
+    const int MT0 = a.MT, m_pad0 = 16 * MT0, d_pad = 4 * KS;
+    double *A0 = lds;
+    double *bias0 = A0 + (size_t)MT0 * KS * 64;
+    double *nprec0 = bias0 + m_pad0;
+    double *dbar0 = nprec0 + m_pad0;
+    double *pmean0 = dbar0 + m_pad0;
+    double *pprec0 = pmean0 + d_pad;
+    double *sigma = pprec0 + d_pad;
+    const size_t blob0 = (size_t)MT0 * KS * 64 + (size_t)m_pad0 * 3 + 3 * (size_t)d_pad;
+
+    const int tid = threadIdx.x;
+    for (size_t i = tid; i < blob0 / 2; i += kNestThreads)
+        reinterpret_cast<double2 *>(lds)[i] = reinterpret_cast<const double2 *>(a.blob)[i];
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+    const uint64_t nct = (a.K + 15) / 16;
+    const uint64_t tile = (uint64_t)blockIdx.x * kNestWaves + wave;
+    if (tile >= nct) return;
+    const uint64_t k = tile * 16 + c;
+    const bool live = k < a.K;
+    const uint32_t chain = (uint32_t)(a.chain0 + k);
+    const int d = a.d, E = a.E;
+    /* a local copy: indexing the argument block with a run-time level would put it in scratch */
+    const PerLevel<int> steps = {a.steps[0], a.steps[1], a.steps[2], a.steps[3]};
+    const uint32_t pair_of_g = (g == 0) ? 0u : (g == 1) ? 2u : (g == 2) ? 1u : 3u;
+    /* parked state of level l >= 1: this lane's column */
+    auto park = [&](int l) { return a.x_tiled + (((uint64_t)(l - 1) * nct + tile) * KS) * 64 + lane; };
+
+    double z[KS], y[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int j = 4 * s + g;
+        z[s] = (live && j < d) ? a.x[k * d + j] : 0.0;
+    }
+    {
+        double *top = park(E - 1);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) top[s * 64] = z[s];
+    }
+    PerLevel<double> lpP = {0.0, 0.0, 0.0, 0.0}, lpQ = {0.0, 0.0, 0.0, 0.0};
+    lpP.set(E - 1, live ? a.lp[k] : 0.0);
+    lpQ.set(E - 1, live ? a.lpc[k] : 0.0);
+    PerLevel<uint64_t> lacc = {0, 0, 0, 0};
+    for (int e = 0; e < E - 1; ++e)
+        if (live) lacc.set(e, a.level_acc[(uint64_t)e * a.K + k]);
+    uint64_t accepted = live ? a.acc_count[k] : 0;
+    uint32_t st = live ? a.status[k] : 0;
+    UniformCache uc;
+    uc.valid = false;
+    uc.pair = 0;
+    RecordClock clk(a.rec_stride, a.rec_since);
+
+    /* log-posterior of v: forward map on the matrix cores, Gaussian-noise likelihood through the row-mean
+     * identity, Gaussian prior (as linear_tile_kernel); fragments and constants from LDS or from global memory */
+    auto logpost = [&](const double *A, int MT, const double *bias, const double *nprec, const double *dbar,
+                       const double *pmean, const double *pprec, double lik_const, const double (&v)[KS]) {
+        double Ssum = 0.0;
+#pragma unroll 1
+        for (int mt = 0; mt < MT; mt += 2) {
+            d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+            const double *Af0 = A + (size_t)mt * KS * 64 + lane;
+            const double *Af1 = Af0 + (size_t)KS * 64;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Af0[s * 64], v[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Af1[s * 64], v[s], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 16 * (mt + h) + 4 * r + g;
+                    const double F = (h ? acc1[r] : acc0[r]) + bias[m];
+                    const double res = F - dbar[m];
+                    const double px = nprec[m] * res;
+                    Ssum = Ssum + res * px;
+                }
+            }
+        }
+        const double logl = -0.5 * (combine4(Ssum) + lik_const);
+        double P = 0.0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int j = 4 * s + g;
+            const double dx = v[s] - pmean[j];
+            const double px = pprec[j] * dx;
+            P = P + dx * px;
+        }
+        return logl + (-0.5 * combine4(P));
+    };
+    auto logpost0 = [&](const double (&v)[KS]) {
+        return logpost(A0, MT0, bias0, nprec0, dbar0, pmean0, pprec0, a.lik_const, v);
+    };
+    /* P[l] (which = 0) or Q[l] (which = 1) of a level above the base: everything from global memory */
+    auto logpost_of = [&](int l, int which, const double (&v)[KS]) {
+        const TileLevel L = a.levels[2 * l + which];
+        const double *consts = L.blob + (size_t)L.MT * KS * 64;
+        const int m_pad = 16 * L.MT;
+        return logpost(L.blob, L.MT, consts, consts + m_pad, consts + 2 * m_pad, consts + 3 * m_pad,
+                       consts + 3 * m_pad + d_pad, L.lik_const, v);
+    };
+    auto any_differs = [&](const double (&p)[KS], const double (&q)[KS]) {
+        bool dl = false;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) dl = dl || !(p[s] == q[s]);
+        int mv = dl ? 1 : 0;
+        mv |= __shfl_xor(mv, 16, 64);
+        mv |= __shfl_xor(mv, 32, 64);
+        return mv != 0;
+    };
+    /* _accept_reject of level l (mlda.py:35-43; the top level's: mlda.py:146-154): the proposal is z, the
+     * level's state is parked; afterwards z and the parking place hold the level's new state */
+    auto decide = [&](int l, uint64_t t) {
+        double *xl = park(l);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) y[s] = xl[s * 64];
+        const bool moved = any_differs(z, y);
+        const double lpPy = logpost_of(l, 0, z);
+        const double lpQy = logpost_of(l, 1, z);
+        const double lpPx = lpP.get(l), lpQx = lpQ.get(l);
+        const double log_ratio = ((lpPy + lpQx) - lpQy) - lpPx;
+        const double u = ymc_uniform_cached(uc, a.seed, chain, t);
+        const bool acc = ymc_accept(log_ratio, moved, ymc_finite(lpPy) && ymc_finite(lpQy), u, st);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            z[s] = acc ? z[s] : y[s];
+            xl[s * 64] = z[s];
+        }
+        lpP.set(l, acc ? lpPy : lpPx);
+        lpQ.set(l, acc ? lpQy : lpQx);
+        return acc;
+    };
+
+#pragma unroll 1
+    for (uint32_t n = 0; n < a.nsteps; ++n) {
+        uint64_t t = (a.t0 + n) * a.cost_top;
+        PerLevel<int> cnt = {0, 0, 0, 0};
+        int from = E - 2; /* the levels below the top are entered afresh: MLDAProposal.generate_proposal, mlda.py:100-116 */
+#pragma unroll 1
+        for (;;) {
+            /* MetropolisHastings.run of levels from .. 1 starts at z (metropolisHastings.py:103-110) */
+#pragma unroll 1
+            for (int l = from; l >= 1; --l) {
+                lpP.set(l, logpost_of(l, 0, z));
+                lpQ.set(l, logpost_of(l, 1, z));
+                double *xl = park(l);
+#pragma unroll
+                for (int s = 0; s < KS; ++s) xl[s * 64] = z[s];
+                cnt.set(l, 0);
+            }
+            /* level 0: a random walk of steps[0] transitions on P[0] (mrw.py:41-57) */
+            double lp0 = logpost0(z);
+            uint64_t acc0 = 0;
+#pragma unroll 1
+            for (int sub = 0; sub < steps.v0; ++sub) {
+#pragma unroll
+                for (int q = 0; q < KS / 2; ++q) {
+                    double xi0, xi1;
+                    ymc_draw_normal_pair(a.seed, chain, t, 4u * (uint32_t)q + pair_of_g, &xi0, &xi1);
+                    swap_odd_even_rows(xi0, xi1);
+                    y[2 * q] = z[2 * q] + sigma[8 * q + g] * xi0;
+                    y[2 * q + 1] = z[2 * q + 1] + sigma[8 * q + 4 + g] * xi1;
+                }
+                const bool moved = any_differs(y, z);
+                const double lpy = logpost0(y);
+                const double u = ymc_uniform_cached(uc, a.seed, chain, t);
+                const bool acc = ymc_accept(lpy - lp0, moved, ymc_finite(lpy), u, st);
+#pragma unroll
+                for (int s = 0; s < KS; ++s) z[s] = acc ? y[s] : z[s];
+                lp0 = acc ? lpy : lp0;
+                acc0 += acc ? 1u : 0u;
+                ++t;
+            }
+            lacc.v0 += acc0;
+            /* upwards: every level whose run below has ended decides; a level with steps left goes down again */
+            int l = 1;
+#pragma unroll 1
+            for (; l < E - 1; ++l) {
+                const bool acc = decide(l, t);
+                ++t;
+                lacc.set(l, lacc.get(l) + (acc ? 1u : 0u));
+                const int done = cnt.get(l) + 1;
+                cnt.set(l, done);
+                if (done < steps.get(l)) break;
+            }
+            if (l == E - 1) break;
+            from = l - 1;
+        }
+        const bool acc = decide(E - 1, t);
+        accepted += acc ? 1u : 0u;
+
+        const bool rec = clk.due();
+        if (rec && a.traj) {
+            double *row = a.traj + (((uint64_t)clk.row * nct + tile) * KS) * 64 + lane;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) row[s * 64] = z[s];
+        }
+        if (live && g == 0) {
+            if (a.acc) a.acc[(uint64_t)n * a.K + k] = acc ? 1 : 0;
+            if (rec && a.lp_out) a.lp_out[(uint64_t)clk.row * a.K + k] = lpP.get(E - 1);
+        }
+        if (rec) clk.wrote();
+    }
+
+    if (live) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int j = 4 * s + g;
+            if (j < d) a.x[k * d + j] = z[s];
+        }
+        if (g == 0) {
+            a.lp[k] = lpP.get(E - 1);
+            a.lpc[k] = lpQ.get(E - 1);
+            a.acc_count[k] = accepted;
+            a.status[k] = st;
+            for (int e = 0; e < E - 1; ++e) a.level_acc[(uint64_t)e * a.K + k] = lacc.get(e);
+        }
+    }
+}
+
+template <int KS>
+hipError_t launch_as(const TileArgs &a, hipStream_t s)
+{
+    const size_t lds = ymc_tile_lds_bytes(KS, a.MT);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_tile_nested_kernel<KS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const uint64_t nct = (a.K + 15) / 16;
+    const unsigned grid = (unsigned)((nct + kNestWaves - 1) / kNestWaves);
+    hipLaunchKernelGGL((linear_tile_nested_kernel<KS>), dim3(grid), dim3(kNestThreads), lds, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t ymc_launch_linear_tile_nested(int KS, const TileArgs &a, hipStream_t s)
+{
+    if (a.E < 2 || a.E > YMC_MAX_LEVELS || !a.levels || !a.x_tiled || !a.level_acc || !a.lpc) return hipErrorInvalidValue;
+    switch (KS) {
+    case 4: return launch_as<4>(a, s);
+    case 8: return launch_as<8>(a, s);
+    case 16: return launch_as<16>(a, s);
+    case 32: return launch_as<32>(a, s);
+    default: return hipErrorInvalidValue;
+    }
+}
