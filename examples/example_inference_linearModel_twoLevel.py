@@ -50,11 +50,16 @@ proposalCov = IIDCovarianceMatrix(DIM, 0.5)
 init = ParameterVector(np.zeros(DIM))
 
 
-def report(name, mc, burnin=500):
+def report(name, mc, burnin=None):
+    burnin = min(500, nSteps // 4) if burnin is None else burnin
     states = mc.chain.ensemble_trajectory
-    iat = np.atleast_1d(mc.integrated_autocorrelation('mean', burnin=burnin))
-    print(f"{name:28s} acceptance {mc.diagnostics.global_acceptance_rate():.3f}   posterior mean "
-          f"{states[burnin:].reshape(-1, DIM).mean(axis=0)}   median IAT {np.median(iat):.0f}")
+    # a chain that did not move after the burn-in has no autocorrelation (short runs of a sampler with a poor
+    # surrogate): ask for the marker instead of the error and say how many there were
+    iat = np.atleast_1d(mc.integrated_autocorrelation('mean', burnin=burnin, allowUndefined=True))
+    moved = iat != np.iinfo(np.int32).min
+    stuck = "" if moved.all() else f"   ({int((~moved).sum())} chains did not move after the burn-in)"
+    print(f"{name:28s} acceptance rate {mc.diagnostics.global_acceptance_rate():.3f}   posterior mean "
+          f"{states[burnin:].reshape(-1, DIM).mean(axis=0)}   median IAT {np.median(iat[moved]):.0f}{stuck}")
 
 
 mrw = MRWBuilder()
