@@ -78,9 +78,12 @@ typedef struct ymc_density_desc {
     /* DenseCovarianceMatrix (covariance.py:69-94) as the NOISE covariance (noise.py:21-22) or the PRIOR covariance
      * (gaussian.py:19-24): the INVERSE of its lower Cholesky factor, [data_dim][data_dim] / [d][d] row-major
      * (entries above the diagonal are ignored), so that |r|^2 in the covariance's norm is |L^-1 r|^2.  NULL = the
-     * diagonal covariance of noise_precision / prior_precision.  Lane-kernel sizes only (d, data_dim <= 8);
-     * not with YMC_METHOD_PCN (its proposal draws from a diagonal prior) or YMC_METHOD_AEM2 (the reference's
-     * AEMNoise refuses non-diagonal noise, noise.py:30-33). */
+     * diagonal covariance of noise_precision / prior_precision.  At lane-kernel sizes (d, data_dim <= 8) the
+     * kernels form the norm per evaluation; beyond (POSTERIOR_LINEAR on the matrix cores, d <= 128) a dense NOISE
+     * covariance is whitened away when the problem is created -- A, b and the data rows are multiplied by L^-1
+     * once, |L^-1 (A v + b - D_i)|^2 = |(L^-1 A) v + L^-1 b - L^-1 D_i|^2 -- and ymc_forward_eval still returns
+     * A v + b; a dense PRIOR covariance is lane-size only.  Not with YMC_METHOD_PCN (its proposal draws from a
+     * diagonal prior) or YMC_METHOD_AEM2 (the reference's AEMNoise refuses non-diagonal noise, noise.py:30-33). */
     const double *noise_chol_inv;
     const double *prior_chol_inv;
 } ymc_density_desc;

@@ -108,15 +108,44 @@ def _posterior_common(kind, dim, data, noise_precision, prior_mean, prior_precis
                 prior_precision=_f64(prior_precision).reshape(-1))
 
 
-def dense_covariances(p, noise_cov=None, prior_cov=None):
+LANE_DMAX = LANE_MMAX = 8   # include/ymc.h: the lane kernels' largest parameter / output dimension
+
+
+def dense_covariances(p, noise_cov=None, prior_cov=None, whiten=None):
     """Replace the diagonal noise / prior covariance of a posterior by a dense one (DenseCovarianceMatrix,
-    covariance.py:69-94): the inverse of its lower Cholesky factor (ymc_whitened_norm_sq)."""
+    covariance.py:69-94): the inverse of its lower Cholesky factor (ymc_whitened_norm_sq).  Beyond the lane
+    kernels' sizes (`whiten`: None = by size, as the product's lowering decides for a single density) a linear
+    problem with a dense NOISE covariance is whitened instead: A, b and the data rows are multiplied by L^-1
+    (ymc_lower_times) and the noise becomes the identity; `forward` still returns A x + b."""
     p = dict(p)
-    for key, cov in (("noise_linv", noise_cov), ("prior_linv", prior_cov)):
-        if cov is not None:
-            L = np.linalg.cholesky(_f64(cov))
-            from scipy.linalg import solve_triangular
-            p[key] = np.tril(solve_triangular(L, np.eye(L.shape[0]), lower=True))
+    from scipy.linalg import solve_triangular
+
+    def inverse_factor(cov):
+        L = np.linalg.cholesky(_f64(cov))
+        return np.ascontiguousarray(np.tril(solve_triangular(L, np.eye(L.shape[0]), lower=True)))
+
+    if prior_cov is not None:
+        p["prior_linv"] = inverse_factor(prior_cov)
+    if noise_cov is not None:
+        linv = inverse_factor(noise_cov)
+        big = p["kind"] == POST_LINEAR and (p["dim"] > LANE_DMAX or p["data_dim"] > LANE_MMAX)
+        if big if whiten is None else whiten:
+            assert p["kind"] == POST_LINEAR
+            m = p["data_dim"]
+
+            def times(src, cols):
+                src = np.ascontiguousarray(_f64(src).reshape(m, cols))
+                out = np.empty_like(src)
+                lib().ymo_lower_times(_ptr(linv), C.c_int32(m), _ptr(src), C.c_int32(cols), _ptr(out))
+                return out
+
+            p["fwd_matrix_raw"], p["fwd_shift_raw"] = p["fwd_matrix"], p["fwd_shift"]
+            p["fwd_matrix"] = times(p["fwd_matrix"], p["dim"])
+            p["fwd_shift"] = times(p["fwd_shift"], 1).reshape(-1)
+            p["data"] = np.stack([times(row, 1).reshape(-1) for row in _f64(p["data"])])
+            p["noise_precision"] = np.ones(m)
+        else:
+            p["noise_linv"] = linv
     return p
 
 
@@ -234,6 +263,8 @@ def logdensity(problem, x):
 
 
 def forward(problem, x):
+    if "fwd_matrix_raw" in problem:   # a whitened problem (dense_covariances): the map the user described
+        problem = dict(problem, fwd_matrix=problem["fwd_matrix_raw"], fwd_shift=problem["fwd_shift_raw"])
     d, keep = _lower(problem)
     x = _f64(x).reshape(-1, problem["dim"])
     m = problem["n_data"] * 2 if problem["kind"] == POST_LV else problem["data_dim"]

@@ -939,6 +939,13 @@ void ymo_aem_advance(const ymo_density *fine, const ymo_density *coarse, const d
     }
 }
 
+/* ymc_lower_times (ymc_numerics.h): the whitening of a linear problem with a dense noise covariance beyond the
+ * lane kernels' sizes, shared with the product's lowering so that both hold the same matrices */
+void ymo_lower_times(const double *linv, int32_t m, const double *src, int32_t cols, double *out)
+{
+    ymc_lower_times(linv, m, src, cols, out);
+}
+
 void ymo_linear_summary(const double *data, const double *prec, int32_t n, int32_t m, double *dbar,
                         double *nprec, double *cst)
 {

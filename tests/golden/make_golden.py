@@ -916,6 +916,64 @@ def fixture_f15():
     print("F15", acc.mean(), lacc.mean())
 
 
+def fixture_f19():
+    """A dense NOISE covariance beyond the lane kernels' sizes (d = 24 parameters, 24 outputs, 5 data rows;
+    CentredGaussianNoise over DenseCovarianceMatrix, covariance.py:69-94, noise.py:21-22): (a) the random walk,
+    (b) two-level delayed acceptance over a hierarchy of two such models (mlda.py:315-335).  The reference
+    solves two triangular systems per norm with LAPACK; the ensemble whitens the problem once (ymc_lower_times).
+    Pinned: decisions, chains, log-posteriors (to rounding)."""
+    from yagremcmc.statistics.modelHierarchy import BayesianRegressionModelHierarchy
+    from yagremcmc.utility.hierarchy import Hierarchy, SharedComponent
+    d, n_data = 24, 5
+    A, b, _, _ = linear_problem(d, n_data, 19)
+    z, _ = oracle.rng_fill(1919, 0, 3 * d + 8, 0, 1, d, uniforms=False)
+    z = z[0]
+    Bn = z[:d] * 0.12
+    noise_cov = Bn @ Bn.T + 0.25 * np.eye(d)
+    Ln = np.linalg.cholesky(noise_cov)
+    theta_true = z[d]
+    data = np.array([A @ theta_true + b + Ln @ z[d + 1 + i] for i in range(n_data)])
+    A_c = A + 0.03 * z[d + 8:2 * d + 8] / np.sqrt(d)
+    b_c = b + 0.05 * z[2 * d + 8]
+    prior_mean, prior_var, prop_var = np.zeros(d), 5.0, 4e-3
+    prior = Gaussian(ParameterVector(prior_mean.copy()), IIDCovarianceMatrix(d, prior_var))
+    noise = CentredGaussianNoise(DenseCovarianceMatrix(noise_cov))
+    lik_f = AdditiveGaussianNoiseLikelihood(Data(data), ForwardModel(ExampleLinearModelSolver(A, b)), noise)
+    lik_c = AdditiveGaussianNoiseLikelihood(Data(data), ForwardModel(ExampleLinearModelSolver(A_c, b_c)), noise)
+    cov = IIDCovarianceMatrix(d, prop_var)
+    seed, K, n = 20250119, 8, 301
+    traj, acc, lp = run_mrw_model(BayesianRegressionModel(lik_f, prior), seed, K, n, cov, np.zeros(d))
+    out = dict(seed=seed, n_states=n, A=A, b=b, A_coarse=A_c, b_coarse=b_c, data=data, noise_cov=noise_cov,
+               prior_mean=prior_mean, prior_precision=np.reciprocal(np.full(d, prior_var)), sigma=sigma_of(cov),
+               x0=np.zeros((K, d)), traj=traj, acc=acc, logpost=lp)
+    # (b) two levels
+    model = BayesianRegressionModelHierarchy(Hierarchy([lik_c, lik_f]), SharedComponent(prior, 2))
+    K2, n2, S = 6, 151, 3
+    traj2 = np.empty((n2, K2, d))
+    acc2 = np.empty((n2 - 1, K2), dtype=np.uint8)
+    sub2 = np.empty((n2 - 1, S, K2), dtype=np.uint8)
+    lp2 = np.empty((n2, K2))
+    for k in range(K2):
+        bld = MLDABuilder()
+        bld.baseProposalCovariance = cov
+        bld.subChainLengths = [S]
+        bld.bayesModel = model
+        bld.surrogateDiagnostics = [AcceptanceRateDiagnostics()]
+        mc = bld.build_method()
+        rp = Replay(seed + 1, k, d, (n2 - 1) * (S + 1), sub_chain_length=S)
+        rp.install()
+        mark_fine_level(mc, rp)
+        mc.run(n2, ParameterVector(np.zeros(d)), verbose=False)
+        traj2[:, k, :] = np.array(mc.chain.trajectory)
+        acc2[:, k] = mc.diagnostics._decisions
+        sub2[:, :, k] = np.array(mc.surrogate(0).diagnostics._decisions, dtype=np.uint8).reshape(n2 - 1, S)
+        lp2[:, k] = eval_log_along(mc.target, traj2[:, k, :], lambda s_: ParameterVector(np.array(s_)))
+    out.update(ml_seed=seed + 1, ml_n_states=n2, ml_S=S, ml_x0=np.zeros((K2, d)), ml_traj=traj2, ml_acc=acc2,
+               ml_sub_acc=sub2, ml_logpost=lp2)
+    np.savez_compressed(os.path.join(HERE, "f19_dense_noise_d24.npz"), **out)
+    print("F19", acc.mean(), acc2.mean(), sub2.mean())
+
+
 def fixture_f18(name="f18_mlda_nested2_linear_d128.npz", d=128, n_models=3, seed=20250118, K=6, n=101,
                 sub_lengths=(3, 4), perturb=0.02, prop_var=1.1e-3):
     """Delayed acceptance over a hierarchy of THREE (and, second fixture, FIVE) linear models at large dimension
@@ -983,7 +1041,7 @@ def fixture_f18(name="f18_mlda_nested2_linear_d128.npz", d=128, n_models=3, seed
 
 def main():
     which = sys.argv[1:] or ["f1", "f2", "f2b", "f3", "f3b", "f4", "f5", "f7", "f8", "f9", "f10", "f11", "f12", "f13",
-                             "f14", "f15", "f16", "f17", "f18"]
+                             "f14", "f15", "f16", "f17", "f18", "f19"]
     if "f1" in which:
         fixture_f1()
     if "f2" in which:
@@ -1021,6 +1079,8 @@ def main():
         fixture_f16()
     if "f17" in which:
         fixture_f17()
+    if "f19" in which:
+        fixture_f19()
     if "f18" in which:
         fixture_f18()
         fixture_f18("f18b_mlda_nested4_linear_d24.npz", d=24, n_models=5, seed=20250119, K=6, n=81,

@@ -708,6 +708,52 @@ def test_dense_noise_and_prior_through_the_builders_f15(golden):
     assert mc.target.evaluate_log(ParameterVector(mc.chain.ensemble_trajectory[n, k].copy())) == mc.log_posterior[n, k]
 
 
+def test_dense_noise_beyond_the_lane_sizes_through_the_builders_f19(golden):
+    """MRWBuilder / MLDABuilder over d = 24 linear models whose noise is CentredGaussianNoise(DenseCovarianceMatrix)
+    (24 x 24): the chains of the live reference (fixture F19), on the matrix-core kernels; the posterior object's
+    own evaluate_log and the solver's forward value go through the same lowering."""
+    from yagremcmc_amd.chain.diagnostics import AcceptanceRateDiagnostics
+    from yagremcmc_amd.chain.method.mlda import MLDABuilder
+    from yagremcmc_amd.chain.method.mrw import MRWBuilder
+    from yagremcmc_amd.exampleSetup import ExampleLinearModelSolver
+    from yagremcmc_amd.model.forwardModel import ForwardModel
+    from yagremcmc_amd.parameter.vector import ParameterVector
+    from yagremcmc_amd.statistics.bayesModel import BayesianRegressionModel
+    from yagremcmc_amd.statistics.covariance import DenseCovarianceMatrix, IIDCovarianceMatrix
+    from yagremcmc_amd.statistics.data import Data
+    from yagremcmc_amd.statistics.gaussian import Gaussian
+    from yagremcmc_amd.statistics.likelihood import AdditiveGaussianNoiseLikelihood
+    from yagremcmc_amd.statistics.modelHierarchy import BayesianRegressionModelHierarchy
+    from yagremcmc_amd.statistics.noise import CentredGaussianNoise
+    from yagremcmc_amd.utility.hierarchy import Hierarchy, SharedComponent
+    g = golden("f19_dense_noise_d24.npz")
+    d = 24
+    noise = CentredGaussianNoise(DenseCovarianceMatrix(g["noise_cov"]))
+    prior = Gaussian(ParameterVector(np.array(g["prior_mean"])), IIDCovarianceMatrix(d, 5.0))
+    lik_f = AdditiveGaussianNoiseLikelihood(Data(g["data"]), ForwardModel(ExampleLinearModelSolver(g["A"], g["b"])), noise)
+    lik_c = AdditiveGaussianNoiseLikelihood(Data(g["data"]), ForwardModel(ExampleLinearModelSolver(g["A_coarse"], g["b_coarse"])), noise)
+    b = MRWBuilder()
+    b.bayesModel = BayesianRegressionModel(lik_f, prior)
+    b.proposalCovariance = IIDCovarianceMatrix(d, 4e-3)
+    b.nChains, b.seed, b.recordLogPosterior = g["x0"].shape[0], int(g["seed"]), True
+    mc = b.build_method()
+    mc.run(int(g["n_states"]), ParameterVector(np.zeros(d)), verbose=False)
+    assert np.array_equal(mc.accept_decisions, g["acc"]) and np.array_equal(mc.chain.ensemble_trajectory, g["traj"])
+    assert np.abs(mc.log_posterior - g["logpost"]).max() <= 1e-12 * np.abs(g["logpost"]).max()
+    k, n = 3, 200
+    assert mc.target.evaluate_log(ParameterVector(mc.chain.ensemble_trajectory[n, k].copy())) == mc.log_posterior[n, k]
+    b = MLDABuilder()
+    b.bayesModel = BayesianRegressionModelHierarchy(Hierarchy([lik_c, lik_f]), SharedComponent(prior, 2))
+    b.baseProposalCovariance = IIDCovarianceMatrix(d, 4e-3)
+    b.subChainLengths = [int(g["ml_S"])]
+    b.surrogateDiagnostics = [AcceptanceRateDiagnostics()]
+    b.nChains, b.seed, b.recordSubChain = g["ml_x0"].shape[0], int(g["ml_seed"]), True
+    mc = b.build_method()
+    mc.run(int(g["ml_n_states"]), ParameterVector(np.zeros(d)), verbose=False)
+    assert np.array_equal(mc.accept_decisions, g["ml_acc"]) and np.array_equal(mc.sub_chain_decisions, g["ml_sub_acc"])
+    assert np.array_equal(mc.chain.ensemble_trajectory, g["ml_traj"])
+
+
 def test_iat_of_a_stuck_chain_is_reported_not_invented():
     """A chain that never moves (or was flagged non-finite and froze) has a constant series: c0 = 0 and the
     autocorrelation is 0 / 0.  The device reports IAT_UNDEFINED for it; the Python layer raises unless asked."""

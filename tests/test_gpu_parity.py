@@ -766,6 +766,92 @@ def test_dense_covariances_other_shapes_vs_oracle(ffi, ctx, d, m, nd, method):
         _same_as_oracle(dev, e, out)
 
 
+def test_f19_dense_noise_d24_matrix_cores(ffi, ctx, golden):
+    """A dense 24 x 24 noise covariance on the matrix-core path: the library whitens the problem once
+    (ymc_lower_times) and runs the diagonal kernels.  Random walk and two-level delayed acceptance: the LIVE
+    reference's decisions and chains, log-posteriors to rounding, == oracle bit for bit; ymc_forward_eval still
+    returns A x + b."""
+    from yagremcmc_amd import lowering
+    g = golden("f19_dense_noise_d24.npz")
+    d = 24
+    common = dict(data=g["data"], noise_precision=np.ones(d), prior_mean=g["prior_mean"], prior_precision=g["prior_precision"])
+    fine = _dense_low(ffi, ffi.POSTERIOR_LINEAR, d, common, g["noise_cov"], None, fwd_matrix=g["A"], fwd_shift=g["b"])
+    coarse = _dense_low(ffi, ffi.POSTERIOR_LINEAR, d, common, g["noise_cov"], None, fwd_matrix=g["A_coarse"], fwd_shift=g["b_coarse"])
+    base = lambda A, b: o.posterior_linear(A, b, g["data"], np.ones(d), g["prior_mean"], g["prior_precision"])
+    of = o.dense_covariances(base(g["A"], g["b"]), noise_cov=g["noise_cov"])
+    oc = o.dense_covariances(base(g["A_coarse"], g["b_coarse"]), noise_cov=g["noise_cov"])
+    n = int(g["n_states"])
+    dev = _device_run(ffi, ctx, fine, g["sigma"], g["x0"], int(g["seed"]), n - 1, splits=2)
+    _same_as_reference(dev, g)
+    e = o.Ensemble(of, g["sigma"], g["x0"], int(g["seed"]))
+    _same_as_oracle(dev, e, e.advance(n - 1))
+    n2, S = int(g["ml_n_states"]), int(g["ml_S"])
+    dev = _device_run(ffi, ctx, fine, g["sigma"], g["ml_x0"], int(g["ml_seed"]), n2 - 1, method=ffi.METHOD_MLDA2, sur=coarse,
+                      S=S, splits=3)
+    _same_as_reference(dev, dict(acc=g["ml_acc"], traj=g["ml_traj"], logpost=g["ml_logpost"]))
+    assert np.array_equal(dev["sub_acc"], g["ml_sub_acc"])
+    e = o.Ensemble(of, g["sigma"], g["ml_x0"], int(g["ml_seed"]), surrogate=oc, sub_chain_length=S)
+    out = e.advance(n2 - 1, want_sub=True)
+    _same_as_oracle(dev, e, out)
+    assert np.array_equal(dev["sub_acc"], out["sub_acc"])
+    prob = lowering.make_problem(ctx, ffi.METHOD_MRW, fine, g["sigma"])
+    x = np.random.default_rng(0).standard_normal((20, d))
+    assert np.array_equal(prob.forward(x), o.forward(of, x))
+    assert np.allclose(prob.forward(x), x @ g["A"].T + g["b"], rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("d,m,nd,K,method", [(128, 128, 3, 40, "mrw"), (9, 3, 2, 33, "pcn"), (16, 40, 1, 64, "mlda2"),
+                                             (5, 30, 4, 50, "mrw"), (40, 20, 2, 129, "nested")])
+def test_tile_kernel_dense_noise_other_shapes(ffi, ctx, d, m, nd, K, method):
+    """Dense noise covariances on every matrix-core sampler that admits them (the adaptive error model refuses
+    non-diagonal noise like the reference's AEMNoise), at ragged shapes; levels with their own covariances."""
+    rng = np.random.default_rng(1900 + d + m)
+
+    def model(scale):
+        B = rng.normal(size=(m, m)) / np.sqrt(m)
+        nc = B @ B.T + 0.4 * np.eye(m)
+        g = dict(data=rng.normal(size=(nd, m)), noise_precision=np.ones(m), prior_mean=rng.normal(size=d) * 0.1,
+                 prior_precision=rng.uniform(0.1, 2, size=d))
+        A, b = scale * rng.normal(size=(m, d)) / np.sqrt(d), rng.normal(size=m)
+        p = o.dense_covariances(o.posterior_linear(A, b, g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"]),
+                                noise_cov=nc, whiten=True)
+        return _dense_low(ffi, ffi.POSTERIOR_LINEAR, d, g, nc, None, fwd_matrix=A, fwd_shift=b), p
+
+    sigma, x0 = rng.uniform(0.02, 0.08, size=d), rng.normal(size=(K, d))
+    if method == "mrw":
+        (lf, pf), = [model(1.0)]
+        dev = _device_run(ffi, ctx, lf, sigma, x0, 78, 40, chain0=7, splits=2)
+        e = o.Ensemble(pf, sigma, x0, 78, chain0=7)
+        _same_as_oracle(dev, e, e.advance(40))
+    elif method == "pcn":
+        lf, pf = model(1.0)
+        lf.desc.likelihood_only, pf["likelihood_only"] = 1, 1
+        prior_sigma = np.sqrt(np.reciprocal(pf["prior_precision"]))
+        from yagremcmc_amd import lowering
+        prob = lowering.make_problem(ctx, ffi.METHOD_PCN, lf, prior_sigma, pcn_step_size=0.02)
+        run = ffi.Run(prob, 78, K, x0, 40, _flags(ffi, True), 7)
+        run.advance(40)
+        dev = dict(traj=run.trajectory(), acc=run.accept(), logpost=run.logpost(), summary=run.summary(), state=run.state())
+        e = o.Ensemble(pf, prior_sigma, x0, 78, chain0=7, pcn_step_size=0.02)
+        _same_as_oracle(dev, e, e.advance(40))
+    elif method == "mlda2":
+        (lf, pf), (lc, pc_) = model(1.0), model(0.9)
+        dev = _device_run(ffi, ctx, lf, sigma, x0, 78, 30, method=ffi.METHOD_MLDA2, sur=lc, S=3, chain0=7, splits=2)
+        e = o.Ensemble(pf, sigma, x0, 78, chain0=7, surrogate=pc_, sub_chain_length=3)
+        out = e.advance(30, want_sub=True)
+        _same_as_oracle(dev, e, out)
+        assert np.array_equal(dev["sub_acc"], out["sub_acc"])
+    else:
+        models = [model(1.0 - 0.03 * i) for i in range(3)]
+        (lt, pt), surs = models[-1], models[:-1]
+        dev = _nested_device_run(ffi, ctx, lt, [l for l, _ in surs], [2, 3], sigma, x0, 78, 20, splits=2, chain0=7)
+        P, Q, steps = o.nested_levels([p for _, p in surs], [2, 3], pt)
+        e = o.NestedEnsemble(P, Q, steps, sigma, x0, 78, chain0=7)
+        out = e.advance(20)
+        _same_as_oracle(dev, e, out)
+        assert np.array_equal(dev["level_acc"], e.level_acc)
+
+
 def _dense_tile_run(ffi, ctx, low, L, x0, seed, nsteps, chain0=0, splits=2):
     from yagremcmc_amd import lowering
     d = x0.shape[1]

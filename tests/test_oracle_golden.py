@@ -356,6 +356,41 @@ def test_f15_dense_noise_and_prior_covariances(golden):
     assert np.allclose(got, want, rtol=1e-12, atol=0)
 
 
+def _f19_problems(g):
+    base = lambda A, b: o.posterior_linear(A, b, g["data"], np.ones(g["data"].shape[1]), g["prior_mean"], g["prior_precision"])
+    fine = o.dense_covariances(base(g["A"], g["b"]), noise_cov=g["noise_cov"])
+    coarse = o.dense_covariances(base(g["A_coarse"], g["b_coarse"]), noise_cov=g["noise_cov"])
+    return fine, coarse
+
+
+def test_f19_dense_noise_covariance_beyond_the_lane_sizes(golden):
+    """A dense 24 x 24 noise covariance over a d = 24 linear model (noise.py:21-22, covariance.py:69-94): the
+    problem is whitened once (ymc_lower_times) and runs as a diagonal one.  The live reference's decisions and
+    chains of a random walk and of two-level delayed acceptance over two such models; log-posteriors to
+    rounding; `forward` still returns A x + b."""
+    g = golden("f19_dense_noise_d24.npz")
+    fine, coarse = _f19_problems(g)
+    assert "fwd_matrix_raw" in fine and np.array_equal(fine["noise_precision"], np.ones(24))
+    n = int(g["n_states"])
+    e = o.Ensemble(fine, g["sigma"], g["x0"], int(g["seed"]))
+    out = e.advance(n - 1)
+    _check(out, g, n)
+    n2, S = int(g["ml_n_states"]), int(g["ml_S"])
+    e = o.Ensemble(fine, g["sigma"], g["ml_x0"], int(g["ml_seed"]), surrogate=coarse, sub_chain_length=S)
+    out = e.advance(n2 - 1, want_sub=True)
+    _check(out, dict(acc=g["ml_acc"], traj=g["ml_traj"], logpost=g["ml_logpost"]), n2)
+    assert np.array_equal(out["sub_acc"], g["ml_sub_acc"])
+    assert 0.3 < g["acc"].mean() < 0.8 and 0.3 < g["ml_sub_acc"].mean() < 0.8
+    x = np.random.default_rng(0).standard_normal((20, 24))
+    assert np.allclose(o.forward(fine, x), x @ g["A"].T + g["b"], rtol=1e-13, atol=1e-13)
+    # the whitened log-likelihood against NumPy: -0.5 sum_i (F - D_i) . Sigma^-1 (F - D_i)
+    like = dict(fine, likelihood_only=1)
+    got, _ = o.logdensity(like, x)
+    F = x @ g["A"].T + g["b"]
+    want = np.array([-0.5 * sum((f - D) @ np.linalg.solve(g["noise_cov"], f - D) for D in g["data"]) for f in F])
+    assert np.allclose(got, want, rtol=1e-11, atol=0)
+
+
 def test_f8_preconditioned_crank_nicolson(golden):
     """pcn.py:9-57 on the Lotka-Volterra likelihood with a centred Gaussian prior"""
     g = golden("f8_pcn_lotka_volterra.npz")

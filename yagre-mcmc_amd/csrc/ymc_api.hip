@@ -101,6 +101,11 @@ struct DensityHost {
     std::vector<double> mean, whiten, data, noise_prec, prior_mean, prior_prec, A, b, design;
     std::vector<double> dbar, nprec; /* POSTERIOR_LINEAR: ymc_linear_data_summary */
     std::vector<double> noise_linv, prior_linv; /* dense covariances: inverse Cholesky factors (empty: diagonal) */
+    /* matrix-core path with a dense noise covariance: the problem is whitened when it is lowered (A, b, data
+     * hold L^-1 A, L^-1 b, L^-1 D_i and the noise is the identity, ymc_lower_times); the forward map a caller
+     * asks for is still A v + b */
+    std::vector<double> A_raw, b_raw;
+    size_t off_A_raw = 0, off_b_raw = 0;
     size_t off_nlinv = 0, off_plinv = 0;
     double lik_const = 0.0;
     DeviceBuf dev;  /* one allocation: data | noise_prec | prior_mean | prior_prec | A | b | design | dbar | nprec */
@@ -238,9 +243,12 @@ int lower_density(ymc_ctx *ctx, const ymc_density_desc &in, DensityHost &out, in
         YMC_TRY(copy_array(out.noise_prec, in.noise_precision, m, "noise_precision"));
         YMC_TRY(copy_array(out.prior_mean, in.prior_mean, d, "prior_mean"));
         YMC_TRY(copy_array(out.prior_prec, in.prior_precision, d, "prior_precision"));
+        if (big && in.prior_chol_inv)
+            return fail(YMC_ERR_UNSUPPORTED, "a dense prior covariance is lowered for the lane kernels (parameter and "
+                                             "data dimension <= %d)", YMC_LANE_DMAX);
+        if (big && in.noise_chol_inv && in.kind != YMC_DENSITY_POSTERIOR_LINEAR)
+            return fail(YMC_ERR_UNSUPPORTED, "a dense noise covariance at this size needs a linear forward map");
         if (in.noise_chol_inv || in.prior_chol_inv) {
-            if (big) return fail(YMC_ERR_UNSUPPORTED, "dense noise / prior covariances are lowered for the lane kernels "
-                                                      "(parameter and data dimension <= %d)", YMC_LANE_DMAX);
             auto lower_tri = [&](std::vector<double> &dst, const double *src, size_t n, const char *what) -> int {
                 YMC_TRY(copy_array(dst, src, n * n, what));
                 for (size_t i = 0; i < n; ++i) {
@@ -266,6 +274,21 @@ int lower_density(ymc_ctx *ctx, const ymc_density_desc &in, DensityHost &out, in
             }
             YMC_TRY(copy_array(out.A, in.fwd_matrix, m * d, "fwd_matrix"));
             YMC_TRY(copy_array(out.b, in.fwd_shift, m, "fwd_shift"));
+            if (big && !out.noise_linv.empty()) {
+                /* whiten the problem (ymc_numerics.h, ymc_lower_times); the lane form of the norm is not used here */
+                const std::vector<double> &Li = out.noise_linv;
+                out.A_raw = out.A;
+                out.b_raw = out.b;
+                ymc_lower_times(Li.data(), (int32_t)m, out.A_raw.data(), d, out.A.data());
+                ymc_lower_times(Li.data(), (int32_t)m, out.b_raw.data(), 1, out.b.data());
+                std::vector<double> row(m);
+                for (size_t i = 0; i < nd; ++i) {
+                    ymc_lower_times(Li.data(), (int32_t)m, out.data.data() + i * m, 1, row.data());
+                    std::copy(row.begin(), row.end(), out.data.begin() + i * m);
+                }
+                std::fill(out.noise_prec.begin(), out.noise_prec.end(), 1.0);
+                out.noise_linv.clear();
+            }
             out.dbar.resize(m);
             out.nprec.resize(m);
             ymc_linear_data_summary(out.data.data(), out.noise_prec.data(), in.n_data, in.data_dim, out.dbar.data(),
@@ -294,6 +317,8 @@ int lower_density(ymc_ctx *ctx, const ymc_density_desc &in, DensityHost &out, in
         put(out.nprec, out.off_nprec);
         put(out.noise_linv, out.off_nlinv);
         put(out.prior_linv, out.off_plinv);
+        put(out.A_raw, out.off_A_raw);
+        put(out.b_raw, out.off_b_raw);
         YMC_TRY(out.dev.alloc(blob.size() * sizeof(double)));
         YMC_HIP(hipMemcpy(out.dev.p, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice));
         break;
@@ -359,12 +384,14 @@ int eval_logdensity_dev(ymc_ctx *ctx, const ymc_problem *p, const DensityHost &h
     default: return fail(YMC_ERR_UNSUPPORTED, "parameter dimension %d has no kernel", D_); \
     }
 
-BigLinearArgs big_view(const DensityHost &h)
+/* raw_forward: the forward map as the caller described it (a whitened problem evaluates L^-1 (A v + b)) */
+BigLinearArgs big_view(const DensityHost &h, bool raw_forward = false)
 {
     BigLinearArgs b{};
     const double *base = h.dev.as<double>();
-    b.A = base + h.off_A;
-    b.b = base + h.off_b;
+    const bool raw = raw_forward && !h.A_raw.empty();
+    b.A = base + (raw ? h.off_A_raw : h.off_A);
+    b.b = base + (raw ? h.off_b_raw : h.off_b);
     b.dbar = base + h.off_dbar;
     b.nprec = base + h.off_nprec;
     b.lik_const = h.lik_const;
@@ -1586,7 +1613,7 @@ int ymc_forward_eval(ymc_ctx *ctx, const ymc_problem *problem, int which, uint64
     YMC_TRY(od.alloc(n * m * sizeof(double)));
     YMC_HIP(hipMemcpyAsync(xd.p, x, xd.bytes, hipMemcpyHostToDevice, ctx->stream));
     if (h.tile) {
-        YMC_HIP(ymc_launch_linear_big_eval(big_view(h), n, xd.as<double>(), nullptr, od.as<double>(), ctx->stream));
+        YMC_HIP(ymc_launch_linear_big_eval(big_view(h, true), n, xd.as<double>(), nullptr, od.as<double>(), ctx->stream));
     } else {
         YMC_DISPATCH_D(D, YMC_HIP(ymc_launch_forward<DD>(problem->kind, device_view<DD>(h), n, xd.as<double>(),
                                                           od.as<double>(), ctx->stream)));

@@ -530,6 +530,24 @@ YMC_FN double ymc_whitened_norm_sq(const double *linv, const double *r, int32_t 
 }
 
 /* ------------------------------------------------------------------------ */
+/* A dense NOISE covariance beyond the lane kernels' sizes (matrix-core       */
+/* path): |L^-1 (A v + b - D_i)|^2 = |(L^-1 A) v + L^-1 b - L^-1 D_i|^2, so the */
+/* problem is whitened ONCE when it is lowered -- A, b and the data rows are  */
+/* multiplied by L^-1 and the noise becomes the identity -- and the kernels   */
+/* run the diagonal case.  out[i][c] = sum_{k <= i} linv[i][k] src[k][c], one  */
+/* k-ordered fma chain per entry (host and CPU checker share this order).     */
+/* ------------------------------------------------------------------------ */
+YMC_FN void ymc_lower_times(const double *linv, int32_t m, const double *src, int32_t cols, double *out)
+{
+    for (int32_t i = 0; i < m; ++i)
+        for (int32_t c = 0; c < cols; ++c) {
+            double acc = 0.0;
+            for (int32_t k = 0; k <= i; ++k) acc = ymc_fma(linv[(int64_t)i * m + k], src[(int64_t)k * cols + c], acc);
+            out[(int64_t)i * cols + c] = acc;
+        }
+}
+
+/* ------------------------------------------------------------------------ */
 /* Lotka-Volterra flow (testSetup.py:96-99) and one step of classical RK4,  */
 /* the ensemble's integrator (the reference integrates adaptively with      */
 /* scipy's solve_ivp; agreement of the forward map is checked to 1e-3, so   */

@@ -86,7 +86,8 @@ def _diag_precision(cov, n, what):
 def _set_covariance(low, cov, n, what, prec_field, linv_field):
     """A noise / prior covariance on the descriptor: Diagonal / IID as its precision vector; a
     DenseCovarianceMatrix (covariance.py:69-94, recognised by its lower Cholesky factor `cholFactor_`) as the
-    inverse of that factor, so that the device forms |L^-1 r|^2 (ymc_whitened_norm_sq)."""
+    inverse of that factor, so that the device forms |L^-1 r|^2 (ymc_whitened_norm_sq; beyond the lane
+    kernels' sizes the library whitens a linear problem with it once, ymc_lower_times)."""
     L = getattr(cov, "cholFactor_", None)
     if L is None:
         low.set_array(prec_field, _diag_precision(cov, n, what))
@@ -95,7 +96,7 @@ def _set_covariance(low, cov, n, what, prec_field, linv_field):
     L = np.tril(np.asarray(L, dtype=np.float64))
     if L.shape != (n, n):
         raise ValueError(f"{what} covariance has dimension {L.shape[0]}, expected {n}")
-    if n > _ffi.LANE_DMAX:
+    if n > _ffi.LANE_DMAX and what != "noise":   # a dense NOISE covariance of a linear model is whitened away (ymc.h)
         raise UnsupportedPlugin(f"a dense {what} covariance is lowered up to dimension {_ffi.LANE_DMAX}, got {n}")
     from scipy.linalg import solve_triangular
     low.set_array(linv_field, np.tril(solve_triangular(L, np.eye(n), lower=True)))
