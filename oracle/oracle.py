@@ -116,7 +116,9 @@ def dense_covariances(p, noise_cov=None, prior_cov=None, whiten=None):
     covariance.py:69-94): the inverse of its lower Cholesky factor (ymc_whitened_norm_sq).  Beyond the lane
     kernels' sizes (`whiten`: None = by size, as the product's lowering decides for a single density) a linear
     problem with a dense NOISE covariance is whitened instead: A, b and the data rows are multiplied by L^-1
-    (ymc_lower_times) and the noise becomes the identity; `forward` still returns A x + b."""
+    (ymc_lower_times) and the noise becomes the identity; a dense PRIOR covariance becomes d more outputs of the
+    forward map there (rows Lp^-1, shift 0, "data" Lp^-1 mu, weight 1; the diagonal prior is switched off).
+    `forward` still returns A x + b."""
     p = dict(p)
     from scipy.linalg import solve_triangular
 
@@ -124,28 +126,43 @@ def dense_covariances(p, noise_cov=None, prior_cov=None, whiten=None):
         L = np.linalg.cholesky(_f64(cov))
         return np.ascontiguousarray(np.tril(solve_triangular(L, np.eye(L.shape[0]), lower=True)))
 
-    if prior_cov is not None:
-        p["prior_linv"] = inverse_factor(prior_cov)
+    big = p["kind"] == POST_LINEAR and (p["dim"] > LANE_DMAX or p["data_dim"] > LANE_MMAX)
+    big = big if whiten is None else whiten
+
+    def times(linv, src, cols):
+        n = linv.shape[0]
+        src = np.ascontiguousarray(_f64(src).reshape(n, cols))
+        out = np.empty_like(src)
+        lib().ymo_lower_times(_ptr(linv), C.c_int32(n), _ptr(src), C.c_int32(cols), _ptr(out))
+        return out
+
+    if big and (noise_cov is not None or prior_cov is not None):
+        assert p["kind"] == POST_LINEAR
+        p["fwd_matrix_raw"], p["fwd_shift_raw"], p["data_dim_raw"] = p["fwd_matrix"], p["fwd_shift"], p["data_dim"]
     if noise_cov is not None:
         linv = inverse_factor(noise_cov)
-        big = p["kind"] == POST_LINEAR and (p["dim"] > LANE_DMAX or p["data_dim"] > LANE_MMAX)
-        if big if whiten is None else whiten:
-            assert p["kind"] == POST_LINEAR
+        if big:
             m = p["data_dim"]
-
-            def times(src, cols):
-                src = np.ascontiguousarray(_f64(src).reshape(m, cols))
-                out = np.empty_like(src)
-                lib().ymo_lower_times(_ptr(linv), C.c_int32(m), _ptr(src), C.c_int32(cols), _ptr(out))
-                return out
-
-            p["fwd_matrix_raw"], p["fwd_shift_raw"] = p["fwd_matrix"], p["fwd_shift"]
-            p["fwd_matrix"] = times(p["fwd_matrix"], p["dim"])
-            p["fwd_shift"] = times(p["fwd_shift"], 1).reshape(-1)
-            p["data"] = np.stack([times(row, 1).reshape(-1) for row in _f64(p["data"])])
+            p["fwd_matrix"] = times(linv, p["fwd_matrix"], p["dim"])
+            p["fwd_shift"] = times(linv, p["fwd_shift"], 1).reshape(-1)
+            p["data"] = np.stack([times(linv, row, 1).reshape(-1) for row in _f64(p["data"])])
             p["noise_precision"] = np.ones(m)
         else:
             p["noise_linv"] = linv
+    if prior_cov is not None:
+        linv = inverse_factor(prior_cov)
+        if big:
+            d, nd = p["dim"], p["n_data"]
+            c = times(linv, p["prior_mean"], 1).reshape(-1)
+            p["fwd_matrix"] = np.vstack([_f64(p["fwd_matrix"]), linv])
+            p["fwd_shift"] = np.concatenate([_f64(p["fwd_shift"]), np.zeros(d)])
+            p["data"] = np.hstack([_f64(p["data"]), np.tile(c, (nd, 1))])
+            p["noise_precision"] = np.concatenate([_f64(p["noise_precision"]), np.full(d, 1.0 / nd)])
+            p["prior_precision"] = np.zeros(d)
+            p["data_dim"] = p["data_dim"] + d
+            p["lin_tail"] = (c, np.ones(d))   # the summary of the pseudo-observations, set exactly (_lower)
+        else:
+            p["prior_linv"] = linv
     return p
 
 
@@ -190,6 +207,9 @@ def _lower(p):
         dbar, nprec, cst = np.zeros(m), np.zeros(m), C.c_double(0.0)
         lib().ymo_linear_summary(d.data, d.noise_precision, C.c_int32(int(p["n_data"])), C.c_int32(m), _ptr(dbar),
                                  _ptr(nprec), C.byref(cst))
+        if "lin_tail" in p:   # a dense prior as pseudo-observations (dense_covariances): weight 1, "data" c, exactly
+            c, w = p["lin_tail"]
+            dbar[m - c.size:], nprec[m - c.size:] = c, w
         keep += [dbar, nprec]
         d.lin_dbar, d.lin_nprec, d.lin_const = _ptr(dbar), _ptr(nprec), cst.value
     return d, keep
@@ -263,8 +283,11 @@ def logdensity(problem, x):
 
 
 def forward(problem, x):
-    if "fwd_matrix_raw" in problem:   # a whitened problem (dense_covariances): the map the user described
-        problem = dict(problem, fwd_matrix=problem["fwd_matrix_raw"], fwd_shift=problem["fwd_shift_raw"])
+    if "fwd_matrix_raw" in problem:   # a whitened / extended problem (dense_covariances): the map the user described
+        m = problem["data_dim_raw"]
+        problem = dict(problem, fwd_matrix=problem["fwd_matrix_raw"], fwd_shift=problem["fwd_shift_raw"], data_dim=m,
+                       data=_f64(problem["data"])[:, :m], noise_precision=_f64(problem["noise_precision"])[:m])
+        problem.pop("lin_tail", None)
     d, keep = _lower(problem)
     x = _f64(x).reshape(-1, problem["dim"])
     m = problem["n_data"] * 2 if problem["kind"] == POST_LV else problem["data_dim"]

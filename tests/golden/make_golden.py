@@ -974,6 +974,33 @@ def fixture_f19():
     print("F19", acc.mean(), acc2.mean(), sub2.mean())
 
 
+def fixture_f20():
+    """Dense PRIOR and dense NOISE covariance beyond the lane kernels' sizes (d = 20 parameters, 20 outputs, 4
+    data rows; Gaussian / CentredGaussianNoise over DenseCovarianceMatrix, gaussian.py:19-24, noise.py:21-22,
+    covariance.py:69-94), prior mean away from zero: a random walk.  Decisions, chains, log-posteriors."""
+    d, n_data = 20, 4
+    A, b, _, _ = linear_problem(d, n_data, 20)
+    z, _ = oracle.rng_fill(2020, 0, 3 * d + 8, 0, 1, d, uniforms=False)
+    z = z[0]
+    Bn = z[:d] * 0.12
+    noise_cov = Bn @ Bn.T + 0.25 * np.eye(d)
+    Bp = z[d:2 * d] * 0.5
+    prior_cov = Bp @ Bp.T + 2.0 * np.eye(d)
+    prior_mean = 0.4 * z[2 * d]
+    theta_true = z[2 * d + 1]
+    data = np.array([A @ theta_true + b + np.linalg.cholesky(noise_cov) @ z[2 * d + 2 + i] for i in range(n_data)])
+    prior = Gaussian(ParameterVector(prior_mean.copy()), DenseCovarianceMatrix(prior_cov))
+    noise = CentredGaussianNoise(DenseCovarianceMatrix(noise_cov))
+    lik = AdditiveGaussianNoiseLikelihood(Data(data), ForwardModel(ExampleLinearModelSolver(A, b)), noise)
+    cov = IIDCovarianceMatrix(d, 6e-3)
+    seed, K, n = 20250120, 8, 301
+    traj, acc, lp = run_mrw_model(BayesianRegressionModel(lik, prior), seed, K, n, cov, np.zeros(d))
+    np.savez_compressed(os.path.join(HERE, "f20_dense_prior_noise_d20.npz"), seed=seed, n_states=n, A=A, b=b, data=data,
+                        noise_cov=noise_cov, prior_cov=prior_cov, prior_mean=prior_mean, sigma=sigma_of(cov),
+                        x0=np.zeros((K, d)), traj=traj, acc=acc, logpost=lp)
+    print("F20", acc.mean())
+
+
 def fixture_f18(name="f18_mlda_nested2_linear_d128.npz", d=128, n_models=3, seed=20250118, K=6, n=101,
                 sub_lengths=(3, 4), perturb=0.02, prop_var=1.1e-3):
     """Delayed acceptance over a hierarchy of THREE (and, second fixture, FIVE) linear models at large dimension
@@ -1041,7 +1068,7 @@ def fixture_f18(name="f18_mlda_nested2_linear_d128.npz", d=128, n_models=3, seed
 
 def main():
     which = sys.argv[1:] or ["f1", "f2", "f2b", "f3", "f3b", "f4", "f5", "f7", "f8", "f9", "f10", "f11", "f12", "f13",
-                             "f14", "f15", "f16", "f17", "f18", "f19"]
+                             "f14", "f15", "f16", "f17", "f18", "f19", "f20"]
     if "f1" in which:
         fixture_f1()
     if "f2" in which:
@@ -1081,6 +1108,8 @@ def main():
         fixture_f17()
     if "f19" in which:
         fixture_f19()
+    if "f20" in which:
+        fixture_f20()
     if "f18" in which:
         fixture_f18()
         fixture_f18("f18b_mlda_nested4_linear_d24.npz", d=24, n_models=5, seed=20250119, K=6, n=81,

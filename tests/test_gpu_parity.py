@@ -852,6 +852,96 @@ def test_tile_kernel_dense_noise_other_shapes(ffi, ctx, d, m, nd, K, method):
         assert np.array_equal(dev["level_acc"], e.level_acc)
 
 
+def test_f20_dense_prior_and_noise_d20_matrix_cores(ffi, ctx, golden):
+    """Dense prior and noise covariances on the matrix-core path (the prior as 20 more outputs of the forward
+    map): the LIVE reference's decisions and chains, log-posteriors to rounding, == oracle bit for bit;
+    ymc_forward_eval returns the model's own 20 outputs."""
+    from yagremcmc_amd import lowering
+    g = golden("f20_dense_prior_noise_d20.npz")
+    d = 20
+    common = dict(data=g["data"], noise_precision=np.ones(d), prior_mean=g["prior_mean"], prior_precision=np.ones(d))
+    low = _dense_low(ffi, ffi.POSTERIOR_LINEAR, d, common, g["noise_cov"], g["prior_cov"], fwd_matrix=g["A"], fwd_shift=g["b"])
+    p = o.dense_covariances(o.posterior_linear(g["A"], g["b"], g["data"], np.ones(d), g["prior_mean"], np.ones(d)),
+                            noise_cov=g["noise_cov"], prior_cov=g["prior_cov"])
+    n = int(g["n_states"])
+    dev = _device_run(ffi, ctx, low, g["sigma"], g["x0"], int(g["seed"]), n - 1, splits=2)
+    _same_as_reference(dev, g)
+    e = o.Ensemble(p, g["sigma"], g["x0"], int(g["seed"]))
+    _same_as_oracle(dev, e, e.advance(n - 1))
+    prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, g["sigma"])
+    x = np.random.default_rng(0).standard_normal((20, d))
+    fwd = prob.forward(x)
+    assert fwd.shape == (20, d) and np.array_equal(fwd, o.forward(p, x))
+    assert np.array_equal(prob.logdensity(x)[0], o.logdensity(p, x)[0])
+
+
+@pytest.mark.parametrize("d,m,nd,K,method", [(64, 64, 3, 40, "mrw"), (9, 3, 2, 33, "mrw"), (16, 40, 1, 64, "mlda2"),
+                                             (5, 30, 4, 50, "mrw"), (24, 20, 2, 129, "nested")])
+def test_tile_kernel_dense_prior_other_shapes(ffi, ctx, d, m, nd, K, method):
+    """Dense prior (and noise) covariances on the matrix-core samplers at ragged shapes; levels with their own
+    covariances and prior means."""
+    rng = np.random.default_rng(2000 + d + m)
+
+    def spd(n, ridge):
+        B = rng.normal(size=(n, n)) / np.sqrt(n)
+        return B @ B.T + ridge * np.eye(n)
+
+    def model(scale, noise=True):
+        nc, pc = (spd(m, 0.4) if noise else None), spd(d, 1.0)
+        g = dict(data=rng.normal(size=(nd, m)), noise_precision=rng.uniform(0.5, 2, size=m) if not noise else np.ones(m),
+                 prior_mean=rng.normal(size=d) * 0.3, prior_precision=np.ones(d))
+        A, b = scale * rng.normal(size=(m, d)) / np.sqrt(d), rng.normal(size=m)
+        p = o.dense_covariances(o.posterior_linear(A, b, g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"]),
+                                noise_cov=nc, prior_cov=pc, whiten=True)
+        return _dense_low(ffi, ffi.POSTERIOR_LINEAR, d, g, nc, pc, fwd_matrix=A, fwd_shift=b), p
+
+    sigma, x0 = rng.uniform(0.02, 0.08, size=d), rng.normal(size=(K, d))
+    if method == "mrw":
+        lf, pf = model(1.0, noise=(d != 9))
+        dev = _device_run(ffi, ctx, lf, sigma, x0, 79, 40, chain0=9, splits=2)
+        e = o.Ensemble(pf, sigma, x0, 79, chain0=9)
+        _same_as_oracle(dev, e, e.advance(40))
+    elif method == "mlda2":
+        (lf, pf), (lc, pc_) = model(1.0), model(0.9, noise=False)
+        dev = _device_run(ffi, ctx, lf, sigma, x0, 79, 30, method=ffi.METHOD_MLDA2, sur=lc, S=3, chain0=9, splits=2)
+        e = o.Ensemble(pf, sigma, x0, 79, chain0=9, surrogate=pc_, sub_chain_length=3)
+        out = e.advance(30, want_sub=True)
+        _same_as_oracle(dev, e, out)
+        assert np.array_equal(dev["sub_acc"], out["sub_acc"])
+    else:
+        models = [model(1.0 - 0.03 * i) for i in range(3)]
+        (lt, pt), surs = models[-1], models[:-1]
+        dev = _nested_device_run(ffi, ctx, lt, [l for l, _ in surs], [2, 3], sigma, x0, 79, 20, splits=2, chain0=9)
+        P, Q, steps = o.nested_levels([p for _, p in surs], [2, 3], pt)
+        e = o.NestedEnsemble(P, Q, steps, sigma, x0, 79, chain0=9)
+        out = e.advance(20)
+        _same_as_oracle(dev, e, out)
+        assert np.array_equal(dev["level_acc"], e.level_acc)
+
+
+def test_tile_kernel_dense_prior_limits(ffi, ctx):
+    """What the dense prior on the matrix-core path cannot be: larger than the LDS together with the forward map,
+    the prior of pCN, the prior of the adaptive error model."""
+    from yagremcmc_amd import lowering
+    rng = np.random.default_rng(3)
+
+    def low(d, m, likelihood_only=0):
+        B = rng.normal(size=(d, d)) / np.sqrt(d)
+        g = dict(data=rng.normal(size=(2, m)), noise_precision=np.ones(m), prior_mean=np.zeros(d), prior_precision=np.ones(d))
+        return _dense_low(ffi, ffi.POSTERIOR_LINEAR, d, g, None, B @ B.T + np.eye(d), fwd_matrix=rng.normal(size=(m, d)),
+                          fwd_shift=np.zeros(m), likelihood_only=likelihood_only)
+
+    with pytest.raises(ffi.YmcError, match="dense prior") as err:
+        lowering.make_problem(ctx, ffi.METHOD_MRW, low(128, 128), np.ones(128))
+    assert err.value.code == ffi.ERR_UNSUPPORTED
+    lowering.make_problem(ctx, ffi.METHOD_MRW, low(96, 16), np.ones(96))        # (16 + 96) outputs x 96 fit
+    with pytest.raises(ffi.YmcError, match="diagonal prior"):
+        lowering.make_problem(ctx, ffi.METHOD_PCN, low(16, 16, likelihood_only=1), np.ones(16), pcn_step_size=0.1)
+    with pytest.raises(ffi.YmcError, match="adaptive error model"):
+        lowering.make_problem(ctx, ffi.METHOD_AEM2, low(16, 16), np.ones(16), surrogate=low(16, 16), sub_chain_length=2,
+                              aem=(5, True))
+
+
 def _dense_tile_run(ffi, ctx, low, L, x0, seed, nsteps, chain0=0, splits=2):
     from yagremcmc_amd import lowering
     d = x0.shape[1]

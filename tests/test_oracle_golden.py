@@ -391,6 +391,26 @@ def test_f19_dense_noise_covariance_beyond_the_lane_sizes(golden):
     assert np.allclose(got, want, rtol=1e-11, atol=0)
 
 
+def test_f20_dense_prior_and_noise_beyond_the_lane_sizes(golden):
+    """Gaussian prior AND noise over DenseCovarianceMatrix at d = 20: the noise is whitened away, the prior becomes
+    20 more outputs of the forward map (oracle.dense_covariances, as the product's lowering).  The live
+    reference's decisions and chains; log-posteriors to rounding; against NumPy on random points."""
+    g = golden("f20_dense_prior_noise_d20.npz")
+    d = 20
+    p = o.dense_covariances(o.posterior_linear(g["A"], g["b"], g["data"], np.ones(d), g["prior_mean"], np.ones(d)),
+                            noise_cov=g["noise_cov"], prior_cov=g["prior_cov"])
+    assert p["data_dim"] == 2 * d and not p["prior_precision"].any() and "lin_tail" in p
+    n = int(g["n_states"])
+    e = o.Ensemble(p, g["sigma"], g["x0"], int(g["seed"]))
+    _check(e.advance(n - 1), g, n)
+    x = np.random.default_rng(1).standard_normal((25, d))
+    F = x @ g["A"].T + g["b"]
+    assert np.allclose(o.forward(p, x), F, rtol=1e-13, atol=1e-13)
+    want = np.array([-0.5 * sum((f - D) @ np.linalg.solve(g["noise_cov"], f - D) for D in g["data"])
+                     - 0.5 * (xi - g["prior_mean"]) @ np.linalg.solve(g["prior_cov"], xi - g["prior_mean"]) for f, xi in zip(F, x)])
+    assert np.allclose(o.logdensity(p, x)[0], want, rtol=1e-12, atol=0)
+
+
 def test_f8_preconditioned_crank_nicolson(golden):
     """pcn.py:9-57 on the Lotka-Volterra likelihood with a centred Gaussian prior"""
     g = golden("f8_pcn_lotka_volterra.npz")

@@ -106,6 +106,8 @@ struct DensityHost {
      * asks for is still A v + b */
     std::vector<double> A_raw, b_raw;
     size_t off_A_raw = 0, off_b_raw = 0;
+    int m_raw = 0; /* a dense prior covariance on that path: the forward map's own output count (d.data_dim counts
+                      the d pseudo-observations of the prior too) */
     size_t off_nlinv = 0, off_plinv = 0;
     double lik_const = 0.0;
     DeviceBuf dev;  /* one allocation: data | noise_prec | prior_mean | prior_prec | A | b | design | dbar | nprec */
@@ -243,11 +245,10 @@ int lower_density(ymc_ctx *ctx, const ymc_density_desc &in, DensityHost &out, in
         YMC_TRY(copy_array(out.noise_prec, in.noise_precision, m, "noise_precision"));
         YMC_TRY(copy_array(out.prior_mean, in.prior_mean, d, "prior_mean"));
         YMC_TRY(copy_array(out.prior_prec, in.prior_precision, d, "prior_precision"));
-        if (big && in.prior_chol_inv)
-            return fail(YMC_ERR_UNSUPPORTED, "a dense prior covariance is lowered for the lane kernels (parameter and "
-                                             "data dimension <= %d)", YMC_LANE_DMAX);
-        if (big && in.noise_chol_inv && in.kind != YMC_DENSITY_POSTERIOR_LINEAR)
-            return fail(YMC_ERR_UNSUPPORTED, "a dense noise covariance at this size needs a linear forward map");
+        if (big && (in.noise_chol_inv || in.prior_chol_inv) && in.kind != YMC_DENSITY_POSTERIOR_LINEAR)
+            return fail(YMC_ERR_UNSUPPORTED, "a dense covariance at this size needs a linear forward map");
+        if (big && in.prior_chol_inv && in.likelihood_only)
+            return fail(YMC_ERR_UNSUPPORTED, "the pCN proposal draws from a diagonal prior covariance");
         if (in.noise_chol_inv || in.prior_chol_inv) {
             auto lower_tri = [&](std::vector<double> &dst, const double *src, size_t n, const char *what) -> int {
                 YMC_TRY(copy_array(dst, src, n * n, what));
@@ -266,10 +267,13 @@ int lower_density(ymc_ctx *ctx, const ymc_density_desc &in, DensityHost &out, in
                 if (d > 128) return fail(YMC_ERR_UNSUPPORTED, "parameter dimension %d exceeds the tile kernel's 128", d);
                 const int ks_need = (d + 3) / 4;
                 out.KS = ks_need <= 4 ? 4 : ks_need <= 8 ? 8 : ks_need <= 16 ? 16 : 32;
-                out.MT = (int)((m + 15) / 16);
+                /* a dense prior covariance adds d pseudo-observations to the forward map (below) */
+                const size_t m_all = m + (out.prior_linv.empty() ? 0 : (size_t)d);
+                out.MT = (int)((m_all + 15) / 16);
                 out.MT += out.MT & 1;
                 if (ymc_tile_lds_bytes(out.KS, out.MT) > kTileLdsLimit)
-                    return fail(YMC_ERR_UNSUPPORTED, "forward map %zu x %d does not fit the 160 KB LDS", m, d);
+                    return fail(YMC_ERR_UNSUPPORTED, "forward map %zu x %d%s does not fit the 160 KB LDS", m, d,
+                                out.prior_linv.empty() ? "" : " plus the dense prior's d x d factor");
                 out.tile = true;
             }
             YMC_TRY(copy_array(out.A, in.fwd_matrix, m * d, "fwd_matrix"));
@@ -293,6 +297,33 @@ int lower_density(ymc_ctx *ctx, const ymc_density_desc &in, DensityHost &out, in
             out.nprec.resize(m);
             ymc_linear_data_summary(out.data.data(), out.noise_prec.data(), in.n_data, in.data_dim, out.dbar.data(),
                                     out.nprec.data(), &out.lik_const);
+            if (big && !out.prior_linv.empty()) {
+                /* -0.5 |Lp^-1 (v - mu)|^2 is the log-likelihood of d more outputs: forward rows Lp^-1, shift 0,
+                 * "data" c = Lp^-1 mu (ymc_lower_times), weight 1 (set on the summary directly: n * (1 / n) and
+                 * the mean of n copies of c are not exact).  The diagonal prior is switched off (precision 0). */
+                const std::vector<double> &Lp = out.prior_linv;
+                std::vector<double> c((size_t)d);
+                ymc_lower_times(Lp.data(), d, out.prior_mean.data(), 1, c.data());
+                if (out.A_raw.empty()) {
+                    out.A_raw = out.A;
+                    out.b_raw = out.b;
+                }
+                out.m_raw = (int)m;
+                out.A.insert(out.A.end(), Lp.begin(), Lp.end());
+                out.b.insert(out.b.end(), (size_t)d, 0.0);
+                out.dbar.insert(out.dbar.end(), c.begin(), c.end());
+                out.nprec.insert(out.nprec.end(), (size_t)d, 1.0);
+                std::vector<double> rows;                       /* the data and the noise precision follow the outputs */
+                for (size_t i = 0; i < nd; ++i) {
+                    rows.insert(rows.end(), out.data.begin() + i * m, out.data.begin() + (i + 1) * m);
+                    rows.insert(rows.end(), c.begin(), c.end());
+                }
+                out.data.swap(rows);
+                out.noise_prec.insert(out.noise_prec.end(), (size_t)d, 1.0 / (double)nd);
+                std::fill(out.prior_prec.begin(), out.prior_prec.end(), 0.0);
+                out.prior_linv.clear();
+                out.d.data_dim = (int32_t)(m + (size_t)d);
+            }
         } else {
             if (d != 2 || m != 2) return fail(YMC_ERR_INVALID, "Lotka-Volterra needs dim 2 and data_dim 2");
             if (in.rk4_steps < 1) return fail(YMC_ERR_INVALID, "rk4_steps must be positive");
@@ -398,7 +429,7 @@ BigLinearArgs big_view(const DensityHost &h, bool raw_forward = false)
     b.prior_mean = base + h.off_pmean;
     b.prior_prec = base + h.off_pprec;
     b.d = h.d.dim;
-    b.m = h.d.data_dim;
+    b.m = raw && h.m_raw ? h.m_raw : h.d.data_dim;
     b.likelihood_only = h.d.likelihood_only;
     return b;
 }
@@ -970,6 +1001,10 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
                       desc->target.data_dim, desc->surrogate.data_dim);
         if (rc == YMC_OK && (desc->target.noise_chol_inv || desc->surrogate.noise_chol_inv))
             rc = fail(YMC_ERR_UNSUPPORTED, "Currently, AEM is only implemented for independent measurement noise.");
+        if (rc == YMC_OK && p->tgt.tile && (desc->target.prior_chol_inv || desc->surrogate.prior_chol_inv))
+            rc = fail(YMC_ERR_UNSUPPORTED, "at this dimension the adaptive error model takes diagonal prior covariances "
+                                           "(a dense one is carried as extra outputs of the forward map, which the "
+                                           "error model would learn from)");
         p->aem_min_data = desc->aem_min_data_size;
         p->aem_heuristic = desc->aem_use_noise_heuristic != 0;
     }
@@ -1602,7 +1637,7 @@ int ymc_forward_eval(ymc_ctx *ctx, const ymc_problem *problem, int which, uint64
         return fail(YMC_ERR_INVALID, "density %d does not exist in this problem", which);
     const DensityHost &h = which ? problem->sur : problem->tgt;
     uint64_t m = 0;
-    if (problem->kind == YMC_DENSITY_POSTERIOR_LINEAR) m = h.d.data_dim;
+    if (problem->kind == YMC_DENSITY_POSTERIOR_LINEAR) m = h.m_raw ? h.m_raw : h.d.data_dim;
     else if (problem->kind == YMC_DENSITY_POSTERIOR_LV) m = 2ull * h.d.n_data;
     else return fail(YMC_ERR_INVALID, "this density has no forward model");
     if (n == 0) return YMC_OK;

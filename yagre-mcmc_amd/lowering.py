@@ -96,8 +96,8 @@ def _set_covariance(low, cov, n, what, prec_field, linv_field):
     L = np.tril(np.asarray(L, dtype=np.float64))
     if L.shape != (n, n):
         raise ValueError(f"{what} covariance has dimension {L.shape[0]}, expected {n}")
-    if n > _ffi.LANE_DMAX and what != "noise":   # a dense NOISE covariance of a linear model is whitened away (ymc.h)
-        raise UnsupportedPlugin(f"a dense {what} covariance is lowered up to dimension {_ffi.LANE_DMAX}, got {n}")
+    # beyond the lane kernels' sizes the library whitens a dense noise covariance away and carries a dense prior
+    # covariance as extra outputs of a LINEAR forward map (include/ymc.h); it refuses what it cannot lower
     from scipy.linalg import solve_triangular
     low.set_array(linv_field, np.tril(solve_triangular(L, np.eye(n), lower=True)))
     low.set_array(prec_field, np.reciprocal(np.diag(L @ L.T)))   # unused by the dense path; keeps the field valid
