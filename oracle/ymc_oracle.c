@@ -415,13 +415,13 @@ static int64_t ymo_block_size(int32_t d)
 /* y = x + L xi for a DenseCovarianceMatrix proposal (covariance.py:69-94; mrw.py:32-38): row i of
  * L xi summed left to right with separate multiplies and adds (the reference's order is BLAS') */
 static void ymo_propose_dense(const double *x, const double *chol, uint64_t seed, uint32_t chain, uint64_t t,
-                              int32_t d, double *y)
+                              int32_t d, int fma_chain, double *y)
 {
     double z[YMO_DMAX + 1];
     for (int32_t j = 0; 2 * j < d; ++j) ymc_draw_normal_pair(seed, chain, t, (uint32_t)j, &z[2 * j], &z[2 * j + 1]);
     for (int32_t i = 0; i < d; ++i) {
         double acc = chol[(int64_t)i * d] * z[0];
-        if (d > 8) /* the matrix-core kernel's order: row i of L xi as one k-ordered fma chain (v_mfma_f64) */
+        if (fma_chain) /* the matrix-core kernel's order: row i of L xi as one k-ordered fma chain (v_mfma_f64) */
             for (int32_t j = 1; j <= i; ++j) acc = ymc_fma(chol[(int64_t)i * d + j], z[j], acc);
         else       /* the lane kernels' order: separate multiplies and adds, left to right */
             for (int32_t j = 1; j <= i; ++j) acc = acc + chol[(int64_t)i * d + j] * z[j];
@@ -437,6 +437,8 @@ void ymo_mrw_advance(const ymo_density *tgt, const double *sigma, int32_t eq_mod
                      int32_t nthreads, const double *chol)
 {
     int32_t d = tgt->dim;
+    /* the path the product takes (needs_tile, ymc_api.hip): the matrix cores beyond the lane kernels' sizes */
+    const int on_matrix_cores = d > 8 || (tgt->kind == YMO_POST_LINEAR && tgt->data_dim > 8);
     /* chains are independent, so they are walked in blocks (a block's record
      * rows are contiguous: cache-friendly on the CPU); per chain the order of
      * operations is exactly the reference's loop */
@@ -455,7 +457,7 @@ void ymo_mrw_advance(const ymo_density *tgt, const double *sigma, int32_t eq_mod
                 double *xs = x + k * d;
                 uint32_t st = status ? status[k] : 0;
                 if (chol)
-                    ymo_propose_dense(xs, chol, seed, chain, t, d, y);
+                    ymo_propose_dense(xs, chol, seed, chain, t, d, on_matrix_cores, y);
                 else
                     ymo_propose(xs, sigma, seed, chain, t, d, y);   /* :116-117 */
                 int accepted = 0;

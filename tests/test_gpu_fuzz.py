@@ -295,3 +295,110 @@ def test_random_adaptive_error_model_matches_oracle(case):
     if flags & ffi.RECORD_MOMENTS:
         s = run.summary()
         assert np.array_equal(s["wf_mean"], e.wf_mean) and np.array_equal(s["wf_m2"], e.wf_m2)
+
+
+@pytest.mark.parametrize("case", range(36))
+def test_random_matrix_core_configuration_matches_oracle(case):
+    """The samplers of the matrix-core path (random walk with a diagonal or dense proposal, pCN, two-level, nested)
+    over random shapes -- parameter dimension 9..128 or a small one with many outputs, per-level output counts,
+    dense or diagonal noise, dense or diagonal prior where the LDS admits it --, ensemble sizes with a partly
+    filled last wave, chain offsets, launch splits, record flags and a thinned record."""
+    from scipy.linalg import solve_triangular
+    from yagremcmc_amd import _ffi as ffi, lowering
+    ctx = ffi.default_context(0)
+    rng = np.random.default_rng(9000 + case)
+    sampler = ["mrw", "pcn", "mlda2", "nested", "mrw_chol", "mrw"][case % 6]
+    d = int(rng.choice([5, 9, 12, 16, 17, 33, 64, 100, 128]))
+    small = d <= 8
+    nd = int(rng.integers(1, 6))
+    dense_noise = bool(rng.integers(0, 2))
+    dense_prior = bool(rng.integers(0, 2)) and sampler not in ("pcn",) and d <= 40
+
+    def spd(n, ridge):
+        B = rng.normal(size=(n, n)) / np.sqrt(n)
+        return B @ B.T + ridge * np.eye(n)
+
+    def inv_factor(cov):
+        return np.tril(solve_triangular(np.linalg.cholesky(cov), np.eye(cov.shape[0]), lower=True))
+
+    def model(scale):
+        m = int(rng.integers(9, 41)) if small else int(rng.integers(1, min(d, 48) + 1))
+        nc = spd(m, 0.4) if dense_noise else None
+        pc = spd(d, 1.0) if dense_prior else None
+        g = dict(data=rng.normal(size=(nd, m)), noise_precision=np.ones(m) if dense_noise else rng.uniform(0.5, 3, size=m),
+                 prior_mean=rng.normal(size=d) * (0.0 if sampler == "pcn" else 0.2),
+                 prior_precision=np.ones(d) if dense_prior else rng.uniform(0.2, 2, size=d))
+        A, b = scale * rng.normal(size=(m, d)) / np.sqrt(d), rng.normal(size=m)
+        low = lowering.Lowered(ffi.POSTERIOR_LINEAR, d)
+        low.desc.n_data, low.desc.data_dim = nd, m
+        for k_, v in (("data", g["data"]), ("noise_precision", g["noise_precision"]), ("prior_mean", g["prior_mean"]),
+                      ("prior_precision", g["prior_precision"]), ("fwd_matrix", A), ("fwd_shift", b)):
+            low.set_array(k_, v)
+        if nc is not None:
+            low.set_array("noise_chol_inv", inv_factor(nc))
+        if pc is not None:
+            low.set_array("prior_chol_inv", inv_factor(pc))
+        p = o.posterior_linear(A, b, g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+        if nc is not None or pc is not None:
+            p = o.dense_covariances(p, noise_cov=nc, prior_cov=pc, whiten=True)
+        return low, p
+
+    K = int(rng.choice([1, 15, 16, 33, 64, 130]))
+    T = int(rng.integers(2, 22))
+    chain0 = int(rng.choice([0, 7, 2**31]))
+    seed = int(rng.integers(0, 2**63))
+    stride = int(rng.choice([1, 1, 3]))
+    flags = ffi.RECORD_TRAJECTORY | int(rng.choice([0, ffi.RECORD_LOGPOST]))
+    if stride == 1:
+        flags |= ffi.RECORD_ACCEPT | int(rng.choice([0, ffi.RECORD_MOMENTS]))
+    sigma = rng.uniform(0.02, 0.1, size=d)
+    x0 = rng.normal(size=(K, d)) * 0.5
+    kw, okw = {}, {}
+    if sampler == "pcn":
+        low, p = model(1.0)
+        low.desc.likelihood_only, p["likelihood_only"] = 1, 1
+        sigma = np.sqrt(np.reciprocal(p["prior_precision"]))
+        h = float(rng.uniform(0.005, 0.1))
+        prob = lowering.make_problem(ctx, ffi.METHOD_PCN, low, sigma, pcn_step_size=h)
+        e = o.Ensemble(p, sigma, x0, seed, chain0=chain0, pcn_step_size=h)
+    elif sampler == "mlda2":
+        (low, p), (lc, pc_) = model(1.0), model(0.92)
+        S = int(rng.integers(1, 5))
+        prob = lowering.make_problem(ctx, ffi.METHOD_MLDA2, low, sigma, surrogate=lc, sub_chain_length=S)
+        e = o.Ensemble(p, sigma, x0, seed, chain0=chain0, surrogate=pc_, sub_chain_length=S)
+    elif sampler == "nested":
+        E = int(rng.integers(2, 4))
+        models = [model(1.0 - 0.03 * i) for i in range(2 * (E - 1) + 1)]
+        subs = [int(v) for v in rng.integers(1, 4, size=len(models) - 1)]
+        prob = _nested_problem(ctx, lowering, models[-1][0], [l for l, _ in models[:-1]], subs, sigma, ffi.EQ_EXACT)
+        P, Q, steps = o.nested_levels([q for _, q in models[:-1]], subs, models[-1][1])
+        e = o.NestedEnsemble(P, Q, steps, sigma, x0, seed, chain0=chain0)
+    elif sampler == "mrw_chol":
+        low, p = model(1.0)
+        L = np.linalg.cholesky(spd(d, 1.0) * 0.004)
+        sigma = np.ones(d)
+        prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, sigma, chol=np.tril(L))
+        e = o.Ensemble(p, sigma, x0, seed, chain0=chain0, chol=L)
+    else:
+        low, p = model(1.0)
+        prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, sigma)
+        e = o.Ensemble(p, sigma, x0, seed, chain0=chain0)
+    run = ffi.Run(prob, seed, K, x0, T // stride + 1, flags, chain0, record_stride=stride)
+    cut = int(rng.integers(0, T + 1))
+    run.advance(cut)
+    run.advance(T - cut)
+    out = e.advance(T)
+    rows = slice(stride - 1, None, stride)
+    assert np.array_equal(run.trajectory(), out["traj"][rows])
+    if flags & ffi.RECORD_ACCEPT:
+        assert np.array_equal(run.accept(), out["acc"])
+    if flags & ffi.RECORD_LOGPOST:
+        assert np.array_equal(run.logpost(), out["logpost"][rows])
+    x, lp = run.state()
+    assert np.array_equal(x, e.x) and np.array_equal(lp, e.lp)
+    s = run.summary()
+    assert np.array_equal(s["accepted"], e.acc_count) and np.array_equal(s["status"], e.status)
+    if flags & ffi.RECORD_MOMENTS:
+        assert np.array_equal(s["wf_mean"], e.wf_mean) and np.array_equal(s["wf_m2"], e.wf_m2)
+    if sampler == "nested":
+        assert np.array_equal(run.level_accept()[0], e.level_acc)
