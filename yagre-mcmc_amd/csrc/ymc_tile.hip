@@ -232,8 +232,16 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
  * the proposal y (as x and y there); the fine state x lives in `x_tiled` (the record's coalesced layout)
  * and is read back once per fine step for the `proposal == state` test and the rejected lanes.
  * Draw addressing as mlda2_kernel: fine step n owns transitions t = n (S + 1) + s.
+ *
+ * STAGED: the eight waves of a workgroup take their fine steps in lockstep (same S for all), so the fine
+ * matrix is brought from L2 ONCE per workgroup and fine step instead of once per wave: it streams through a
+ * double buffer in the last 16 KB of LDS (units of a quarter of the k-steps of a pair of output tiles;
+ * every thread fetches its share of the next unit into registers while the MFMAs of the current one run; one
+ * barrier per unit).  A wave reading its own fragments from L2 keeps few loads in flight beside x and y --
+ * measured 5.7 x the cost of an LDS-fed GEMV.  Waves past the last tile stay in the loop for the barriers and
+ * touch no memory.  The plain form remains for shapes whose constants leave no room for the buffer.
  */
-template <int KS>
+template <int KS, bool STAGED>
 __global__ __launch_bounds__(kTileThreads) void linear_tile_mlda2_kernel(const TileArgs a)
 {
     ymc_stage_tables();
@@ -256,6 +264,9 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_mlda2_kernel(const T
     double *pprec_f = pmean_f + d_pad;
     const size_t consts_f = (size_t)m_pad_f * 3 + 2 * (size_t)d_pad;
     const double *Af = a.blob_f;
+    constexpr int kUnit = 2 * (KS / 4) * 64;                    /* doubles per staged unit: two tiles x KS/4 k-steps */
+    constexpr int kPer = (kUnit + kTileThreads - 1) / kTileThreads;
+    double *stage = bias_f + consts_f;                           /* STAGED: [2][kUnit] */
 
     const int tid = threadIdx.x;
     for (size_t i = tid; i < blob_c / 2; i += kTileThreads)
@@ -266,20 +277,21 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_mlda2_kernel(const T
     const int lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
     const uint64_t nct = (a.K + 15) / 16;
     const uint64_t tile = (uint64_t)blockIdx.x * kTileWaves + wave;
-    if (tile >= nct) return;
+    const bool wave_live = tile < nct; /* a wave past the last tile: STAGED keeps it for the barriers, it touches no memory */
+    if (!STAGED && !wave_live) return;
     const uint64_t k = tile * 16 + c;
-    const bool live = k < a.K;
+    const bool live = wave_live && k < a.K;
     const uint32_t chain = (uint32_t)(a.chain0 + k);
     const int d = a.d, S = a.S;
     const uint32_t pair_of_g = (g == 0) ? 0u : (g == 1) ? 2u : (g == 2) ? 1u : 3u;
-    double *xt = a.x_tiled + (tile * KS) * 64 + lane; /* this lane's column of the carried fine state */
+    double *xt = a.x_tiled + ((wave_live ? tile : 0) * KS) * 64 + lane; /* this lane's column of the carried fine state */
 
     double z[KS], y[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const int j = 4 * s + g;
         z[s] = (live && j < d) ? a.x[k * d + j] : 0.0;
-        xt[s * 64] = z[s];
+        if (wave_live) xt[s * 64] = z[s];
     }
     double lpf = live ? a.lp[k] : 0.0;
     double lpc = live ? a.lpc[k] : 0.0;
@@ -340,6 +352,60 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_mlda2_kernel(const T
         mv |= __shfl_xor(mv, 32, 64);
         return mv != 0;
     };
+    /* STAGED: the fine level's log-likelihood with the workgroup's shared stream of the fine matrix.  Unit
+     * (pair, q) = k-steps [q KS/4, (q + 1) KS/4) of output tiles 2 pair and 2 pair + 1; the MFMA order per
+     * accumulator is the plain form's (k ascending), so the value is the same bits.  EVERY wave of the
+     * workgroup calls this at the same point of the loop. */
+    auto fetch_unit = [&](int pair, int q, double (&r)[kPer]) {
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const int idx = tid + j * kTileThreads;
+            if (kUnit % kTileThreads == 0 || idx < kUnit) {
+                const int blk = idx / (KS * 16), off = idx % (KS * 16);
+                r[j] = Af[((size_t)(2 * pair + blk) * KS + (size_t)q * (KS / 4)) * 64 + off];
+            }
+        }
+    };
+    auto loglik_fine_staged = [&](const double (&v)[KS]) {
+        double Ssum = 0.0;
+        double r[kPer];
+        fetch_unit(0, 0, r);
+        int buf = 0;
+#pragma unroll 1
+        for (int pair = 0; pair < MTf / 2; ++pair) {
+            d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double *stg = stage + buf * kUnit;
+#pragma unroll
+                for (int j = 0; j < kPer; ++j) {
+                    const int idx = tid + j * kTileThreads;
+                    if (kUnit % kTileThreads == 0 || idx < kUnit) stg[idx] = r[j];
+                }
+                __syncthreads(); /* the unit is complete; everyone has left the buffer that is written next */
+                if (q < 3) fetch_unit(pair, q + 1, r);
+                else if (pair + 1 < MTf / 2) fetch_unit(pair + 1, 0, r);
+#pragma unroll
+                for (int sl = 0; sl < KS / 4; ++sl) {
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(stg[sl * 64 + lane], v[q * (KS / 4) + sl], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(stg[(KS / 4 + sl) * 64 + lane], v[q * (KS / 4) + sl], acc1, 0, 0, 0);
+                }
+                buf ^= 1;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int m = 16 * (2 * pair + h) + 4 * rr + g;
+                    const double F = (h ? acc1[rr] : acc0[rr]) + bias_f[m];
+                    const double res = F - dbar_f[m];
+                    const double px = nprec_f[m] * res;
+                    Ssum = Ssum + res * px;
+                }
+            }
+        }
+        return -0.5 * (combine4(Ssum) + a.lik_const_f);
+    };
 
 #pragma unroll 1
     for (uint32_t n = 0; n < a.nsteps; ++n) {
@@ -368,23 +434,26 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_mlda2_kernel(const T
         }
         /* fine accept / reject (mlda.py:146-154); y <- the fine state x */
 #pragma unroll
-        for (int s = 0; s < KS; ++s) y[s] = xt[s * 64];
+        for (int s = 0; s < KS; ++s) y[s] = wave_live ? xt[s * 64] : 0.0;
         const bool moved = any_differs(z, y);
-        const double lpfy = loglik(Af, MTf, bias_f, nprec_f, dbar_f, a.lik_const_f, z) + logprior(pmean_f, pprec_f, z);
+        double llf;
+        if constexpr (STAGED) llf = loglik_fine_staged(z);
+        else llf = loglik(Af, MTf, bias_f, nprec_f, dbar_f, a.lik_const_f, z);
+        const double lpfy = llf + logprior(pmean_f, pprec_f, z);
         const double log_ratio = ((lpfy + lpc) - lpcz) - lpf;
         const double u = ymc_uniform_cached(uc, a.seed, chain, tbase + (uint64_t)S);
         const bool acc = ymc_accept(log_ratio, moved, ymc_finite(lpfy) && ymc_finite(lpcz), u, st);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             z[s] = acc ? z[s] : y[s];
-            xt[s * 64] = z[s];
+            if (wave_live) xt[s * 64] = z[s];
         }
         lpf = acc ? lpfy : lpf;
         lpc = acc ? lpcz : lpc;
         accepted += acc ? 1u : 0u;
 
         const bool rec = clk.due();
-        if (rec && a.traj) {
+        if (rec && a.traj && wave_live) {
             double *row = a.traj + (((uint64_t)clk.row * nct + tile) * KS) * 64 + lane;
 #pragma unroll
             for (int s = 0; s < KS; ++s) row[s * 64] = z[s];
@@ -526,17 +595,28 @@ size_t ymc_tile_mlda2_lds_bytes(int KS, int MT_coarse, int MT_fine)
     return ymc_tile_lds_bytes(KS, MT_coarse) + (16 * (size_t)MT_fine * 3 + 2 * 4 * (size_t)KS) * sizeof(double);
 }
 
-template <int KS>
-static hipError_t launch_tile_mlda2(const TileArgs &a, hipStream_t s)
+template <int KS, bool STAGED>
+static hipError_t launch_tile_mlda2_as(const TileArgs &a, size_t lds, hipStream_t s)
 {
-    const size_t lds = ymc_tile_mlda2_lds_bytes(KS, a.MT, a.MT_f);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_tile_mlda2_kernel<KS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_tile_mlda2_kernel<KS, STAGED>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const uint64_t nct = (a.K + 15) / 16;
     const unsigned grid = (unsigned)((nct + kTileWaves - 1) / kTileWaves);
-    hipLaunchKernelGGL((linear_tile_mlda2_kernel<KS>), dim3(grid), dim3(kTileThreads), lds, s, a);
+    hipLaunchKernelGGL((linear_tile_mlda2_kernel<KS, STAGED>), dim3(grid), dim3(kTileThreads), lds, s, a);
     return hipGetLastError();
+}
+
+template <int KS>
+static hipError_t launch_tile_mlda2(const TileArgs &a, hipStream_t s)
+{
+    /* the fine matrix through a shared double buffer when the LDS has 16 KB left for it (identical results;
+     * YMC_TILE_STAGE=0|1 overrides, the tests run both) */
+    const size_t plain = ymc_tile_mlda2_lds_bytes(KS, a.MT, a.MT_f);
+    const size_t staged = plain + 2 * (size_t)(2 * (KS / 4) * 64) * sizeof(double);
+    bool stage = staged <= kTileLdsLimit;
+    if (const char *env = std::getenv("YMC_TILE_STAGE")) stage = stage && env[0] != '0';
+    return stage ? launch_tile_mlda2_as<KS, true>(a, staged, s) : launch_tile_mlda2_as<KS, false>(a, plain, s);
 }
 
 hipError_t ymc_launch_linear_tile_mlda2(int KS, const TileArgs &a, hipStream_t s)
