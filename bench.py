@@ -324,6 +324,9 @@ def main():
 
     from yagremcmc_amd import _ffi as ffi, distributed, lowering
     device = local_rank if world > 1 else 0
+    if world > 1 and ffi.device_count() == 1 and any(os.environ.get(v) for v in
+                                                       ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")):
+        device = 0  # a launcher that gives every rank its own single visible GPU (RCCL refuses a shared one loudly)
     if os.environ.get("YMC_BENCH_ALLOW_SHARED_GPU") == "1":
         device %= ffi.device_count()  # rehearsal of the N > 1 flow on a box with fewer GPUs than ranks
     ctx = ffi.Context(device)
