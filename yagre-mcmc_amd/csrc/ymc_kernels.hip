@@ -15,7 +15,17 @@
  */
 /* Polynomial coefficients as loop-invariant VGPR pairs (ymc_numerics.h, ymc_fma_c): 11 % fewer
  * instructions per transition than re-materialising them, at the same or better occupancy. */
+/* Experiment switches (tools/exp_occupancy.sh; the results are in profiles/r02_exp_occupancy.txt and DESIGN.md
+ * section 5): -DYMC_EXP_SGPR keeps the coefficients in SGPR pairs instead, -DYMC_EXP_WAVES=4,4 / 8,8 builds the
+ * random-walk kernel for four / eight resident waves per SIMD instead of at most two. */
+#if defined(YMC_EXP_SGPR)
+#define YMC_COEFF_IN_SGPR 1
+#else
 #define YMC_COEFF_HOISTED 1
+#endif
+#ifndef YMC_EXP_WAVES
+#define YMC_EXP_WAVES 1, 2
+#endif
 #include "ymc_kernels.h"
 
 /* This file is compiled four times (Makefile, -DYMC_KERNELS_PART=0..3): the dimensions are independent
@@ -172,7 +182,7 @@ __global__ __launch_bounds__(kBlock) void mrw_kernel(const ChainArgs<D> a)
  * or two resident waves never stall on their own latencies.  Same instruction count, 170 instead of
  * 142 VGPRs; measured +8 % at 65 536 chains, +3 % at 131 072, +1 % at 1 M (tools: YMC A/B in DESIGN.md). */
 template <int KIND, int D, unsigned REC, int EQ>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 2))) void mrw_kernel_two_waves(const ChainArgs<D> a)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(YMC_EXP_WAVES))) void mrw_kernel_two_waves(const ChainArgs<D> a)
 {
     mrw_body<KIND, D, REC, EQ, kPropDiag>(a);
 }
