@@ -1001,6 +1001,40 @@ def fixture_f20():
     print("F20", acc.mean())
 
 
+def fixture_f21():
+    """Preconditioned Crank-Nicolson (pcn.py:9-57) on a d = 64 linear model with a centred prior -- the size of
+    the matrix-core kernel's pCN proposal: 8 chains x 301 states."""
+    from yagremcmc.chain.method.pcn import PCNBuilder
+    d, n_data = 64, 5
+    A, b, data, noise_var = linear_problem(d, n_data, 21)
+    prior_var = np.linspace(0.5, 2.0, d)
+    prior_cov = DiagonalCovarianceMatrix(prior_var.copy())
+    prior = Gaussian(ParameterVector(np.zeros(d)), prior_cov)
+    like = AdditiveGaussianNoiseLikelihood(Data(data), ForwardModel(ExampleLinearModelSolver(A, b)),
+                                           CentredGaussianNoise(IIDCovarianceMatrix(d, noise_var)))
+    model = BayesianRegressionModel(like, prior)
+    seed, K, n, h = 20250121, 8, 301, 0.004
+    traj = np.empty((n, K, d))
+    acc = np.empty((n - 1, K), dtype=np.uint8)
+    lp = np.empty((n, K))
+    for k in range(K):
+        bld = PCNBuilder()
+        bld.stepSize = h
+        bld.bayesModel = model
+        mc = bld.build_method()
+        rp = Replay(seed, k, d, n - 1)
+        rp.install()
+        mc.run(n, ParameterVector(np.zeros(d)), verbose=False)
+        traj[:, k, :] = np.array(mc.chain.trajectory)
+        acc[:, k] = mc.diagnostics._decisions
+        lp[:, k] = eval_log_along(mc.target, traj[:, k, :], lambda s_: ParameterVector(np.array(s_)))
+    np.savez_compressed(
+        os.path.join(HERE, "f21_pcn_linear_d64.npz"), seed=seed, n_states=n, step_size=h, A=A, b=b, data=data,
+        noise_precision=np.reciprocal(np.full(d, noise_var)), prior_mean=np.zeros(d), prior_precision=prior_cov._precision,
+        prior_sigma=sigma_of(prior_cov), x0=np.zeros((K, d)), traj=traj, acc=acc, loglik=lp)
+    print("F21", acc.mean())
+
+
 def fixture_f18(name="f18_mlda_nested2_linear_d128.npz", d=128, n_models=3, seed=20250118, K=6, n=101,
                 sub_lengths=(3, 4), perturb=0.02, prop_var=1.1e-3):
     """Delayed acceptance over a hierarchy of THREE (and, second fixture, FIVE) linear models at large dimension
@@ -1068,7 +1102,7 @@ def fixture_f18(name="f18_mlda_nested2_linear_d128.npz", d=128, n_models=3, seed
 
 def main():
     which = sys.argv[1:] or ["f1", "f2", "f2b", "f3", "f3b", "f4", "f5", "f7", "f8", "f9", "f10", "f11", "f12", "f13",
-                             "f14", "f15", "f16", "f17", "f18", "f19", "f20"]
+                             "f14", "f15", "f16", "f17", "f18", "f19", "f20", "f21"]
     if "f1" in which:
         fixture_f1()
     if "f2" in which:
@@ -1110,6 +1144,8 @@ def main():
         fixture_f19()
     if "f20" in which:
         fixture_f20()
+    if "f21" in which:
+        fixture_f21()
     if "f18" in which:
         fixture_f18()
         fixture_f18("f18b_mlda_nested4_linear_d24.npz", d=24, n_models=5, seed=20250119, K=6, n=81,

@@ -693,6 +693,27 @@ def test_tile_kernel_preconditioned_crank_nicolson(ffi, ctx, d, m, nd, K, h):
     _same_as_oracle(dev, e, out)
 
 
+def test_f21_pcn_linear_d64_matrix_cores(ffi, ctx, golden):
+    """pCN on the matrix-core kernel (`linear_tile_kernel<KS, kPropPcn>`): the LIVE reference's decisions and
+    chains at d = 64, log-likelihoods to rounding; == oracle bit for bit."""
+    from yagremcmc_amd import lowering
+    g = golden("f21_pcn_linear_d64.npz")
+    n, d, h = int(g["n_states"]), 64, float(g["step_size"])
+    common = dict(data=g["data"], noise_precision=g["noise_precision"], prior_mean=g["prior_mean"], prior_precision=g["prior_precision"])
+    low = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, common, fwd_matrix=g["A"], fwd_shift=g["b"], likelihood_only=1)
+    prob = lowering.make_problem(ctx, ffi.METHOD_PCN, low, g["prior_sigma"], pcn_step_size=h)
+    run = ffi.Run(prob, int(g["seed"]), g["x0"].shape[0], g["x0"], n - 1, _flags(ffi, True), 0)
+    run.advance(100)
+    run.advance(n - 1 - 100)
+    dev = dict(traj=run.trajectory(), acc=run.accept(), logpost=run.logpost(), summary=run.summary(), state=run.state())
+    assert np.array_equal(dev["acc"], g["acc"]) and np.array_equal(dev["traj"], g["traj"][1:])
+    assert np.abs(dev["logpost"] - g["loglik"][1:]).max() <= 1e-12 * np.abs(g["loglik"]).max()
+    p = o.posterior_linear(g["A"], g["b"], g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+    p["likelihood_only"] = 1
+    e = o.Ensemble(p, g["prior_sigma"], g["x0"], int(g["seed"]), pcn_step_size=h)
+    _same_as_oracle(dev, e, e.advance(n - 1))
+
+
 def _dense_low(ffi, kind, dim, g, noise_cov=None, prior_cov=None, **extra):
     from scipy.linalg import solve_triangular
     low = _posterior_low(ffi, kind, dim, g, **extra)

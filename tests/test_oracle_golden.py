@@ -422,3 +422,17 @@ def test_f8_preconditioned_crank_nicolson(golden):
     out = e.advance(n - 1)
     assert np.array_equal(out["acc"], g["acc"]) and np.array_equal(out["traj"], g["traj"][1:])
     assert np.abs(out["logpost"] - g["loglik"][1:]).max() <= LP_RTOL * np.abs(g["loglik"]).max()
+
+
+def test_f21_preconditioned_crank_nicolson_linear_d64(golden):
+    """pcn.py:9-57 on a d = 64 linear model with a centred prior of non-uniform variances (the matrix-core
+    kernel's pCN proposal): the live reference's decisions and chains, log-likelihoods to rounding"""
+    g = golden("f21_pcn_linear_d64.npz")
+    n = int(g["n_states"])
+    p = o.posterior_linear(g["A"], g["b"], g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+    p["likelihood_only"] = 1
+    e = o.Ensemble(p, g["prior_sigma"], g["x0"], int(g["seed"]), pcn_step_size=float(g["step_size"]))
+    out = e.advance(n - 1)
+    assert np.array_equal(out["acc"], g["acc"]) and np.array_equal(out["traj"], g["traj"][1:])
+    assert np.abs(out["logpost"] - g["loglik"][1:]).max() <= LP_RTOL * np.abs(g["loglik"]).max()
+    assert 0.1 < g["acc"].mean() < 0.6
