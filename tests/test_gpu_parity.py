@@ -407,6 +407,38 @@ def test_aem_other_shapes_vs_oracle(ffi, ctx, d, m, nd):
     assert dev["err"]["has_precision"].mean() > 0.5
 
 
+def test_aem_with_a_dense_prior_at_lane_sizes_vs_oracle(ffi, ctx):
+    """The adaptive error model takes diagonal noise only (noise.py:30-33) but any prior: a dense 3 x 3 prior
+    covariance on both levels (lane kernel; at matrix-core sizes the combination is refused)."""
+    from yagremcmc_amd import lowering
+    rng = np.random.default_rng(515)
+    d, m, nd = 3, 4, 5
+    A = rng.normal(size=(m, d)) / np.sqrt(d)
+    b = rng.normal(size=m) * 0.3
+    As, bs = A + 0.2 * rng.normal(size=(m, d)), b + 0.2 * rng.normal(size=m)
+    data = np.array([A @ rng.normal(size=d) + b + 0.5 * rng.normal(size=m) for _ in range(nd)])
+    B = rng.normal(size=(d, d))
+    pc = B @ B.T + 2.0 * np.eye(d)
+    g = dict(data=data, noise_precision=np.full(m, 4.0), prior_mean=rng.normal(size=d) * 0.2, prior_precision=np.ones(d))
+    fine = _dense_low(ffi, ffi.POSTERIOR_LINEAR, d, g, None, pc, fwd_matrix=A, fwd_shift=b)
+    coarse = _dense_low(ffi, ffi.POSTERIOR_LINEAR, d, g, None, pc, fwd_matrix=As, fwd_shift=bs)
+    sigma, x0 = np.full(d, 0.35), rng.normal(size=(200, d)) * 0.5
+    prob = lowering.make_problem(ctx, ffi.METHOD_AEM2, fine, sigma, ffi.EQ_EXACT, surrogate=coarse, sub_chain_length=3,
+                                 aem=(4, 1))
+    run = ffi.Run(prob, 99, 200, x0, 150, _flags(ffi, True, sub=True), 11)
+    run.advance(70)
+    run.advance(80)
+    dev = dict(traj=run.trajectory(), acc=run.accept(), logpost=run.logpost(), summary=run.summary(), state=run.state(),
+               sub_acc=run.sub_accept(), err=run.error_model())
+    of = o.dense_covariances(o.posterior_linear(A, b, **g), prior_cov=pc)
+    oc = o.dense_covariances(o.posterior_linear(As, bs, **g), prior_cov=pc)
+    e = o.AemEnsemble(of, oc, sigma, x0, 99, 3, 4, 1, chain0=11)
+    out = e.advance(150, want_sub=True)
+    _same_as_oracle(dev, e, out)
+    assert np.array_equal(dev["sub_acc"], out["sub_acc"])
+    _same_error_model(dev, e)
+
+
 def test_f16_adaptive_error_model_d128_matrix_cores(ffi, ctx, golden):
     """The adaptive error model on the matrix-core kernel (linear_tile_aem2_kernel: per-output error-model
     arrays in the tiled layout, cache keyed by the identity of the points): the live reference's chains at
