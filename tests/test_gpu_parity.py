@@ -1148,6 +1148,39 @@ def test_tile_kernel_nested_levels_vs_oracle(ffi, ctx, d, ms, nd, K, E):
     assert 0 < dev["acc"].mean() < 1
 
 
+@pytest.mark.parametrize("stage", ["0", "1"])
+def test_tile_kernels_with_and_without_the_shared_matrix_stream(ffi, ctx, monkeypatch, stage):
+    """The two-level and nested matrix-core kernels bring the upper level's matrices from L2 once per workgroup
+    through an LDS double buffer when there is room (YMC_TILE_STAGE=1, the default) or once per wave
+    (YMC_TILE_STAGE=0): both forms == oracle, at a shape with waves past the last tile in the last workgroup."""
+    monkeypatch.setenv("YMC_TILE_STAGE", stage)
+    rng = np.random.default_rng(4321)
+    d, nd, K = 96, 3, 37
+
+    def model(m, scale):
+        g = dict(data=rng.normal(size=(nd, m)), noise_precision=rng.uniform(0.5, 3, size=m), prior_mean=rng.normal(size=d) * 0.1,
+                 prior_precision=rng.uniform(0.1, 2, size=d))
+        A, b = scale * rng.normal(size=(m, d)) / np.sqrt(d), rng.normal(size=m)
+        return (_posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, g, fwd_matrix=A, fwd_shift=b),
+                o.posterior_linear(A, b, g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"]))
+
+    models = [model(m, 1.0 - 0.03 * i) for i, m in enumerate((64, 100, 33, 96, 80))]
+    sigma, x0 = rng.uniform(0.02, 0.06, size=d), rng.normal(size=(K, d))
+    (lf, pf), (lc, pc) = models[4], models[0]
+    dev = _device_run(ffi, ctx, lf, sigma, x0, 4712, 24, method=ffi.METHOD_MLDA2, sur=lc, S=3, chain0=2000, splits=2)
+    e = o.Ensemble(pf, sigma, x0, 4712, chain0=2000, surrogate=pc, sub_chain_length=3)
+    out = e.advance(24, want_sub=True)
+    _same_as_oracle(dev, e, out)
+    assert np.array_equal(dev["sub_acc"], out["sub_acc"])
+    subs = [2, 2, 3, 2]
+    dev = _nested_device_run(ffi, ctx, models[4][0], [l for l, _ in models[:4]], subs, sigma, x0, 777, 12, splits=2, chain0=3000)
+    P, Q, steps = o.nested_levels([p for _, p in models[:4]], subs, models[4][1])
+    e = o.NestedEnsemble(P, Q, steps, sigma, x0, 777, chain0=3000)
+    out = e.advance(12)
+    _same_as_oracle(dev, e, out)
+    assert np.array_equal(dev["level_acc"], e.level_acc)
+
+
 def test_tile_kernel_limits(ffi, ctx):
     from yagremcmc_amd import lowering
     rng = np.random.default_rng(1)

@@ -18,8 +18,14 @@
  * x_l, evaluates P[l](z) and Q[l](z) (two GEMVs on the matrix cores) and keeps one of the two; the counters
  * of the levels are wave-uniform, so the walk is straight-line code for the whole wave.  Decisions take
  * consecutive transition indices in execution order, exactly as in mlda_nested_kernel and the oracle.
+ *
+ * STAGED (as linear_tile_mlda2_kernel): the waves of a workgroup walk in lockstep, so a matrix of an upper
+ * level comes from L2 once per workgroup and evaluation, through a double buffer in the LDS left beside level
+ * 0's block; waves past the last tile stay in the walk for the barriers and touch no memory.
  */
 #define YMC_COEFF_IN_SGPR 1
+#include <cstdlib>
+
 #include "ymc_kernels.h"
 #include "ymc_tile.h"
 #include "ymc_tile_dev.h"
@@ -48,7 +54,7 @@ struct PerLevel {
     }
 };
 
-template <int KS>
+template <int KS, bool STAGED>
 __global__ __launch_bounds__(kNestThreads) void linear_tile_nested_kernel(const TileArgs a)
 {
     ymc_stage_tables();
@@ -62,6 +68,9 @@ __global__ __launch_bounds__(kNestThreads) void linear_tile_nested_kernel(const 
     double *pprec0 = pmean0 + d_pad;
     double *sigma = pprec0 + d_pad;
     const size_t blob0 = (size_t)MT0 * KS * 64 + (size_t)m_pad0 * 3 + 3 * (size_t)d_pad;
+    constexpr int kUnit = 2 * (KS / 4) * 64;                    /* doubles per staged unit: two tiles x KS/4 k-steps */
+    constexpr int kPer = (kUnit + kNestThreads - 1) / kNestThreads;
+    double *stage = lds + blob0;                                 /* STAGED: [2][kUnit] */
 
     const int tid = threadIdx.x;
     for (size_t i = tid; i < blob0 / 2; i += kNestThreads)
@@ -71,16 +80,17 @@ __global__ __launch_bounds__(kNestThreads) void linear_tile_nested_kernel(const 
     const int lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
     const uint64_t nct = (a.K + 15) / 16;
     const uint64_t tile = (uint64_t)blockIdx.x * kNestWaves + wave;
-    if (tile >= nct) return;
+    const bool wave_live = tile < nct;
+    if (!STAGED && !wave_live) return;
     const uint64_t k = tile * 16 + c;
-    const bool live = k < a.K;
+    const bool live = wave_live && k < a.K;
     const uint32_t chain = (uint32_t)(a.chain0 + k);
     const int d = a.d, E = a.E;
     /* a local copy: indexing the argument block with a run-time level would put it in scratch */
     const PerLevel<int> steps = {a.steps[0], a.steps[1], a.steps[2], a.steps[3]};
     const uint32_t pair_of_g = (g == 0) ? 0u : (g == 1) ? 2u : (g == 2) ? 1u : 3u;
     /* parked state of level l >= 1: this lane's column */
-    auto park = [&](int l) { return a.x_tiled + (((uint64_t)(l - 1) * nct + tile) * KS) * 64 + lane; };
+    auto park = [&](int l) { return a.x_tiled + (((uint64_t)(l - 1) * nct + (wave_live ? tile : 0)) * KS) * 64 + lane; };
 
     double z[KS], y[KS];
 #pragma unroll
@@ -88,7 +98,7 @@ __global__ __launch_bounds__(kNestThreads) void linear_tile_nested_kernel(const 
         const int j = 4 * s + g;
         z[s] = (live && j < d) ? a.x[k * d + j] : 0.0;
     }
-    {
+    if (wave_live) {
         double *top = park(E - 1);
 #pragma unroll
         for (int s = 0; s < KS; ++s) top[s * 64] = z[s];
@@ -148,12 +158,79 @@ __global__ __launch_bounds__(kNestThreads) void linear_tile_nested_kernel(const 
         return logpost(A0, MT0, bias0, nprec0, dbar0, pmean0, pprec0, a.lik_const, v);
     };
     /* P[l] (which = 0) or Q[l] (which = 1) of a level above the base: everything from global memory */
+    /* STAGED: unit (pair, q) = k-steps [q KS/4, (q + 1) KS/4) of output tiles 2 pair, 2 pair + 1 of matrix A; the
+     * MFMA order per accumulator is the plain form's, so the value is the same bits.  Every wave of the
+     * workgroup evaluates the same level at the same point of the walk. */
+    auto fetch_unit = [&](const double *A, int pair, int q, double (&r)[kPer]) {
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const int idx = tid + j * kNestThreads;
+            if (kUnit % kNestThreads == 0 || idx < kUnit) {
+                const int blk = idx / (KS * 16), off = idx % (KS * 16);
+                r[j] = A[((size_t)(2 * pair + blk) * KS + (size_t)q * (KS / 4)) * 64 + off];
+            }
+        }
+    };
+    auto logpost_staged = [&](const double *A, int MT, const double *bias, const double *nprec, const double *dbar,
+                              const double *pmean, const double *pprec, double lik_const, const double (&v)[KS]) {
+        double Ssum = 0.0;
+        double r[kPer];
+        fetch_unit(A, 0, 0, r);
+        int buf = 0;
+#pragma unroll 1
+        for (int pair = 0; pair < MT / 2; ++pair) {
+            d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double *stg = stage + buf * kUnit;
+#pragma unroll
+                for (int j = 0; j < kPer; ++j) {
+                    const int idx = tid + j * kNestThreads;
+                    if (kUnit % kNestThreads == 0 || idx < kUnit) stg[idx] = r[j];
+                }
+                __syncthreads(); /* the unit is complete; everyone has left the buffer that is written next */
+                if (q < 3) fetch_unit(A, pair, q + 1, r);
+                else if (pair + 1 < MT / 2) fetch_unit(A, pair + 1, 0, r);
+#pragma unroll
+                for (int sl = 0; sl < KS / 4; ++sl) {
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(stg[sl * 64 + lane], v[q * (KS / 4) + sl], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(stg[(KS / 4 + sl) * 64 + lane], v[q * (KS / 4) + sl], acc1, 0, 0, 0);
+                }
+                buf ^= 1;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int m = 16 * (2 * pair + h) + 4 * rr + g;
+                    const double F = (h ? acc1[rr] : acc0[rr]) + bias[m];
+                    const double res = F - dbar[m];
+                    const double px = nprec[m] * res;
+                    Ssum = Ssum + res * px;
+                }
+            }
+        }
+        const double logl = -0.5 * (combine4(Ssum) + lik_const);
+        double P = 0.0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int j = 4 * s + g;
+            const double dx = v[s] - pmean[j];
+            const double px = pprec[j] * dx;
+            P = P + dx * px;
+        }
+        return logl + (-0.5 * combine4(P));
+    };
     auto logpost_of = [&](int l, int which, const double (&v)[KS]) {
         const TileLevel L = a.levels[2 * l + which];
         const double *consts = L.blob + (size_t)L.MT * KS * 64;
         const int m_pad = 16 * L.MT;
-        return logpost(L.blob, L.MT, consts, consts + m_pad, consts + 2 * m_pad, consts + 3 * m_pad,
-                       consts + 3 * m_pad + d_pad, L.lik_const, v);
+        if constexpr (STAGED)
+            return logpost_staged(L.blob, L.MT, consts, consts + m_pad, consts + 2 * m_pad, consts + 3 * m_pad,
+                                  consts + 3 * m_pad + d_pad, L.lik_const, v);
+        else
+            return logpost(L.blob, L.MT, consts, consts + m_pad, consts + 2 * m_pad, consts + 3 * m_pad,
+                           consts + 3 * m_pad + d_pad, L.lik_const, v);
     };
     auto any_differs = [&](const double (&p)[KS], const double (&q)[KS]) {
         bool dl = false;
@@ -169,10 +246,15 @@ __global__ __launch_bounds__(kNestThreads) void linear_tile_nested_kernel(const 
     auto decide = [&](int l, uint64_t t) {
         double *xl = park(l);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) y[s] = xl[s * 64];
+        for (int s = 0; s < KS; ++s) y[s] = wave_live ? xl[s * 64] : 0.0;
         const bool moved = any_differs(z, y);
-        const double lpPy = logpost_of(l, 0, z);
-        const double lpQy = logpost_of(l, 1, z);
+        double lpPy = 0.0, lpQy = 0.0;
+#pragma unroll 1
+        for (int which = 0; which < 2; ++which) { /* one copy of the evaluation's code for both densities */
+            const double val = logpost_of(l, which, z);
+            lpPy = which == 0 ? val : lpPy;
+            lpQy = which == 1 ? val : lpQy;
+        }
         const double lpPx = lpP.get(l), lpQx = lpQ.get(l);
         const double log_ratio = ((lpPy + lpQx) - lpQy) - lpPx;
         const double u = ymc_uniform_cached(uc, a.seed, chain, t);
@@ -180,7 +262,7 @@ __global__ __launch_bounds__(kNestThreads) void linear_tile_nested_kernel(const 
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             z[s] = acc ? z[s] : y[s];
-            xl[s * 64] = z[s];
+            if (wave_live) xl[s * 64] = z[s];
         }
         lpP.set(l, acc ? lpPy : lpPx);
         lpQ.set(l, acc ? lpQy : lpQx);
@@ -192,16 +274,23 @@ __global__ __launch_bounds__(kNestThreads) void linear_tile_nested_kernel(const 
         uint64_t t = (a.t0 + n) * a.cost_top;
         PerLevel<int> cnt = {0, 0, 0, 0};
         int from = E - 2; /* the levels below the top are entered afresh: MLDAProposal.generate_proposal, mlda.py:100-116 */
+        bool acc_top = false;
 #pragma unroll 1
         for (;;) {
             /* MetropolisHastings.run of levels from .. 1 starts at z (metropolisHastings.py:103-110) */
 #pragma unroll 1
             for (int l = from; l >= 1; --l) {
-                lpP.set(l, logpost_of(l, 0, z));
-                lpQ.set(l, logpost_of(l, 1, z));
+#pragma unroll 1
+                for (int which = 0; which < 2; ++which) {
+                    const double val = logpost_of(l, which, z);
+                    if (which == 0) lpP.set(l, val);
+                    else lpQ.set(l, val);
+                }
                 double *xl = park(l);
+                if (wave_live) {
 #pragma unroll
-                for (int s = 0; s < KS; ++s) xl[s * 64] = z[s];
+                    for (int s = 0; s < KS; ++s) xl[s * 64] = z[s];
+                }
                 cnt.set(l, 0);
             }
             /* level 0: a random walk of steps[0] transitions on P[0] (mrw.py:41-57) */
@@ -230,23 +319,28 @@ __global__ __launch_bounds__(kNestThreads) void linear_tile_nested_kernel(const 
             lacc.v0 += acc0;
             /* upwards: every level whose run below has ended decides; a level with steps left goes down again */
             int l = 1;
+            bool top = false;
 #pragma unroll 1
-            for (; l < E - 1; ++l) {
-                const bool acc = decide(l, t);
+            for (;; ++l) { /* one call site of decide(): the recorded level's decision ends the walk */
+                acc_top = decide(l, t);
                 ++t;
-                lacc.set(l, lacc.get(l) + (acc ? 1u : 0u));
+                if (l == E - 1) {
+                    top = true;
+                    break;
+                }
+                lacc.set(l, lacc.get(l) + (acc_top ? 1u : 0u));
                 const int done = cnt.get(l) + 1;
                 cnt.set(l, done);
                 if (done < steps.get(l)) break;
             }
-            if (l == E - 1) break;
+            if (top) break;
             from = l - 1;
         }
-        const bool acc = decide(E - 1, t);
+        const bool acc = acc_top;
         accepted += acc ? 1u : 0u;
 
         const bool rec = clk.due();
-        if (rec && a.traj) {
+        if (rec && a.traj && wave_live) {
             double *row = a.traj + (((uint64_t)clk.row * nct + tile) * KS) * 64 + lane;
 #pragma unroll
             for (int s = 0; s < KS; ++s) row[s * 64] = z[s];
@@ -274,17 +368,28 @@ __global__ __launch_bounds__(kNestThreads) void linear_tile_nested_kernel(const 
     }
 }
 
-template <int KS>
-hipError_t launch_as(const TileArgs &a, hipStream_t s)
+template <int KS, bool STAGED>
+hipError_t launch_staged_or_not(const TileArgs &a, size_t lds, hipStream_t s)
 {
-    const size_t lds = ymc_tile_lds_bytes(KS, a.MT);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_tile_nested_kernel<KS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_tile_nested_kernel<KS, STAGED>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const uint64_t nct = (a.K + 15) / 16;
     const unsigned grid = (unsigned)((nct + kNestWaves - 1) / kNestWaves);
-    hipLaunchKernelGGL((linear_tile_nested_kernel<KS>), dim3(grid), dim3(kNestThreads), lds, s, a);
+    hipLaunchKernelGGL((linear_tile_nested_kernel<KS, STAGED>), dim3(grid), dim3(kNestThreads), lds, s, a);
     return hipGetLastError();
+}
+
+template <int KS>
+hipError_t launch_as(const TileArgs &a, hipStream_t s)
+{
+    /* the upper levels' matrices through a shared double buffer when the LDS has room beside level 0's block
+     * (identical results; YMC_TILE_STAGE=0|1 overrides, the tests run both) */
+    const size_t plain = ymc_tile_lds_bytes(KS, a.MT);
+    const size_t staged = plain + 2 * (size_t)(2 * (KS / 4) * 64) * sizeof(double);
+    bool stage = staged <= kTileLdsLimit;
+    if (const char *env = std::getenv("YMC_TILE_STAGE")) stage = stage && env[0] != '0';
+    return stage ? launch_staged_or_not<KS, true>(a, staged, s) : launch_staged_or_not<KS, false>(a, plain, s);
 }
 
 }  // namespace
