@@ -1179,6 +1179,21 @@ def test_tile_kernels_with_and_without_the_shared_matrix_stream(ffi, ctx, monkey
     out = e.advance(12)
     _same_as_oracle(dev, e, out)
     assert np.array_equal(dev["level_acc"], e.level_acc)
+    # the adaptive error model: both levels with the same outputs and data; units of KS/4 k-steps here, of KS/8
+    # at d = m = 128 (test_f16, where the data rows leave 11 KB)
+    m = 40
+    A, b = rng.normal(size=(m, d)) / np.sqrt(d), rng.normal(size=m) * 0.3
+    As, bs = A + 0.05 * rng.normal(size=(m, d)) / np.sqrt(d), b + 0.1 * rng.normal(size=m)
+    data = np.array([A @ rng.normal(size=d) + b + 0.5 * rng.normal(size=m) for _ in range(nd)])
+    common = dict(data=data, noise_precision=np.full(m, 4.0), prior_mean=np.zeros(d), prior_precision=np.full(d, 0.25))
+    dev = _aem_device_run(ffi, ctx, None, dict(common, A=A, b=b), dict(common, A=As, b=bs), sigma, x0, 31337, 60, 3, 4, 1,
+                          splits=2, chain0=77)
+    e = o.AemEnsemble(o.posterior_linear(A, b, **common), o.posterior_linear(As, bs, **common), sigma, x0, 31337, 3, 4, 1,
+                      chain0=77)
+    out = e.advance(60, want_sub=True)
+    _same_as_oracle(dev, e, out)
+    assert np.array_equal(dev["sub_acc"], out["sub_acc"])
+    _same_error_model(dev, e)
 
 
 def test_tile_kernel_limits(ffi, ctx):

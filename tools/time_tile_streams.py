@@ -25,3 +25,12 @@ run.rewind_record()
 run.advance(20); run.sync()
 ms, n = run.kernel_time_ms()
 print("YMC_TILE_STAGE", os.environ.get("YMC_TILE_STAGE"), "nested E=2 S=4 d=128 K=65536: %.2f ms per 20 top steps -> %.3g top steps/s" % (ms, K * 20 / ms * 1e3))
+
+# the adaptive error model over two d = 128 models, 5 data rows (the LDS leaves room for 8 KB units only)
+prob = lowering.make_problem(ctx, ffi.METHOD_AEM2, lows[2], np.full(d, 0.03), surrogate=lows[0], sub_chain_length=4, aem=(8, True))
+run = ffi.Run(prob, 1, K, x0, 20, ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT, 0)
+run.advance(10); run.sync(); run.kernel_time_ms()
+run.rewind_record()
+run.advance(20); run.sync()
+ms, n = run.kernel_time_ms()
+print("YMC_TILE_STAGE", os.environ.get("YMC_TILE_STAGE"), "adaptive error model S=4 d=128 K=65536: %.2f ms per 20 fine steps -> %.3g fine steps/s" % (ms, K * 20 / ms * 1e3))

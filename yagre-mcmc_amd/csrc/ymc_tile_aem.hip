@@ -22,6 +22,8 @@
  * Same draws and the same arithmetic in the same order as ymo_aem_advance / aem2_kernel: bit-identical.
  */
 #define YMC_COEFF_IN_SGPR 1
+#include <cstdlib>
+
 #include "ymc_kernels.h"
 #include "ymc_tile.h"
 #include "ymc_tile_dev.h"
@@ -92,9 +94,22 @@ struct AemCache {
     }
 };
 
-template <int KS>
+/* STG: 0 = every wave reads the fine matrix's fragments from L2 itself; 4 / 8 = the workgroup's four waves (in
+ * lockstep: same S for all) share one stream of it through an LDS double buffer, in units of KS/4 or KS/8 k-steps
+ * of a pair of output tiles (16 or 8 KB at KS = 32 -- the data rows leave 11 KB at d = m = 128), one barrier per
+ * unit, the next unit fetched into registers while the MFMAs of the current one run.  With one wave per SIMD
+ * nothing else hides the L2 latency (ymc_tile_nested.hip: +67 %).  Waves past the last tile stay in the loop for
+ * the barriers and touch no memory; the update of the error model is then evaluated by every wave on every fine
+ * step (it applies to accepted chains only, as before). */
+template <int KS, int STG>
 __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const TileArgs a)
 {
+    constexpr bool STAGED = STG != 0;
+    constexpr int kDiv = STAGED ? STG : 4;
+    static_assert(KS % kDiv == 0, "staged units are whole k-steps");
+    constexpr int kSteps = KS / kDiv;                            /* k-steps per staged unit */
+    constexpr int kUnit = 2 * kSteps * 64;                       /* doubles per unit: two tiles */
+    constexpr int kPer = (kUnit + kAemThreads - 1) / kAemThreads;
     ymc_stage_tables();
     extern __shared__ double lds[];
     const int MT = a.MT, m_pad = 16 * MT, d_pad = 4 * KS, Q = 4 * MT; /* both levels have a.m outputs */
@@ -117,6 +132,7 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
     double *data_c = nprec_c + m_pad;
     const size_t rows_c = (size_t)m_pad * (1 + (size_t)a.n_data);
     const double *Af = a.blob_f;
+    double *stage = nprec_c + rows_c;                            /* STAGED: [2][kUnit] */
 
     const int tid = threadIdx.x;
     for (size_t i = tid; i < blob_c / 2; i += kAemThreads)
@@ -127,10 +143,12 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
 
     const int lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
     const uint64_t nct = (a.K + 15) / 16;
-    const uint64_t tile = (uint64_t)blockIdx.x * kAemWaves + wave;
-    if (tile >= nct) return;
-    const uint64_t k = tile * 16 + c;
-    const bool live = k < a.K;
+    const uint64_t tile_raw = (uint64_t)blockIdx.x * kAemWaves + wave;
+    const bool wave_live = tile_raw < nct;
+    if (!STAGED && !wave_live) return;
+    const uint64_t tile = wave_live ? tile_raw : 0; /* a wave past the last tile reads tile 0's arrays and writes nothing */
+    const uint64_t k = tile_raw * 16 + c;
+    const bool live = wave_live && k < a.K;
     const uint64_t kk = live ? k : 0;
     const uint32_t chain = (uint32_t)(a.chain0 + kk);
     const int d = a.d, S = a.S, m_real = a.m, n_data = a.n_data;
@@ -146,7 +164,7 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
     for (int s = 0; s < KS; ++s) {
         const int j = 4 * s + g;
         z[s] = (live && j < d) ? a.x[k * d + j] : 0.0;
-        xt[s * 64] = z[s];
+        if (wave_live) xt[s * 64] = z[s];
     }
     double lpf = live ? a.lp[k] : 0.0;
     uint64_t accepted = live ? a.acc_count[k] : 0;
@@ -210,19 +228,66 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
             if (i < n_data) total = total + combine4(Srow[i]);
         return -0.5 * total;
     };
-    /* the fine model's plain likelihood through the row-mean identity, matrix fragments from global memory */
+    /* the fine forward map of v, a pair of output tiles at a time: emit(mt, acc0, acc1) receives the MFMA
+     * accumulators of tiles mt and mt + 1 (k ascending per accumulator in both forms: the same bits).  STAGED:
+     * EVERY wave of the workgroup calls this at the same point of the loop. */
+    auto fetch_unit = [&](int pair, int q, double (&r)[kPer]) {
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const int idx = tid + j * kAemThreads;
+            if (kUnit % kAemThreads == 0 || idx < kUnit) {
+                const int blk = idx / (kSteps * 64), off = idx % (kSteps * 64);
+                r[j] = Af[((size_t)(2 * pair + blk) * KS + (size_t)q * kSteps) * 64 + off];
+            }
+        }
+    };
+    auto fine_pairs = [&](const double (&v)[KS], auto &&emit) {
+        if constexpr (STAGED) {
+            double r[kPer];
+            fetch_unit(0, 0, r);
+            int buf = 0;
+#pragma unroll 1
+            for (int pair = 0; pair < MT / 2; ++pair) {
+                d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < kDiv; ++q) {
+                    double *stg = stage + buf * kUnit;
+#pragma unroll
+                    for (int j = 0; j < kPer; ++j) {
+                        const int idx = tid + j * kAemThreads;
+                        if (kUnit % kAemThreads == 0 || idx < kUnit) stg[idx] = r[j];
+                    }
+                    __syncthreads(); /* the unit is complete; everyone has left the buffer that is written next */
+                    if (q + 1 < kDiv) fetch_unit(pair, q + 1, r);
+                    else if (pair + 1 < MT / 2) fetch_unit(pair + 1, 0, r);
+#pragma unroll
+                    for (int sl = 0; sl < kSteps; ++sl) {
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(stg[sl * 64 + lane], v[q * kSteps + sl], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(stg[(kSteps + sl) * 64 + lane], v[q * kSteps + sl], acc1, 0, 0, 0);
+                    }
+                    buf ^= 1;
+                }
+                emit(2 * pair, acc0, acc1);
+            }
+        } else {
+#pragma unroll 1
+            for (int mt = 0; mt < MT; mt += 2) {
+                d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+                const double *A0 = Af + (size_t)mt * KS * 64 + lane;
+                const double *A1 = A0 + (size_t)KS * 64;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[s * 64], v[s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1[s * 64], v[s], acc1, 0, 0, 0);
+                }
+                emit(mt, acc0, acc1);
+            }
+        }
+    };
+    /* the fine model's plain likelihood through the row-mean identity */
     auto loglik_fine = [&](const double (&v)[KS]) {
         double Ssum = 0.0;
-#pragma unroll 1
-        for (int mt = 0; mt < MT; mt += 2) {
-            d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-            const double *A0 = Af + (size_t)mt * KS * 64 + lane;
-            const double *A1 = A0 + (size_t)KS * 64;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[s * 64], v[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1[s * 64], v[s], acc1, 0, 0, 0);
-            }
+        fine_pairs(v, [&](int mt, const d4 &acc0, const d4 &acc1) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -234,7 +299,7 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
                     Ssum = Ssum + res * px;
                 }
             }
-        }
+        });
         return -0.5 * (combine4(Ssum) + a.lik_const_f);
     };
     auto logprior = [&](const double *pmean, const double *pprec, const double (&v)[KS]) {
@@ -274,17 +339,13 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
         const bool inflate = n_new > (uint64_t)a.min_data;
         double lo = 0.0, hi = 0.0;
         bool first = true;
-#pragma unroll 1
-        for (int mt = 0; mt < MT; mt += 2) {
-            d4 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0}, f0 = {0.0, 0.0, 0.0, 0.0}, f1 = {0.0, 0.0, 0.0, 0.0};
+        fine_pairs(v, [&](int mt, const d4 &f0, const d4 &f1) {
+            d4 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0};
             const double *C0 = Ac + (size_t)mt * KS * 64 + lane, *C1 = C0 + (size_t)KS * 64;
-            const double *F0 = Af + (size_t)mt * KS * 64 + lane, *F1 = F0 + (size_t)KS * 64;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(C0[s * 64], v[s], c0, 0, 0, 0);
                 c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(C1[s * 64], v[s], c1, 0, 0, 0);
-                f0 = __builtin_amdgcn_mfma_f64_16x16x4f64(F0[s * 64], v[s], f0, 0, 0, 0);
-                f1 = __builtin_amdgcn_mfma_f64_16x16x4f64(F1[s * 64], v[s], f1, 0, 0, 0);
             }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -309,7 +370,7 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
                     }
                 }
             }
-        }
+        });
         if (__builtin_amdgcn_ballot_w64(mine && inflate) != 0) {
             /* min / max of the marginal variances over ALL outputs of the chain: the four lanes' ranges joined
              * (a lane without a real output holds none) */
@@ -374,26 +435,27 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
         }
         /* fine accept / reject, mlda.py:146-154: tgt(y), finest(x), finest(y), tgt(x); y <- the fine state x */
 #pragma unroll
-        for (int s = 0; s < KS; ++s) y[s] = xt[s * 64];
+        for (int s = 0; s < KS; ++s) y[s] = wave_live ? xt[s * 64] : 0.0;
         const double u = ymc_uniform_cached(uc, a.seed, chain, tbase + (uint64_t)S);
         const bool moved = any_differs(z, y);
         const double lpfy = loglik_fine(z) + logprior(pmean_f, pprec_f, z);
         const double cx = query(x_id, y, moved) + logprior(pmean_c, pprec_c, y);
         const double cy = query(z_id, z, moved) + logprior(pmean_c, pprec_c, z);
         const double log_ratio = ((lpfy + cx) - cy) - lpf;
-        const bool acc = moved && ymc_accept(log_ratio, true, ymc_finite(lpfy) && ymc_finite(cy), u, st);
-        if (__builtin_amdgcn_ballot_w64(acc) != 0) update(z, acc); /* aem.py:26-56, before the chain moves */
+        const bool acc = wave_live && moved && ymc_accept(log_ratio, true, ymc_finite(lpfy) && ymc_finite(cy), u, st);
+        /* aem.py:26-56, before the chain moves; STAGED: by every wave (the shared stream), else by the waves with an accepted chain */
+        if (STAGED || __builtin_amdgcn_ballot_w64(acc) != 0) update(z, acc);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             z[s] = acc ? z[s] : y[s];
-            xt[s * 64] = z[s];
+            if (wave_live) xt[s * 64] = z[s];
         }
         lpf = acc ? lpfy : lpf;
         x_id = acc ? z_id : x_id;
         accepted += acc ? 1u : 0u;
 
         const bool rec = clk.due();
-        if (rec && a.traj) {
+        if (rec && a.traj && wave_live) {
             double *row = a.traj + (((uint64_t)clk.row * nct + tile) * KS) * 64 + lane;
 #pragma unroll
             for (int s = 0; s < KS; ++s) row[s * 64] = z[s];
@@ -428,17 +490,31 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
     }
 }
 
-template <int KS>
-hipError_t launch_as(const TileArgs &a, hipStream_t s)
+template <int KS, int STG>
+hipError_t launch_staged(const TileArgs &a, size_t lds, hipStream_t s)
 {
-    const size_t lds = ymc_tile_aem2_lds_bytes(KS, a.MT, a.n_data);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_tile_aem2_kernel<KS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_tile_aem2_kernel<KS, STG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const uint64_t nct = (a.K + 15) / 16;
     const unsigned grid = (unsigned)((nct + kAemWaves - 1) / kAemWaves);
-    hipLaunchKernelGGL((linear_tile_aem2_kernel<KS>), dim3(grid), dim3(kAemThreads), lds, s, a);
+    hipLaunchKernelGGL((linear_tile_aem2_kernel<KS, STG>), dim3(grid), dim3(kAemThreads), lds, s, a);
     return hipGetLastError();
+}
+
+template <int KS>
+hipError_t launch_as(const TileArgs &a, hipStream_t s)
+{
+    /* the fine matrix through the shared double buffer in the largest unit the LDS has room for (identical
+     * results; YMC_TILE_STAGE=0 switches it off, the tests run both) */
+    const size_t plain = ymc_tile_aem2_lds_bytes(KS, a.MT, a.n_data);
+    const size_t unit4 = 2 * (size_t)(2 * (KS / 4) * 64) * sizeof(double);
+    bool stage = true;
+    if (const char *env = std::getenv("YMC_TILE_STAGE")) stage = env[0] != '0';
+    if (stage && plain + unit4 <= kTileLdsLimit) return launch_staged<KS, 4>(a, plain + unit4, s);
+    if constexpr (KS >= 8)
+        if (stage && plain + unit4 / 2 <= kTileLdsLimit) return launch_staged<KS, 8>(a, plain + unit4 / 2, s);
+    return launch_staged<KS, 0>(a, plain, s);
 }
 
 }  // namespace
