@@ -1179,6 +1179,12 @@ def test_tile_kernels_with_and_without_the_shared_matrix_stream(ffi, ctx, monkey
     out = e.advance(12)
     _same_as_oracle(dev, e, out)
     assert np.array_equal(dev["level_acc"], e.level_acc)
+    # the random walk with a dense proposal covariance: its factor L through the same stream
+    Bm = rng.normal(size=(d, d)) * 0.02 / np.sqrt(d)
+    L = np.linalg.cholesky(Bm @ Bm.T + 0.002 * np.eye(d))
+    dev = _dense_tile_run(ffi, ctx, models[4][0], L, x0, 4713, 30, chain0=3000, splits=3)
+    e = o.Ensemble(models[4][1], np.ones(d), x0, 4713, chain0=3000, chol=L)
+    _same_as_oracle(dev, e, e.advance(30))
     # the adaptive error model: both levels with the same outputs and data; units of KS/4 k-steps here, of KS/8
     # at d = m = 128 (test_f16, where the data rows leave 11 KB)
     m = 40

@@ -34,3 +34,14 @@ run.rewind_record()
 run.advance(20); run.sync()
 ms, n = run.kernel_time_ms()
 print("YMC_TILE_STAGE", os.environ.get("YMC_TILE_STAGE"), "adaptive error model S=4 d=128 K=65536: %.2f ms per 20 fine steps -> %.3g fine steps/s" % (ms, K * 20 / ms * 1e3))
+
+# the random walk with a dense proposal covariance at d = 128 (L read by every transition)
+B = rng.normal(size=(d, d)) * 0.02 / np.sqrt(d)
+L = np.linalg.cholesky(B @ B.T + 0.001 * np.eye(d))
+prob = lowering.make_problem(ctx, ffi.METHOD_MRW, lows[2], np.ones(d), chol=np.tril(L))
+run = ffi.Run(prob, 1, K, x0, 40, ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT, 0)
+run.advance(20); run.sync(); run.kernel_time_ms()
+run.rewind_record()
+run.advance(40); run.sync()
+ms, n = run.kernel_time_ms()
+print("YMC_TILE_STAGE", os.environ.get("YMC_TILE_STAGE"), "dense-proposal random walk d=128 K=65536: %.2f ms per 40 transitions -> %.3g steps/s" % (ms, K * 40 / ms * 1e3))

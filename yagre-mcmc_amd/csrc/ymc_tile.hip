@@ -39,12 +39,18 @@ namespace {
 /* PROP: the proposal of the kernel -- diagonal random walk, pCN, or random walk with a dense covariance.  A
  * compile-time choice: the dense branch as a run-time test cost the diagonal kernel 20 VGPRs (8 spilled at
  * KS = 32) and 20 % of its speed. */
-enum { kPropDiag = 0, kPropPcn = 1, kPropDense = 2 };
+enum { kPropDiag = 0, kPropPcn = 1, kPropDense = 2, kPropDenseStaged = 3 };
 
+/* kPropDenseStaged: the dense proposal's factor L (read by every transition) through the workgroup's shared LDS
+ * double buffer instead of every wave's own L2 reads, as the fine matrix of linear_tile_mlda2_kernel; waves past
+ * the last tile then stay in the loop for the barriers and touch no memory. */
 template <int KS, int PROP>
 __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArgs a)
 {
-    constexpr bool PCN = PROP == kPropPcn, DENSE = PROP == kPropDense;
+    constexpr bool PCN = PROP == kPropPcn, DENSE = PROP == kPropDense || PROP == kPropDenseStaged;
+    constexpr bool STAGED = PROP == kPropDenseStaged;
+    constexpr int kUnit = 2 * (KS / 4) * 64;                    /* doubles per staged unit: two tiles x KS/4 k-steps */
+    constexpr int kPer = (kUnit + kTileThreads - 1) / kTileThreads;
     ymc_stage_tables();
     extern __shared__ double lds[];
     const int MT = a.MT, m_pad = 16 * MT, d_pad = 4 * KS;
@@ -65,12 +71,14 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
     const int lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
     const uint64_t nct = (a.K + 15) / 16;
     const uint64_t tile = (uint64_t)blockIdx.x * kTileWaves + wave;
-    if (tile >= nct) return;
+    const bool wave_live = tile < nct;
+    if (!STAGED && !wave_live) return;
     const uint64_t k = tile * 16 + c;
-    const bool live = k < a.K;
+    const bool live = wave_live && k < a.K;
     const uint32_t chain = (uint32_t)(a.chain0 + k);
     const int d = a.d;
     const uint32_t pair_of_g = (g == 0) ? 0u : (g == 1) ? 2u : (g == 2) ? 1u : 3u;
+    double *stage = lds + blob_doubles;                          /* STAGED: [2][kUnit] */
 
     double x[KS], y[KS];
 #pragma unroll
@@ -119,21 +127,66 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
              * lane.  The rows pass through a scratch in the record's layout, because y holds xi until the last
              * product (L's fragments come from global memory: 128 KB, L2-resident, as the fine matrix of the
              * two-level kernel). */
-            double *wt = a.w_tiled + (tile * KS) * 64 + lane;
+            double *wt = a.w_tiled + ((wave_live ? tile : 0) * KS) * 64 + lane;
+            if constexpr (STAGED) {
+                auto fetch_unit = [&](int pair, int q, double (&r)[kPer]) {
+#pragma unroll
+                    for (int j = 0; j < kPer; ++j) {
+                        const int idx = tid + j * kTileThreads;
+                        if (kUnit % kTileThreads == 0 || idx < kUnit) {
+                            const int blk = idx / (KS * 16), off = idx % (KS * 16);
+                            r[j] = a.chol_frag[((size_t)(2 * pair + blk) * KS + (size_t)q * (KS / 4)) * 64 + off];
+                        }
+                    }
+                };
+                double r[kPer];
+                fetch_unit(0, 0, r);
+                int buf = 0;
 #pragma unroll 1
-            for (int mt = 0; mt < a.MT_L; mt += 2) {
-                d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-                const double *L0 = a.chol_frag + (size_t)mt * KS * 64 + lane;
-                const double *L1 = L0 + (size_t)KS * 64;
+                for (int pair = 0; pair < a.MT_L / 2; ++pair) {
+                    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(L0[s * 64], y[s], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(L1[s * 64], y[s], acc1, 0, 0, 0);
+                    for (int q = 0; q < 4; ++q) {
+                        double *stg = stage + buf * kUnit;
+#pragma unroll
+                        for (int j = 0; j < kPer; ++j) {
+                            const int idx = tid + j * kTileThreads;
+                            if (kUnit % kTileThreads == 0 || idx < kUnit) stg[idx] = r[j];
+                        }
+                        __syncthreads(); /* the unit is complete; everyone has left the buffer that is written next */
+                        if (q < 3) fetch_unit(pair, q + 1, r);
+                        else if (pair + 1 < a.MT_L / 2) fetch_unit(pair + 1, 0, r);
+#pragma unroll
+                        for (int sl = 0; sl < KS / 4; ++sl) {
+                            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(stg[sl * 64 + lane], y[q * (KS / 4) + sl], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(stg[(KS / 4 + sl) * 64 + lane], y[q * (KS / 4) + sl], acc1, 0, 0, 0);
+                        }
+                        buf ^= 1;
+                    }
+                    if (wave_live) {
+#pragma unroll
+                        for (int r_ = 0; r_ < 4; ++r_) {
+                            if (8 * pair + r_ < KS) wt[(8 * pair + r_) * 64] = acc0[r_];
+                            if (8 * pair + 4 + r_ < KS) wt[(8 * pair + 4 + r_) * 64] = acc1[r_];
+                        }
+                    }
                 }
+            } else {
+#pragma unroll 1
+                for (int mt = 0; mt < a.MT_L; mt += 2) {
+                    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+                    const double *L0 = a.chol_frag + (size_t)mt * KS * 64 + lane;
+                    const double *L1 = L0 + (size_t)KS * 64;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (4 * mt + r < KS) wt[(4 * mt + r) * 64] = acc0[r];
-                    if (4 * (mt + 1) + r < KS) wt[(4 * (mt + 1) + r) * 64] = acc1[r];
+                    for (int s = 0; s < KS; ++s) {
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(L0[s * 64], y[s], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(L1[s * 64], y[s], acc1, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (4 * mt + r < KS) wt[(4 * mt + r) * 64] = acc0[r];
+                        if (4 * (mt + 1) + r < KS) wt[(4 * (mt + 1) + r) * 64] = acc1[r];
+                    }
                 }
             }
 #pragma unroll
@@ -197,7 +250,7 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
         accepted += acc ? 1u : 0u;
 
         const bool rec = clk.due();
-        if (rec && a.traj) {
+        if (rec && a.traj && wave_live) {
             double *row = a.traj + (((uint64_t)clk.row * nct + tile) * KS) * 64 + lane;
 #pragma unroll
             for (int s = 0; s < KS; ++s) row[s * 64] = x[s];
@@ -578,9 +631,9 @@ size_t ymc_tile_lds_bytes(int KS, int MT)
 }
 
 template <int KS, int PROP>
-static hipError_t launch_tile_as(const TileArgs &a, hipStream_t s)
+static hipError_t launch_tile_as(const TileArgs &a, hipStream_t s, size_t extra_lds = 0)
 {
-    const size_t lds = ymc_tile_lds_bytes(KS, a.MT);
+    const size_t lds = ymc_tile_lds_bytes(KS, a.MT) + extra_lds;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_tile_kernel<KS, PROP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -633,7 +686,15 @@ hipError_t ymc_launch_linear_tile_mlda2(int KS, const TileArgs &a, hipStream_t s
 template <int KS>
 static hipError_t launch_tile(const TileArgs &a, hipStream_t s)
 {
-    if (a.chol_frag) return a.pcn ? hipErrorInvalidValue : launch_tile_as<KS, kPropDense>(a, s);
+    if (a.chol_frag) {
+        if (a.pcn) return hipErrorInvalidValue;
+        /* L through the shared double buffer when the LDS has room beside the forward map (identical results;
+         * YMC_TILE_STAGE=0 switches it off, the tests run both) */
+        const size_t extra = 2 * (size_t)(2 * (KS / 4) * 64) * sizeof(double);
+        bool stage = ymc_tile_lds_bytes(KS, a.MT) + extra <= kTileLdsLimit;
+        if (const char *env = std::getenv("YMC_TILE_STAGE")) stage = stage && env[0] != '0';
+        return stage ? launch_tile_as<KS, kPropDenseStaged>(a, s, extra) : launch_tile_as<KS, kPropDense>(a, s);
+    }
     return a.pcn ? launch_tile_as<KS, kPropPcn>(a, s) : launch_tile_as<KS, kPropDiag>(a, s);
 }
 
