@@ -49,8 +49,6 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
 {
     constexpr bool PCN = PROP == kPropPcn, DENSE = PROP == kPropDense || PROP == kPropDenseStaged;
     constexpr bool STAGED = PROP == kPropDenseStaged;
-    constexpr int kUnit = 2 * (KS / 4) * 64;                    /* doubles per staged unit: two tiles x KS/4 k-steps */
-    constexpr int kPer = (kUnit + kTileThreads - 1) / kTileThreads;
     ymc_stage_tables();
     extern __shared__ double lds[];
     const int MT = a.MT, m_pad = 16 * MT, d_pad = 4 * KS;
@@ -78,7 +76,7 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
     const uint32_t chain = (uint32_t)(a.chain0 + k);
     const int d = a.d;
     const uint32_t pair_of_g = (g == 0) ? 0u : (g == 1) ? 2u : (g == 2) ? 1u : 3u;
-    double *stage = lds + blob_doubles;                          /* STAGED: [2][kUnit] */
+    double *stage = lds + blob_doubles;                          /* STAGED: the stream's double buffer (ymc_tile_dev.h) */
 
     double x[KS], y[KS];
 #pragma unroll
@@ -129,48 +127,16 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
              * two-level kernel). */
             double *wt = a.w_tiled + ((wave_live ? tile : 0) * KS) * 64 + lane;
             if constexpr (STAGED) {
-                auto fetch_unit = [&](int pair, int q, double (&r)[kPer]) {
-#pragma unroll
-                    for (int j = 0; j < kPer; ++j) {
-                        const int idx = tid + j * kTileThreads;
-                        if (kUnit % kTileThreads == 0 || idx < kUnit) {
-                            const int blk = idx / (KS * 16), off = idx % (KS * 16);
-                            r[j] = a.chol_frag[((size_t)(2 * pair + blk) * KS + (size_t)q * (KS / 4)) * 64 + off];
-                        }
-                    }
-                };
-                double r[kPer];
-                fetch_unit(0, 0, r);
-                int buf = 0;
-#pragma unroll 1
-                for (int pair = 0; pair < a.MT_L / 2; ++pair) {
-                    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        double *stg = stage + buf * kUnit;
-#pragma unroll
-                        for (int j = 0; j < kPer; ++j) {
-                            const int idx = tid + j * kTileThreads;
-                            if (kUnit % kTileThreads == 0 || idx < kUnit) stg[idx] = r[j];
-                        }
-                        __syncthreads(); /* the unit is complete; everyone has left the buffer that is written next */
-                        if (q < 3) fetch_unit(pair, q + 1, r);
-                        else if (pair + 1 < a.MT_L / 2) fetch_unit(pair + 1, 0, r);
-#pragma unroll
-                        for (int sl = 0; sl < KS / 4; ++sl) {
-                            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(stg[sl * 64 + lane], y[q * (KS / 4) + sl], acc0, 0, 0, 0);
-                            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(stg[(KS / 4 + sl) * 64 + lane], y[q * (KS / 4) + sl], acc1, 0, 0, 0);
-                        }
-                        buf ^= 1;
-                    }
+                ymc_stream_tile_pairs<KS, 4, kTileThreads>(a.chol_frag, a.MT_L / 2, stage, tid, lane, y,
+                                                           [&](int pair, const d4 &acc0, const d4 &acc1) {
                     if (wave_live) {
 #pragma unroll
-                        for (int r_ = 0; r_ < 4; ++r_) {
-                            if (8 * pair + r_ < KS) wt[(8 * pair + r_) * 64] = acc0[r_];
-                            if (8 * pair + 4 + r_ < KS) wt[(8 * pair + 4 + r_) * 64] = acc1[r_];
+                        for (int r = 0; r < 4; ++r) {
+                            if (8 * pair + r < KS) wt[(8 * pair + r) * 64] = acc0[r];
+                            if (8 * pair + 4 + r < KS) wt[(8 * pair + 4 + r) * 64] = acc1[r];
                         }
                     }
-                }
+                });
             } else {
 #pragma unroll 1
                 for (int mt = 0; mt < a.MT_L; mt += 2) {
@@ -317,9 +283,7 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_mlda2_kernel(const T
     double *pprec_f = pmean_f + d_pad;
     const size_t consts_f = (size_t)m_pad_f * 3 + 2 * (size_t)d_pad;
     const double *Af = a.blob_f;
-    constexpr int kUnit = 2 * (KS / 4) * 64;                    /* doubles per staged unit: two tiles x KS/4 k-steps */
-    constexpr int kPer = (kUnit + kTileThreads - 1) / kTileThreads;
-    double *stage = bias_f + consts_f;                           /* STAGED: [2][kUnit] */
+    double *stage = bias_f + consts_f;                           /* STAGED: the stream's double buffer (ymc_tile_dev.h) */
 
     const int tid = threadIdx.x;
     for (size_t i = tid; i < blob_c / 2; i += kTileThreads)
@@ -405,46 +369,11 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_mlda2_kernel(const T
         mv |= __shfl_xor(mv, 32, 64);
         return mv != 0;
     };
-    /* STAGED: the fine level's log-likelihood with the workgroup's shared stream of the fine matrix.  Unit
-     * (pair, q) = k-steps [q KS/4, (q + 1) KS/4) of output tiles 2 pair and 2 pair + 1; the MFMA order per
-     * accumulator is the plain form's (k ascending), so the value is the same bits.  EVERY wave of the
-     * workgroup calls this at the same point of the loop. */
-    auto fetch_unit = [&](int pair, int q, double (&r)[kPer]) {
-#pragma unroll
-        for (int j = 0; j < kPer; ++j) {
-            const int idx = tid + j * kTileThreads;
-            if (kUnit % kTileThreads == 0 || idx < kUnit) {
-                const int blk = idx / (KS * 16), off = idx % (KS * 16);
-                r[j] = Af[((size_t)(2 * pair + blk) * KS + (size_t)q * (KS / 4)) * 64 + off];
-            }
-        }
-    };
+    /* STAGED: the fine level's log-likelihood over the workgroup's shared stream of the fine matrix
+     * (ymc_stream_tile_pairs, ymc_tile_dev.h); every wave calls it at the same point of the loop */
     auto loglik_fine_staged = [&](const double (&v)[KS]) {
         double Ssum = 0.0;
-        double r[kPer];
-        fetch_unit(0, 0, r);
-        int buf = 0;
-#pragma unroll 1
-        for (int pair = 0; pair < MTf / 2; ++pair) {
-            d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                double *stg = stage + buf * kUnit;
-#pragma unroll
-                for (int j = 0; j < kPer; ++j) {
-                    const int idx = tid + j * kTileThreads;
-                    if (kUnit % kTileThreads == 0 || idx < kUnit) stg[idx] = r[j];
-                }
-                __syncthreads(); /* the unit is complete; everyone has left the buffer that is written next */
-                if (q < 3) fetch_unit(pair, q + 1, r);
-                else if (pair + 1 < MTf / 2) fetch_unit(pair + 1, 0, r);
-#pragma unroll
-                for (int sl = 0; sl < KS / 4; ++sl) {
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(stg[sl * 64 + lane], v[q * (KS / 4) + sl], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(stg[(KS / 4 + sl) * 64 + lane], v[q * (KS / 4) + sl], acc1, 0, 0, 0);
-                }
-                buf ^= 1;
-            }
+        ymc_stream_tile_pairs<KS, 4, kTileThreads>(Af, MTf / 2, stage, tid, lane, v, [&](int pair, const d4 &acc0, const d4 &acc1) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -456,7 +385,7 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_mlda2_kernel(const T
                     Ssum = Ssum + res * px;
                 }
             }
-        }
+        });
         return -0.5 * (combine4(Ssum) + a.lik_const_f);
     };
 
@@ -666,7 +595,7 @@ static hipError_t launch_tile_mlda2(const TileArgs &a, hipStream_t s)
     /* the fine matrix through a shared double buffer when the LDS has 16 KB left for it (identical results;
      * YMC_TILE_STAGE=0|1 overrides, the tests run both) */
     const size_t plain = ymc_tile_mlda2_lds_bytes(KS, a.MT, a.MT_f);
-    const size_t staged = plain + 2 * (size_t)(2 * (KS / 4) * 64) * sizeof(double);
+    const size_t staged = plain + 2 * (size_t)ymc_stream_unit<KS, 4>() * sizeof(double);
     bool stage = staged <= kTileLdsLimit;
     if (const char *env = std::getenv("YMC_TILE_STAGE")) stage = stage && env[0] != '0';
     return stage ? launch_tile_mlda2_as<KS, true>(a, staged, s) : launch_tile_mlda2_as<KS, false>(a, plain, s);
@@ -690,7 +619,7 @@ static hipError_t launch_tile(const TileArgs &a, hipStream_t s)
         if (a.pcn) return hipErrorInvalidValue;
         /* L through the shared double buffer when the LDS has room beside the forward map (identical results;
          * YMC_TILE_STAGE=0 switches it off, the tests run both) */
-        const size_t extra = 2 * (size_t)(2 * (KS / 4) * 64) * sizeof(double);
+        const size_t extra = 2 * (size_t)ymc_stream_unit<KS, 4>() * sizeof(double);
         bool stage = ymc_tile_lds_bytes(KS, a.MT) + extra <= kTileLdsLimit;
         if (const char *env = std::getenv("YMC_TILE_STAGE")) stage = stage && env[0] != '0';
         return stage ? launch_tile_as<KS, kPropDenseStaged>(a, s, extra) : launch_tile_as<KS, kPropDense>(a, s);

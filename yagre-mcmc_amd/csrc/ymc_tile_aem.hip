@@ -107,9 +107,7 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
     constexpr bool STAGED = STG != 0;
     constexpr int kDiv = STAGED ? STG : 4;
     static_assert(KS % kDiv == 0, "staged units are whole k-steps");
-    constexpr int kSteps = KS / kDiv;                            /* k-steps per staged unit */
-    constexpr int kUnit = 2 * kSteps * 64;                       /* doubles per unit: two tiles */
-    constexpr int kPer = (kUnit + kAemThreads - 1) / kAemThreads;
+
     ymc_stage_tables();
     extern __shared__ double lds[];
     const int MT = a.MT, m_pad = 16 * MT, d_pad = 4 * KS, Q = 4 * MT; /* both levels have a.m outputs */
@@ -132,7 +130,7 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
     double *data_c = nprec_c + m_pad;
     const size_t rows_c = (size_t)m_pad * (1 + (size_t)a.n_data);
     const double *Af = a.blob_f;
-    double *stage = nprec_c + rows_c;                            /* STAGED: [2][kUnit] */
+    double *stage = nprec_c + rows_c;                            /* STAGED: the stream's double buffer (ymc_tile_dev.h) */
 
     const int tid = threadIdx.x;
     for (size_t i = tid; i < blob_c / 2; i += kAemThreads)
@@ -231,44 +229,10 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
     /* the fine forward map of v, a pair of output tiles at a time: emit(mt, acc0, acc1) receives the MFMA
      * accumulators of tiles mt and mt + 1 (k ascending per accumulator in both forms: the same bits).  STAGED:
      * EVERY wave of the workgroup calls this at the same point of the loop. */
-    auto fetch_unit = [&](int pair, int q, double (&r)[kPer]) {
-#pragma unroll
-        for (int j = 0; j < kPer; ++j) {
-            const int idx = tid + j * kAemThreads;
-            if (kUnit % kAemThreads == 0 || idx < kUnit) {
-                const int blk = idx / (kSteps * 64), off = idx % (kSteps * 64);
-                r[j] = Af[((size_t)(2 * pair + blk) * KS + (size_t)q * kSteps) * 64 + off];
-            }
-        }
-    };
     auto fine_pairs = [&](const double (&v)[KS], auto &&emit) {
         if constexpr (STAGED) {
-            double r[kPer];
-            fetch_unit(0, 0, r);
-            int buf = 0;
-#pragma unroll 1
-            for (int pair = 0; pair < MT / 2; ++pair) {
-                d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int q = 0; q < kDiv; ++q) {
-                    double *stg = stage + buf * kUnit;
-#pragma unroll
-                    for (int j = 0; j < kPer; ++j) {
-                        const int idx = tid + j * kAemThreads;
-                        if (kUnit % kAemThreads == 0 || idx < kUnit) stg[idx] = r[j];
-                    }
-                    __syncthreads(); /* the unit is complete; everyone has left the buffer that is written next */
-                    if (q + 1 < kDiv) fetch_unit(pair, q + 1, r);
-                    else if (pair + 1 < MT / 2) fetch_unit(pair + 1, 0, r);
-#pragma unroll
-                    for (int sl = 0; sl < kSteps; ++sl) {
-                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(stg[sl * 64 + lane], v[q * kSteps + sl], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(stg[(kSteps + sl) * 64 + lane], v[q * kSteps + sl], acc1, 0, 0, 0);
-                    }
-                    buf ^= 1;
-                }
-                emit(2 * pair, acc0, acc1);
-            }
+            ymc_stream_tile_pairs<KS, kDiv, kAemThreads>(Af, MT / 2, stage, tid, lane, v,
+                                                         [&](int pair, const d4 &acc0, const d4 &acc1) { emit(2 * pair, acc0, acc1); });
         } else {
 #pragma unroll 1
             for (int mt = 0; mt < MT; mt += 2) {
@@ -508,7 +472,7 @@ hipError_t launch_as(const TileArgs &a, hipStream_t s)
     /* the fine matrix through the shared double buffer in the largest unit the LDS has room for (identical
      * results; YMC_TILE_STAGE=0 switches it off, the tests run both) */
     const size_t plain = ymc_tile_aem2_lds_bytes(KS, a.MT, a.n_data);
-    const size_t unit4 = 2 * (size_t)(2 * (KS / 4) * 64) * sizeof(double);
+    const size_t unit4 = 2 * (size_t)ymc_stream_unit<KS, 4>() * sizeof(double);
     bool stage = true;
     if (const char *env = std::getenv("YMC_TILE_STAGE")) stage = env[0] != '0';
     if (stage && plain + unit4 <= kTileLdsLimit) return launch_staged<KS, 4>(a, plain + unit4, s);

@@ -1,4 +1,5 @@
-/* ymc_tile_dev.h -- device helpers shared by the matrix-core kernels (ymc_tile.hip, ymc_tile_aem.hip). */
+/* ymc_tile_dev.h -- device helpers shared by the matrix-core kernels (ymc_tile.hip, ymc_tile_aem.hip,
+ * ymc_tile_nested.hip). */
 #ifndef YMC_TILE_DEV_H
 #define YMC_TILE_DEV_H
 
@@ -36,6 +37,64 @@ __device__ __forceinline__ double combine4(double s)
 {
     double v = s + shfl_xor_f64(s, 16);
     return v + shfl_xor_f64(v, 32);
+}
+
+/* A matrix that does not live in LDS (a fine or upper-level forward map, a dense proposal's factor), streamed
+ * from L2 ONCE PER WORKGROUP through a double buffer in LDS -- `stage`, 2 x ymc_stream_unit<KS, DIV>() doubles --
+ * instead of once per wave: with one or two waves per SIMD a wave that reads its own MFMA fragments from L2 keeps
+ * too few loads in flight (measured 5.7 x the cost of an LDS-fed GEMV).  A is in fragment order [MT][KS][64];
+ * unit (pair, q) = k-steps [q KS/DIV, (q + 1) KS/DIV) of output tiles 2 pair and 2 pair + 1.  Every thread
+ * fetches its share of the next unit into registers while the MFMAs of the current one run; one barrier per unit
+ * (it also guarantees that everyone has left the buffer that is written next).  emit(pair, acc0, acc1) receives
+ * the accumulators of the two tiles; per accumulator the MFMA order is k ascending, as in a loop over LDS- or
+ * L2-resident fragments: the same bits.
+ * EVERY wave of the workgroup must call this at the same point of its loop (the callers keep waves past the last
+ * tile alive for it); `v` is the wave's B operand (component 4 s + g of chain c in register s of lane (g, c)). */
+template <int KS, int DIV>
+constexpr int ymc_stream_unit() { return 2 * (KS / DIV) * 64; }
+
+template <int KS, int DIV, int THREADS, typename Emit>
+__device__ __forceinline__ void ymc_stream_tile_pairs(const double *__restrict__ A, int n_pairs, double *stage, int tid,
+                                                      int lane, const double (&v)[KS], Emit &&emit)
+{
+    static_assert(KS % DIV == 0, "staged units are whole k-steps");
+    constexpr int kSteps = KS / DIV, kUnit = ymc_stream_unit<KS, DIV>(), kPer = (kUnit + THREADS - 1) / THREADS;
+    auto fetch = [&](int pair, int q, double (&r)[kPer]) {
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const int idx = tid + j * THREADS;
+            if (kUnit % THREADS == 0 || idx < kUnit) {
+                const int blk = idx / (kSteps * 64), off = idx % (kSteps * 64);
+                r[j] = A[((size_t)(2 * pair + blk) * KS + (size_t)q * kSteps) * 64 + off];
+            }
+        }
+    };
+    double r[kPer];
+    fetch(0, 0, r);
+    int buf = 0;
+#pragma unroll 1
+    for (int pair = 0; pair < n_pairs; ++pair) {
+        d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < DIV; ++q) {
+            double *stg = stage + buf * kUnit;
+#pragma unroll
+            for (int j = 0; j < kPer; ++j) {
+                const int idx = tid + j * THREADS;
+                if (kUnit % THREADS == 0 || idx < kUnit) stg[idx] = r[j];
+            }
+            __syncthreads();
+            if (q + 1 < DIV) fetch(pair, q + 1, r);
+            else if (pair + 1 < n_pairs) fetch(pair + 1, 0, r);
+#pragma unroll
+            for (int sl = 0; sl < kSteps; ++sl) {
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(stg[sl * 64 + lane], v[q * kSteps + sl], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(stg[(kSteps + sl) * 64 + lane], v[q * kSteps + sl], acc1, 0, 0, 0);
+            }
+            buf ^= 1;
+        }
+        emit(pair, acc0, acc1);
+    }
 }
 
 }  // namespace

@@ -68,9 +68,7 @@ __global__ __launch_bounds__(kNestThreads) void linear_tile_nested_kernel(const 
     double *pprec0 = pmean0 + d_pad;
     double *sigma = pprec0 + d_pad;
     const size_t blob0 = (size_t)MT0 * KS * 64 + (size_t)m_pad0 * 3 + 3 * (size_t)d_pad;
-    constexpr int kUnit = 2 * (KS / 4) * 64;                    /* doubles per staged unit: two tiles x KS/4 k-steps */
-    constexpr int kPer = (kUnit + kNestThreads - 1) / kNestThreads;
-    double *stage = lds + blob0;                                 /* STAGED: [2][kUnit] */
+    double *stage = lds + blob0;                                 /* STAGED: the stream's double buffer (ymc_tile_dev.h) */
 
     const int tid = threadIdx.x;
     for (size_t i = tid; i < blob0 / 2; i += kNestThreads)
@@ -158,46 +156,12 @@ __global__ __launch_bounds__(kNestThreads) void linear_tile_nested_kernel(const 
         return logpost(A0, MT0, bias0, nprec0, dbar0, pmean0, pprec0, a.lik_const, v);
     };
     /* P[l] (which = 0) or Q[l] (which = 1) of a level above the base: everything from global memory */
-    /* STAGED: unit (pair, q) = k-steps [q KS/4, (q + 1) KS/4) of output tiles 2 pair, 2 pair + 1 of matrix A; the
-     * MFMA order per accumulator is the plain form's, so the value is the same bits.  Every wave of the
-     * workgroup evaluates the same level at the same point of the walk. */
-    auto fetch_unit = [&](const double *A, int pair, int q, double (&r)[kPer]) {
-#pragma unroll
-        for (int j = 0; j < kPer; ++j) {
-            const int idx = tid + j * kNestThreads;
-            if (kUnit % kNestThreads == 0 || idx < kUnit) {
-                const int blk = idx / (KS * 16), off = idx % (KS * 16);
-                r[j] = A[((size_t)(2 * pair + blk) * KS + (size_t)q * (KS / 4)) * 64 + off];
-            }
-        }
-    };
+    /* STAGED: the same value over the workgroup's shared stream of the matrix (ymc_stream_tile_pairs,
+     * ymc_tile_dev.h); every wave of the workgroup evaluates the same level at the same point of the walk */
     auto logpost_staged = [&](const double *A, int MT, const double *bias, const double *nprec, const double *dbar,
                               const double *pmean, const double *pprec, double lik_const, const double (&v)[KS]) {
         double Ssum = 0.0;
-        double r[kPer];
-        fetch_unit(A, 0, 0, r);
-        int buf = 0;
-#pragma unroll 1
-        for (int pair = 0; pair < MT / 2; ++pair) {
-            d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                double *stg = stage + buf * kUnit;
-#pragma unroll
-                for (int j = 0; j < kPer; ++j) {
-                    const int idx = tid + j * kNestThreads;
-                    if (kUnit % kNestThreads == 0 || idx < kUnit) stg[idx] = r[j];
-                }
-                __syncthreads(); /* the unit is complete; everyone has left the buffer that is written next */
-                if (q < 3) fetch_unit(A, pair, q + 1, r);
-                else if (pair + 1 < MT / 2) fetch_unit(A, pair + 1, 0, r);
-#pragma unroll
-                for (int sl = 0; sl < KS / 4; ++sl) {
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(stg[sl * 64 + lane], v[q * (KS / 4) + sl], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(stg[(KS / 4 + sl) * 64 + lane], v[q * (KS / 4) + sl], acc1, 0, 0, 0);
-                }
-                buf ^= 1;
-            }
+        ymc_stream_tile_pairs<KS, 4, kNestThreads>(A, MT / 2, stage, tid, lane, v, [&](int pair, const d4 &acc0, const d4 &acc1) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -209,7 +173,7 @@ __global__ __launch_bounds__(kNestThreads) void linear_tile_nested_kernel(const 
                     Ssum = Ssum + res * px;
                 }
             }
-        }
+        });
         const double logl = -0.5 * (combine4(Ssum) + lik_const);
         double P = 0.0;
 #pragma unroll
@@ -386,7 +350,7 @@ hipError_t launch_as(const TileArgs &a, hipStream_t s)
     /* the upper levels' matrices through a shared double buffer when the LDS has room beside level 0's block
      * (identical results; YMC_TILE_STAGE=0|1 overrides, the tests run both) */
     const size_t plain = ymc_tile_lds_bytes(KS, a.MT);
-    const size_t staged = plain + 2 * (size_t)(2 * (KS / 4) * 64) * sizeof(double);
+    const size_t staged = plain + 2 * (size_t)ymc_stream_unit<KS, 4>() * sizeof(double);
     bool stage = staged <= kTileLdsLimit;
     if (const char *env = std::getenv("YMC_TILE_STAGE")) stage = stage && env[0] != '0';
     return stage ? launch_staged_or_not<KS, true>(a, staged, s) : launch_staged_or_not<KS, false>(a, plain, s);
