@@ -168,44 +168,11 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
 
         /* forward map on the matrix cores + Gaussian-noise likelihood (likelihood.py:74-84) through
          * the row-mean identity: |F - Dbar|^2_{n P} + const (ymc_linear_data_summary) */
-        double S = 0.0;
-#pragma unroll 1
-        for (int mt = 0; mt < MT; mt += 2) {
-            d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-            const double *Af0 = Alds + (size_t)mt * KS * 64 + lane;
-            const double *Af1 = Af0 + (size_t)KS * 64;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Af0[s * 64], y[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Af1[s * 64], y[s], acc1, 0, 0, 0);
-            }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = 16 * (mt + h) + 4 * r + g;
-                    const double F = (h ? acc1[r] : acc0[r]) + bias[m];
-                    const double res = F - dbar[m];
-                    const double px = nprec[m] * res;
-                    S = S + res * px;
-                }
-            }
-        }
-        const double logl = -0.5 * (combine4(S) + a.lik_const);
+        const double logl = -0.5 * (combine4(ymc_tile_residual_sum<KS>(Alds, MT, bias, nprec, dbar, lane, g, y)) + a.lik_const);
 
         /* Gaussian prior (gaussian.py:19-24); the target of pCN is the likelihood alone (pcn.py:51-57) */
         double lpy = logl;
-        if constexpr (!PCN) {
-            double P = 0.0;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const int j = 4 * s + g;
-                const double dx = y[s] - pmean[j];
-                const double px = pprec[j] * dx;
-                P = P + dx * px;
-            }
-            lpy = logl + (-0.5 * combine4(P));
-        }
+        if constexpr (!PCN) lpy = logl + ymc_tile_logprior<KS>(pmean, pprec, g, y);
 
         /* accept / reject (metropolisHastings.py:55-73, mrw.py:51-57) */
         const double u = ymc_uniform_cached(uc, a.seed, chain, t);
@@ -323,68 +290,18 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_mlda2_kernel(const T
      * on the matrix cores (as linear_tile_kernel); A's fragments come from LDS or from global memory */
     auto loglik = [&](const double *A, int MT, const double *bias, const double *nprec, const double *dbar,
                       double lik_const, const double (&v)[KS]) {
-        double Ssum = 0.0;
-#pragma unroll 1
-        for (int mt = 0; mt < MT; mt += 2) {
-            d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-            const double *Af0 = A + (size_t)mt * KS * 64 + lane;
-            const double *Af1 = Af0 + (size_t)KS * 64;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Af0[s * 64], v[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Af1[s * 64], v[s], acc1, 0, 0, 0);
-            }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = 16 * (mt + h) + 4 * r + g;
-                    const double F = (h ? acc1[r] : acc0[r]) + bias[m];
-                    const double res = F - dbar[m];
-                    const double px = nprec[m] * res;
-                    Ssum = Ssum + res * px;
-                }
-            }
-        }
-        return -0.5 * (combine4(Ssum) + lik_const);
+        return -0.5 * (combine4(ymc_tile_residual_sum<KS>(A, MT, bias, nprec, dbar, lane, g, v)) + lik_const);
     };
-    /* Gaussian prior (gaussian.py:19-24) */
     auto logprior = [&](const double *pmean, const double *pprec, const double (&v)[KS]) {
-        double P = 0.0;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int j = 4 * s + g;
-            const double dx = v[s] - pmean[j];
-            const double px = pprec[j] * dx;
-            P = P + dx * px;
-        }
-        return -0.5 * combine4(P);
+        return ymc_tile_logprior<KS>(pmean, pprec, g, v);
     };
-    auto any_differs = [&](const double (&p)[KS], const double (&q)[KS]) {
-        bool dl = false;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) dl = dl || !(p[s] == q[s]);
-        int mv = dl ? 1 : 0;
-        mv |= __shfl_xor(mv, 16, 64);
-        mv |= __shfl_xor(mv, 32, 64);
-        return mv != 0;
-    };
+    auto any_differs = [&](const double (&p)[KS], const double (&q)[KS]) { return ymc_tile_any_differs<KS>(p, q); };
     /* STAGED: the fine level's log-likelihood over the workgroup's shared stream of the fine matrix
      * (ymc_stream_tile_pairs, ymc_tile_dev.h); every wave calls it at the same point of the loop */
     auto loglik_fine_staged = [&](const double (&v)[KS]) {
         double Ssum = 0.0;
         ymc_stream_tile_pairs<KS, 4, kTileThreads>(Af, MTf / 2, stage, tid, lane, v, [&](int pair, const d4 &acc0, const d4 &acc1) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int m = 16 * (2 * pair + h) + 4 * rr + g;
-                    const double F = (h ? acc1[rr] : acc0[rr]) + bias_f[m];
-                    const double res = F - dbar_f[m];
-                    const double px = nprec_f[m] * res;
-                    Ssum = Ssum + res * px;
-                }
-            }
+            ymc_tile_add_residuals(2 * pair, acc0, acc1, bias_f, nprec_f, dbar_f, g, Ssum);
         });
         return -0.5 * (combine4(Ssum) + a.lik_const_f);
     };

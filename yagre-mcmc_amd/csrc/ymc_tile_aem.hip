@@ -252,40 +252,14 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
     auto loglik_fine = [&](const double (&v)[KS]) {
         double Ssum = 0.0;
         fine_pairs(v, [&](int mt, const d4 &acc0, const d4 &acc1) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = 16 * (mt + h) + 4 * r + g;
-                    const double F = (h ? acc1[r] : acc0[r]) + bias_f[m];
-                    const double res = F - dbar_f[m];
-                    const double px = nprec_f[m] * res;
-                    Ssum = Ssum + res * px;
-                }
-            }
+            ymc_tile_add_residuals(mt, acc0, acc1, bias_f, nprec_f, dbar_f, g, Ssum);
         });
         return -0.5 * (combine4(Ssum) + a.lik_const_f);
     };
     auto logprior = [&](const double *pmean, const double *pprec, const double (&v)[KS]) {
-        double P = 0.0;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int j = 4 * s + g;
-            const double dx = v[s] - pmean[j];
-            const double px = pprec[j] * dx;
-            P = P + dx * px;
-        }
-        return -0.5 * combine4(P);
+        return ymc_tile_logprior<KS>(pmean, pprec, g, v);
     };
-    auto any_differs = [&](const double (&p)[KS], const double (&q)[KS]) {
-        bool dl = false;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) dl = dl || !(p[s] == q[s]);
-        int mv = dl ? 1 : 0;
-        mv |= __shfl_xor(mv, 16, 64);
-        mv |= __shfl_xor(mv, 32, 64);
-        return mv != 0;
-    };
+    auto any_differs = [&](const double (&p)[KS], const double (&q)[KS]) { return ymc_tile_any_differs<KS>(p, q); };
     /* one cache query of every chain of the wave (`active` lanes only): the current-model likelihood is
      * evaluated for the wave iff some active chain misses */
     auto query = [&](uint64_t id, const double (&v)[KS], bool active) {

@@ -39,6 +39,79 @@ __device__ __forceinline__ double combine4(double s)
     return v + shfl_xor_f64(v, 32);
 }
 
+/* The pieces of a linear-model posterior in the kernels' operand layout: lane (g, c) of a wave holds component
+ * 4 s + g of chain c in register s (the MFMA B operand) and, after a pass over output tiles, rows 4 r + g of every
+ * tile in accumulator entry r.  Sums over a chain's outputs / components are the canonical four interleaved
+ * partial sums (one per g) joined by combine4 -- the order of ymc_linear_data_summary / ymo_diag_norm_sq. */
+
+/* adds the terms of output tiles mt, mt + 1 (accumulators acc0, acc1 of the forward map without its shift) to this
+ * lane's partial sum of |F - Dbar|^2 in the precision n P (likelihood.py:74-84 through the row-mean identity) */
+__device__ __forceinline__ void ymc_tile_add_residuals(int mt, const d4 &acc0, const d4 &acc1, const double *bias,
+                                                       const double *nprec, const double *dbar, int g, double &Ssum)
+{
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = 16 * (mt + h) + 4 * r + g;
+            const double F = (h ? acc1[r] : acc0[r]) + bias[m];
+            const double res = F - dbar[m];
+            const double px = nprec[m] * res;
+            Ssum = Ssum + res * px;
+        }
+    }
+}
+
+/* this lane's partial sum for the forward map A v + b with A's fragments [MT][KS][64] in LDS or in global memory
+ * (every wave reading its own): two accumulator chains of KS MFMAs per pair of output tiles */
+template <int KS>
+__device__ __forceinline__ double ymc_tile_residual_sum(const double *A, int MT, const double *bias, const double *nprec,
+                                                        const double *dbar, int lane, int g, const double (&v)[KS])
+{
+    double Ssum = 0.0;
+#pragma unroll 1
+    for (int mt = 0; mt < MT; mt += 2) {
+        d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        const double *A0 = A + (size_t)mt * KS * 64 + lane;
+        const double *A1 = A0 + (size_t)KS * 64;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[s * 64], v[s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1[s * 64], v[s], acc1, 0, 0, 0);
+        }
+        ymc_tile_add_residuals(mt, acc0, acc1, bias, nprec, dbar, g, Ssum);
+    }
+    return Ssum;
+}
+
+/* Gaussian prior with a diagonal covariance (gaussian.py:19-24): -0.5 |v - mean|^2 in the precision */
+template <int KS>
+__device__ __forceinline__ double ymc_tile_logprior(const double *pmean, const double *pprec, int g, const double (&v)[KS])
+{
+    double P = 0.0;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int j = 4 * s + g;
+        const double dx = v[s] - pmean[j];
+        const double px = pprec[j] * dx;
+        P = P + dx * px;
+    }
+    return -0.5 * combine4(P);
+}
+
+/* `proposal == state` of metropolisHastings.py:60-61 for the 16 chains of a wave: true where any component differs */
+template <int KS>
+__device__ __forceinline__ bool ymc_tile_any_differs(const double (&p)[KS], const double (&q)[KS])
+{
+    bool dl = false;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) dl = dl || !(p[s] == q[s]);
+    int mv = dl ? 1 : 0;
+    mv |= __shfl_xor(mv, 16, 64);
+    mv |= __shfl_xor(mv, 32, 64);
+    return mv != 0;
+}
+
 /* A matrix that does not live in LDS (a fine or upper-level forward map, a dense proposal's factor), streamed
  * from L2 ONCE PER WORKGROUP through a double buffer in LDS -- `stage`, 2 x ymc_stream_unit<KS, DIV>() doubles --
  * instead of once per wave: with one or two waves per SIMD a wave that reads its own MFMA fragments from L2 keeps

@@ -118,39 +118,8 @@ __global__ __launch_bounds__(kNestThreads) void linear_tile_nested_kernel(const 
      * identity, Gaussian prior (as linear_tile_kernel); fragments and constants from LDS or from global memory */
     auto logpost = [&](const double *A, int MT, const double *bias, const double *nprec, const double *dbar,
                        const double *pmean, const double *pprec, double lik_const, const double (&v)[KS]) {
-        double Ssum = 0.0;
-#pragma unroll 1
-        for (int mt = 0; mt < MT; mt += 2) {
-            d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-            const double *Af0 = A + (size_t)mt * KS * 64 + lane;
-            const double *Af1 = Af0 + (size_t)KS * 64;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Af0[s * 64], v[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Af1[s * 64], v[s], acc1, 0, 0, 0);
-            }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = 16 * (mt + h) + 4 * r + g;
-                    const double F = (h ? acc1[r] : acc0[r]) + bias[m];
-                    const double res = F - dbar[m];
-                    const double px = nprec[m] * res;
-                    Ssum = Ssum + res * px;
-                }
-            }
-        }
-        const double logl = -0.5 * (combine4(Ssum) + lik_const);
-        double P = 0.0;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int j = 4 * s + g;
-            const double dx = v[s] - pmean[j];
-            const double px = pprec[j] * dx;
-            P = P + dx * px;
-        }
-        return logl + (-0.5 * combine4(P));
+        const double logl = -0.5 * (combine4(ymc_tile_residual_sum<KS>(A, MT, bias, nprec, dbar, lane, g, v)) + lik_const);
+        return logl + ymc_tile_logprior<KS>(pmean, pprec, g, v);
     };
     auto logpost0 = [&](const double (&v)[KS]) {
         return logpost(A0, MT0, bias0, nprec0, dbar0, pmean0, pprec0, a.lik_const, v);
@@ -162,28 +131,10 @@ __global__ __launch_bounds__(kNestThreads) void linear_tile_nested_kernel(const 
                               const double *pmean, const double *pprec, double lik_const, const double (&v)[KS]) {
         double Ssum = 0.0;
         ymc_stream_tile_pairs<KS, 4, kNestThreads>(A, MT / 2, stage, tid, lane, v, [&](int pair, const d4 &acc0, const d4 &acc1) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int m = 16 * (2 * pair + h) + 4 * rr + g;
-                    const double F = (h ? acc1[rr] : acc0[rr]) + bias[m];
-                    const double res = F - dbar[m];
-                    const double px = nprec[m] * res;
-                    Ssum = Ssum + res * px;
-                }
-            }
+            ymc_tile_add_residuals(2 * pair, acc0, acc1, bias, nprec, dbar, g, Ssum);
         });
         const double logl = -0.5 * (combine4(Ssum) + lik_const);
-        double P = 0.0;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int j = 4 * s + g;
-            const double dx = v[s] - pmean[j];
-            const double px = pprec[j] * dx;
-            P = P + dx * px;
-        }
-        return logl + (-0.5 * combine4(P));
+        return logl + ymc_tile_logprior<KS>(pmean, pprec, g, v);
     };
     auto logpost_of = [&](int l, int which, const double (&v)[KS]) {
         const TileLevel L = a.levels[2 * l + which];
@@ -196,15 +147,7 @@ __global__ __launch_bounds__(kNestThreads) void linear_tile_nested_kernel(const 
             return logpost(L.blob, L.MT, consts, consts + m_pad, consts + 2 * m_pad, consts + 3 * m_pad,
                            consts + 3 * m_pad + d_pad, L.lik_const, v);
     };
-    auto any_differs = [&](const double (&p)[KS], const double (&q)[KS]) {
-        bool dl = false;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) dl = dl || !(p[s] == q[s]);
-        int mv = dl ? 1 : 0;
-        mv |= __shfl_xor(mv, 16, 64);
-        mv |= __shfl_xor(mv, 32, 64);
-        return mv != 0;
-    };
+    auto any_differs = [&](const double (&p)[KS], const double (&q)[KS]) { return ymc_tile_any_differs<KS>(p, q); };
     /* _accept_reject of level l (mlda.py:35-43; the top level's: mlda.py:146-154): the proposal is z, the
      * level's state is parked; afterwards z and the parking place hold the level's new state */
     auto decide = [&](int l, uint64_t t) {
