@@ -55,9 +55,16 @@ void run(const char* name, int ninstr_per_iter)
     for (int wps : {1, 2, 4, 8}) {
         int blocks = cus * wps;  // 256-thread blocks: 4 waves per block = 1 per SIMD
         int iters = 2000;
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
         hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, iters, 1.0);
+        hipEventRecord(e0, 0);
         hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, iters, 1.0);
+        hipEventRecord(e1, 0);
         hipDeviceSynchronize();
+        float wall_ms = 0.f;
+        hipEventElapsedTime(&wall_ms, e0, e1);
         std::vector<unsigned long long> h(2 * blocks);
         hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
         std::vector<double> cyc, clk;
@@ -67,8 +74,14 @@ void run(const char* name, int ninstr_per_iter)
         }
         std::sort(cyc.begin(), cyc.end());
         std::sort(clk.begin(), clk.end());
-        printf("%-34s waves/SIMD %d: %.2f cycles per wave-instr (per wave), SIMD throughput %.2f cyc/instr, clock %.2f GHz\n",
-               name, wps, cyc[cyc.size() / 2], cyc[cyc.size() / 2] / wps, clk[clk.size() / 2]);
+        /* the wall-clock rate of the whole launch: what a SIMD really sustains (the per-wave figure divided by the
+         * nominal wave count overstates it when fewer waves than launched are resident together) */
+        const double ghz = clk[clk.size() / 2];
+        const double wall_cyc = (double)wall_ms * 1e-3 * ghz * 1e9 * (cus * 4.0) / ((double)blocks * 4.0 * iters * ninstr_per_iter);
+        printf("%-34s waves/SIMD %d: %.2f cycles per wave-instr (per wave), /waves %.2f, WALL-CLOCK %.2f cycles per instr per SIMD "
+               "(%.3g wave-instr/s on the chip), clock %.2f GHz\n",
+               name, wps, cyc[cyc.size() / 2], cyc[cyc.size() / 2] / wps, wall_cyc,
+               (double)blocks * 4.0 * iters * ninstr_per_iter / ((double)wall_ms * 1e-3), ghz);
     }
     hipFree(d);
 }
