@@ -12,8 +12,10 @@ is refilled by every launch).  The defaults make a step ~0.1 s, so the
 driver's 20 timed steps are a ~2 s region at the clock the chip SUSTAINS, and
 the W warm-up steps bring it there (no other pre-heating).  Default workload =
 BASELINE.json configs[1]: the 2-D Gaussian target, random-walk proposal,
-65 536 chains per GPU.  For N > 1 the driver launches one process per GPU
-(torchrun env: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); chains shard by
+65 536 chains per GPU.  For N > 1: one process per GPU, either started by a
+launcher (torchrun env: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*) or, when
+`python bench.py --gpus N` is run as one plain process, by bench.py itself
+(N fresh children before anything touches the GPU); chains shard by
 global chain id, nothing is exchanged while sampling (weak scaling), and the
 single collective is an RCCL all-gather of the per-chain summaries after the
 timed region.  RCCL failing to come up is an error (exit code 1), never a
@@ -316,11 +318,12 @@ def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as ONE plain process: become the launcher of N fresh ranks (nothing here has touched the GPU yet)
+        from yagremcmc_amd import distributed
+        sys.exit(distributed.spawn_local_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched as N processes (torch.distributed.run / torchrun)")
-        args.gpus = world
+    args.gpus = world           # under a launcher the launch decides
 
     from yagremcmc_amd import _ffi as ffi, distributed, lowering
     device = local_rank if world > 1 else 0

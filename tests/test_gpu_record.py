@@ -199,6 +199,18 @@ def test_egress_double_buffer_equals_fetch(ffi, ctx, golden):
     # misuse
     with pytest.raises(ffi.YmcError, match="slot"):
         run.egress_begin(2, 0, 1)
+    # a view points into the run's page-locked staging memory: it keeps the run alive, and the run refuses to
+    # re-allocate (grow) the slot or to be closed under it
+    with pytest.raises(RuntimeError, match="must grow"):
+        run.egress_begin(0, 0, 2 * n)
+    with pytest.raises(RuntimeError, match="live egress views"):
+        run.close()
+    keep = v["trajectory"][1:3]          # a derived view is enough to hold the memory
+    del v
+    with pytest.raises(RuntimeError, match="live egress views"):
+        run.close()
+    assert np.array_equal(keep, want_t[(blocks - 1) * n + 1:(blocks - 1) * n + 3])
+    del keep
     with pytest.raises(ffi.YmcError, match="recorded"):
         run.egress_begin(0, 0, 10 * n)
     bare = ffi.Run(prob, 1, 8, x0[:8], 4, ffi.RECORD_TRAJECTORY)

@@ -145,16 +145,23 @@ def test_bench_under_the_drivers_launcher_two_ranks(ffi):
     RCCL refuses two ranks on one device, and every rank exits non-zero with the reason -- no line is printed."""
     import json
     import socket
-    with socket.socket() as s_:
-        s_.bind(("127.0.0.1", 0))
-        port = s_.getsockname()[1]
+    def free_port():
+        # the store probes MASTER_PORT + 1 .. + 32: keep all of them valid port numbers
+        for _ in range(64):
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                p = s_.getsockname()[1]
+            if p + 33 <= 65535:
+                return p
+        return 29500
+    port = free_port()
     r = _launch_bench(2, port, {"YMC_COMM": "tcp"})
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["collective"] == "tcp" and line["nranks_seen"] == 2
     assert line["config"]["chains_total"] == 16384 and line["value"] > 0 and line["scaling"] == "weak"
     assert 0.3 < line["acceptance_rate"] < 0.8 and line["chains_flagged_nonfinite"] == 0
-    r = _launch_bench(2, port + 40, {"YMC_COMM_TIMEOUT": "60"})
+    r = _launch_bench(2, free_port(), {"YMC_COMM_TIMEOUT": "60"})
     assert r.returncode != 0
     assert "RCCL is required for more than one rank" in r.stderr and "ncclCommInitRank" in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -6,6 +6,7 @@ exception is raised.
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -315,6 +316,17 @@ class Problem(Handle):
         return out
 
 
+class EgressArray(np.ndarray):
+    """A view into a run's page-locked staging memory (Run.egress_wait).  It keeps its run alive -- the memory is
+    freed with the run -- and the run keeps count of the views it has handed out: it refuses to be closed, or to
+    grow the slot, under a live one."""
+
+    _owner = None
+
+    def __array_finalize__(self, obj):
+        self._owner = getattr(obj, "_owner", None)
+
+
 class Run(Handle):
     _destroy = "ymc_run_destroy"
 
@@ -334,6 +346,18 @@ class Run(Handle):
         self.K, self.d, self.S = int(n_chains), problem.dim, problem.S
         self.flags = record_flags
         self.stride = max(int(record_stride), 1)
+        self._egress_views = [[], []]     # weak references to the staging views handed out, per slot
+        self._egress_rows = [0, 0]        # the largest request a slot has been sized for
+
+    def _live_egress_views(self, slot):
+        self._egress_views[slot] = [w for w in self._egress_views[slot] if w() is not None]
+        return len(self._egress_views[slot])
+
+    def close(self):
+        if self.raw is not None and any(self._live_egress_views(s) for s in (0, 1)):
+            raise RuntimeError("this run still has live egress views (Run.egress_wait): drop them (or copy them) "
+                               "before closing it -- they point into its page-locked staging memory")
+        super().close()
 
     def advance(self, nsteps):
         check(lib().ymc_run_advance(self.raw, int(nsteps)))
@@ -420,22 +444,36 @@ class Run(Handle):
     def egress_begin(self, slot, first, n, what=RECORD_TRAJECTORY):
         """Start copying record rows [first, first + n) to the run's page-locked staging slot 0 | 1 on the copy
         stream; returns at once and the copy runs beside later launches (include/ymc.h, egress)."""
-        check(lib().ymc_run_egress_begin(self.raw, int(slot), int(first), int(n), int(what)))
+        slot = int(slot)
+        if slot in (0, 1) and int(n) > self._egress_rows[slot]:
+            # the library re-allocates a slot that has to grow: nothing may still point into the old block
+            if self._live_egress_views(slot):
+                raise RuntimeError(f"egress slot {slot} must grow from {self._egress_rows[slot]} to {int(n)} rows while "
+                                   "views of it are alive: drop or copy them first (or begin with the largest block)")
+        check(lib().ymc_run_egress_begin(self.raw, slot, int(first), int(n), int(what)))
+        if slot in (0, 1):
+            self._egress_rows[slot] = max(self._egress_rows[slot], int(n))
 
     def egress_wait(self, slot):
         """Block until the slot's copy is done; -> dict of NumPy VIEWS into the page-locked staging memory
-        (trajectory (n, K, d), accept (n, K), logpost (n, K) as requested; `first`), valid until the next
-        egress_begin on that slot."""
+        (trajectory (n, K, d), accept (n, K), logpost (n, K) as requested; `first`); their CONTENT is valid until
+        the next egress_begin on that slot, the memory for as long as a view exists (each holds its run)."""
         v = EgressView()
         check(lib().ymc_run_egress_wait(self.raw, int(slot), C.byref(v)))
         n = int(v.rows)
         out = dict(first=int(v.first))
+
+        def view(ptr, shape):
+            a = np.ctypeslib.as_array(ptr, shape=shape).view(EgressArray)
+            a._owner = self           # the staging memory lives exactly as long as the run
+            self._egress_views[int(slot)].append(weakref.ref(a))
+            return a
         if v.trajectory:
-            out["trajectory"] = np.ctypeslib.as_array(v.trajectory, shape=(n, self.K, self.d))
+            out["trajectory"] = view(v.trajectory, (n, self.K, self.d))
         if v.accept:
-            out["accept"] = np.ctypeslib.as_array(v.accept, shape=(n, self.K))
+            out["accept"] = view(v.accept, (n, self.K))
         if v.logpost:
-            out["logpost"] = np.ctypeslib.as_array(v.logpost, shape=(n, self.K))
+            out["logpost"] = view(v.logpost, (n, self.K))
         return out
 
     def packed_summary(self):

@@ -122,7 +122,10 @@ __device__ __forceinline__ bool ymc_tile_any_differs(const double (&p)[KS], cons
  * the accumulators of the two tiles; per accumulator the MFMA order is k ascending, as in a loop over LDS- or
  * L2-resident fragments: the same bits.
  * EVERY wave of the workgroup must call this at the same point of its loop (the callers keep waves past the last
- * tile alive for it); `v` is the wave's B operand (component 4 s + g of chain c in register s of lane (g, c)). */
+ * tile alive for it); `v` is the wave's B operand (component 4 s + g of chain c in register s of lane (g, c)).
+ * Back-to-back calls: a call starts writing buffer 0 with no barrier of its own, which is safe only if the
+ * previous call's LAST unit was read from buffer 1, i.e. if it staged an even number of units.  DIV is even
+ * (asserted), so n_pairs * DIV always is. */
 template <int KS, int DIV>
 constexpr int ymc_stream_unit() { return 2 * (KS / DIV) * 64; }
 
@@ -131,6 +134,7 @@ __device__ __forceinline__ void ymc_stream_tile_pairs(const double *__restrict__
                                                       int lane, const double (&v)[KS], Emit &&emit)
 {
     static_assert(KS % DIV == 0, "staged units are whole k-steps");
+    static_assert(DIV % 2 == 0, "an even number of units per call: the next call's first write goes to buffer 0 unguarded");
     constexpr int kSteps = KS / DIV, kUnit = ymc_stream_unit<KS, DIV>(), kPer = (kUnit + THREADS - 1) / THREADS;
     auto fetch = [&](int pair, int q, double (&r)[kPer]) {
 #pragma unroll

@@ -82,14 +82,17 @@ def pooled_diagnostics(summary, steps):
 # the TCP store
 # ---------------------------------------------------------------------------
 
-_MAGIC = b"YMCSTOR2"           # client -> server
-_MAGIC_REPLY = b"YMCSTOK2"     # server -> client: differs, so a TCP self-connection (a client whose ephemeral
+_MAGIC = b"YMCSTOR3"           # client -> server
+_MAGIC_REPLY = b"YMCSTOK3"     # server -> client: differs, so a TCP self-connection (a client whose ephemeral
 #                                source port equals the candidate port it probes, which echoes its own hello
 #                                back) cannot pass for a store
 _PORT_SPAN = 32          # candidate ports after MASTER_PORT
 _HELLO = struct.Struct("<8s16sII")     # magic, key, rank, world
 _WELCOME = struct.Struct("<8s16s")     # magic, nonce of this launch
 _MSG = struct.Struct("<QQ")            # collective sequence number, payload bytes
+_MAX_PAYLOAD = 1 << 28   # one rank's part of a collective (C5's summaries are 11.5 MB per rank)
+_HELLO_PATIENCE_S = 2.0  # an accepted connection that has not said a full hello by then is dropped
+_LOOPBACK = "127.0.0.1"
 
 
 def _recv_exact(sock, n):
@@ -104,10 +107,12 @@ def _recv_exact(sock, n):
 
 def _launch_key(world, port):
     """Identifies ONE launch: ranks of another job that shares the machine (and possibly a
-    candidate port) never pass each other's handshake."""
+    candidate port) never pass each other's handshake.  YMC_LAUNCH_SECRET (set to random bytes by
+    `spawn_local_ranks`; torchrun's --standalone run id is random as well) makes it unguessable."""
     run_id = os.environ.get("TORCHELASTIC_RUN_ID", "none")
     restart = os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
-    return hashlib.sha256(f"{run_id}|{restart}|{world}|{port}".encode()).digest()[:16]
+    secret = os.environ.get("YMC_LAUNCH_SECRET", "")
+    return hashlib.sha256(f"{run_id}|{restart}|{world}|{port}|{secret}".encode()).digest()[:16]
 
 
 def candidate_ports(master_port):
@@ -127,15 +132,68 @@ def candidate_ports(master_port):
     return out
 
 
+def _resolve(addr):
+    """IPv4 addresses of a host name ([] when it does not resolve -- the GPU boxes' own hostname does not)."""
+    try:
+        infos = socket.getaddrinfo(addr, None, socket.AF_INET, socket.SOCK_STREAM)
+    except (socket.gaierror, UnicodeError, OSError):
+        return []
+    out = []
+    for info in infos:
+        if info[4][0] not in out:
+            out.append(info[4][0])
+    return out
+
+
+def _single_node(world, resolved):
+    """All ranks of this launch on one machine?  The launcher says so (LOCAL_WORLD_SIZE == WORLD_SIZE);
+    without that, a master address that is loopback or does not resolve at all can only be local."""
+    local = os.environ.get("LOCAL_WORLD_SIZE")
+    if local is not None:
+        try:
+            return int(local) == int(world)
+        except ValueError:
+            pass
+    return not resolved or all(a.startswith("127.") for a in resolved)
+
+
+def store_addresses(addr, world):
+    """-> (address rank 0 binds, addresses a client tries in turn).  Rank 0 never binds MASTER_ADDR *by name*
+    (a name that does not resolve on the box -- `runc` -- used to end the launch there): loopback when every
+    rank is on this machine, every interface otherwise.  Clients try MASTER_ADDR as resolved and loopback,
+    loopback first on one node; a peer that is not this launch's store fails the handshake and is passed over."""
+    override = os.environ.get("YMC_STORE_BIND")
+    resolved = _resolve(addr)
+    single = _single_node(world, resolved)
+    bind = override or (_LOOPBACK if single else "0.0.0.0")
+    tries = [_LOOPBACK] + [a for a in resolved if a != _LOOPBACK] if single else resolved + [_LOOPBACK]
+    seen = []
+    for a in tries:
+        if a not in seen:
+            seen.append(a)
+    return bind, seen
+
+
+class _Peer:
+    __slots__ = ("sock", "rank", "buf", "since")
+
+    def __init__(self, sock):
+        self.sock, self.rank, self.buf, self.since = sock, None, bytearray(), time.monotonic()
+
+
 class _StoreServer(threading.Thread):
     """Rank 0's side: W persistent connections; collective number `seq` completes when every rank has
-    sent its part, and every rank then receives all parts in rank order."""
+    sent its part, and every rank then receives all parts in rank order.  One selector thread that never
+    blocks on a peer: every readable socket gets ONE recv per wake-up into its own buffer, the handshake and
+    the messages are parsed from there; a connection that has not completed its hello within
+    _HELLO_PATIENCE_S, a header announcing more than _MAX_PAYLOAD bytes and a message that stays partial for
+    longer than `stall_s` end that connection only."""
 
-    def __init__(self, listener, world, key, nonce):
+    def __init__(self, listener, world, key, nonce, stall_s=60.0):
         super().__init__(name="ymc-store", daemon=True)
-        self.listener, self.world, self.key, self.nonce = listener, world, key, nonce
+        self.listener, self.world, self.key, self.nonce, self.stall_s = listener, world, key, nonce, stall_s
         self.sel = selectors.DefaultSelector()
-        self.conns = {}          # sock -> rank
+        self.peers = {}          # sock -> _Peer
         self.parts = {}          # seq -> {rank: payload}
         self.stop = threading.Event()
         listener.setblocking(False)
@@ -148,9 +206,10 @@ class _StoreServer(threading.Thread):
                     if key.fileobj is self.listener:
                         self._accept()
                     else:
-                        self._serve(key.fileobj)
+                        self._readable(self.peers.get(key.fileobj))
+                self._reap()
         finally:
-            for s in list(self.conns) + [self.listener]:
+            for s in list(self.peers) + [self.listener]:
                 try:
                     s.close()
                 except OSError:
@@ -161,44 +220,90 @@ class _StoreServer(threading.Thread):
             sock, _ = self.listener.accept()
         except OSError:
             return
-        sock.settimeout(5.0)
-        try:
-            magic, key, rank, world = _HELLO.unpack(_recv_exact(sock, _HELLO.size))
-            if magic != _MAGIC or key != self.key or world != self.world or not 0 <= rank < world \
-                    or rank in self.conns.values():
-                sock.close()
-                return
-            sock.sendall(_WELCOME.pack(_MAGIC_REPLY, self.nonce))
-        except (OSError, ConnectionError, struct.error):
-            sock.close()
-            return
-        sock.settimeout(None)
-        sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-        self.conns[sock] = rank
+        sock.settimeout(10.0)      # bounds the sends to a peer that has stopped reading; recv is only called when readable
+        self.peers[sock] = _Peer(sock)
         self.sel.register(sock, selectors.EVENT_READ, None)
 
-    def _drop(self, sock):
-        self.sel.unregister(sock)
-        self.conns.pop(sock, None)
-        sock.close()
-
-    def _serve(self, sock):
+    def _drop(self, peer):
         try:
-            seq, nbytes = _MSG.unpack(_recv_exact(sock, _MSG.size))
-            payload = _recv_exact(sock, nbytes) if nbytes else b""
-        except (OSError, ConnectionError):
-            self._drop(sock)
+            self.sel.unregister(peer.sock)
+        except (KeyError, ValueError):
+            pass
+        self.peers.pop(peer.sock, None)
+        try:
+            peer.sock.close()
+        except OSError:
+            pass
+
+    def _reap(self):
+        now = time.monotonic()
+        for peer in list(self.peers.values()):
+            if peer.rank is None and now - peer.since > _HELLO_PATIENCE_S:
+                self._drop(peer)
+            elif peer.rank is not None and peer.buf and now - peer.since > self.stall_s:
+                self._drop(peer)
+
+    def _readable(self, peer):
+        if peer is None:
             return
+        try:
+            chunk = peer.sock.recv(1 << 20)
+        except (BlockingIOError, InterruptedError, socket.timeout):
+            return
+        except OSError:
+            chunk = b""
+        if not chunk:
+            self._drop(peer)
+            return
+        if not peer.buf:
+            peer.since = time.monotonic()     # a new message starts now
+        peer.buf += chunk
+        if peer.rank is None and not self._hello(peer):
+            return
+        while peer.sock in self.peers and len(peer.buf) >= _MSG.size:
+            seq, nbytes = _MSG.unpack_from(peer.buf)
+            if nbytes > _MAX_PAYLOAD:
+                self._drop(peer)
+                return
+            if len(peer.buf) < _MSG.size + nbytes:
+                return
+            payload = bytes(peer.buf[_MSG.size:_MSG.size + nbytes])
+            del peer.buf[:_MSG.size + nbytes]
+            peer.since = time.monotonic()
+            self._deliver(peer, seq, payload)
+
+    def _hello(self, peer):
+        """-> True once the peer is a greeted rank (its buffer then holds whatever followed the hello)."""
+        if len(peer.buf) < _HELLO.size:
+            return False
+        magic, key, rank, world = _HELLO.unpack_from(peer.buf)
+        taken = any(p.rank == rank for p in self.peers.values())
+        if magic != _MAGIC or key != self.key or world != self.world or not 0 <= rank < world or taken:
+            self._drop(peer)
+            return False
+        del peer.buf[:_HELLO.size]
+        try:
+            peer.sock.sendall(_WELCOME.pack(_MAGIC_REPLY, self.nonce))
+            peer.sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+        except OSError:
+            self._drop(peer)
+            return False
+        peer.rank = rank
+        return True
+
+    def _deliver(self, peer, seq, payload):
         got = self.parts.setdefault(seq, {})
-        got[self.conns[sock]] = payload
+        got[peer.rank] = payload
         if len(got) == self.world:
             body = b"".join(struct.pack("<Q", len(got[r])) + got[r] for r in range(self.world))
             del self.parts[seq]
-            for s in list(self.conns):
+            for p in list(self.peers.values()):
+                if p.rank is None:
+                    continue
                 try:
-                    s.sendall(_MSG.pack(seq, len(body)) + body)
+                    p.sock.sendall(_MSG.pack(seq, len(body)) + body)
                 except OSError:
-                    self._drop(s)
+                    self._drop(p)
 
 
 class TcpStore:
@@ -207,14 +312,16 @@ class TcpStore:
 
     def __init__(self, rank, world, addr=None, port=None, timeout=None):
         self.rank, self.world = int(rank), int(world)
-        self.addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        self.addr = addr or os.environ.get("MASTER_ADDR", _LOOPBACK)
         self.master_port = int(port if port is not None else os.environ.get("MASTER_PORT", "29500"))
         self.timeout = float(timeout if timeout is not None else os.environ.get("YMC_COMM_TIMEOUT", "300"))
         self.key = _launch_key(self.world, self.master_port)
+        self.bind_addr, self.try_addrs = store_addresses(self.addr, self.world)
         self.seq = 0
         self.server = None
         self.nonce = None
         self.port = None
+        self.peer_addr = None
         if self.rank == 0:
             self._serve()
         self.sock = self._connect()
@@ -225,47 +332,52 @@ class TcpStore:
             s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             try:
-                s.bind((self.addr, p))
+                s.bind((self.bind_addr, p))
                 s.listen(self.world + 8)
             except OSError as e:
                 last = e
                 s.close()
                 continue
-            self.server = _StoreServer(s, self.world, self.key, os.urandom(16))
+            self.server = _StoreServer(s, self.world, self.key, os.urandom(16), stall_s=max(self.timeout, 5.0))
             self.server.start()
             self.port = p
             return
         raise CommError(f"rank 0 cannot serve the store on any of {candidate_ports(self.master_port)} "
-                        f"at {self.addr}: {last}")
+                        f"at {self.bind_addr}: {last}")
 
     def _connect(self):
         deadline = time.time() + self.timeout
         ports = [self.port] if self.port else candidate_ports(self.master_port)
+        if self.rank == 0:       # its own server, in this process
+            addrs = [_LOOPBACK if self.bind_addr == "0.0.0.0" else self.bind_addr]
+        else:
+            addrs = self.try_addrs
         while True:
-            for p in ports:
-                try:
-                    s = socket.create_connection((self.addr, p), timeout=2.0)
-                except OSError:
-                    continue
-                try:
-                    if s.getsockname() == s.getpeername():
-                        raise ConnectionError("connected to itself")
-                    s.settimeout(5.0)
-                    s.sendall(_HELLO.pack(_MAGIC, self.key, self.rank, self.world))
-                    magic, nonce = _WELCOME.unpack(_recv_exact(s, _WELCOME.size))
-                    if magic != _MAGIC_REPLY:
-                        raise ConnectionError("not this launch's store")
-                except (OSError, ConnectionError, struct.error):
-                    s.close()
-                    continue
-                s.settimeout(self.timeout)
-                s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                self.nonce, self.port = nonce, p
-                return s
+            for a in addrs:
+                for p in ports:
+                    try:
+                        s = socket.create_connection((a, p), timeout=2.0)
+                    except OSError:
+                        continue
+                    try:
+                        if s.getsockname() == s.getpeername():
+                            raise ConnectionError("connected to itself")
+                        s.settimeout(5.0)
+                        s.sendall(_HELLO.pack(_MAGIC, self.key, self.rank, self.world))
+                        magic, nonce = _WELCOME.unpack(_recv_exact(s, _WELCOME.size))
+                        if magic != _MAGIC_REPLY:
+                            raise ConnectionError("not this launch's store")
+                    except (OSError, ConnectionError, struct.error):
+                        s.close()
+                        continue
+                    s.settimeout(self.timeout)
+                    s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    self.nonce, self.port, self.peer_addr = nonce, p, a
+                    return s
             if time.time() > deadline:
-                raise CommError(f"rank {self.rank}: no store of this launch answered on {self.addr} ports {ports} "
-                                f"within {self.timeout:.0f} s (is rank 0 running with the same MASTER_ADDR / "
-                                "MASTER_PORT / WORLD_SIZE?)")
+                raise CommError(f"rank {self.rank}: no store of this launch answered on {addrs} (MASTER_ADDR "
+                                f"{self.addr!r}) ports {ports} within {self.timeout:.0f} s (is rank 0 running with "
+                                "the same MASTER_ADDR / MASTER_PORT / WORLD_SIZE?)")
             time.sleep(0.05)
 
     def allgather(self, payload):
@@ -305,6 +417,75 @@ class TcpStore:
             self.server.stop.set()
             self.server.join(timeout=2.0)
             self.server = None
+
+
+# ---------------------------------------------------------------------------
+# launching the ranks of one node without a launcher
+# ---------------------------------------------------------------------------
+
+def free_master_port():
+    """A port P that is free now and leaves P+1 .. P+32 (the store's candidates) below 65536."""
+    for _ in range(64):
+        with socket.socket() as s:
+            s.bind((_LOOPBACK, 0))
+            p = s.getsockname()[1]
+        if p + _PORT_SPAN <= 65535:
+            return p
+    return 29500
+
+
+def spawn_local_ranks(n, argv=None, grace_s=10.0):
+    """`python prog.py --gpus N` started as ONE plain process: run this command line as N fresh child
+    processes, one per GPU of this node, with the environment a launcher would export (RANK, LOCAL_RANK,
+    WORLD_SIZE, LOCAL_WORLD_SIZE, MASTER_ADDR = 127.0.0.1, a free MASTER_PORT, a random YMC_LAUNCH_SECRET).
+    Rank 0 inherits this process's stdout (its single result line), the other ranks' stdout goes to stderr.
+    -> the exit code: 0 only if every rank returned 0; the first failure ends the others (by their PIDs).
+
+    Must be called BEFORE anything in this process touches the GPU: the children are fresh processes
+    (fork + exec from a process without a HIP context), never a re-exec of an initialised one."""
+    import secrets
+    import subprocess
+    argv = list(sys.argv if argv is None else argv)
+    n = int(n)
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR=_LOOPBACK,
+                MASTER_PORT=str(free_master_port()), YMC_LAUNCH_SECRET=secrets.token_hex(16))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.stdout.flush()
+    procs = []
+    try:
+        for r in range(n):
+            env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen([sys.executable] + argv, env=env,
+                                          stdout=None if r == 0 else sys.stderr.fileno()))
+        codes = [None] * n
+        failed_at = None
+        while any(c is None for c in codes):
+            for r, pr in enumerate(procs):
+                if codes[r] is None:
+                    codes[r] = pr.poll()
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad and failed_at is None:
+                failed_at = time.monotonic()
+            if failed_at is not None and time.monotonic() - failed_at > grace_s:
+                break       # the others had their chance to notice (store collectives fail, watchdogs fire)
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.terminate()
+        for pr in procs:
+            try:
+                pr.wait(timeout=5.0)
+            except subprocess.TimeoutExpired:
+                pr.kill()
+                pr.wait()
+    codes = [pr.returncode for pr in procs]
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print("spawn_local_ranks: " + ", ".join(f"rank {r} exited {c}" for r, c in bad), file=sys.stderr, flush=True)
+        first = bad[0][1]
+        return first if 0 < first < 256 else 1
+    return 0
 
 
 # ---------------------------------------------------------------------------
