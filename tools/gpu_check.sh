@@ -18,10 +18,13 @@ python bench.py --workload iat --steps 3 --warmup 1 > $OUT/${TAG}_bench_iat.json
 YMC_BENCH_FORCE_COMM=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_rccl1.json 2> $OUT/${TAG}_rccl1.err || { cat $OUT/${TAG}_rccl1.err; exit 1; }
 YMC_COMM=tcp YMC_BENCH_ALLOW_SHARED_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 \
     bench.py --gpus 2 --steps 3 --warmup 1 --chains 32768 > $OUT/${TAG}_tcp2.json 2> $OUT/${TAG}_tcp2.err || { tail -20 $OUT/${TAG}_tcp2.err; exit 1; }
+# the same two ranks started by bench.py itself (one plain process, no launcher environment)
+env -u WORLD_SIZE -u RANK YMC_COMM=tcp YMC_BENCH_ALLOW_SHARED_GPU=1 python bench.py --gpus 2 --steps 3 --warmup 1 --chains 32768 --no-cpu-baseline \
+    > $OUT/${TAG}_tcp2plain.json 2> $OUT/${TAG}_tcp2plain.err || { tail -20 $OUT/${TAG}_tcp2plain.err; exit 1; }
 YMC_COMM_TIMEOUT=60 YMC_BENCH_ALLOW_SHARED_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29631 \
     bench.py --gpus 2 --steps 3 --warmup 1 --chains 32768 > $OUT/${TAG}_rccl2_shared.json 2> $OUT/${TAG}_rccl2_shared.err
 echo "two RCCL ranks on one GPU: exit code $? (non-zero expected)" | tee $OUT/${TAG}_rccl2_shared.rc
-for f in c2 c3 c4 c5 iat rccl1 tcp2; do python - $OUT/${TAG}_$( [ $f = rccl1 -o $f = tcp2 ] && echo $f || echo bench_$f ).json <<'PY'
+for f in c2 c3 c4 c5 iat rccl1 tcp2 tcp2plain; do python - $OUT/${TAG}_$( [ $f = rccl1 -o $f = tcp2 -o $f = tcp2plain ] && echo $f || echo bench_$f ).json <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 r = d["roofline"]
