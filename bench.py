@@ -137,13 +137,14 @@ def make_workload(name, ffi, ctx, lowering):
             for k, v in (("data", data), ("noise_precision", noise_prec), ("prior_mean", prior_mean),
                          ("prior_precision", prior_prec), ("fwd_matrix", A_c), ("fwd_shift", b_c)):
                 coarse.set_array(k, v)
-            prob = lowering.make_problem(ctx, ffi.METHOD_MLDA2, low, sigma, surrogate=coarse, sub_chain_length=5)
+            S = int(os.environ.get("YMC_C3M_S", "5"))     # the workload is S = 5; other values for kernel experiments
+            prob = lowering.make_problem(ctx, ffi.METHOD_MLDA2, low, sigma, surrogate=coarse, sub_chain_length=S)
             lin = lambda A_, b_: dict(kind="linear", A=A_, b=b_, data=data, noise_prec=noise_prec,  # noqa: E731
                                       prior_mean=prior_mean, prior_prec=prior_prec)
             return dict(problem=prob, x0=np.zeros((1, d)), K=262144, T=20, L=5, d=d,
                         desc="C3 two-level: delayed acceptance over two linear models, d = m = 128, nData = 5, S = 5 "
                              "(fp64 MFMA tile kernel; steps = FINE steps, each with 5 coarse transitions)",
-                        spec=dict(target=lin(A, b), surrogate=lin(A_c, b_c), S=5, sigma=sigma))
+                        spec=dict(target=lin(A, b), surrogate=lin(A_c, b_c), S=S, sigma=sigma))
         prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, sigma)
         return dict(problem=prob, x0=np.zeros((1, d)), K=262144, T=100, L=5, d=d,
                     desc="C3: linear forward model posterior d = m = 128, nData = 5 (fp64 MFMA tile kernel)",
@@ -261,7 +262,8 @@ def roofline_block(args, wl, K, T, kernel_ms, launches, clock_mhz, info):
                         "instruction counts per wave of chains and transition",
                 "source": {"instr": rec.get("source"), "kernel_time_and_clock": "this run"}}
     if args.workload in ("c3", "c3m"):
-        flops = 2.0 * d * d * K * T * (6 if args.workload == "c3m" else 1)   # c3m: 5 coarse + 1 fine map per fine step
+        maps = 1 + wl["spec"].get("S", 0)    # c3m: S = 5 coarse + 1 fine forward map per fine step
+        flops = 2.0 * d * d * K * T * maps
         tf = flops / ksec / 1e12 if ksec > 0 else 0.0
         return dict(common, bound="mfma", achieved=tf, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / FP64_PEAK_TFLOPS,
                     algorithmic_flops_per_launch=flops, valu=valu,

@@ -1202,6 +1202,36 @@ def test_tile_kernels_with_and_without_the_shared_matrix_stream(ffi, ctx, monkey
     _same_error_model(dev, e)
 
 
+@pytest.mark.parametrize("mode", ["mem", "regs", "lds", "plain"])
+@pytest.mark.parametrize("d,mc,mf,K,S", [(128, 128, 128, 150, 5), (128, 96, 112, 37, 2), (96, 64, 80, 200, 3), (20, 24, 17, 130, 4),
+                                          (7, 5, 9, 300, 1)])
+def test_tile_mlda2_builds_agree_with_the_oracle(ffi, ctx, monkeypatch, mode, d, mc, mf, K, S):
+    """The three builds of the two-level matrix-core kernel (ymc_tile.hip: fine state in LDS with both matrices
+    streamed / in registers with the coarse matrix resident / the latter with per-wave L2 reads of the fine
+    matrix), forced through YMC_TILE_MLDA2: each == oracle -- chains, decisions of both levels, log-posteriors,
+    carried state -- at the d = 128 shape of C3's two-level workload, at ragged shapes, with several workgroups
+    and waves past the last tile, across launches."""
+    monkeypatch.setenv("YMC_TILE_MLDA2", mode)
+    rng = np.random.default_rng(77 + d + mc + K)
+    nd = 3
+
+    def model(m, scale):
+        g = dict(data=rng.normal(size=(nd, m)), noise_precision=rng.uniform(0.5, 3, size=m), prior_mean=rng.normal(size=d) * 0.1,
+                 prior_precision=rng.uniform(0.1, 2, size=d))
+        A, b = scale * rng.normal(size=(m, d)) / np.sqrt(d), rng.normal(size=m)
+        return (_posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, g, fwd_matrix=A, fwd_shift=b),
+                o.posterior_linear(A, b, g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"]))
+
+    (lf, pf), (lc, pc) = model(mf, 1.0), model(mc, 0.95)
+    sigma, x0 = rng.uniform(0.02, 0.06, size=d), rng.normal(size=(K, d))
+    dev = _device_run(ffi, ctx, lf, sigma, x0, 991, 18, method=ffi.METHOD_MLDA2, sur=lc, S=S, chain0=5000, splits=3)
+    e = o.Ensemble(pf, sigma, x0, 991, chain0=5000, surrogate=pc, sub_chain_length=S)
+    out = e.advance(18, want_sub=True)
+    _same_as_oracle(dev, e, out)
+    assert np.array_equal(dev["sub_acc"], out["sub_acc"])
+    assert 0 < dev["acc"].mean() < 1
+
+
 def test_tile_kernel_limits(ffi, ctx):
     from yagremcmc_amd import lowering
     rng = np.random.default_rng(1)

@@ -36,6 +36,13 @@
 
 namespace {
 
+/* A wave raises its priority while it draws and proposes (vector instructions) and drops it for its forward map:
+ * next to a SIMD partner that is issuing MFMAs the drawing wave otherwise gets the issue slots the older wave leaves
+ * it.  +1.5...2 % on C3 and on its two-level workload; s_sleep or a scalar-memory wait at the phase boundaries and
+ * the opposite priorities change nothing (profiles/r03_tile_experiments.txt). */
+#define YMC_PHASE_DRAWS() __builtin_amdgcn_s_setprio(1)
+#define YMC_PHASE_MAP() __builtin_amdgcn_s_setprio(0)
+
 /* PROP: the proposal of the kernel -- diagonal random walk, pCN, or random walk with a dense covariance.  A
  * compile-time choice: the dense branch as a run-time test cost the diagonal kernel 20 VGPRs (8 spilled at
  * KS = 32) and 20 % of its speed. */
@@ -69,7 +76,7 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
     const int lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
     const uint64_t nct = (a.K + 15) / 16;
     const uint64_t tile = (uint64_t)blockIdx.x * kTileWaves + wave;
-    const bool wave_live = tile < nct;
+    const bool wave_live = tile < nct;   /* STAGED: a wave past the last tile stays for the barriers and touches no memory */
     if (!STAGED && !wave_live) return;
     const uint64_t k = tile * 16 + c;
     const bool live = wave_live && k < a.K;
@@ -95,6 +102,7 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
 #pragma unroll 1
     for (uint32_t n = 0; n < a.nsteps; ++n) {
         const uint64_t t = a.t0 + n;
+        YMC_PHASE_DRAWS();
         /* proposal y = x + sigma * xi (mrw.py:32-38) in the MFMA operand layout */
         bool moved_l = false;
 #pragma unroll
@@ -148,10 +156,12 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
                         acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(L0[s * 64], y[s], acc0, 0, 0, 0);
                         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(L1[s * 64], y[s], acc1, 0, 0, 0);
                     }
+                    if (wave_live) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (4 * mt + r < KS) wt[(4 * mt + r) * 64] = acc0[r];
-                        if (4 * (mt + 1) + r < KS) wt[(4 * (mt + 1) + r) * 64] = acc1[r];
+                        for (int r = 0; r < 4; ++r) {
+                            if (4 * mt + r < KS) wt[(4 * mt + r) * 64] = acc0[r];
+                            if (4 * (mt + 1) + r < KS) wt[(4 * (mt + 1) + r) * 64] = acc1[r];
+                        }
                     }
                 }
             }
@@ -168,6 +178,7 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
 
         /* forward map on the matrix cores + Gaussian-noise likelihood (likelihood.py:74-84) through
          * the row-mean identity: |F - Dbar|^2_{n P} + const (ymc_linear_data_summary) */
+        YMC_PHASE_MAP();
         const double logl = -0.5 * (combine4(ymc_tile_residual_sum<KS>(Alds, MT, bias, nprec, dbar, lane, g, y)) + a.lik_const);
 
         /* Gaussian prior (gaussian.py:19-24); the target of pCN is the likelihood alone (pcn.py:51-57) */
@@ -213,13 +224,16 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
  * Two-level delayed acceptance over two linear models at large dimension (MLDABuilder.bayesModel = a
  * BayesianRegressionModelHierarchy, mlda.py:315-335; example_inference_linearModel_twoLevel.py at C3's size).
  * Same mapping as linear_tile_kernel.  The COARSE model is evaluated S times per fine step, so its matrix is
- * the one staged in LDS; the FINE model's fragments are read straight from global memory (128 KB, resident
- * in every XCD's L2) -- two matrices do not fit the 160 KB of LDS.  Registers hold the sub-chain state z and
- * the proposal y (as x and y there); the fine state x lives in `x_tiled` (the record's coalesced layout)
- * and is read back once per fine step for the `proposal == state` test and the rejected lanes.
+ * the one staged in LDS; the FINE model's fragments come from global memory (128 KB, resident in every XCD's
+ * L2) -- two matrices do not fit the 160 KB of LDS.  Registers hold the fine state x, the sub-chain state z and
+ * the proposal y: nothing of a chain's state goes through memory between fine steps (up to round 2 the fine
+ * state was parked in a tiled scratch and read back once per fine step: 2 KB of HBM traffic per chain and fine
+ * step beside the 1 KB of the record, and at KS = 32 the 256 registers of two waves per SIMD did not hold z, y
+ * and the working set of the draws -- 32 VGPRs spilled into the loops).  WAVES = waves per workgroup: 4 at
+ * KS = 32 (one wave per SIMD, up to 512 registers -- the LDS admits one workgroup per CU anyway), 8 below.
  * Draw addressing as mlda2_kernel: fine step n owns transitions t = n (S + 1) + s.
  *
- * STAGED: the eight waves of a workgroup take their fine steps in lockstep (same S for all), so the fine
+ * STAGED: the waves of a workgroup take their fine steps in lockstep (same S for all), so the fine
  * matrix is brought from L2 ONCE per workgroup and fine step instead of once per wave: it streams through a
  * double buffer in the last 16 KB of LDS (units of a quarter of the k-steps of a pair of output tiles;
  * every thread fetches its share of the next unit into registers while the MFMAs of the current one run; one
@@ -227,23 +241,44 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
  * measured 5.7 x the cost of an LDS-fed GEMV.  Waves past the last tile stay in the loop for the barriers and
  * touch no memory.  The plain form remains for shapes whose constants leave no room for the buffer.
  */
-template <int KS, bool STAGED>
-__global__ __launch_bounds__(kTileThreads) void linear_tile_mlda2_kernel(const TileArgs a)
+#ifdef YMC_TILE_PROFILE
+/* Development build only (make prof -> libymc_prof.so, tools/tile_sections.py): cycles per section of the
+ * two-level kernel as seen by wave 0 of workgroup 0 (s_memtime; every stamp drains the wave's LDS queue, so
+ * the sections add up to slightly more than the uninstrumented loop). */
+__device__ unsigned long long ymc_tile_prof[16];
+#define YMC_PROF_DECL unsigned long long prof_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_ = 0
+#define YMC_PROF_START() stamp_ = __builtin_amdgcn_s_memtime()
+#define YMC_PROF(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); prof_[i] += now_ - stamp_; stamp_ = now_; } while (0)
+#define YMC_PROF_FLUSH() do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int i_ = 0; i_ < 10; ++i_) ymc_tile_prof[i_] = prof_[i_]; } while (0)
+#else
+#define YMC_PROF_DECL
+#define YMC_PROF_START()
+#define YMC_PROF(i)
+#define YMC_PROF_FLUSH()
+#endif
+
+enum { kXRegs = 0, kXLds = 1, kXMem = 2 };   /* where the fine state x lives between fine steps */
+
+template <int KS, bool STAGED, int WAVES, int XM>
+__global__ __launch_bounds__(64 * WAVES) void linear_tile_mlda2_kernel(const TileArgs a)
 {
+    constexpr bool XLDS = XM == kXLds, XMEM = XM == kXMem;
+    static_assert(!XLDS || STAGED, "the fine state lives in LDS only where both matrices stream");
+    constexpr int kThreads = 64 * WAVES;
     ymc_stage_tables();
     extern __shared__ double lds[];
     const int MTc = a.MT, MTf = a.MT_f, m_pad_c = 16 * MTc, m_pad_f = 16 * MTf, d_pad = 4 * KS;
-    /* coarse level: A fragments | bias | n * noise_prec | row mean | prior mean | prior prec | sigma */
-    double *Ac = lds;
-    double *bias_c = Ac + (size_t)MTc * KS * 64;
+    /* coarse level: [A fragments, unless XLDS] | bias | n * noise_prec | row mean | prior mean | prior prec | sigma */
+    const size_t frag_c = (size_t)MTc * KS * 64, consts_c = (size_t)m_pad_c * 3 + 3 * (size_t)d_pad;
+    const double *Ac = XLDS ? a.blob : lds;
+    double *bias_c = lds + (XLDS ? 0 : frag_c);
     double *nprec_c = bias_c + m_pad_c;
     double *dbar_c = nprec_c + m_pad_c;
     double *pmean_c = dbar_c + m_pad_c;
     double *pprec_c = pmean_c + d_pad;
     double *sigma = pprec_c + d_pad;
-    const size_t blob_c = (size_t)MTc * KS * 64 + (size_t)m_pad_c * 3 + 3 * (size_t)d_pad;
     /* fine level: the constants only */
-    double *bias_f = lds + blob_c;
+    double *bias_f = bias_c + consts_c;
     double *nprec_f = bias_f + m_pad_f;
     double *dbar_f = nprec_f + m_pad_f;
     double *pmean_f = dbar_f + m_pad_f;
@@ -253,14 +288,18 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_mlda2_kernel(const T
     double *stage = bias_f + consts_f;                           /* STAGED: the stream's double buffer (ymc_tile_dev.h) */
 
     const int tid = threadIdx.x;
-    for (size_t i = tid; i < blob_c / 2; i += kTileThreads)
-        reinterpret_cast<double2 *>(lds)[i] = reinterpret_cast<const double2 *>(a.blob)[i];
-    for (size_t i = tid; i < consts_f; i += kTileThreads) bias_f[i] = a.blob_f[(size_t)MTf * KS * 64 + i];
+    if constexpr (XLDS) {
+        for (size_t i = tid; i < consts_c; i += kThreads) bias_c[i] = a.blob[frag_c + i];
+    } else {
+        for (size_t i = tid; i < (frag_c + consts_c) / 2; i += kThreads)
+            reinterpret_cast<double2 *>(lds)[i] = reinterpret_cast<const double2 *>(a.blob)[i];
+    }
+    for (size_t i = tid; i < consts_f; i += kThreads) bias_f[i] = a.blob_f[(size_t)MTf * KS * 64 + i];
     __syncthreads();
 
     const int lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
     const uint64_t nct = (a.K + 15) / 16;
-    const uint64_t tile = (uint64_t)blockIdx.x * kTileWaves + wave;
+    const uint64_t tile = (uint64_t)blockIdx.x * WAVES + wave;
     const bool wave_live = tile < nct; /* a wave past the last tile: STAGED keeps it for the barriers, it touches no memory */
     if (!STAGED && !wave_live) return;
     const uint64_t k = tile * 16 + c;
@@ -268,14 +307,23 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_mlda2_kernel(const T
     const uint32_t chain = (uint32_t)(a.chain0 + k);
     const int d = a.d, S = a.S;
     const uint32_t pair_of_g = (g == 0) ? 0u : (g == 1) ? 2u : (g == 2) ? 1u : 3u;
-    double *xt = a.x_tiled + ((wave_live ? tile : 0) * KS) * 64 + lane; /* this lane's column of the carried fine state */
 
-    double z[KS], y[KS];
+    /* the fine state x: registers; (XLDS) this lane's column of the wave's block in LDS; or (XMEM) memory -- the
+     * record row written last (it IS the fine state) when every fine step is recorded, else a scratch in the
+     * record's layout --, read into y's registers once per fine step (y is dead between sub-chain and decision) */
+    constexpr int KX = XM == kXRegs ? KS : 1;
+    double x[KX], z[KS], y[KS];
+    double *xs = stage + 2 * ymc_stream_unit<KS, 4>() + (size_t)wave * KS * 64 + lane;
+    double *xt = a.x_tiled + ((wave_live ? tile : 0) * KS) * 64 + lane;
+    const double *xsrc = xt;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const int j = 4 * s + g;
         z[s] = (live && j < d) ? a.x[k * d + j] : 0.0;
-        if (wave_live) xt[s * 64] = z[s];
+        if constexpr (XLDS) xs[s * 64] = z[s];
+        else if constexpr (XMEM) {
+            if (wave_live) xt[s * 64] = z[s];
+        } else x[s] = z[s];
     }
     double lpf = live ? a.lp[k] : 0.0;
     double lpc = live ? a.lpc[k] : 0.0;
@@ -296,24 +344,28 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_mlda2_kernel(const T
         return ymc_tile_logprior<KS>(pmean, pprec, g, v);
     };
     auto any_differs = [&](const double (&p)[KS], const double (&q)[KS]) { return ymc_tile_any_differs<KS>(p, q); };
-    /* STAGED: the fine level's log-likelihood over the workgroup's shared stream of the fine matrix
+    /* STAGED: a level's log-likelihood over the workgroup's shared stream of its matrix
      * (ymc_stream_tile_pairs, ymc_tile_dev.h); every wave calls it at the same point of the loop */
-    auto loglik_fine_staged = [&](const double (&v)[KS]) {
+    auto loglik_staged = [&](const double *A, int MT, const double *bias, const double *nprec, const double *dbar,
+                             double lik_const, const double (&v)[KS]) {
         double Ssum = 0.0;
-        ymc_stream_tile_pairs<KS, 4, kTileThreads>(Af, MTf / 2, stage, tid, lane, v, [&](int pair, const d4 &acc0, const d4 &acc1) {
-            ymc_tile_add_residuals(2 * pair, acc0, acc1, bias_f, nprec_f, dbar_f, g, Ssum);
+        ymc_stream_tile_pairs<KS, 4, kThreads>(A, MT / 2, stage, tid, lane, v, [&](int pair, const d4 &acc0, const d4 &acc1) {
+            ymc_tile_add_residuals(2 * pair, acc0, acc1, bias, nprec, dbar, g, Ssum);
         });
-        return -0.5 * (combine4(Ssum) + a.lik_const_f);
+        return -0.5 * (combine4(Ssum) + lik_const);
     };
 
+    YMC_PROF_DECL;
 #pragma unroll 1
     for (uint32_t n = 0; n < a.nsteps; ++n) {
         const uint64_t tbase = (a.t0 + n) * (uint64_t)(S + 1);
         double lpcz = lpc;
-        /* surrogate.run(S + 1, state): S random-walk transitions on the coarse posterior */
+        YMC_PROF_START();
+        /* surrogate.run(S + 1, state): S random-walk transitions on the coarse posterior, from z == x */
 #pragma unroll 1
         for (int sub = 0; sub < S; ++sub) {
             const uint64_t t = tbase + (uint64_t)sub;
+            YMC_PHASE_DRAWS();
 #pragma unroll
             for (int q = 0; q < KS / 2; ++q) {
                 double xi0, xi1;
@@ -323,46 +375,87 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_mlda2_kernel(const T
                 y[2 * q + 1] = z[2 * q + 1] + sigma[8 * q + 4 + g] * xi1;
             }
             const bool moved = any_differs(y, z);
-            const double lpcy = loglik(Ac, MTc, bias_c, nprec_c, dbar_c, a.lik_const, y) + logprior(pmean_c, pprec_c, y);
+            YMC_PROF(0);
+            YMC_PHASE_MAP();
+            double llc;
+            if constexpr (XLDS) llc = loglik_staged(Ac, MTc, bias_c, nprec_c, dbar_c, a.lik_const, y);
+            else llc = loglik(Ac, MTc, bias_c, nprec_c, dbar_c, a.lik_const, y);
+                YMC_PROF(1);
+            const double lpcy = llc + logprior(pmean_c, pprec_c, y);
             const double u = ymc_uniform_cached(uc, a.seed, chain, t);
             const bool acc = ymc_accept(lpcy - lpcz, moved, ymc_finite(lpcy), u, st);
 #pragma unroll
             for (int s = 0; s < KS; ++s) z[s] = acc ? y[s] : z[s];
             lpcz = acc ? lpcy : lpcz;
             if (a.sub_acc && live && g == 0) a.sub_acc[((uint64_t)n * S + sub) * a.K + k] = acc ? 1 : 0;
+            YMC_PROF(2);
         }
-        /* fine accept / reject (mlda.py:146-154); y <- the fine state x */
+        /* fine accept / reject (mlda.py:146-154) of the proposal z against the fine state x */
+        if constexpr (XMEM) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) y[s] = wave_live ? xt[s * 64] : 0.0;
-        const bool moved = any_differs(z, y);
+            for (int s = 0; s < KS; ++s) y[s] = wave_live ? xsrc[s * 64] : 0.0;     /* in flight while the fine map runs */
+        }
+        bool moved = false;
+        if constexpr (XMEM) {
+        } else if constexpr (XLDS) {
+            bool dl = false;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) dl = dl || !(z[s] == xs[s * 64]);
+            int mv = dl ? 1 : 0;
+            mv |= __shfl_xor(mv, 16, 64);
+            mv |= __shfl_xor(mv, 32, 64);
+            moved = mv != 0;
+        } else {
+            moved = ymc_tile_any_differs<KS>(z, reinterpret_cast<const double (&)[KS]>(x));
+        }
+        YMC_PROF(3);
         double llf;
-        if constexpr (STAGED) llf = loglik_fine_staged(z);
+        if constexpr (STAGED) llf = loglik_staged(Af, MTf, bias_f, nprec_f, dbar_f, a.lik_const_f, z);
         else llf = loglik(Af, MTf, bias_f, nprec_f, dbar_f, a.lik_const_f, z);
+        YMC_PROF(4);
+        if constexpr (XMEM) moved = any_differs(z, y);
         const double lpfy = llf + logprior(pmean_f, pprec_f, z);
         const double log_ratio = ((lpfy + lpc) - lpcz) - lpf;
         const double u = ymc_uniform_cached(uc, a.seed, chain, tbase + (uint64_t)S);
         const bool acc = ymc_accept(log_ratio, moved, ymc_finite(lpfy) && ymc_finite(lpcz), u, st);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            z[s] = acc ? z[s] : y[s];
-            if (wave_live) xt[s * 64] = z[s];
+            if constexpr (XLDS) {
+                z[s] = acc ? z[s] : xs[s * 64];
+                xs[s * 64] = z[s];
+            } else if constexpr (XMEM) {
+                z[s] = acc ? z[s] : y[s];
+            } else {
+                x[s] = acc ? z[s] : x[s];
+                z[s] = x[s];
+            }
         }
         lpf = acc ? lpfy : lpf;
         lpc = acc ? lpcz : lpc;
         accepted += acc ? 1u : 0u;
+        YMC_PROF(5);
 
         const bool rec = clk.due();
         if (rec && a.traj && wave_live) {
             double *row = a.traj + (((uint64_t)clk.row * nct + tile) * KS) * 64 + lane;
 #pragma unroll
-            for (int s = 0; s < KS; ++s) row[s * 64] = z[s];
+            for (int s = 0; s < KS; ++s) row[s * 64] = z[s];       /* z == x here */
+            if constexpr (XMEM) xsrc = row;
+        } else if constexpr (XMEM) {
+            if (wave_live) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) xt[s * 64] = z[s];
+                xsrc = xt;
+            }
         }
         if (live && g == 0) {
             if (a.acc) a.acc[(uint64_t)n * a.K + k] = acc ? 1 : 0;
             if (rec && a.lp_out) a.lp_out[(uint64_t)clk.row * a.K + k] = lpf;
         }
         if (rec) clk.wrote();
+        YMC_PROF(6);
     }
+    YMC_PROF_FLUSH();
 
     if (live) {
 #pragma unroll
@@ -494,29 +587,55 @@ size_t ymc_tile_mlda2_lds_bytes(int KS, int MT_coarse, int MT_fine)
     return ymc_tile_lds_bytes(KS, MT_coarse) + (16 * (size_t)MT_fine * 3 + 2 * 4 * (size_t)KS) * sizeof(double);
 }
 
-template <int KS, bool STAGED>
+/* The builds of the two-level kernel (identical results; YMC_TILE_MLDA2=mem|regs|lds|plain and YMC_TILE_STAGE=0
+ * override the choice, the tests run all of them):
+ *   mem    the coarse matrix resident in LDS, the fine one streamed, 8 waves (two per SIMD: z and y in 128 of their
+ *          256 registers); the fine state is read back from the record row written last, once per fine step
+ *   lds    both matrices stream through the shared double buffer, the fine state in LDS, 8 waves (two per SIMD,
+ *          z and y in 128 of their 256 registers) -- KS = 32 when the constants leave the room
+ *   regs   the coarse matrix resident in LDS, the fine one streamed, the fine state in registers; 4 waves at
+ *          KS = 32 (one per SIMD, 512 registers), 8 below
+ *   plain  as regs, every wave reading the fine matrix from L2 itself (no room for the double buffer) */
+template <int KS>
+constexpr int mlda2_waves() { return KS >= 32 ? 4 : 8; }
+
+template <int KS, bool STAGED, int XM>
 static hipError_t launch_tile_mlda2_as(const TileArgs &a, size_t lds, hipStream_t s)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_tile_mlda2_kernel<KS, STAGED>),
+    constexpr int W = XM == kXRegs ? mlda2_waves<KS>() : 8;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_tile_mlda2_kernel<KS, STAGED, W, XM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const uint64_t nct = (a.K + 15) / 16;
-    const unsigned grid = (unsigned)((nct + kTileWaves - 1) / kTileWaves);
-    hipLaunchKernelGGL((linear_tile_mlda2_kernel<KS, STAGED>), dim3(grid), dim3(kTileThreads), lds, s, a);
+    const unsigned grid = (unsigned)((nct + W - 1) / W);
+    hipLaunchKernelGGL((linear_tile_mlda2_kernel<KS, STAGED, W, XM>), dim3(grid), dim3(64 * W), lds, s, a);
     return hipGetLastError();
 }
 
 template <int KS>
 static hipError_t launch_tile_mlda2(const TileArgs &a, hipStream_t s)
 {
-    /* the fine matrix through a shared double buffer when the LDS has 16 KB left for it (identical results;
-     * YMC_TILE_STAGE=0|1 overrides, the tests run both) */
-    const size_t plain = ymc_tile_mlda2_lds_bytes(KS, a.MT, a.MT_f);
-    const size_t staged = plain + 2 * (size_t)ymc_stream_unit<KS, 4>() * sizeof(double);
+    const size_t unit2 = 2 * (size_t)ymc_stream_unit<KS, 4>() * sizeof(double);
+    const size_t consts = ymc_tile_mlda2_lds_bytes(KS, a.MT, a.MT_f) - (size_t)a.MT * KS * 64 * sizeof(double);
+    const size_t plain = ymc_tile_mlda2_lds_bytes(KS, a.MT, a.MT_f), staged = plain + unit2;
+    const size_t xlds = consts + unit2 + (size_t)8 * KS * 64 * sizeof(double);
     bool stage = staged <= kTileLdsLimit;
     if (const char *env = std::getenv("YMC_TILE_STAGE")) stage = stage && env[0] != '0';
-    return stage ? launch_tile_mlda2_as<KS, true>(a, staged, s) : launch_tile_mlda2_as<KS, false>(a, plain, s);
+    char mode = 'r';
+    if (const char *env = std::getenv("YMC_TILE_MLDA2")) mode = env[0];
+    if (mode == 'p') stage = false;
+    if (mode == 'l' && stage && xlds <= kTileLdsLimit) return launch_tile_mlda2_as<KS, true, kXLds>(a, xlds, s);
+    if (mode == 'm')
+        return stage ? launch_tile_mlda2_as<KS, true, kXMem>(a, staged, s) : launch_tile_mlda2_as<KS, false, kXMem>(a, plain, s);
+    return stage ? launch_tile_mlda2_as<KS, true, kXRegs>(a, staged, s) : launch_tile_mlda2_as<KS, false, kXRegs>(a, plain, s);
 }
+
+#ifdef YMC_TILE_PROFILE
+extern "C" int ymc_debug_tile_sections(unsigned long long *out16)
+{
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(ymc_tile_prof), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -2;
+}
+#endif
 
 hipError_t ymc_launch_linear_tile_mlda2(int KS, const TileArgs &a, hipStream_t s)
 {

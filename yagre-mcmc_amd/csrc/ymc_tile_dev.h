@@ -63,7 +63,10 @@ __device__ __forceinline__ void ymc_tile_add_residuals(int mt, const d4 &acc0, c
 }
 
 /* this lane's partial sum for the forward map A v + b with A's fragments [MT][KS][64] in LDS or in global memory
- * (every wave reading its own): two accumulator chains of KS MFMAs per pair of output tiles */
+ * (every wave reading its own): two accumulator chains of KS MFMAs per pair of output tiles.
+ * The compiler requests each fragment one or two MFMAs before its use; requesting them a block ahead (stages with
+ * scheduling barriers) bought nothing at one wave per SIMD and cost 19 % at two (profiles/r03_tile_experiments.txt):
+ * the matrix pipe takes 66-68 cycles per f64 MFMA in every order (tools/probe_mfma_rate.hip). */
 template <int KS>
 __device__ __forceinline__ double ymc_tile_residual_sum(const double *A, int MT, const double *bias, const double *nprec,
                                                         const double *dbar, int lane, int g, const double (&v)[KS])
@@ -125,7 +128,10 @@ __device__ __forceinline__ bool ymc_tile_any_differs(const double (&p)[KS], cons
  * tile alive for it); `v` is the wave's B operand (component 4 s + g of chain c in register s of lane (g, c)).
  * Back-to-back calls: a call starts writing buffer 0 with no barrier of its own, which is safe only if the
  * previous call's LAST unit was read from buffer 1, i.e. if it staged an even number of units.  DIV is even
- * (asserted), so n_pairs * DIV always is. */
+ * (asserted), so n_pairs * DIV always is.
+ * Measured alternatives, none faster (profiles/r03_tile_experiments.txt): writing unit u + 1 before the MFMAs of unit
+ * u with the barrier at the end of the unit (the LDS write latency off the critical path: +4...15 % time), reading
+ * all fragments of a unit before its first MFMA. */
 template <int KS, int DIV>
 constexpr int ymc_stream_unit() { return 2 * (KS / DIV) * 64; }
 
