@@ -8,8 +8,9 @@ One bench "step" = one pass of the hot path over this rank's batch of chains:
 kernel, each advancing every chain by `transitions_per_launch` MH transitions
 into the record in HBM (full trajectory + accept mask + FullDiagnostics'
 Welford moments, i.e. what example_mcmc_2d_singleLevel.py records; the record
-is refilled by every launch).  The defaults make a step ~0.1 s, so the
-driver's 20 timed steps are a ~2 s region at the clock the chip SUSTAINS, and
+is refilled by every launch).  The defaults make a step ~0.5 s, so the
+driver's 20 timed steps are a ~10 s region at the clock the chip SUSTAINS (long
+enough for a once-per-few-seconds utilisation sampler to see the load), and
 the W warm-up steps bring it there (no other pre-heating).  Default workload =
 BASELINE.json configs[1]: the 2-D Gaussian target, random-walk proposal,
 65 536 chains per GPU.  For N > 1: one process per GPU, either started by a
@@ -41,7 +42,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6  # AMD MI355X data sheet: FP64 vector = FP64 matrix = 78.6 TFLOP/s (the guide lists no f64 rate)
-STEP_TARGET_S = 0.1      # a bench step is sized to about this much device time
+STEP_TARGET_S = 0.5      # a bench step is sized to about this much device time
 
 
 def parse():
@@ -49,7 +50,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "c4", "iat", "c3m"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "c4", "iat", "c3m", "c3a"])
     ap.add_argument("--chains", type=int, default=0, help="chains per GPU (default: the workload's)")
     ap.add_argument("--transitions", type=int, default=0, help="MH transitions per chain per launch")
     ap.add_argument("--launches-per-step", type=int, default=0, help="kernel launches per bench step")
@@ -102,17 +103,17 @@ def make_workload(name, ffi, ctx, lowering):
         x0 = np.array([[-8.0, -7.0]])
         if name in ("c2", "iat"):
             prob = lowering.make_problem(ctx, ffi.METHOD_MRW, fine, sigma)
-            return dict(problem=prob, x0=x0, K=65536, T=10000, L=20, d=2,
+            return dict(problem=prob, x0=x0, K=65536, T=10000, L=100, d=2,
                         desc="C2: 2-D Gaussian target (example_mcmc_2d_singleLevel.py), random-walk proposal "
                              "var 1.0, x0=(-8,-7)", spec=dict(target=s_fine, sigma=sigma))
         cm = TGT_MEAN + np.array([0.15, -0.2])
         cc = 2.0 * TGT_COV + np.array([[0.1, 1.2], [1.2, 0.05]])
         coarse, s_coarse = _gauss(ffi, lowering, cm, cc)
         prob = lowering.make_problem(ctx, ffi.METHOD_MLDA2, fine, sigma, surrogate=coarse, sub_chain_length=6)
-        return dict(problem=prob, x0=x0, K=131072, T=1000, L=20, d=2,
+        return dict(problem=prob, x0=x0, K=131072, T=1000, L=100, d=2,
                     desc="C5: two-level delayed acceptance (example_mcmc_2d_twoLevel.py), S=6",
                     spec=dict(target=s_fine, sigma=sigma, surrogate=s_coarse, S=6))
-    if name in ("c3", "c3m"):
+    if name in ("c3", "c3m", "c3a"):
         # linear forward model, d = m = 128, nData = 5
         d = 128
         rng = np.random.default_rng(7)
@@ -128,6 +129,20 @@ def make_workload(name, ffi, ctx, lowering):
                      ("prior_precision", prior_prec), ("fwd_matrix", A), ("fwd_shift", b)):
             low.set_array(k, v)
         sigma = np.sqrt(np.reciprocal(np.reciprocal(np.full(d, 1.1e-3))))
+        if name == "c3a":
+            # the adaptive error model over two models of C3's size: S = 4 coarse transitions per fine step,
+            # the coarse likelihood learning the model error F_fine - F_coarse (minDataSize 8, noise heuristic on)
+            A_c, b_c = A + 0.02 * rng.standard_normal((d, d)) / np.sqrt(d), b + 0.05 * rng.standard_normal(d)
+            coarse = lowering.Lowered(ffi.POSTERIOR_LINEAR, d)
+            coarse.desc.n_data, coarse.desc.data_dim = data.shape[0], d
+            for k, v in (("data", data), ("noise_precision", noise_prec), ("prior_mean", prior_mean),
+                         ("prior_precision", prior_prec), ("fwd_matrix", A_c), ("fwd_shift", b_c)):
+                coarse.set_array(k, v)
+            prob = lowering.make_problem(ctx, ffi.METHOD_AEM2, low, sigma, surrogate=coarse, sub_chain_length=4, aem=(8, True))
+            return dict(problem=prob, x0=np.zeros((1, d)), K=65536, T=20, L=30, d=d,
+                        desc="C3 adaptive error model: AEM delayed acceptance over two linear models, d = m = 128, nData = 5, "
+                             "S = 4 (fp64 MFMA tile kernel; steps = FINE steps)",
+                        spec=dict(S=4, fine_maps=2, aem=True))
         if name == "c3m":
             # two-level delayed acceptance over a model hierarchy at C3's size (configs[2] is named after
             # example_inference_linearModel_twoLevel.py): the coarse model is a perturbation of the fine one
@@ -141,12 +156,12 @@ def make_workload(name, ffi, ctx, lowering):
             prob = lowering.make_problem(ctx, ffi.METHOD_MLDA2, low, sigma, surrogate=coarse, sub_chain_length=S)
             lin = lambda A_, b_: dict(kind="linear", A=A_, b=b_, data=data, noise_prec=noise_prec,  # noqa: E731
                                       prior_mean=prior_mean, prior_prec=prior_prec)
-            return dict(problem=prob, x0=np.zeros((1, d)), K=262144, T=20, L=5, d=d,
+            return dict(problem=prob, x0=np.zeros((1, d)), K=262144, T=20, L=18, d=d,
                         desc="C3 two-level: delayed acceptance over two linear models, d = m = 128, nData = 5, S = 5 "
                              "(fp64 MFMA tile kernel; steps = FINE steps, each with 5 coarse transitions)",
                         spec=dict(target=lin(A, b), surrogate=lin(A_c, b_c), S=S, sigma=sigma))
         prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, sigma)
-        return dict(problem=prob, x0=np.zeros((1, d)), K=262144, T=100, L=5, d=d,
+        return dict(problem=prob, x0=np.zeros((1, d)), K=262144, T=100, L=25, d=d,
                     desc="C3: linear forward model posterior d = m = 128, nData = 5 (fp64 MFMA tile kernel)",
                     spec=dict(target=dict(kind="linear", A=A, b=b, data=data, noise_prec=noise_prec,
                                           prior_mean=prior_mean, prior_prec=prior_prec), sigma=sigma))
@@ -163,7 +178,7 @@ def make_workload(name, ffi, ctx, lowering):
     data = clean + np.sqrt(0.04) * np.random.default_rng(2222).standard_normal((10, 2))
     prob = lowering.make_problem(ctx, ffi.METHOD_MRW,
                                  _lv_lowered(ffi, lowering, design, data, noise_prec, prior_mean, prior_prec), sigma)
-    return dict(problem=prob, x0=np.array([[-0.6, -0.3]]), K=16384, T=1000, L=10, d=2,
+    return dict(problem=prob, x0=np.array([[-0.6, -0.3]]), K=16384, T=1000, L=40, d=2,
                 desc="C4: Lotka-Volterra posterior, nData=10, T=10, RK4 x 50",
                 spec=dict(target=dict(kind="lv", design=design, data=data, noise_prec=noise_prec,
                                       prior_mean=prior_mean, prior_prec=prior_prec), sigma=sigma))
@@ -245,7 +260,7 @@ def roofline_block(args, wl, K, T, kernel_ms, launches, clock_mhz, info):
     sq = rec.get("sq_per_launch") or {}
     valu = None
     if sq.get("SQ_INSTS_VALU") and clock_mhz and ksec > 0:
-        waves = math.ceil(K / (16 if args.workload in ("c3", "c3m") else 64))   # waves' worth of chains
+        waves = math.ceil(K / (16 if args.workload in ("c3", "c3m", "c3a") else 64))   # waves' worth of chains
         simds = 4 * info["compute_units"]
         avail = ksec * clock_mhz * 1e6 * simds          # SIMD issue cycles in one launch
         mfma = sq.get("SQ_INSTS_MFMA", 0.0)
@@ -261,8 +276,9 @@ def roofline_block(args, wl, K, T, kernel_ms, launches, clock_mhz, info):
                         "and a VALU instruction never execute together on gfx950: SQ_VALU_MFMA_COEXEC_CYCLES = 0); "
                         "instruction counts per wave of chains and transition",
                 "source": {"instr": rec.get("source"), "kernel_time_and_clock": "this run"}}
-    if args.workload in ("c3", "c3m"):
-        maps = 1 + wl["spec"].get("S", 0)    # c3m: S = 5 coarse + 1 fine forward map per fine step
+    if args.workload in ("c3", "c3m", "c3a"):
+        # c3m: S = 5 coarse + 1 fine forward map per fine step; c3a: S = 4 coarse + the fine matrix twice (likelihood, model error)
+        maps = wl["spec"].get("fine_maps", 1) + wl["spec"].get("S", 0)
         flops = 2.0 * d * d * K * T * maps
         tf = flops / ksec / 1e12 if ksec > 0 else 0.0
         return dict(common, bound="mfma", achieved=tf, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / FP64_PEAK_TFLOPS,
@@ -343,7 +359,7 @@ def main():
     T = args.transitions or wl["T"]
     L = args.launches_per_step or wl["L"]
     d, x0 = wl["d"], wl["x0"]
-    if args.workload in ("c3", "c3m"):
+    if args.workload in ("c3", "c3m", "c3a"):
         args.no_moments = True   # the reference's default diagnostics; the tile kernel keeps no Welford state
     stride = max(args.record_stride, 1)
     flags = ffi.RECORD_TRAJECTORY | (ffi.RECORD_ACCEPT if stride == 1 else 0) | (0 if args.no_moments else ffi.RECORD_MOMENTS)
@@ -448,7 +464,7 @@ def main():
     }
     if args.workload == "c5":
         out["coarse_sub_steps_per_s"] = value * 6
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not wl["spec"].get("aem"):
         out["cpu_baseline"] = cpu_baseline(wl["spec"], x0)
     print(json.dumps(out))
 

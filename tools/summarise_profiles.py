@@ -25,7 +25,7 @@ def one(pattern):
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-    wls = sys.argv[2:] or ["c2", "c3", "c5", "c4"]
+    wls = sys.argv[2:] or ["c2", "c3", "c3m", "c3a", "c5", "c4", "iat"]
     tpath = os.path.join(PROF, "pmc_traffic.json")
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
     for wl in wls:
@@ -33,7 +33,9 @@ def main():
         if not os.path.isdir(sdir):
             continue
         line = json.loads(open(os.path.join(OUT, f"prof_{wl}_stats.json")).read().strip().splitlines()[-1])
-        K, T = line["config"]["chains_per_gpu"], line["config"].get("transitions_per_launch", line["config"]["transitions_per_step"])
+        cfg = line["config"]
+        K = cfg["chains_per_gpu"]
+        T = cfg.get("transitions_per_launch") or cfg.get("transitions_per_step") or cfg.get("states")
         stem = os.path.join(PROF, f"{tag}_{wl}_K{K}_T{T}")
         rows = list(csv.DictReader(open(one(os.path.join(sdir, "**", "*_kernel_stats.csv")))))
         with open(stem + "_kernel_stats.csv", "w", newline="") as f:
@@ -67,14 +69,14 @@ def main():
                 w.writerows(pmc_rows)
         med = {k: sorted(v)[len(v) // 2] for k, v in sums.items()}
         if "WRITE_SIZE" in med and "FETCH_SIZE" in med:
-            d = 2 if wl != "c3" else 128
+            d = 128 if wl.startswith("c3") else 2
             traffic[f"{wl}_K{K}_T{T}"] = {
                 "hbm_bytes_per_launch": med["WRITE_SIZE"] * 1024 + 2 * med["FETCH_SIZE"] * 1024,
                 "WRITE_SIZE_KB": med["WRITE_SIZE"], "FETCH_SIZE_KB_raw": med["FETCH_SIZE"],
                 "correction": "bytes = WRITE_SIZE*1024 + 2*FETCH_SIZE*1024 (gfx950: FETCH_SIZE reports half of a "
                               "coalesced read; WRITE_SIZE exact for 16-B/lane stores, uncalibrated for the tile "
                               "kernel's 8-B/lane stores)",
-                "algorithmic_bytes_per_launch": K * T * (8 * d + 1),
+                "algorithmic_bytes_per_launch": K * T * (8 * d + 1) if wl != "iat" else K * T * 8 * d,
                 "dominant_kernel": dominant,
                 "sq_per_launch": {k: v for k, v in med.items() if k.startswith("SQ_") or k.startswith("GRBM_")},
                 "waves_per_launch": (grid // 64) if grid else None, "workgroup_size": wg if grid else None,
