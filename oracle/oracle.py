@@ -184,8 +184,14 @@ def posterior_lv(design, t_final, alpha, gamma, rk4_steps, data, noise_precision
     return p
 
 
+DMAX, MMAX = 256, 8192     # YMO_DMAX, YMO_MMAX of ymc_oracle.c (its work arrays live on the stack)
+
+
 def _lower(p):
     """dict -> (_Density, keepalive)"""
+    if p["dim"] > DMAX or p.get("data_dim", 0) > MMAX:
+        raise ValueError(f"the checker handles dimensions up to {DMAX} and {MMAX} forward outputs, got {p['dim']} and "
+                         f"{p.get('data_dim', 0)}")
     d = _Density()
     d.kind, d.dim = p["kind"], p["dim"]
     keep = []

@@ -36,7 +36,7 @@
 #endif
 
 #define YMO_DMAX 256  /* largest parameter dimension the oracle handles */
-#define YMO_MMAX 256  /* largest forward-map output dimension */
+#define YMO_MMAX 8192 /* largest forward-map output dimension (stack arrays: 64 KB each) */
 
 enum {
     YMO_GAUSS_WHITENED = 1, /* testSetup.py:32-40  GaussianTargetDensity2d (any d) */

@@ -338,6 +338,29 @@ def fixture_f3():
     print("F3", acc.mean())
 
 
+def fixture_f22():
+    """Beyond the LDS-resident shapes: d = 192 parameters, m = 160 outputs (a 240 KB forward matrix), the reference's
+    shape-agnostic linear model (exampleSetup.py:42-52, likelihood.py:74-84) under a random walk, 8 chains x 200 states."""
+    d, m, n_data, seed, K, n = 192, 160, 4, 20250122, 8, 200
+    z, _ = oracle.rng_fill(22, 0, m + 3 + n_data, 0, 1, d, uniforms=False)
+    z = z[0]
+    A = z[:m] / np.sqrt(d)
+    b = z[m][:m]
+    theta_true = z[m + 1]
+    noise_var = 0.3
+    data = np.array([A @ theta_true + b + np.sqrt(noise_var) * z[m + 3 + i][:m] for i in range(n_data)])
+    prior_mean, prior_var, prop_var = np.zeros(d), 5.0, 8e-4
+    model = build_linear_reference(A, b, data, noise_var, prior_mean, prior_var)
+    prop_cov = IIDCovarianceMatrix(d, prop_var)
+    traj, acc, lp = run_mrw_model(model, seed, K, n, prop_cov, np.zeros(d))
+    np.savez_compressed(
+        os.path.join(HERE, "f22_linear_d192_m160.npz"), seed=seed, n_states=n, A=A, b=b, data=data,
+        noise_precision=np.reciprocal(np.full(m, noise_var)), prior_mean=prior_mean,
+        prior_precision=np.reciprocal(np.full(d, prior_var)), sigma=sigma_of(prop_cov),
+        x0=np.zeros((K, d)), traj_head=traj[:, :2, :], traj_sha256=sha(traj), acc=acc, logpost=lp)
+    print("F22", acc.mean())
+
+
 def fixture_f3b():
     """The shipped 2x2 example model (example_inference_linearModel_twoLevel.py:24-82)."""
     from numpy.random import seed as np_seed, standard_normal
@@ -1102,7 +1125,7 @@ def fixture_f18(name="f18_mlda_nested2_linear_d128.npz", d=128, n_models=3, seed
 
 def main():
     which = sys.argv[1:] or ["f1", "f2", "f2b", "f3", "f3b", "f4", "f5", "f7", "f8", "f9", "f10", "f11", "f12", "f13",
-                             "f14", "f15", "f16", "f17", "f18", "f19", "f20", "f21"]
+                             "f14", "f15", "f16", "f17", "f18", "f19", "f20", "f21", "f22"]
     if "f1" in which:
         fixture_f1()
     if "f2" in which:
@@ -1116,6 +1139,8 @@ def main():
         fixture_f3()
     if "f3b" in which:
         fixture_f3b()
+    if "f22" in which:
+        fixture_f22()
     if "f4" in which:
         fixture_f4()
     if "f5" in which:

@@ -754,6 +754,39 @@ def test_dense_noise_beyond_the_lane_sizes_through_the_builders_f19(golden):
     assert np.array_equal(mc.chain.ensemble_trajectory, g["ml_traj"])
 
 
+def test_linear_model_d192_through_the_builder_f22(golden):
+    """MRWBuilder over the reference's shape-agnostic linear model at d = 192, m = 160 (exampleSetup.py:42-52,
+    likelihood.py:74-84; fixture F22 = the live reference's chains): the forward matrix streams from L2, one wave per
+    SIMD holds 192 components per chain."""
+    import hashlib
+    from yagremcmc_amd.chain.method.mrw import MRWBuilder
+    from yagremcmc_amd.exampleSetup import ExampleLinearModelSolver
+    from yagremcmc_amd.model.forwardModel import ForwardModel
+    from yagremcmc_amd.parameter.vector import ParameterVector
+    from yagremcmc_amd.statistics.bayesModel import BayesianRegressionModel
+    from yagremcmc_amd.statistics.covariance import IIDCovarianceMatrix
+    from yagremcmc_amd.statistics.data import Data
+    from yagremcmc_amd.statistics.gaussian import Gaussian
+    from yagremcmc_amd.statistics.likelihood import AdditiveGaussianNoiseLikelihood
+    from yagremcmc_amd.statistics.noise import CentredGaussianNoise
+    g = golden("f22_linear_d192_m160.npz")
+    d, m = 192, 160
+    like = AdditiveGaussianNoiseLikelihood(Data(g["data"]), ForwardModel(ExampleLinearModelSolver(g["A"], g["b"])),
+                                           CentredGaussianNoise(IIDCovarianceMatrix(m, 0.3)))
+    b = MRWBuilder()
+    b.bayesModel = BayesianRegressionModel(like, Gaussian(ParameterVector(np.zeros(d)), IIDCovarianceMatrix(d, 5.0)))
+    b.proposalCovariance = IIDCovarianceMatrix(d, 8e-4)
+    b.nChains, b.seed, b.recordLogPosterior = g["x0"].shape[0], int(g["seed"]), True
+    mc = b.build_method()
+    mc.run(int(g["n_states"]), ParameterVector(np.zeros(d)), verbose=False)
+    assert np.array_equal(mc.accept_decisions, g["acc"])
+    traj = mc.chain.ensemble_trajectory
+    assert np.array_equal(traj[:, :2, :], g["traj_head"])
+    assert hashlib.sha256(np.ascontiguousarray(traj).tobytes()).hexdigest() == str(g["traj_sha256"])
+    assert np.abs(mc.log_posterior - g["logpost"]).max() <= 1e-12 * np.abs(g["logpost"]).max()
+    assert mc.integrated_autocorrelation("mean", 20).shape == (8,)
+
+
 def test_iat_of_a_stuck_chain_is_reported_not_invented():
     """A chain that never moves (or was flagged non-finite and froze) has a constant series: c0 = 0 and the
     autocorrelation is 0 / 0.  The device reports IAT_UNDEFINED for it; the Python layer raises unless asked."""
@@ -812,10 +845,10 @@ def test_iat_kernels_on_ragged_series(monkeypatch, kernel, N):
     assert np.array_equal(got, want), (got - want)[got != want]
 
 
-@pytest.mark.parametrize("d", [8, 24, 128])
+@pytest.mark.parametrize("d", [8, 24, 128, 136, 200, 256])
 def test_integrated_autocorrelation_from_the_tiled_record_and_numpy_mean_order(d):
     """'mean' IAT at d >= 8: the per-state mean is formed in NumPy's pairwise order (bit-identical to
-    np.mean(seq, axis=1)); d > 8 reads the tile kernel's record layout in HBM."""
+    np.mean(seq, axis=1), whose blocks split beyond 128 terms); d > 8 reads the tile kernel's record layout in HBM."""
     from yagremcmc_amd import _ffi, lowering
     rng = np.random.default_rng(d)
     m = min(d, 16)

@@ -681,6 +681,80 @@ def test_f3_linear_d128_matrix_cores(ffi, ctx, golden):
     assert np.array_equal(prob.forward(xs), o.forward(p, xs))
 
 
+def test_f22_linear_d192_m160_streamed_matrix(ffi, ctx, golden):
+    """The forward matrix streamed from L2 (it does not fit the LDS) and 192 parameter components per chain (KS = 64,
+    one wave per SIMD): device == oracle == the live reference's chains (fixture F22, exampleSetup.py:42-52,
+    likelihood.py:74-84), the IAT of the d = 192 record included ('mean' sums 192 components in NumPy's pairwise order)."""
+    import hashlib
+    g = golden("f22_linear_d192_m160.npz")
+    n = int(g["n_states"])
+    low = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, 192, g, fwd_matrix=np.asarray(g["A"]), fwd_shift=np.asarray(g["b"]))
+    dev = _device_run(ffi, ctx, low, g["sigma"], g["x0"], int(g["seed"]), n - 1, moments=True, splits=3)
+    p = o.posterior_linear(g["A"], g["b"], g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+    e = o.Ensemble(p, g["sigma"], g["x0"], int(g["seed"]))
+    out = e.advance(n - 1)
+    _same_as_oracle(dev, e, out)
+    _same_as_reference(dev, g)
+    assert np.array_equal(dev["traj"][:, :2, :], g["traj_head"][1:])
+    full = np.concatenate([g["x0"][None], dev["traj"]])
+    assert hashlib.sha256(np.ascontiguousarray(full).tobytes()).hexdigest() == str(g["traj_sha256"])
+    from yagremcmc_amd import lowering
+    prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, g["sigma"])
+    xs = dev["traj"][-1]
+    assert np.array_equal(prob.logdensity(xs)[0], o.logdensity(p, xs)[0])
+    assert np.array_equal(prob.forward(xs), o.forward(p, xs))
+    # post-processing on the d = 192 record, read in place in the tiled layout
+    run = ffi.Run(prob, int(g["seed"]), 8, g["x0"], n - 1, ffi.RECORD_TRAJECTORY)
+    run.advance(n - 1)
+    states = run.trajectory()
+    for method in (0, 1):
+        assert np.array_equal(run.iat(0, n - 1, method), ctx.iat_states(states, method))
+    series = np.ascontiguousarray(states.mean(axis=2).T)        # NumPy's own row means
+    assert np.array_equal(run.iat(0, n - 1, 0), ctx.iat_series(series)[0])
+
+
+@pytest.mark.parametrize("stream", ["0", "1"])
+@pytest.mark.parametrize("d,m,nd,K,pcn", [(128, 160, 3, 150, False), (200, 48, 2, 70, False), (256, 256, 2, 40, False),
+                                           (130, 1000, 1, 33, False), (96, 400, 4, 129, True), (256, 20, 3, 65, True),
+                                           (40, 70, 8, 50, False), (20, 24, 2, 600, True)])
+def test_tile_kernel_streamed_forward_matrix(ffi, ctx, monkeypatch, stream, d, m, nd, K, pcn):
+    """Shapes beyond the LDS (any m whose constants fit, d <= 256) take the forward matrix from L2 through the
+    workgroup's double buffer; shapes that fit can be forced onto that build (YMC_TILE_ASTREAM=1): == oracle for the
+    random walk and pCN, ragged shapes, several workgroups, waves past the last tile, across launches."""
+    fits = d <= 128 and (16 * ((m + 15) // 16 + ((m + 15) // 16) % 2)) * (4 * (1 << max(2, int(np.ceil(np.log2((d + 3) // 4)))))) * 8 < 150_000
+    if stream == "0" and not fits:
+        pytest.skip("this shape only exists streamed")
+    monkeypatch.setenv("YMC_TILE_ASTREAM", stream)
+    rng = np.random.default_rng(500 + d + m)
+    g = dict(A=rng.normal(size=(m, d)) / np.sqrt(d), b=rng.normal(size=m), data=rng.normal(size=(nd, m)),
+             noise_precision=rng.uniform(0.5, 3, size=m), prior_mean=rng.normal(size=d) * 0.1,
+             prior_precision=rng.uniform(0.1, 2, size=d))
+    p = o.posterior_linear(g["A"], g["b"], g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+    x0 = rng.normal(size=(K, d)) * 0.3
+    if pcn:
+        from yagremcmc_amd import lowering
+        g["prior_mean"] = np.zeros(d)
+        p = o.posterior_linear(g["A"], g["b"], g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+        low = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, g, fwd_matrix=g["A"], fwd_shift=g["b"], likelihood_only=1)
+        sig = np.sqrt(np.reciprocal(g["prior_precision"]))
+        prob = lowering.make_problem(ctx, ffi.METHOD_PCN, low, sig, pcn_step_size=0.002)
+        run = ffi.Run(prob, 31, K, x0, 25, _flags(ffi, True), 400)
+        run.advance(12)
+        run.advance(13)
+        run.sync()
+        dev = dict(traj=run.trajectory(), acc=run.accept(), logpost=run.logpost(), summary=run.summary(), state=run.state())
+        p["likelihood_only"] = 1
+        e = o.Ensemble(p, sig, x0, 31, chain0=400, pcn_step_size=0.002)
+    else:
+        low = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, g, fwd_matrix=g["A"], fwd_shift=g["b"])
+        sig = rng.uniform(0.01, 0.04, size=d)
+        dev = _device_run(ffi, ctx, low, sig, x0, 31, 25, chain0=400, splits=2)
+        e = o.Ensemble(p, sig, x0, 31, chain0=400)
+    out = e.advance(25)
+    _same_as_oracle(dev, e, out)
+    assert 0 < dev["acc"].mean() < 1
+
+
 @pytest.mark.parametrize("d,m,nd,K", [(128, 128, 5, 100), (9, 3, 2, 33), (16, 16, 1, 64), (40, 70, 8, 50),
                                       (64, 200, 3, 17), (100, 20, 4, 129), (7, 30, 5, 40)])
 def test_tile_kernel_other_shapes(ffi, ctx, d, m, nd, K):
@@ -984,10 +1058,24 @@ def test_tile_kernel_dense_prior_limits(ffi, ctx):
         return _dense_low(ffi, ffi.POSTERIOR_LINEAR, d, g, None, B @ B.T + np.eye(d), fwd_matrix=rng.normal(size=(m, d)),
                           fwd_shift=np.zeros(m), likelihood_only=likelihood_only)
 
+    # two-level samplers keep their coarse matrix in LDS: (128 + 128) outputs x 128 do not fit
     with pytest.raises(ffi.YmcError, match="dense prior") as err:
-        lowering.make_problem(ctx, ffi.METHOD_MRW, low(128, 128), np.ones(128))
+        lowering.make_problem(ctx, ffi.METHOD_MLDA2, low(128, 128), np.ones(128), surrogate=low(128, 128), sub_chain_length=2)
     assert err.value.code == ffi.ERR_UNSUPPORTED
     lowering.make_problem(ctx, ffi.METHOD_MRW, low(96, 16), np.ones(96))        # (16 + 96) outputs x 96 fit
+    # the random walk streams its matrix: a dense prior at d = 128 (and beyond) == oracle
+    for d, m, K in ((128, 128, 40), (160, 30, 33)):
+        B = rng.normal(size=(d, d)) / np.sqrt(d)
+        pc = B @ B.T + np.eye(d)
+        g = dict(data=rng.normal(size=(2, m)), noise_precision=rng.uniform(0.5, 2, m), prior_mean=rng.normal(size=d) * 0.1,
+                 prior_precision=np.ones(d))
+        A, b = rng.normal(size=(m, d)) / np.sqrt(d), rng.normal(size=m)
+        lw = _dense_low(ffi, ffi.POSTERIOR_LINEAR, d, g, None, pc, fwd_matrix=A, fwd_shift=b)
+        po = o.dense_covariances(o.posterior_linear(A, b, g["data"], g["noise_precision"], g["prior_mean"], np.ones(d)), prior_cov=pc)
+        sig, x0 = np.full(d, 0.02), rng.normal(size=(K, d)) * 0.2
+        dev = _device_run(ffi, ctx, lw, sig, x0, 8, 20, splits=2)
+        e = o.Ensemble(po, sig, x0, 8)
+        _same_as_oracle(dev, e, e.advance(20))
     with pytest.raises(ffi.YmcError, match="diagonal prior"):
         lowering.make_problem(ctx, ffi.METHOD_PCN, low(16, 16, likelihood_only=1), np.ones(16), pcn_step_size=0.1)
     with pytest.raises(ffi.YmcError, match="adaptive error model"):
@@ -1246,11 +1334,22 @@ def test_tile_kernel_limits(ffi, ctx):
                                       g["prior_precision"]), np.full(16, 0.05), x0, 5)
     out = e.advance(30)
     assert np.array_equal(dev["traj"], out["traj"]) and np.array_equal(dev["logpost"], out["logpost"])
-    g = dict(data=rng.normal(size=(2, 4)), noise_precision=np.ones(4), prior_mean=np.zeros(200),
-             prior_precision=np.ones(200))
-    low = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, 200, g, fwd_matrix=rng.normal(size=(4, 200)), fwd_shift=np.zeros(4))
-    with pytest.raises(ffi.YmcError) as err:   # d > 128
-        lowering.make_problem(ctx, ffi.METHOD_MRW, low, np.ones(200))
+    # parameter dimensions: 256 for the single-level samplers (matrix streamed, one wave per SIMD), 128 for the others
+    def lin(d, m):
+        gg = dict(data=rng.normal(size=(2, m)), noise_precision=np.ones(m), prior_mean=np.zeros(d), prior_precision=np.ones(d))
+        return _posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, gg, fwd_matrix=rng.normal(size=(m, d)), fwd_shift=np.zeros(m))
+    lowering.make_problem(ctx, ffi.METHOD_MRW, lin(256, 4), np.ones(256))
+    with pytest.raises(ffi.YmcError, match="exceeds the matrix-core kernels' 256") as err:
+        lowering.make_problem(ctx, ffi.METHOD_MRW, lin(257, 4), np.ones(257))
+    assert err.value.code == ffi.ERR_UNSUPPORTED
+    with pytest.raises(ffi.YmcError, match="exceeds the matrix-core kernels' 128") as err:   # two-level: d <= 128
+        lowering.make_problem(ctx, ffi.METHOD_MLDA2, lin(200, 4), np.ones(200), surrogate=lin(200, 4), sub_chain_length=2)
+    assert err.value.code == ffi.ERR_UNSUPPORTED
+    with pytest.raises(ffi.YmcError, match="does not fit the 160 KB LDS") as err:             # nor a matrix beyond the LDS
+        lowering.make_problem(ctx, ffi.METHOD_MLDA2, lin(128, 400), np.ones(128), surrogate=lin(128, 400), sub_chain_length=2)
+    assert err.value.code == ffi.ERR_UNSUPPORTED
+    with pytest.raises(ffi.YmcError, match="too many outputs") as err:                        # constants alone beyond the LDS
+        lowering.make_problem(ctx, ffi.METHOD_MRW, lin(64, 8000), np.ones(64))
     assert err.value.code == ffi.ERR_UNSUPPORTED
 
 

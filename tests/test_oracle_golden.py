@@ -71,6 +71,20 @@ def test_f3_linear_d128(golden):
     assert hashlib.sha256(np.ascontiguousarray(full).tobytes()).hexdigest() == str(g["traj_sha256"])
 
 
+def test_f22_linear_d192_m160(golden):
+    """d = 192, m = 160: beyond what one wave's registers and the LDS held up to round 2 (the reference is
+    shape-agnostic, exampleSetup.py:42-52)."""
+    g = golden("f22_linear_d192_m160.npz")
+    n = int(g["n_states"])
+    p = o.posterior_linear(g["A"], g["b"], g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+    e = o.Ensemble(p, g["sigma"], g["x0"], int(g["seed"]))
+    out = e.advance(n - 1)
+    _check(out, g, n)
+    assert np.array_equal(out["traj"][:, :2, :], g["traj_head"][1:])
+    full = np.concatenate([g["x0"][None], out["traj"]])
+    assert hashlib.sha256(np.ascontiguousarray(full).tobytes()).hexdigest() == str(g["traj_sha256"])
+
+
 def test_f3b_linear_2x2_example(golden):
     g = golden("f3b_linear_2x2.npz")
     n = int(g["n_states"])

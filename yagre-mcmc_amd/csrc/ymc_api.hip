@@ -212,7 +212,11 @@ bool needs_tile(const ymc_density_desc &in)
 
 /* force_tile: lower a linear posterior for the matrix-core path even if it would fit the lane kernels (the
  * levels of a two-level sampler run in ONE kernel: both on the same path) */
-int lower_density(ymc_ctx *ctx, const ymc_density_desc &in, DensityHost &out, int expect_dim, bool force_tile = false)
+/* may_stream: the sampler can take its forward matrix from L2 through the workgroup's LDS double buffer
+ * (linear_tile_kernel<.., ASTREAM>: random walk with a diagonal proposal, pCN): any number of outputs whose
+ * constants fit the LDS, parameter dimensions up to 256 */
+int lower_density(ymc_ctx *ctx, const ymc_density_desc &in, DensityHost &out, int expect_dim, bool force_tile = false,
+                  bool may_stream = false)
 {
     (void)ctx;
     out.d = in;
@@ -263,17 +267,24 @@ int lower_density(ymc_ctx *ctx, const ymc_density_desc &in, DensityHost &out, in
         }
         if (in.kind == YMC_DENSITY_POSTERIOR_LINEAR) {
             if (big) {
-                /* the matrix-core tile kernel: A staged in LDS, d <= 128 */
-                if (d > 128) return fail(YMC_ERR_UNSUPPORTED, "parameter dimension %d exceeds the tile kernel's 128", d);
+                /* the matrix-core tile kernels: d <= 128 with A staged in LDS; the single-level samplers also stream
+                 * A from L2 (d <= 256, any m whose constants fit) */
+                const int d_max = may_stream ? 256 : 128;
+                if (d > d_max)
+                    return fail(YMC_ERR_UNSUPPORTED, "parameter dimension %d exceeds the matrix-core kernels' %d%s", d, d_max,
+                                may_stream ? "" : " for this sampler (the random walk with a diagonal proposal and pCN take 256)");
                 const int ks_need = (d + 3) / 4;
-                out.KS = ks_need <= 4 ? 4 : ks_need <= 8 ? 8 : ks_need <= 16 ? 16 : 32;
+                out.KS = ks_need <= 4 ? 4 : ks_need <= 8 ? 8 : ks_need <= 16 ? 16 : ks_need <= 32 ? 32 : 64;
                 /* a dense prior covariance adds d pseudo-observations to the forward map (below) */
                 const size_t m_all = m + (out.prior_linv.empty() ? 0 : (size_t)d);
                 out.MT = (int)((m_all + 15) / 16);
                 out.MT += out.MT & 1;
-                if (ymc_tile_lds_bytes(out.KS, out.MT) > kTileLdsLimit)
-                    return fail(YMC_ERR_UNSUPPORTED, "forward map %zu x %d%s does not fit the 160 KB LDS", m, d,
-                                out.prior_linv.empty() ? "" : " plus the dense prior's d x d factor");
+                const bool fits = out.KS <= 32 && ymc_tile_lds_bytes(out.KS, out.MT) <= kTileLdsLimit;
+                if (!fits && !(may_stream && ymc_tile_stream_lds_bytes(out.KS, out.MT) <= kTileLdsLimit))
+                    return fail(YMC_ERR_UNSUPPORTED, "forward map %zu x %d%s does not fit the 160 KB LDS%s", m, d,
+                                out.prior_linv.empty() ? "" : " plus the dense prior's d x d factor",
+                                may_stream ? " (nor do its constants alone: too many outputs)"
+                                           : "; only the random walk with a diagonal proposal and pCN stream it from L2");
                 out.tile = true;
             }
             YMC_TRY(copy_array(out.A, in.fwd_matrix, m * d, "fwd_matrix"));
@@ -977,7 +988,8 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
         for (int e = 0; e < desc->n_levels - 1; ++e)
             joint_tile = joint_tile || needs_tile(desc->level_target[e]) || needs_tile(desc->level_correction[e]);
     }
-    int rc = lower_density(ctx, desc->target, p->tgt, 0, joint_tile);
+    const bool may_stream = (desc->method == YMC_METHOD_MRW || desc->method == YMC_METHOD_PCN) && !desc->proposal_chol;
+    int rc = lower_density(ctx, desc->target, p->tgt, 0, joint_tile, may_stream);
     if (rc == YMC_OK) {
         p->D = desc->target.dim;
         p->kind = desc->target.kind;

@@ -63,28 +63,42 @@ struct RecordView {
     }
 };
 
-/* np.mean(seq, axis=1) (autocorrelation.py:126-129) in NumPy's own summation order for a contiguous
- * axis of length d <= 128 (pairwise_sum's unrolled block): fewer than 8 terms left to right; else
- * eight interleaved partial sums combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), the remainder added
- * one by one; then a division by d. */
+/* np.mean(seq, axis=1) (autocorrelation.py:126-129) in NumPy's own summation order for a contiguous axis
+ * (pairwise_sum): a block of fewer than 8 terms left to right; a block of up to 128 as eight interleaved partial
+ * sums combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), the remainder added one by one; a longer one split at
+ * n/2 rounded down to a multiple of 8, each half summed the same way (one split covers d <= 256, the matrix-core
+ * kernels' limit); then a division by d. */
+__device__ __forceinline__ double numpy_block_sum(const RecordView &v, uint64_t n, uint64_t k, int j0, int len)
+{
+    double res;
+    if (len < 8) {
+        res = v.at(n, k, j0);
+        for (int j = 1; j < len; ++j) res = res + v.at(n, k, j0 + j);
+    } else {
+        double r[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r[q] = v.at(n, k, j0 + q);
+        int i = 8;
+        for (; i < len - (len % 8); i += 8) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) r[q] = r[q] + v.at(n, k, j0 + i + q);
+        }
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < len; ++i) res = res + v.at(n, k, j0 + i);
+    }
+    return res;
+}
+
 __device__ __forceinline__ double numpy_row_mean(const RecordView &v, uint64_t n, uint64_t k)
 {
     const int d = v.d;
     double res;
-    if (d < 8) {
-        res = v.at(n, k, 0);
-        for (int j = 1; j < d; ++j) res = res + v.at(n, k, j);
+    if (d <= 128) {
+        res = numpy_block_sum(v, n, k, 0, d);
     } else {
-        double r[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) r[q] = v.at(n, k, q);
-        int i = 8;
-        for (; i < d - (d % 8); i += 8) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) r[q] = r[q] + v.at(n, k, i + q);
-        }
-        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-        for (; i < d; ++i) res = res + v.at(n, k, i);
+        int n2 = d / 2;
+        n2 -= n2 % 8;
+        res = numpy_block_sum(v, n, k, 0, n2) + numpy_block_sum(v, n, k, n2, d - n2);
     }
     return res / (double)d;
 }

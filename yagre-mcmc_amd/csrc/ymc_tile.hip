@@ -51,31 +51,42 @@ enum { kPropDiag = 0, kPropPcn = 1, kPropDense = 2, kPropDenseStaged = 3 };
 /* kPropDenseStaged: the dense proposal's factor L (read by every transition) through the workgroup's shared LDS
  * double buffer instead of every wave's own L2 reads, as the fine matrix of linear_tile_mlda2_kernel; waves past
  * the last tile then stay in the loop for the barriers and touch no memory. */
-template <int KS, int PROP>
-__global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArgs a)
+/* ASTREAM: the forward matrix does not fit the LDS beside its constants (m d > ~19 000 entries, or d > 128): it stays
+ * in global memory (L2-resident up to a few MB) and streams through the workgroup's shared double buffer like the
+ * upper matrices of the multi-level kernels -- any number of outputs whose constants fit the LDS (m <~ 5 000), and,
+ * with WAVES = 4 (one wave per SIMD: x and y are 256 registers at KS = 64), parameter dimensions up to 256. */
+template <int KS, int PROP, int WAVES = kTileWaves, bool ASTREAM = false>
+__global__ __launch_bounds__(64 * WAVES) void linear_tile_kernel(const TileArgs a)
 {
     constexpr bool PCN = PROP == kPropPcn, DENSE = PROP == kPropDense || PROP == kPropDenseStaged;
-    constexpr bool STAGED = PROP == kPropDenseStaged;
+    constexpr bool STAGED = PROP == kPropDenseStaged || ASTREAM;
+    constexpr int kThreads = 64 * WAVES;
+    static_assert(!(ASTREAM && DENSE), "one matrix stream per kernel");
     ymc_stage_tables();
     extern __shared__ double lds[];
     const int MT = a.MT, m_pad = 16 * MT, d_pad = 4 * KS;
-    double *Alds = lds;
-    double *bias = Alds + (size_t)MT * KS * 64;
+    const size_t frag_doubles = (size_t)MT * KS * 64, const_doubles = (size_t)m_pad * 3 + 3 * (size_t)d_pad;
+    const double *Alds = ASTREAM ? a.blob : lds;            /* ASTREAM: the fragments stay in global memory */
+    double *bias = lds + (ASTREAM ? 0 : frag_doubles);
     double *nprec = bias + m_pad;
     double *dbar = nprec + m_pad;
     double *pmean = dbar + m_pad;
     double *pprec = pmean + d_pad;
     double *sigma = pprec + d_pad;
-    const size_t blob_doubles = (size_t)MT * KS * 64 + (size_t)m_pad * 3 + 3 * (size_t)d_pad;
+    const size_t blob_doubles = (ASTREAM ? 0 : frag_doubles) + const_doubles;
 
     const int tid = threadIdx.x;
-    for (size_t i = tid; i < blob_doubles / 2; i += kTileThreads)
-        reinterpret_cast<double2 *>(lds)[i] = reinterpret_cast<const double2 *>(a.blob)[i];
+    if constexpr (ASTREAM) {
+        for (size_t i = tid; i < const_doubles; i += kThreads) bias[i] = a.blob[frag_doubles + i];
+    } else {
+        for (size_t i = tid; i < blob_doubles / 2; i += kThreads)
+            reinterpret_cast<double2 *>(lds)[i] = reinterpret_cast<const double2 *>(a.blob)[i];
+    }
     __syncthreads();
 
     const int lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
     const uint64_t nct = (a.K + 15) / 16;
-    const uint64_t tile = (uint64_t)blockIdx.x * kTileWaves + wave;
+    const uint64_t tile = (uint64_t)blockIdx.x * WAVES + wave;
     const bool wave_live = tile < nct;   /* STAGED: a wave past the last tile stays for the barriers and touches no memory */
     if (!STAGED && !wave_live) return;
     const uint64_t k = tile * 16 + c;
@@ -135,7 +146,7 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
              * two-level kernel). */
             double *wt = a.w_tiled + ((wave_live ? tile : 0) * KS) * 64 + lane;
             if constexpr (STAGED) {
-                ymc_stream_tile_pairs<KS, 4, kTileThreads>(a.chol_frag, a.MT_L / 2, stage, tid, lane, y,
+                ymc_stream_tile_pairs<KS, 4, kThreads>(a.chol_frag, a.MT_L / 2, stage, tid, lane, y,
                                                            [&](int pair, const d4 &acc0, const d4 &acc1) {
                     if (wave_live) {
 #pragma unroll
@@ -179,7 +190,16 @@ __global__ __launch_bounds__(kTileThreads) void linear_tile_kernel(const TileArg
         /* forward map on the matrix cores + Gaussian-noise likelihood (likelihood.py:74-84) through
          * the row-mean identity: |F - Dbar|^2_{n P} + const (ymc_linear_data_summary) */
         YMC_PHASE_MAP();
-        const double logl = -0.5 * (combine4(ymc_tile_residual_sum<KS>(Alds, MT, bias, nprec, dbar, lane, g, y)) + a.lik_const);
+        double Sres;
+        if constexpr (ASTREAM) {
+            Sres = 0.0;
+            ymc_stream_tile_pairs<KS, 4, kThreads>(Alds, MT / 2, stage, tid, lane, y, [&](int pair, const d4 &acc0, const d4 &acc1) {
+                ymc_tile_add_residuals(2 * pair, acc0, acc1, bias, nprec, dbar, g, Sres);
+            });
+        } else {
+            Sres = ymc_tile_residual_sum<KS>(Alds, MT, bias, nprec, dbar, lane, g, y);
+        }
+        const double logl = -0.5 * (combine4(Sres) + a.lik_const);
 
         /* Gaussian prior (gaussian.py:19-24); the target of pCN is the likelihood alone (pcn.py:51-57) */
         double lpy = logl;
@@ -569,16 +589,23 @@ size_t ymc_tile_lds_bytes(int KS, int MT)
     return ((size_t)MT * KS * 64 + m_pad * 3 + 3 * d_pad) * sizeof(double);  /* + 2 KB static (log table) */
 }
 
-template <int KS, int PROP>
+size_t ymc_tile_stream_lds_bytes(int KS, int MT)
+{
+    const size_t m_pad = 16 * (size_t)MT, d_pad = 4 * (size_t)KS;
+    const size_t unit = (size_t)2 * (KS / 4) * 64;     /* ymc_stream_unit<KS, 4>() */
+    return (m_pad * 3 + 3 * d_pad + 2 * unit) * sizeof(double);
+}
+
+template <int KS, int PROP, int WAVES = kTileWaves, bool ASTREAM = false>
 static hipError_t launch_tile_as(const TileArgs &a, hipStream_t s, size_t extra_lds = 0)
 {
-    const size_t lds = ymc_tile_lds_bytes(KS, a.MT) + extra_lds;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_tile_kernel<KS, PROP>),
+    const size_t lds = ASTREAM ? ymc_tile_stream_lds_bytes(KS, a.MT) : ymc_tile_lds_bytes(KS, a.MT) + extra_lds;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_tile_kernel<KS, PROP, WAVES, ASTREAM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const uint64_t nct = (a.K + 15) / 16;
-    const unsigned grid = (unsigned)((nct + kTileWaves - 1) / kTileWaves);
-    hipLaunchKernelGGL((linear_tile_kernel<KS, PROP>), dim3(grid), dim3(kTileThreads), lds, s, a);
+    const unsigned grid = (unsigned)((nct + WAVES - 1) / WAVES);
+    hipLaunchKernelGGL((linear_tile_kernel<KS, PROP, WAVES, ASTREAM>), dim3(grid), dim3(64 * WAVES), lds, s, a);
     return hipGetLastError();
 }
 
@@ -651,16 +678,28 @@ hipError_t ymc_launch_linear_tile_mlda2(int KS, const TileArgs &a, hipStream_t s
 template <int KS>
 static hipError_t launch_tile(const TileArgs &a, hipStream_t s)
 {
-    if (a.chol_frag) {
-        if (a.pcn) return hipErrorInvalidValue;
-        /* L through the shared double buffer when the LDS has room beside the forward map (identical results;
-         * YMC_TILE_STAGE=0 switches it off, the tests run both) */
-        const size_t extra = 2 * (size_t)ymc_stream_unit<KS, 4>() * sizeof(double);
-        bool stage = ymc_tile_lds_bytes(KS, a.MT) + extra <= kTileLdsLimit;
-        if (const char *env = std::getenv("YMC_TILE_STAGE")) stage = stage && env[0] != '0';
-        return stage ? launch_tile_as<KS, kPropDenseStaged>(a, s, extra) : launch_tile_as<KS, kPropDense>(a, s);
+    /* the forward matrix streamed from L2 where it does not fit the LDS (YMC_TILE_ASTREAM=1 forces it: the tests
+     * compare both forms); one wave per SIMD at KS = 64 */
+    bool astream = KS >= 64 || ymc_tile_lds_bytes(KS, a.MT) > kTileLdsLimit;
+    if (const char *env = std::getenv("YMC_TILE_ASTREAM")) astream = astream || env[0] == '1';
+    if (astream) {
+        if (a.chol_frag) return hipErrorInvalidValue;
+        constexpr int W = KS >= 64 ? 4 : kTileWaves;
+        return a.pcn ? launch_tile_as<KS, kPropPcn, W, true>(a, s) : launch_tile_as<KS, kPropDiag, W, true>(a, s);
     }
-    return a.pcn ? launch_tile_as<KS, kPropPcn>(a, s) : launch_tile_as<KS, kPropDiag>(a, s);
+    if constexpr (KS < 64) {
+        if (a.chol_frag) {
+            if (a.pcn) return hipErrorInvalidValue;
+            /* L through the shared double buffer when the LDS has room beside the forward map (identical results;
+             * YMC_TILE_STAGE=0 switches it off, the tests run both) */
+            const size_t extra = 2 * (size_t)ymc_stream_unit<KS, 4>() * sizeof(double);
+            bool stage = ymc_tile_lds_bytes(KS, a.MT) + extra <= kTileLdsLimit;
+            if (const char *env = std::getenv("YMC_TILE_STAGE")) stage = stage && env[0] != '0';
+            return stage ? launch_tile_as<KS, kPropDenseStaged>(a, s, extra) : launch_tile_as<KS, kPropDense>(a, s);
+        }
+        return a.pcn ? launch_tile_as<KS, kPropPcn>(a, s) : launch_tile_as<KS, kPropDiag>(a, s);
+    }
+    return hipErrorInvalidValue;
 }
 
 hipError_t ymc_launch_linear_tile(int KS, const TileArgs &a, hipStream_t s)
@@ -670,6 +709,7 @@ hipError_t ymc_launch_linear_tile(int KS, const TileArgs &a, hipStream_t s)
     case 8: return launch_tile<8>(a, s);
     case 16: return launch_tile<16>(a, s);
     case 32: return launch_tile<32>(a, s);
+    case 64: return launch_tile<64>(a, s);
     default: return hipErrorInvalidValue;
     }
 }
