@@ -196,18 +196,27 @@ YMC_FN double ymc_u53_to_unit(uint64_t m)
     return ymc_fma(hi, 0x1p-21, lo * 0x1p-53);
 }
 
+/* The 53-bit mantissa m = (hi:lo) >> 11 of two words, as m 2^-53, WITHOUT forming m: m = hi 2^21 + (lo >> 11), so
+ * m 2^-53 = hi 2^-32 + (lo >> 11) 2^-53 -- two exact conversions, an exact product and a sum of at most 53
+ * significant bits: the same double as ymc_u53_to_unit(m) with a 32-bit shift in place of the 64-bit one
+ * (`add` = 1 gives (m + 1) 2^-53: lo >> 11 is at most 2^21 - 1, so the increment stays in its word). */
+YMC_FN double ymc_words_to_unit(uint32_t lo, uint32_t hi, uint32_t add)
+{
+    double h = (double)hi;
+    double l = (double)((lo >> 11) + add);
+    return ymc_fma(h, 0x1p-32, l * 0x1p-53);
+}
+
 /* 53-bit mantissa from two words -> [0,1) on the 2^-53 grid */
 YMC_FN double ymc_u01_co(uint32_t lo, uint32_t hi)
 {
-    uint64_t m = (((uint64_t)hi << 32) | lo) >> 11;
-    return ymc_u53_to_unit(m);
+    return ymc_words_to_unit(lo, hi, 0u);
 }
 
 /* 53-bit mantissa from two words -> (0,1] on the 2^-53 grid */
 YMC_FN double ymc_u01_oc(uint32_t lo, uint32_t hi)
 {
-    uint64_t m = ((((uint64_t)hi << 32) | lo) >> 11) + 1u;
-    return ymc_u53_to_unit(m);
+    return ymc_words_to_unit(lo, hi, 1u);
 }
 
 YMC_FN ymc_u32x4 ymc_uniform_block(uint64_t seed, uint32_t chain, uint64_t t)
@@ -283,11 +292,14 @@ YMC_FN double ymc_log(double x)
 {
     const double Ln2hi = 0x1.62e42fefa3800p-1; /* 42 bits: k * Ln2hi is exact */
     const double Ln2lo = 0x1.ef35793c76730p-45;
+    /* everything the reduction needs sits in the HIGH word (YMC_LOG_OFF's low word is zero): the interval index, the
+     * exponent k and the exponent bits to clear -- 32-bit operations, the low word of x passes through */
     uint64_t ix = ymc_bits(x);
-    uint64_t tmp = ix - YMC_LOG_OFF;
-    int32_t i = (int32_t)((tmp >> 45) & 127u);
-    int32_t k = (int32_t)((int64_t)tmp >> 52);
-    double z = ymc_from_bits(ix - (tmp & 0xfff0000000000000ull));
+    uint32_t hx = (uint32_t)(ix >> 32);
+    uint32_t ht = hx - (uint32_t)(YMC_LOG_OFF >> 32);
+    int32_t i = (int32_t)((ht >> 13) & 127u);
+    int32_t k = (int32_t)ht >> 20;
+    double z = ymc_from_bits(((uint64_t)(hx - (ht & 0xfff00000u)) << 32) | (uint32_t)ix);
     double invc = YMC_LOGTAB[2 * i], logc = YMC_LOGTAB[2 * i + 1];
     double r = ymc_fma(z, invc, -1.0);
     double kd = (double)k;
