@@ -74,12 +74,32 @@ __global__ __launch_bounds__(kBlock) YMC_MLDA2_ATTR void mlda2_static_kernel(con
         ymc_load_row<D>(a.wf_m2, k, wm2);
     }
 
+    /* The two Gaussians' parameters (14 doubles at d = 2) in VGPR pairs: as kernel arguments they sit in SGPRs, and
+     * with the draws' constants beside them the unit needs more than the 104 a wave has -- the compiler then parks
+     * scalars in VGPR lanes and pays a v_readlane / v_writelane per use inside the unit (95 of its 2 400 vector
+     * instructions).  The kernel has the vector registers to spare (two waves per SIMD). */
+    DensityDev<D> sur = a.sur, tgt = a.tgt;
+    if constexpr (KIND == YMC_DENSITY_GAUSS_WHITENED) {
+        auto pin = [](double &v) { asm volatile("" : "+v"(v)); };
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            pin(sur.mean[j]);
+            pin(tgt.mean[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < D * D; ++j) {
+            pin(sur.whiten[j]);
+            pin(tgt.whiten[j]);
+        }
+        pin(sur.log_norm);
+        pin(tgt.log_norm);
+    }
     /* surrogate.run(S + 1, state), one sub-step: a random-walk transition on the coarse density */
     auto coarse = [&](uint64_t t, double u, double (&z)[D], double &lpcz) {
         double y[D];
         ymc_propose<D>(z, sigma, a.seed, chain, t, y);
         const bool moved = !ymc_states_equal<D>(y, z, YMC_EQ_EXACT);
-        const double lpcy = Density<KIND, D>::eval(a.sur, y, st);
+        const double lpcy = Density<KIND, D>::eval(sur, y, st);
         const bool acc = ymc_accept(lpcy - lpcz, moved, ymc_finite(lpcy), u, st);
 #pragma unroll
         for (int j = 0; j < D; ++j) z[j] = acc ? y[j] : z[j];
@@ -88,7 +108,7 @@ __global__ __launch_bounds__(kBlock) YMC_MLDA2_ATTR void mlda2_static_kernel(con
     /* fine accept / reject (mlda.py:146-154), diagnostics and record of fine step n */
     auto fine = [&](uint32_t n, double u, const double (&z)[D], double lpcz) {
         const bool moved = !ymc_states_equal<D>(z, x, YMC_EQ_EXACT);
-        const double lpfy = Density<KIND, D>::eval(a.tgt, z, st);
+        const double lpfy = Density<KIND, D>::eval(tgt, z, st);
         const double log_ratio = ((lpfy + lpc) - lpcz) - lpf;
         const bool acc = ymc_accept(log_ratio, moved, ymc_finite(lpfy) && ymc_finite(lpcz), u, st);
         if (moments) ymc_welford<D>(x, (double)(a.wf_n0 + n + 1), ymc_recip_at(a.recip, n), wmean, wm2);
