@@ -161,6 +161,8 @@ typedef struct ymc_problem_desc {
 
 /* per-chain status bits */
 #define YMC_CHAIN_NONFINITE 1u    /* a proposal's log-density was not finite; it was rejected */
+#define YMC_CHAIN_HANDOFF 2u      /* internal error: a launch cut into hand-over pieces (Lotka-Volterra, small ensembles)
+                                     never received this chain's state from the preceding piece; the chain stopped there */
 
 /* MetropolisHastings.run(chainLength, initialState) for n_chains chains
  * (metropolisHastings.py:103-110): chain k of this run is GLOBAL chain

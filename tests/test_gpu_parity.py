@@ -1636,6 +1636,47 @@ def test_random_walk_with_helper_waves_for_the_draws(ffi, ctx, golden, monkeypat
         assert np.array_equal(run.summary()["wf_mean"], g["wf_mean"])
 
 
+@pytest.mark.parametrize("pieces,K,steps", [(12, 60, (300,)), (3, 11, (100, 200, 50)), (23, 131, (140,)), (16, 96, (60, 240)),
+                                           (0, 131, (140,))])
+def test_lotka_volterra_launch_in_handover_pieces(ffi, ctx, monkeypatch, pieces, K, steps):
+    """mrw_lv_rows_balanced_kernel: the launch cut into equal pieces of the ribbon of all chain waves' transitions, every
+    wave running the head of one chain wave and then the tail of its predecessor's (state handed over through the run's
+    arrays behind a flag).  Forced here with piece counts that cut chain waves at various places (the product chooses a
+    whole number of waves per SIMD): == oracle bit for bit -- chains, decisions, log-posteriors, moments, counters, the
+    flagged stiff chains --, no chain flagged with YMC_CHAIN_HANDOFF, across launches, with and without a thinned record."""
+    monkeypatch.setenv("YMC_LV_ROWS", "1")
+    monkeypatch.setenv("YMC_LV_PIECES", str(pieces))
+    from yagremcmc_amd import lowering
+    rng = np.random.default_rng(80 + pieces)
+    design = rng.uniform(0.5, 1.5, size=(10, 2))
+    base = dict(noise_precision=np.array([25.0, 20.0]), prior_mean=np.array([0.1, -0.2]), prior_precision=np.array([0.7, 0.9]))
+    data = rng.uniform(0.2, 2.0, size=(10, 2))
+    p = o.posterior_lv(design, 10.0, 0.8, 0.4, 50, data, **base)
+    low = _posterior_low(ffi, ffi.POSTERIOR_LV, 2, dict(base, data=data), design=design, t_final=10.0, alpha=0.8,
+                         gamma=0.4, rk4_steps=50)
+    x0 = np.tile([[-0.6, -0.3]], (K, 1)) + 0.05 * rng.normal(size=(K, 2))
+    x0[-3:] = [-7.0, 2.8]                                   # stiff starts: flagged non-finite, never accepted
+    sigma = np.array([0.4, 0.3])
+    prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, sigma)
+    total = sum(steps)
+    run = ffi.Run(prob, 17, K, x0, total, _flags(ffi, True), 4000)
+    for n in steps:
+        run.advance(n)
+    run.sync()
+    dev = dict(traj=run.trajectory(), acc=run.accept(), logpost=run.logpost(), summary=run.summary(), state=run.state())
+    e = o.Ensemble(p, sigma, x0, 17, chain0=4000)
+    out = e.advance(total)
+    _same_as_oracle(dev, e, out)
+    assert not (dev["summary"]["status"] & ffi.CHAIN_HANDOFF).any()
+    assert (dev["summary"]["status"][-3:] & ffi.CHAIN_NONFINITE).all()
+    # thinned record: rows s-1::s of the full one, moments over every transition
+    thin = ffi.Run(prob, 17, K, x0, total // 4 + 1, ffi.RECORD_TRAJECTORY | ffi.RECORD_MOMENTS, 4000, record_stride=4)
+    for n in steps:
+        thin.advance(n)
+    assert np.array_equal(thin.trajectory(), dev["traj"][3::4])
+    assert np.array_equal(thin.summary()["wf_mean"], e.wf_mean) and np.array_equal(thin.summary()["accepted"], e.acc_count)
+
+
 @pytest.mark.parametrize("rows", ["0", "1"])
 def test_lotka_volterra_row_parallel_variant(ffi, ctx, golden, monkeypatch, rows):
     """One lane per chain vs one lane per (chain, design row): a speed choice, same bits."""

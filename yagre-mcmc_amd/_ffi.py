@@ -27,6 +27,7 @@ EQ_EXACT, EQ_ISCLOSE = 0, 1
 # record flags
 RECORD_TRAJECTORY, RECORD_ACCEPT, RECORD_LOGPOST, RECORD_SUB_ACCEPT, RECORD_MOMENTS = 1, 2, 4, 8, 16
 CHAIN_NONFINITE = 1
+CHAIN_HANDOFF = 2
 IAT_UNDEFINED = -2147483648
 UNIQUE_ID_BYTES = 128
 

@@ -172,6 +172,7 @@ struct ymc_run {
     uint32_t stride = 1; /* record_stride: rows hold the states after transitions stride, 2 stride, ... of the run */
     DeviceBuf x, lp, lpc, acc_count, wf_mean, wf_m2, status, traj, acc, lp_out, sub_acc, summary, x_before, recip;
     DeviceBuf level_acc; /* MLDA_NESTED: [E-1][K] */
+    DeviceBuf handoff;   /* Lotka-Volterra rows kernel in hand-over pieces: transitions published per chain wave */
     DeviceBuf x_tiled;   /* two-level tile kernel: the carried state in the record's tiled layout */
     DeviceBuf w_tiled;   /* dense proposal on the tile kernel: L xi in the record's tiled layout */
     DeviceBuf err_n, err_mean, err_m2, aem_prec, aem_flags, cache_key, cache_val; /* AEM2 */
@@ -505,6 +506,30 @@ int launch_advance(ymc_run *r, uint64_t nsteps)
     a.eq_mode = p->eq_mode;
     a.S = p->S;
     a.lv_rows = choose_lv_rows(r);
+    if constexpr (D == 2) {
+        if (a.lv_rows && p->eq_mode == YMC_EQ_EXACT && !p->tgt.d.likelihood_only && !p->chol.p) {
+            /* a number of chain waves that is not a multiple of the SIMD count leaves CUs idle for the tail of the
+             * launch: cut it into a whole number of equal pieces per SIMD (mrw_lv_rows_balanced_kernel).  Pieces
+             * start on draw rounds; identical results; YMC_LV_PIECES=n forces n pieces (0: never), the tests do */
+            const int nd = p->tgt.d.n_data, cpw = 64 / nd;
+            const uint64_t G = (r->K + cpw - 1) / cpw, simds = 4ull * (uint64_t)r->ctx->prop.multiProcessorCount;
+            uint64_t pieces = 0;
+            if (G > simds && G % simds != 0) pieces = ((G + simds - 1) / simds) * simds;
+            if (const char *env = std::getenv("YMC_LV_PIECES")) pieces = (uint64_t)std::strtoull(env, nullptr, 10);
+            if (pieces > 0 && nsteps % (uint64_t)nd == 0) {
+                uint64_t len = (G * nsteps + pieces - 1) / pieces;
+                len = ((len + nd - 1) / nd) * nd;
+                /* a piece spans at most two chain waves and waits for at most one predecessor's head */
+                if (len <= nsteps && 2 * len >= nsteps && pieces < (1ull << 31)) {
+                    if (r->handoff.bytes < G * sizeof(uint32_t)) YMC_TRY(r->handoff.alloc(G * sizeof(uint32_t)));
+                    YMC_HIP(hipMemsetAsync(r->handoff.p, 0, G * sizeof(uint32_t), r->ctx->stream));
+                    a.lv_pieces = (int32_t)pieces;
+                    a.lv_piece_len = (uint32_t)len;
+                    a.handoff = r->handoff.as<uint32_t>();
+                }
+            }
+        }
+    }
     a.rec_stride = r->stride;
     a.rec_since = (uint32_t)(r->steps_done % r->stride);
     a.split = choose_split(r);

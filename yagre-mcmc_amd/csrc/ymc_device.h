@@ -356,6 +356,13 @@ struct RecordClock {
         return false;
     }
     __device__ __forceinline__ void wrote() { ++row; }
+    /* start n transitions into the launch (a segment of it): the state after n calls of due() / wrote() */
+    __device__ __forceinline__ void skip(uint32_t n)
+    {
+        const uint32_t total = since + n;
+        row += total / stride;
+        since = total % stride;
+    }
 };
 
 template <int D>

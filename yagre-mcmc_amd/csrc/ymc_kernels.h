@@ -18,6 +18,11 @@ struct ChainArgs {
     uint32_t nsteps, flags;
     int32_t eq_mode, S;
     int32_t lv_rows;     /* Lotka-Volterra: spread a chain over n_data lanes (a speed choice, same results) */
+    /* ... and cut the launch into lv_pieces equal pieces of lv_piece_len transitions handed from wave to wave
+     * (mrw_lv_rows_balanced_kernel; 0 = one wave per chain wave); handoff[chain wave] = transitions published */
+    int32_t lv_pieces;
+    uint32_t lv_piece_len;
+    uint32_t *handoff;
     int32_t split;       /* random walk, at most one wave of chains per SIMD: draws made by helper waves (same results) */
     uint32_t rec_stride, rec_since; /* thinned record (RecordClock): stride, transitions since the last recorded one */
     /* carried per-chain state */

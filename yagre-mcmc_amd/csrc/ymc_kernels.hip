@@ -433,10 +433,12 @@ __global__ __launch_bounds__(kBlock) void mlda2_kernel(const ChainArgs<D> a)
  * rest (prior, exp, accept, moments).  64 / G chains per wave.  Same bits as
  * mrw_kernel.
  */
+/* transitions [n_begin, n_end) of this launch for the cpw chains of chain wave `cwave` (state loaded from and
+ * stored to the run's arrays, so a chain wave's launch can be cut into segments run by different waves) */
 template <unsigned REC>
-__global__ __launch_bounds__(kBlock) void mrw_lv_rows_kernel(const ChainArgs<2> a)
+__device__ __forceinline__ void lv_rows_segment(const ChainArgs<2> &a, uint64_t cwave, uint32_t n_begin, uint32_t n_end,
+                                                double (*slots)[3])
 {
-    ymc_stage_tables();
     constexpr int D = 2;
     using R = Rec<REC>;
     const DensityDev<2> &p = a.tgt;
@@ -444,8 +446,7 @@ __global__ __launch_bounds__(kBlock) void mrw_lv_rows_kernel(const ChainArgs<2> 
     const int cpw = 64 / G;                                  /* chains per wave */
     const int lane = threadIdx.x & 63;
     const int slot = lane / G, row = lane - slot * G;
-    const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const uint64_t k = wave * cpw + slot;
+    const uint64_t k = cwave * cpw + slot;
     const bool live = slot < cpw && k < a.K;
     const uint64_t kk = live ? k : 0;                        /* idle lanes shadow chain 0 and never store */
     const uint32_t chain = (uint32_t)(a.chain0 + kk);
@@ -468,12 +469,11 @@ __global__ __launch_bounds__(kBlock) void mrw_lv_rows_kernel(const ChainArgs<2> 
     const double dx0 = p.design[2 * myrow], dy0 = p.design[2 * myrow + 1];
     const double obs0 = p.data[2 * myrow], obs1 = p.data[2 * myrow + 1];
     RecordClock clk(a.rec_stride, a.rec_since);
-    __shared__ double draw_slots[kBlock / 64][64][3]; /* per wave and lane: sigma_0 z_0, sigma_1 z_1, u */
-    double (*slots)[3] = draw_slots[threadIdx.x >> 6];
-    int in_round = 0;                                   /* transition index within the round of G */
+    clk.skip(n_begin);
+    int in_round = 0;                                   /* transition index within the round of G (segments start on rounds) */
 
 #pragma unroll 1
-    for (uint32_t n = 0; n < a.nsteps; ++n) {
+    for (uint32_t n = n_begin; n < n_end; ++n) {
         if (in_round == 0) { /* wave-uniform: lane r of every group makes the draws of transition n + r */
             const uint64_t tr = a.t0 + n + (uint64_t)row;
             double z0, z1;
@@ -546,6 +546,83 @@ __global__ __launch_bounds__(kBlock) void mrw_lv_rows_kernel(const ChainArgs<2> 
         if (moments) {
             ymc_store_row<D>(a.wf_mean, k, wmean);
             ymc_store_row<D>(a.wf_m2, k, wm2);
+        }
+    }
+}
+
+template <unsigned REC>
+__global__ __launch_bounds__(kBlock) void mrw_lv_rows_kernel(const ChainArgs<2> a)
+{
+    ymc_stage_tables();
+    __shared__ double draw_slots[kBlock / 64][64][3]; /* per wave and lane: sigma_0 z_0, sigma_1 z_1, u */
+    const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    lv_rows_segment<REC>(a, wave, 0u, a.nsteps, draw_slots[threadIdx.x >> 6]);
+}
+
+/*
+ * The same work cut to fit the chip.  BASELINE configs[3] gives a GPU 16 384 chains = 2 731 chain waves for 1 024
+ * SIMDs: a third of the CUs carry two workgroups instead of three and idle for the last third of the launch, whatever
+ * a wave's lane count (profiles/r03_c4_shape.txt).  Here the launch has a whole number of waves per SIMD (P = pieces)
+ * and every wave takes an equal piece of the RIBBON of all chain waves' transitions laid end to end: the tail
+ * [t0, T) of chain wave g and the head [0, h) of chain wave g + 1.  A wave runs its HEAD first -- it depends on nothing
+ * -- and publishes (g + 1, h) in `handoff`; then it waits for its predecessor's publication of (g, t0), which that wave
+ * made after ITS head, and runs the tail from the state the predecessor left in the run's arrays.  Pieces start on
+ * draw rounds (multiples of n_data), so a chain's draws and arithmetic are those of mrw_lv_rows_kernel: same bits.
+ * Waiting waves sleep; the SIMD's other waves use the slots, so a SIMD is busy for the sum of its pieces.  A wave that
+ * waits beyond any plausible launch length flags its chains (YMC_CHAIN_HANDOFF) and leaves: the grid always drains.
+ */
+template <unsigned REC>
+__global__ __launch_bounds__(kBlock) void mrw_lv_rows_balanced_kernel(const ChainArgs<2> a)
+{
+    ymc_stage_tables();
+    __shared__ double draw_slots[kBlock / 64][64][3];
+    double (*slots)[3] = draw_slots[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    const uint64_t piece = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const uint64_t T = a.nsteps, L = a.lv_piece_len;
+    const int cpw = 64 / a.tgt.n_data;
+    const uint64_t G = (a.K + cpw - 1) / cpw, end = G * T;
+    const uint64_t r0 = piece * L, r1 = (r0 + L < end) ? r0 + L : end;
+    if (piece >= (uint64_t)a.lv_pieces || r0 >= r1) return;
+    const uint64_t g0 = r0 / T;
+    const uint32_t t0 = (uint32_t)(r0 - g0 * T);
+    const uint32_t tail_end = (uint32_t)((r1 - r0) < (T - t0) ? t0 + (r1 - r0) : T);
+    const uint32_t head_len = (uint32_t)((r1 - r0) - (tail_end - t0));
+
+    /* phase 0: the head of chain wave g0 + 1 (no dependency); phase 1: the tail of g0, after its predecessor's head.
+     * One call site of the segment (a loop, not two inlined copies: half the code, fewer live scalars) */
+#pragma unroll 1
+    for (int phase = 0; phase < 2; ++phase) {
+        const uint64_t g = phase == 0 ? g0 + 1 : g0;
+        const uint32_t nb = phase == 0 ? 0u : t0, ne = phase == 0 ? head_len : tail_end;
+        if (nb >= ne) continue;
+        if (nb > 0) {
+            int ok = 1;
+            if (lane == 0) {
+                uint32_t spins = 0;
+                /* relaxed polls (an agent-scope load goes to L2; an ACQUIRE here would invalidate the CU's caches under
+                 * its working waves at every poll), one acquire fence after the loop */
+                while (__hip_atomic_load(a.handoff + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != nb) {
+                    __builtin_amdgcn_s_sleep(127);
+                    if (++spins > (1u << 22)) {           /* tens of seconds: something is wrong, do not hang the device */
+                        ok = 0;
+                        break;
+                    }
+                }
+            }
+            ok = __shfl(ok, 0, 64);
+            __threadfence();                              /* nothing of the predecessor's state from a stale cache line */
+            if (!ok) {
+                const int nd = a.tgt.n_data, slot = lane / nd, row = lane - slot * nd;
+                const uint64_t k = g * cpw + slot;
+                if (slot < cpw && k < a.K && row == 0) a.status[k] |= YMC_CHAIN_HANDOFF;
+                return;
+            }
+        }
+        lv_rows_segment<REC>(a, g, nb, ne, slots);
+        if (ne < T) {
+            __threadfence();                              /* the segment's state stores before the flag */
+            if (lane == 0) __hip_atomic_store(a.handoff + g, ne, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -776,8 +853,12 @@ hipError_t ymc_launch_chain(int kind, int method, const ChainArgs<D> &a, hipStre
                 /* small ensemble: n_data lanes per chain */
                 const int cpw = 64 / a.tgt.n_data;
                 const uint64_t waves = (a.K + cpw - 1) / cpw;
-                hipLaunchKernelGGL((mrw_lv_rows_kernel<kRuntimeRec>), dim3((unsigned)((waves * 64 + kBlock - 1) / kBlock)),
-                                   dim3(kBlock), 0, s, a);
+                if (a.lv_pieces > 0) /* a whole number of waves per SIMD, equal pieces of the ribbon (see the kernel) */
+                    hipLaunchKernelGGL((mrw_lv_rows_balanced_kernel<kRuntimeRec>),
+                                       dim3((unsigned)(((uint64_t)a.lv_pieces * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, a);
+                else
+                    hipLaunchKernelGGL((mrw_lv_rows_kernel<kRuntimeRec>), dim3((unsigned)((waves * 64 + kBlock - 1) / kBlock)),
+                                       dim3(kBlock), 0, s, a);
                 return hipGetLastError();
             }
             return launch_chain<YMC_DENSITY_POSTERIOR_LV, 2>(method, a, s);
