@@ -195,6 +195,15 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
             d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
             const double *A0 = Ac + (size_t)mt * KS * 64 + lane;
             const double *A1 = A0 + (size_t)KS * 64;
+            /* this pair's entries of the chain's error model, requested BEFORE its 64 MFMAs: they come from HBM (134 MB
+             * of them at 65 536 chains) and with one wave per SIMD nothing else hides that latency -- read in the
+             * epilogue they made an evaluation six times as long as its matrix product (profiles/r03_c3a_*) */
+            double em_v[8], ep_v[8];
+#pragma unroll
+            for (int hq = 0; hq < 8; ++hq) {
+                em_v[hq] = em[(4 * mt + hq) * 64];
+                ep_v[hq] = has_prec ? ep[(4 * mt + hq) * 64] : 0.0;
+            }
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[s * 64], v[s], acc0, 0, 0, 0);
@@ -204,10 +213,10 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
             for (int h = 0; h < 2; ++h) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = 16 * (mt + h) + 4 * r + g, q = 4 * (mt + h) + r;
+                    const int m = 16 * (mt + h) + 4 * r + g;
                     const double F = (h ? acc1[r] : acc0[r]) + bias_c[m];
-                    const double mean = em[q * 64];
-                    const double pe = has_prec ? ep[q * 64] : nprec_c[m];
+                    const double mean = em_v[4 * h + r];
+                    const double pe = has_prec ? ep_v[4 * h + r] : nprec_c[m];
 #pragma unroll
                     for (int i = 0; i < kAemRows; ++i) {
                         if (i < n_data) {
@@ -280,6 +289,12 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
         fine_pairs(v, [&](int mt, const d4 &f0, const d4 &f1) {
             d4 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0};
             const double *C0 = Ac + (size_t)mt * KS * 64 + lane, *C1 = C0 + (size_t)KS * 64;
+            double em_v[8], e2_v[8];        /* requested before the coarse MFMAs, as in now() */
+#pragma unroll
+            for (int hq = 0; hq < 8; ++hq) {
+                em_v[hq] = em[(4 * mt + hq) * 64];
+                e2_v[hq] = e2[(4 * mt + hq) * 64];
+            }
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(C0[s * 64], v[s], c0, 0, 0, 0);
@@ -293,7 +308,7 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
                     const double Ff = (h ? f1[r] : f0[r]) + bias_f[m];
                     const double Fc = (h ? c1[r] : c0[r]) + bias_c[m];
                     const double e = Ff - Fc;
-                    double mean = em[q * 64], m2 = e2[q * 64];
+                    double mean = em_v[4 * h + r], m2 = e2_v[4 * h + r];
                     const double delta = e - mean; /* estimation.py:36-53 */
                     mean = mean + delta / dn;
                     const double delta2 = e - mean;
