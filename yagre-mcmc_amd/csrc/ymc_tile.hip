@@ -208,8 +208,10 @@ __global__ __launch_bounds__(64 * WAVES) void linear_tile_kernel(const TileArgs 
         /* accept / reject (metropolisHastings.py:55-73, mrw.py:51-57) */
         const double u = ymc_uniform_cached(uc, a.seed, chain, t);
         const bool acc = ymc_accept(lpy - lp, moved, ymc_finite(lpy), u, st);
+        if (acc) { /* under the accepting lanes' EXEC mask: KS 64-bit moves instead of 2 KS selects */
 #pragma unroll
-        for (int s = 0; s < KS; ++s) x[s] = acc ? y[s] : x[s];
+            for (int s = 0; s < KS; ++s) x[s] = y[s];
+        }
         lp = acc ? lpy : lp;
         accepted += acc ? 1u : 0u;
 
@@ -404,8 +406,10 @@ __global__ __launch_bounds__(64 * WAVES) void linear_tile_mlda2_kernel(const Til
             const double lpcy = llc + logprior(pmean_c, pprec_c, y);
             const double u = ymc_uniform_cached(uc, a.seed, chain, t);
             const bool acc = ymc_accept(lpcy - lpcz, moved, ymc_finite(lpcy), u, st);
+            if (acc) { /* 64-bit moves under the accepting lanes' EXEC mask instead of 2 KS selects */
 #pragma unroll
-            for (int s = 0; s < KS; ++s) z[s] = acc ? y[s] : z[s];
+                for (int s = 0; s < KS; ++s) z[s] = y[s];
+            }
             lpcz = acc ? lpcy : lpcz;
             if (a.sub_acc && live && g == 0) a.sub_acc[((uint64_t)n * S + sub) * a.K + k] = acc ? 1 : 0;
             YMC_PROF(2);
