@@ -685,7 +685,7 @@ static hipError_t launch_tile(const TileArgs &a, hipStream_t s)
     /* the forward matrix streamed from L2 where it does not fit the LDS (YMC_TILE_ASTREAM=1 forces it: the tests
      * compare both forms); one wave per SIMD at KS = 64 */
     bool astream = KS >= 64 || ymc_tile_lds_bytes(KS, a.MT) > kTileLdsLimit;
-    if (const char *env = std::getenv("YMC_TILE_ASTREAM")) astream = astream || env[0] == '1';
+    if (const char *env = std::getenv("YMC_TILE_ASTREAM")) astream = astream || (env[0] == '1' && !a.chol_frag);
     if (astream) {
         if (a.chol_frag) return hipErrorInvalidValue;
         constexpr int W = KS >= 64 ? 4 : kTileWaves;
