@@ -263,22 +263,6 @@ __global__ __launch_bounds__(64 * WAVES) void linear_tile_kernel(const TileArgs 
  * measured 5.7 x the cost of an LDS-fed GEMV.  Waves past the last tile stay in the loop for the barriers and
  * touch no memory.  The plain form remains for shapes whose constants leave no room for the buffer.
  */
-#ifdef YMC_TILE_PROFILE
-/* Development build only (make prof -> libymc_prof.so, tools/tile_sections.py): cycles per section of the
- * two-level kernel as seen by wave 0 of workgroup 0 (s_memtime; every stamp drains the wave's LDS queue, so
- * the sections add up to slightly more than the uninstrumented loop). */
-__device__ unsigned long long ymc_tile_prof[16];
-#define YMC_PROF_DECL unsigned long long prof_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_ = 0
-#define YMC_PROF_START() stamp_ = __builtin_amdgcn_s_memtime()
-#define YMC_PROF(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); prof_[i] += now_ - stamp_; stamp_ = now_; } while (0)
-#define YMC_PROF_FLUSH() do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int i_ = 0; i_ < 10; ++i_) ymc_tile_prof[i_] = prof_[i_]; } while (0)
-#else
-#define YMC_PROF_DECL
-#define YMC_PROF_START()
-#define YMC_PROF(i)
-#define YMC_PROF_FLUSH()
-#endif
-
 enum { kXRegs = 0, kXLds = 1, kXMem = 2 };   /* where the fine state x lives between fine steps */
 
 template <int KS, bool STAGED, int WAVES, int XM>

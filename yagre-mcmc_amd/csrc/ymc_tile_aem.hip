@@ -35,59 +35,54 @@ constexpr int kAemRows = 8; /* data rows whose partial sums a lane keeps in regi
  * than the 256 registers a wave has at two per SIMD (345 spills at d = 128) */
 constexpr int kAemWaves = 4, kAemThreads = 64 * kAemWaves;
 
+/* the three-entry cache in NAMED registers: with arrays the one run-time index (put at position nkeys, a per-lane
+ * value) made the whole object private memory -- 64 B of scratch per lane and a memory round trip per cache
+ * operation on the critical path of every evaluation */
 struct AemCache {
     int32_t nkeys;
-    uint64_t key[3];
-    double val[3];
+    uint64_t k0, k1, k2;
+    double v0, v1, v2;
 
     __device__ __forceinline__ int find(uint64_t id) const
     {
-        if (nkeys > 0 && key[0] == id) return 0;
-        if (nkeys > 1 && key[1] == id) return 1;
-        if (nkeys > 2 && key[2] == id) return 2;
+        if (nkeys > 0 && k0 == id) return 0;
+        if (nkeys > 1 && k1 == id) return 1;
+        if (nkeys > 2 && k2 == id) return 2;
         return -1;
-    }
-    __device__ __forceinline__ void put(int slot, uint64_t id, double v)
-    {
-        key[slot] = id;
-        val[slot] = v;
-    }
-    __device__ __forceinline__ void copy(int dst, int src)
-    {
-        key[dst] = key[src];
-        val[dst] = val[src];
     }
     /* AEMLikelihood.query_log_likelihood + update_cache (likelihood.py:121-126,135-141) given where the key
      * was found (-1: not) and, for a miss, the likelihood under the current error model */
     __device__ __forceinline__ double take(uint64_t id, int hit, double fresh)
     {
         if (hit == 0) { /* retrieve: the entry moves to the back (memoisation.py:98-103) */
-            const double v = val[0];
+            const double v = v0;
             if (nkeys == 2) {
-                copy(0, 1);
-                put(1, id, v);
+                k0 = k1, v0 = v1;
+                k1 = id, v1 = v;
             } else if (nkeys == 3) {
-                copy(0, 1);
-                copy(1, 2);
-                put(2, id, v);
+                k0 = k1, v0 = v1;
+                k1 = k2, v1 = v2;
+                k2 = id, v2 = v;
             }
             return v;
         }
         if (hit == 1) {
-            const double v = val[1];
+            const double v = v1;
             if (nkeys == 3) {
-                copy(1, 2);
-                put(2, id, v);
+                k1 = k2, v1 = v2;
+                k2 = id, v2 = v;
             }
             return v;
         }
-        if (hit == 2) return val[2];
+        if (hit == 2) return v2;
         if (nkeys == 3) { /* evict the oldest (memoisation.py:92-96) */
-            copy(0, 1);
-            copy(1, 2);
-            put(2, id, fresh);
-        } else {
-            put(nkeys, id, fresh);
+            k0 = k1, v0 = v1;
+            k1 = k2, v1 = v2;
+            k2 = id, v2 = fresh;
+        } else { /* append at position nkeys */
+            k0 = nkeys == 0 ? id : k0, v0 = nkeys == 0 ? fresh : v0;
+            k1 = nkeys == 1 ? id : k1, v1 = nkeys == 1 ? fresh : v1;
+            k2 = nkeys == 2 ? id : k2, v2 = nkeys == 2 ? fresh : v2;
             nkeys += 1;
         }
         return fresh;
@@ -171,11 +166,9 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
     bool has_prec = a.aem_flags[2 * kk] != 0;
     AemCache cache;
     cache.nkeys = a.aem_flags[2 * kk + 1];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        cache.key[i] = a.cache_id[kk * 4 + i];
-        cache.val[i] = a.cache_val[kk * 3 + i];
-    }
+    cache.k0 = a.cache_id[kk * 4 + 0], cache.v0 = a.cache_val[kk * 3 + 0];
+    cache.k1 = a.cache_id[kk * 4 + 1], cache.v1 = a.cache_val[kk * 3 + 1];
+    cache.k2 = a.cache_id[kk * 4 + 2], cache.v2 = a.cache_val[kk * 3 + 2];
     uint64_t x_id = a.cache_id[kk * 4 + 3];
     UniformCache uc;
     uc.valid = false;
@@ -187,9 +180,11 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
      * row by row; every row's terms in the canonical four partial sums */
     auto now = [&](const double (&v)[KS]) {
         const bool shift = n_err >= (uint64_t)a.min_data;
-        double Srow[kAemRows];
-#pragma unroll
-        for (int i = 0; i < kAemRows; ++i) Srow[i] = 0.0;
+        /* the rows' partial sums as two 4-vectors: an array here stays a private-memory object (64 B of scratch per
+         * lane, a serialised load / add / store per row and output -- it made an evaluation 2.5 x as long as its matrix
+         * product, profiles/r03_tile_experiments.txt), vector elements are always registers */
+        static_assert(kAemRows == 8, "two 4-vectors of row sums");
+        d4 SA = {0.0, 0.0, 0.0, 0.0}, SB = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 1
         for (int mt = 0; mt < MT; mt += 2) {
             d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
@@ -223,7 +218,8 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
                             double res = F - data_c[i * m_pad + m];
                             res = shift ? res + mean : res;
                             const double px = pe * res;
-                            Srow[i] = Srow[i] + res * px;
+                            if (i < 4) SA[i & 3] = SA[i & 3] + res * px;
+                            else SB[i & 3] = SB[i & 3] + res * px;
                         }
                     }
                 }
@@ -232,7 +228,7 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
         double total = 0.0;
 #pragma unroll
         for (int i = 0; i < kAemRows; ++i)
-            if (i < n_data) total = total + combine4(Srow[i]);
+            if (i < n_data) total = total + combine4(i < 4 ? SA[i & 3] : SB[i & 3]);
         return -0.5 * total;
     };
     /* the fine forward map of v, a pair of output tiles at a time: emit(mt, acc0, acc1) receives the MFMA
@@ -358,10 +354,12 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
         if (mine) n_err = n_new;
     };
 
+    YMC_PROF_DECL;
 #pragma unroll 1
     for (uint32_t n = 0; n < a.nsteps; ++n) {
         const uint64_t tbase = (a.t0 + n) * (uint64_t)(S + 1);
         uint64_t z_id = x_id;
+        YMC_PROF_START();
         /* surrogate.run(S + 1, state), mlda.py:102-110 */
 #pragma unroll 1
         for (int sub = 0; sub < S; ++sub) {
@@ -376,28 +374,36 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
             }
             const double u = ymc_uniform_cached(uc, a.seed, chain, t);
             const bool moved = any_differs(y, z);
+            YMC_PROF(0);
             /* mrw.py:51-57: evaluate_log(proposal), then evaluate_log(state) */
             const uint64_t y_id = t + 1;
             const double ly = query(y_id, y, moved) + logprior(pmean_c, pprec_c, y);
+            YMC_PROF(1);
             const double lz = query(z_id, z, moved) + logprior(pmean_c, pprec_c, z);
+            YMC_PROF(2);
             const bool acc = moved && ymc_accept(ly - lz, true, ymc_finite(ly), u, st);
 #pragma unroll
             for (int s = 0; s < KS; ++s) z[s] = acc ? y[s] : z[s];
             z_id = acc ? y_id : z_id;
             if (a.sub_acc && live && g == 0) a.sub_acc[((uint64_t)n * S + sub) * a.K + k] = acc ? 1 : 0;
+            YMC_PROF(3);
         }
         /* fine accept / reject, mlda.py:146-154: tgt(y), finest(x), finest(y), tgt(x); y <- the fine state x */
 #pragma unroll
         for (int s = 0; s < KS; ++s) y[s] = wave_live ? xt[s * 64] : 0.0;
         const double u = ymc_uniform_cached(uc, a.seed, chain, tbase + (uint64_t)S);
         const bool moved = any_differs(z, y);
+        YMC_PROF(4);
         const double lpfy = loglik_fine(z) + logprior(pmean_f, pprec_f, z);
+        YMC_PROF(5);
         const double cx = query(x_id, y, moved) + logprior(pmean_c, pprec_c, y);
         const double cy = query(z_id, z, moved) + logprior(pmean_c, pprec_c, z);
+        YMC_PROF(6);
         const double log_ratio = ((lpfy + cx) - cy) - lpf;
         const bool acc = wave_live && moved && ymc_accept(log_ratio, true, ymc_finite(lpfy) && ymc_finite(cy), u, st);
         /* aem.py:26-56, before the chain moves; STAGED: by every wave (the shared stream), else by the waves with an accepted chain */
         if (STAGED || __builtin_amdgcn_ballot_w64(acc) != 0) update(z, acc);
+        YMC_PROF(7);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             z[s] = acc ? z[s] : y[s];
@@ -418,7 +424,9 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
             if (rec && a.lp_out) a.lp_out[(uint64_t)clk.row * a.K + k] = lpf;
         }
         if (rec) clk.wrote();
+        YMC_PROF(8);
     }
+    YMC_PROF_FLUSH();
 
     if (live) {
 #pragma unroll
@@ -433,11 +441,9 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
             a.err_n[k] = n_err;
             a.aem_flags[2 * k] = has_prec ? 1 : 0;
             a.aem_flags[2 * k + 1] = cache.nkeys;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                a.cache_id[k * 4 + i] = cache.key[i];
-                a.cache_val[k * 3 + i] = cache.val[i];
-            }
+            a.cache_id[k * 4 + 0] = cache.k0, a.cache_val[k * 3 + 0] = cache.v0;
+            a.cache_id[k * 4 + 1] = cache.k1, a.cache_val[k * 3 + 1] = cache.v1;
+            a.cache_id[k * 4 + 2] = cache.k2, a.cache_val[k * 3 + 2] = cache.v2;
             a.cache_id[k * 4 + 3] = x_id;
         }
     }
@@ -478,6 +484,13 @@ size_t ymc_tile_aem2_lds_bytes(int KS, int MT, int n_data)
 }
 
 int ymc_tile_aem2_max_rows(void) { return kAemRows; }
+
+#ifdef YMC_TILE_PROFILE
+extern "C" int ymc_debug_tile_aem_sections(unsigned long long *out16)
+{
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(ymc_tile_prof), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -2;
+}
+#endif
 
 hipError_t ymc_launch_linear_tile_aem2(int KS, const TileArgs &a, hipStream_t s)
 {

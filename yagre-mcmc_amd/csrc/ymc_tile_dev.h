@@ -10,6 +10,26 @@ namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+#ifdef YMC_TILE_PROFILE
+/* Development build only (make prof -> libymc_prof.so, tools/tile_sections.py): cycles per section of the
+ * instrumented kernel (the two-level one in ymc_tile.hip, or with -DYMC_TILE_PROFILE_AEM the adaptive error model's) as seen
+ * by wave 0 of workgroup 0 (s_memtime; every stamp drains the wave's LDS queue, so
+ * the sections add up to slightly more than the uninstrumented loop). */
+#ifndef YMC_TILE_PROF_EXTERN
+__device__ unsigned long long ymc_tile_prof[16];
+#endif
+#define YMC_PROF_DECL unsigned long long prof_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_ = 0
+#define YMC_PROF_START() stamp_ = __builtin_amdgcn_s_memtime()
+#define YMC_PROF(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); prof_[i] += now_ - stamp_; stamp_ = now_; } while (0)
+#define YMC_PROF_FLUSH() do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int i_ = 0; i_ < 10; ++i_) ymc_tile_prof[i_] = prof_[i_]; } while (0)
+#else
+#define YMC_PROF_DECL
+#define YMC_PROF_START()
+#define YMC_PROF(i)
+#define YMC_PROF_FLUSH()
+#endif
+
+
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask)
 {
     uint64_t b = ymc_bits(v);
