@@ -340,12 +340,20 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
                 scaling = scaling < 100.0 ? scaling : 100.0;
             }
             if (mine && inflate) {
+                /* eight outputs at a time: their M2 entries requested together (one at a time, each waited for its own
+                 * trip to L2 -- 32 in a row on the accepting chains' critical path) */
 #pragma unroll 1
-                for (int q = 0; q < Q; ++q) {
-                    const int m = 16 * (q >> 2) + 4 * (q & 3) + g;
-                    if (m < m_real) {
-                        const double mvar = e2[q * 64] / nm1;
-                        ep[q * 64] = 1.0 / (scaling * mvar + 1.0 / nprec_c[m]); /* noise.py:51-53, covariance.py:36-41 */
+                for (int q0 = 0; q0 < Q; q0 += 8) {
+                    double m2v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) m2v[i] = (q0 + i < Q) ? e2[(q0 + i) * 64] : 0.0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int q = q0 + i, m = 16 * (q >> 2) + 4 * (q & 3) + g;
+                        if (q < Q && m < m_real) {
+                            const double mvar = m2v[i] / nm1;
+                            ep[q * 64] = 1.0 / (scaling * mvar + 1.0 / nprec_c[m]); /* noise.py:51-53, covariance.py:36-41 */
+                        }
                     }
                 }
                 has_prec = true;
