@@ -177,8 +177,20 @@ __global__ __launch_bounds__(64) void iat_wave_kernel(const double *__restrict__
     const double *x = series + sidx * N;
     const int lane = threadIdx.x;
 
+    /* the lane's elements in the order t = lane, lane + 64, ...: eight loads in flight at a time (one at a time, each
+     * waited for its own trip to HBM: the kernel spent 78 % of its wave cycles parked), summed in the same order */
     double part = 0.0;
-    for (uint64_t t = lane; t < N; t += 64) part = part + x[t];
+    {
+        uint64_t t = lane;
+        for (; t + 7 * 64 < N; t += 8 * 64) {
+            double v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = x[t + (uint64_t)j * 64];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part = part + v[j];
+        }
+        for (; t < N; t += 64) part = part + x[t];
+    }
     const double mean = wave_sum(part) / (double)N;
 
     double c0 = 0.0, cum = 1.0, iat_at = 1.0;
@@ -194,15 +206,25 @@ __global__ __launch_bounds__(64) void iat_wave_kernel(const double *__restrict__
         for (uint64_t T0 = 0; T0 + l0 < N; T0 += TB) { /* tiles whose elements still have a partner at lag l0 */
             __syncthreads();
             const int na = near ? TB + (int)l0 + L : TB;
-            for (int q = lane; q < na; q += 64) {
-                const uint64_t t = T0 + q;
-                tileA[iat_pad(q)] = t < N ? x[t] - mean : 0.0;
-            }
-            if (!near)
-                for (int q = lane; q < TB + L; q += 64) {
-                    const uint64_t t = T0 + l0 + q;
-                    tileB[iat_pad(q)] = t < N ? x[t] - mean : 0.0;
+            /* stage a tile with all its loads in flight together: up to kStage = 10 elements per lane
+             * (TB + kIatNear + L = 640 = 10 x 64) */
+            auto stage_tile = [&](double *dst, uint64_t base, int count) {
+                constexpr int kStage = (TB + kIatNear + L + 63) / 64;
+                double v[kStage];
+#pragma unroll
+                for (int j = 0; j < kStage; ++j) {
+                    const int q = lane + 64 * j;
+                    const uint64_t t = base + (uint64_t)q;
+                    v[j] = (q < count && t < N) ? x[t] : mean;      /* past the end: x - mean = 0 */
                 }
+#pragma unroll
+                for (int j = 0; j < kStage; ++j) {
+                    const int q = lane + 64 * j;
+                    if (q < count) dst[iat_pad(q)] = v[j] - mean;
+                }
+            };
+            stage_tile(tileA, T0, na);
+            if (!near) stage_tile(tileB, T0 + l0, TB + L);
             __syncthreads();
             double a[P], w[L];
 #pragma unroll

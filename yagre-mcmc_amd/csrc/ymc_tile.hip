@@ -513,14 +513,23 @@ __global__ __launch_bounds__(256) void welford_replay_kernel(const double *__res
     if (k >= K || j >= d) return;
     double mean = wf_mean[k * d + j], m2 = wf_m2[k * d + j];
     double v = x_before[k * d + j];
-    for (uint64_t n = 0; n < rows; ++n) {
+    auto step = [&](uint64_t n, double next) {
         const double dn = (double)(wf_n0 + n + 1);
         const double delta = v - mean;
         mean = mean + delta / dn;
         const double delta2 = v - mean;
         m2 = m2 + delta * delta2;
-        v = tiled[n * per_row + i];
+        v = next;
+    };
+    uint64_t n = 0;
+    for (; n + 8 <= rows; n += 8) { /* eight rows requested together: the updates are sequential, the loads need not be */
+        double nx[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) nx[q] = tiled[(n + q) * per_row + i];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) step(n + q, nx[q]);
     }
+    for (; n < rows; ++n) step(n, tiled[n * per_row + i]);
     wf_mean[k * d + j] = mean;
     wf_m2[k * d + j] = m2;
 }
