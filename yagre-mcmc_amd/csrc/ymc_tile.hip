@@ -79,8 +79,7 @@ __global__ __launch_bounds__(64 * WAVES) void linear_tile_kernel(const TileArgs 
     if constexpr (ASTREAM) {
         for (size_t i = tid; i < const_doubles; i += kThreads) bias[i] = a.blob[frag_doubles + i];
     } else {
-        for (size_t i = tid; i < blob_doubles / 2; i += kThreads)
-            reinterpret_cast<double2 *>(lds)[i] = reinterpret_cast<const double2 *>(a.blob)[i];
+        ymc_stage_block<kThreads>(lds, a.blob, blob_doubles / 2, tid);
     }
     __syncthreads();
 
@@ -297,8 +296,7 @@ __global__ __launch_bounds__(64 * WAVES) void linear_tile_mlda2_kernel(const Til
     if constexpr (XLDS) {
         for (size_t i = tid; i < consts_c; i += kThreads) bias_c[i] = a.blob[frag_c + i];
     } else {
-        for (size_t i = tid; i < (frag_c + consts_c) / 2; i += kThreads)
-            reinterpret_cast<double2 *>(lds)[i] = reinterpret_cast<const double2 *>(a.blob)[i];
+        ymc_stage_block<kThreads>(lds, a.blob, (frag_c + consts_c) / 2, tid);
     }
     for (size_t i = tid; i < consts_f; i += kThreads) bias_f[i] = a.blob_f[(size_t)MTf * KS * 64 + i];
     __syncthreads();

@@ -128,8 +128,7 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
     double *stage = nprec_c + rows_c;                            /* STAGED: the stream's double buffer (ymc_tile_dev.h) */
 
     const int tid = threadIdx.x;
-    for (size_t i = tid; i < blob_c / 2; i += kAemThreads)
-        reinterpret_cast<double2 *>(lds)[i] = reinterpret_cast<const double2 *>(a.blob)[i];
+    ymc_stage_block<kAemThreads>(lds, a.blob, blob_c / 2, tid);
     for (size_t i = tid; i < consts_f; i += kAemThreads) bias_f[i] = a.blob_f[(size_t)MT * KS * 64 + i];
     for (size_t i = tid; i < rows_c; i += kAemThreads) nprec_c[i] = a.aem_rows[i];
     __syncthreads();

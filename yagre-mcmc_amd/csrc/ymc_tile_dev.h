@@ -59,6 +59,25 @@ __device__ __forceinline__ double combine4(double s)
     return v + shfl_xor_f64(v, 32);
 }
 
+/* A workgroup copies `n2` 16-byte words of a problem block from global memory into LDS, every thread's loads eight at a
+ * time: one load per loop iteration, each waited for before its LDS write, left the staging of a 128 KB matrix at
+ * sixteen L2 round trips in a row per workgroup. */
+template <int THREADS>
+__device__ __forceinline__ void ymc_stage_block(double *lds_dst, const double *__restrict__ src, size_t n2, int tid)
+{
+    double2 *dst = reinterpret_cast<double2 *>(lds_dst);
+    const double2 *s2 = reinterpret_cast<const double2 *>(src);
+    size_t i = tid;
+    for (; i + 7 * (size_t)THREADS < n2; i += 8 * (size_t)THREADS) {
+        double2 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = s2[i + (size_t)j * THREADS];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[i + (size_t)j * THREADS] = v[j];
+    }
+    for (; i < n2; i += THREADS) dst[i] = s2[i];
+}
+
 /* The pieces of a linear-model posterior in the kernels' operand layout: lane (g, c) of a wave holds component
  * 4 s + g of chain c in register s (the MFMA B operand) and, after a pass over output tiles, rows 4 r + g of every
  * tile in accumulator entry r.  Sums over a chain's outputs / components are the canonical four interleaved

@@ -71,8 +71,7 @@ __global__ __launch_bounds__(kNestThreads) void linear_tile_nested_kernel(const 
     double *stage = lds + blob0;                                 /* STAGED: the stream's double buffer (ymc_tile_dev.h) */
 
     const int tid = threadIdx.x;
-    for (size_t i = tid; i < blob0 / 2; i += kNestThreads)
-        reinterpret_cast<double2 *>(lds)[i] = reinterpret_cast<const double2 *>(a.blob)[i];
+    ymc_stage_block<kNestThreads>(lds, a.blob, blob0 / 2, tid);
     __syncthreads();
 
     const int lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
