@@ -23,6 +23,24 @@ def test_philox_known_answers():
         assert [int(v) for v in o.philox(ctr, key)] == want
 
 
+def test_uniforms_are_the_53_bit_mantissas_of_their_philox_words():
+    """The accept uniform of transition t is m 2^-53 with m = (hi:lo) >> 11 of words {0,1} (even t) / {2,3} (odd t) of the
+    block with counter (chain, 0, t >> 1) -- DESIGN section 2.  The header forms it as hi 2^-32 + (lo >> 11) 2^-53 without
+    the 64-bit shift; here the definition is evaluated with Python integers (exact) from the pinned Philox function."""
+    seed, chain0, K, t0, nt = 0x9E3779B97F4A7C15, 2**31 - 3, 5, 2**33 + 1, 9
+    _, u = o.rng_fill(seed, chain0, K, t0, nt, 1, normals=False)
+    key = [seed & 0xFFFFFFFF, seed >> 32]
+    for i in range(nt):
+        t = t0 + i
+        p = t >> 1
+        for k in range(K):
+            chain = (chain0 + k) & 0xFFFFFFFF
+            w = [int(v) for v in o.philox([chain, 0, p & 0xFFFFFFFF, p >> 32], key)]
+            lo, hi = (w[2], w[3]) if t & 1 else (w[0], w[1])
+            m = ((hi << 32) | lo) >> 11
+            assert u[i, k] == m / 2.0**53 and 0 <= m < 2**53     # an exactly representable quotient
+
+
 def _ulps(got, want):
     want = np.asarray(want, dtype=np.float64)
     return np.abs(got - want) / np.spacing(np.abs(want))
