@@ -135,12 +135,11 @@ def test_invalid_descriptions_are_refused_with_messages():
                               chol=np.eye(2))
     # a surrogate whose forward map is too wide for the lane kernels takes BOTH levels to the matrix-core
     # kernel (it must never be evaluated truncated next to a lane-kernel target); there the adaptive error
-    # model keeps the partial sums of at most 8 data rows
+    # model takes its data rows eight to a pass over the forward map, as many as the LDS holds
     lowering.make_problem(ctx, _ffi.METHOD_MLDA2, linear(m=2), np.ones(2), surrogate=linear(m=12), sub_chain_length=2)
     lowering.make_problem(ctx, _ffi.METHOD_AEM2, linear(m=12), np.ones(2), surrogate=linear(m=12), sub_chain_length=2, aem=(5, 0))
-    with pytest.raises(_ffi.YmcError, match="up to 8 data rows"):
-        lowering.make_problem(ctx, _ffi.METHOD_AEM2, linear(m=12, nd=9), np.ones(2), surrogate=linear(m=12, nd=9),
-                              sub_chain_length=2, aem=(5, 0))
+    lowering.make_problem(ctx, _ffi.METHOD_AEM2, linear(m=12, nd=9), np.ones(2), surrogate=linear(m=12, nd=9),
+                          sub_chain_length=2, aem=(5, 0))
     with pytest.raises(_ffi.YmcError, match="not finite"):
         lowering.make_problem(ctx, _ffi.METHOD_MRW, gauss(), np.ones(2), chol=np.array([[1.0, 0.0], [np.nan, 1.0]]))
     # fetches that do not belong to the method

@@ -465,7 +465,8 @@ def test_f16_adaptive_error_model_d128_matrix_cores(ffi, ctx, golden):
     assert np.allclose(dev["err"]["precision"], g["aem_prec"], rtol=1e-11, atol=0)
 
 
-@pytest.mark.parametrize("d,m,nd,K", [(128, 128, 5, 70), (9, 3, 2, 33), (16, 40, 1, 64), (40, 70, 8, 50), (5, 30, 6, 40)])
+@pytest.mark.parametrize("d,m,nd,K", [(128, 128, 5, 70), (9, 3, 2, 33), (16, 40, 1, 64), (40, 70, 8, 50), (5, 30, 6, 40),
+                                      (40, 70, 9, 50), (24, 33, 21, 40), (128, 96, 14, 36)])
 def test_tile_kernel_adaptive_error_model_other_shapes(ffi, ctx, d, m, nd, K):
     rng = np.random.default_rng(40 + d + m)
     A = rng.normal(size=(m, d)) / np.sqrt(d)

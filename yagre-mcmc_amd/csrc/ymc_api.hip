@@ -1026,9 +1026,6 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
         if (desc->target.kind != YMC_DENSITY_POSTERIOR_LINEAR || desc->surrogate.kind != YMC_DENSITY_POSTERIOR_LINEAR)
             rc = fail(YMC_ERR_INVALID, "Adaptive error correction only makes sense if the target emerges from a "
                                        "Bayesian model.");
-        else if (p->tgt.tile && desc->target.n_data > ymc_tile_aem2_max_rows())
-            rc = fail(YMC_ERR_UNSUPPORTED, "at this dimension the adaptive error model handles up to %d data rows, got %d",
-                      ymc_tile_aem2_max_rows(), desc->target.n_data);
         else if (desc->aem_min_data_size < 2)
             rc = fail(YMC_ERR_INVALID, "Smallest senisible data size for AEM is 2.");
         else if (desc->target.likelihood_only || desc->surrogate.likelihood_only)

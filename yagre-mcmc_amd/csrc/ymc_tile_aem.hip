@@ -96,7 +96,7 @@ struct AemCache {
  * nothing else hides the L2 latency (ymc_tile_nested.hip: +67 %).  Waves past the last tile stay in the loop for
  * the barriers and touch no memory; the update of the error model is then evaluated by every wave on every fine
  * step (it applies to accepted chains only, as before). */
-template <int KS, int STG>
+template <int KS, int STG, bool ROWBLOCKS = false>
 __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const TileArgs a)
 {
     constexpr bool STAGED = STG != 0;
@@ -183,51 +183,59 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
          * lane, a serialised load / add / store per row and output -- it made an evaluation 2.5 x as long as its matrix
          * product, profiles/r03_tile_experiments.txt), vector elements are always registers */
         static_assert(kAemRows == 8, "two 4-vectors of row sums");
-        d4 SA = {0.0, 0.0, 0.0, 0.0}, SB = {0.0, 0.0, 0.0, 0.0};
+        /* ROWBLOCKS (more than eight data rows): one pass over the forward map per block of eight rows -- the rows' sums
+         * join the total in row order either way, the same bits a single pass would give.  Its own instantiation: the
+         * loop's bookkeeping cost the eight-row kernel 13 % when it carried it (22 spilled registers at KS = 32) */
+        double total = 0.0;
 #pragma unroll 1
-        for (int mt = 0; mt < MT; mt += 2) {
-            d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-            const double *A0 = Ac + (size_t)mt * KS * 64 + lane;
-            const double *A1 = A0 + (size_t)KS * 64;
-            /* this pair's entries of the chain's error model, requested BEFORE its 64 MFMAs: they come from HBM (134 MB
-             * of them at 65 536 chains) and with one wave per SIMD nothing else hides that latency -- read in the
-             * epilogue they made an evaluation six times as long as its matrix product (profiles/r03_c3a_*) */
-            double em_v[8], ep_v[8];
+        for (int r0 = 0; r0 < (ROWBLOCKS ? n_data : 1); r0 += kAemRows) {
+            const double *rows = ROWBLOCKS ? data_c + (size_t)r0 * m_pad : data_c;
+            const int nr = ROWBLOCKS && n_data - r0 >= kAemRows ? kAemRows : n_data - r0;
+            d4 SA = {0.0, 0.0, 0.0, 0.0}, SB = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+            for (int mt = 0; mt < MT; mt += 2) {
+                d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+                const double *A0 = Ac + (size_t)mt * KS * 64 + lane;
+                const double *A1 = A0 + (size_t)KS * 64;
+                /* this pair's entries of the chain's error model, requested BEFORE its 64 MFMAs: they come from HBM (134 MB
+                 * of them at 65 536 chains) and with one wave per SIMD nothing else hides that latency -- read in the
+                 * epilogue they made an evaluation six times as long as its matrix product (profiles/r03_c3a_*) */
+                double em_v[8], ep_v[8];
 #pragma unroll
-            for (int hq = 0; hq < 8; ++hq) {
-                em_v[hq] = em[(4 * mt + hq) * 64];
-                ep_v[hq] = has_prec ? ep[(4 * mt + hq) * 64] : 0.0;
-            }
+                for (int hq = 0; hq < 8; ++hq) {
+                    em_v[hq] = em[(4 * mt + hq) * 64];
+                    ep_v[hq] = has_prec ? ep[(4 * mt + hq) * 64] : 0.0;
+                }
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[s * 64], v[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1[s * 64], v[s], acc1, 0, 0, 0);
-            }
+                for (int s = 0; s < KS; ++s) {
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[s * 64], v[s], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1[s * 64], v[s], acc1, 0, 0, 0);
+                }
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < 2; ++h) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = 16 * (mt + h) + 4 * r + g;
-                    const double F = (h ? acc1[r] : acc0[r]) + bias_c[m];
-                    const double mean = em_v[4 * h + r];
-                    const double pe = has_prec ? ep_v[4 * h + r] : nprec_c[m];
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = 16 * (mt + h) + 4 * r + g;
+                        const double F = (h ? acc1[r] : acc0[r]) + bias_c[m];
+                        const double mean = em_v[4 * h + r];
+                        const double pe = has_prec ? ep_v[4 * h + r] : nprec_c[m];
 #pragma unroll
-                    for (int i = 0; i < kAemRows; ++i) {
-                        if (i < n_data) {
-                            double res = F - data_c[i * m_pad + m];
-                            res = shift ? res + mean : res;
-                            const double px = pe * res;
-                            if (i < 4) SA[i & 3] = SA[i & 3] + res * px;
-                            else SB[i & 3] = SB[i & 3] + res * px;
+                        for (int i = 0; i < kAemRows; ++i) {
+                            if (i < nr) {
+                                double res = F - rows[i * m_pad + m];
+                                res = shift ? res + mean : res;
+                                const double px = pe * res;
+                                if (i < 4) SA[i & 3] = SA[i & 3] + res * px;
+                                else SB[i & 3] = SB[i & 3] + res * px;
+                            }
                         }
                     }
                 }
             }
-        }
-        double total = 0.0;
 #pragma unroll
-        for (int i = 0; i < kAemRows; ++i)
-            if (i < n_data) total = total + combine4(i < 4 ? SA[i & 3] : SB[i & 3]);
+            for (int i = 0; i < kAemRows; ++i)
+                if (i < nr) total = total + combine4(i < 4 ? SA[i & 3] : SB[i & 3]);
+        }
         return -0.5 * total;
     };
     /* the fine forward map of v, a pair of output tiles at a time: emit(mt, acc0, acc1) receives the MFMA
@@ -456,15 +464,15 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
     }
 }
 
-template <int KS, int STG>
+template <int KS, int STG, bool ROWBLOCKS = false>
 hipError_t launch_staged(const TileArgs &a, size_t lds, hipStream_t s)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_tile_aem2_kernel<KS, STG>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_tile_aem2_kernel<KS, STG, ROWBLOCKS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const uint64_t nct = (a.K + 15) / 16;
     const unsigned grid = (unsigned)((nct + kAemWaves - 1) / kAemWaves);
-    hipLaunchKernelGGL((linear_tile_aem2_kernel<KS, STG>), dim3(grid), dim3(kAemThreads), lds, s, a);
+    hipLaunchKernelGGL((linear_tile_aem2_kernel<KS, STG, ROWBLOCKS>), dim3(grid), dim3(kAemThreads), lds, s, a);
     return hipGetLastError();
 }
 
@@ -474,6 +482,7 @@ hipError_t launch_as(const TileArgs &a, hipStream_t s)
     /* the fine matrix through the shared double buffer in the largest unit the LDS has room for (identical
      * results; YMC_TILE_STAGE=0 switches it off, the tests run both) */
     const size_t plain = ymc_tile_aem2_lds_bytes(KS, a.MT, a.n_data);
+    if (a.n_data > kAemRows) return launch_staged<KS, 0, true>(a, plain, s);
     const size_t unit4 = 2 * (size_t)ymc_stream_unit<KS, 4>() * sizeof(double);
     bool stage = true;
     if (const char *env = std::getenv("YMC_TILE_STAGE")) stage = env[0] != '0';
@@ -490,7 +499,7 @@ size_t ymc_tile_aem2_lds_bytes(int KS, int MT, int n_data)
     return ymc_tile_mlda2_lds_bytes(KS, MT, MT) + 16 * (size_t)MT * (1 + (size_t)n_data) * sizeof(double);
 }
 
-int ymc_tile_aem2_max_rows(void) { return kAemRows; }
+int ymc_tile_aem2_max_rows(void) { return kAemRows; } /* rows per pass over the forward map (more rows: more passes) */
 
 #ifdef YMC_TILE_PROFILE
 extern "C" int ymc_debug_tile_aem_sections(unsigned long long *out16)
