@@ -119,7 +119,7 @@ typedef enum ymc_method {
     YMC_METHOD_AEM2 = 5
 } ymc_method;
 
-#define YMC_MAX_LEVELS 4 /* effective levels E of YMC_METHOD_MLDA_NESTED (n <= 6 surrogates) */
+#define YMC_MAX_LEVELS 8 /* effective levels E of YMC_METHOD_MLDA_NESTED (n <= 14 surrogates) */
 
 typedef enum ymc_state_eq {
     YMC_EQ_EXACT = 0,   /* ParameterVector.__eq__, parameter/vector.py:37-45 */

@@ -652,6 +652,24 @@ def fixture_f11():
                [6, 4, 4, 3], [2.0, -3.0])
 
 
+def fixture_f23():
+    # deeper than any of the reference's own examples: eight and fourteen surrogates (mlda.py:46-73 builds any
+    # number of levels) = five and eight effective levels; the coarser a surrogate, the wider and the further off
+    tm = np.array([1.0, 1.5])
+    base = np.array([[2.4, -0.5], [-0.5, 0.7]])
+
+    def hierarchy(ns):
+        means = [tm + (ns - i) * np.array([0.04, -0.03]) * (-1.0) ** i for i in range(ns)]
+        covs = [(1.0 + 0.45 * (ns - i)) * (base + 0.05 * (ns - i) * np.eye(2)) for i in range(ns)]
+        return means, covs
+
+    means, covs = hierarchy(8)
+    run_nested("f23_mlda_nested8.npz", 20250123, 8, 150, tm, base, means, covs, [2, 3, 5, 2, 1, 2, 4, 2], [2.0, -3.0])
+    means, covs = hierarchy(14)
+    run_nested("f23b_mlda_nested14.npz", 20250124, 6, 40, tm, base, means, covs,
+               [3, 2, 2, 2, 5, 1, 1, 2, 7, 2, 2, 2, 1, 2], [-1.0, 0.5])
+
+
 # ---------------------------------------------------------------------------
 # F12: adaptive error model (chain/method/aem.py) on the linear two-level example's models
 # (example_inference_linearModel_twoLevel.py:33-56,95-100,181-191), with a milder surrogate
@@ -1125,7 +1143,7 @@ def fixture_f18(name="f18_mlda_nested2_linear_d128.npz", d=128, n_models=3, seed
 
 def main():
     which = sys.argv[1:] or ["f1", "f2", "f2b", "f3", "f3b", "f4", "f5", "f7", "f8", "f9", "f10", "f11", "f12", "f13",
-                             "f14", "f15", "f16", "f17", "f18", "f19", "f20", "f21", "f22"]
+                             "f14", "f15", "f16", "f17", "f18", "f19", "f20", "f21", "f22", "f23"]
     if "f1" in which:
         fixture_f1()
     if "f2" in which:
@@ -1175,6 +1193,10 @@ def main():
         fixture_f18()
         fixture_f18("f18b_mlda_nested4_linear_d24.npz", d=24, n_models=5, seed=20250119, K=6, n=81,
                     sub_lengths=(2, 3, 2, 2), perturb=0.03, prop_var=6e-3)
+        fixture_f18("f18c_mlda_nested8_linear_d24.npz", d=24, n_models=9, seed=20250125, K=4, n=25,
+                    sub_lengths=(2, 2, 3, 2, 1, 2, 2, 2), perturb=0.015, prop_var=6e-3)
+    if "f23" in which:
+        fixture_f23()
     if "f12" in which:
         fixture_f12()
         fixture_f12("f12b_aem_linear_noheuristic.npz", use_heuristic=False, seed=20250113, min_data=5, K=12,

@@ -113,8 +113,10 @@ def test_invalid_descriptions_are_refused_with_messages():
     real = lowering.lower_density
     lowering.lower_density = lambda d, rk4_steps=None: d.low if isinstance(d, Pre) else real(d, rk4_steps)
     try:
-        with pytest.raises(lowering.UnsupportedPlugin, match="nested levels"):     # 8 surrogates = 5 levels
-            lowering.make_nested_problem(ctx, Pre(gauss()), [Pre(gauss())] * 8, [1] * 8, np.ones(2))
+        with pytest.raises(lowering.UnsupportedPlugin, match="nested levels"):     # 16 surrogates = 9 levels
+            lowering.make_nested_problem(ctx, Pre(gauss()), [Pre(gauss())] * 16, [1] * 16, np.ones(2))
+        with pytest.warns(RuntimeWarning, match="degenerates"):                    # 14 surrogates = 8 levels
+            lowering.make_nested_problem(ctx, Pre(gauss()), [Pre(gauss())] * 14, [1] * 14, np.ones(2))
         with pytest.raises(_ffi.YmcError, match="Subchain lengths"):
             lowering.make_nested_problem(ctx, Pre(gauss()), [Pre(gauss())] * 2, [1, 0], np.ones(2))
         with pytest.raises(_ffi.YmcError, match="kinds"):

@@ -271,7 +271,8 @@ def _nested_device_run(ffi, ctx, g_tgt, g_surs, sub_lengths, sigma, x0, seed, ns
                 state=run.state(), level_acc=acc, level_made=made)
 
 
-@pytest.mark.parametrize("name", ["f10_mlda_nested2.npz", "f11_mlda_nested4.npz"])
+@pytest.mark.parametrize("name", ["f10_mlda_nested2.npz", "f11_mlda_nested4.npz", "f23_mlda_nested8.npz",
+                                  "f23b_mlda_nested14.npz"])
 def test_f10_f11_even_surrogate_hierarchies(ffi, ctx, golden, name):
     g = golden(name)
     n = int(g["n_states"])
@@ -295,7 +296,7 @@ def test_f10_f11_even_surrogate_hierarchies(ffi, ctx, golden, name):
         assert dev["level_made"][e_] == made
 
 
-@pytest.mark.parametrize("d,E", [(1, 2), (3, 3), (5, 4), (8, 4)])
+@pytest.mark.parametrize("d,E", [(1, 2), (3, 3), (5, 4), (8, 4), (1, 5), (2, 7), (4, 6), (8, 8), (3, 5)])
 def test_nested_other_dimensions_and_depths_vs_oracle(ffi, ctx, d, E):
     rng = np.random.default_rng(100 * d + E)
     ns = 2 * (E - 1)
@@ -307,15 +308,16 @@ def test_nested_other_dimensions_and_depths_vs_oracle(ffi, ctx, d, E):
 
     ot = rand_gauss(1.0)
     osur = [rand_gauss(1.5 + 0.5 * (ns - i)) for i in range(ns)]
-    subs = [int(v) for v in rng.integers(1, 4, size=ns)]
+    subs = [int(v) for v in rng.integers(1, 4 if E <= 5 else 3, size=ns)]
     low = lambda p: _gauss_low(ffi, p["mean"], p["whiten"], p["log_norm"])
     sigma = np.full(d, 0.9)
+    n = 60 if E <= 4 else 14
     x0 = rng.normal(size=(300, d))
-    dev = _nested_device_run(ffi, ctx, low(ot), [low(s_) for s_ in osur], subs, sigma, x0, 4242, 60, splits=2,
+    dev = _nested_device_run(ffi, ctx, low(ot), [low(s_) for s_ in osur], subs, sigma, x0, 4242, n, splits=2,
                              chain0=1000)
     P, Q, steps = o.nested_levels(osur, subs, ot)
     e = o.NestedEnsemble(P, Q, steps, sigma, x0, 4242, chain0=1000)
-    out = e.advance(60)
+    out = e.advance(n)
     _same_as_oracle(dev, e, out)
     assert np.array_equal(dev["level_acc"], e.level_acc)
 
@@ -1177,9 +1179,10 @@ def test_tile_kernel_two_level_other_shapes(ffi, ctx, d, mf, mc, nd, K, S):
     assert np.array_equal(dev["sub_acc"], out["sub_acc"])
 
 
-@pytest.mark.parametrize("name", ["f18_mlda_nested2_linear_d128.npz", "f18b_mlda_nested4_linear_d24.npz"])
+@pytest.mark.parametrize("name", ["f18_mlda_nested2_linear_d128.npz", "f18b_mlda_nested4_linear_d24.npz",
+                                  "f18c_mlda_nested8_linear_d24.npz"])
 def test_f18_nested_levels_matrix_cores(ffi, ctx, golden, name):
-    """Hierarchies of three (d = 128) and five (d = 24) linear models (linear_tile_nested_kernel): the LIVE
+    """Hierarchies of three (d = 128), five and nine (d = 24) linear models (linear_tile_nested_kernel): the LIVE
     reference's top-level decisions, accepted counts of the lower levels, chains (sha256) and log-posteriors;
     == oracle."""
     import hashlib
@@ -1206,7 +1209,9 @@ def test_f18_nested_levels_matrix_cores(ffi, ctx, golden, name):
 
 @pytest.mark.parametrize("d,ms,nd,K,E", [(128, (128, 128, 128), 5, 40, 2), (12, (5, 20, 9), 3, 33, 2),
                                          (24, (16, 40, 8, 30, 12), 2, 70, 3), (64, (64, 30, 64, 10, 48), 4, 17, 3),
-                                         (9, (3, 3, 4, 2, 5, 3, 6), 1, 129, 4), (5, (30, 12, 6), 2, 20, 2)])
+                                         (9, (3, 3, 4, 2, 5, 3, 6), 1, 129, 4), (5, (30, 12, 6), 2, 20, 2),
+                                         (20, (12, 9, 16, 5, 20, 7, 11, 18, 10), 2, 40, 5),
+                                         (128, (16,) * 14 + (128,), 3, 20, 8), (10, (3, 9) * 5 + (12,), 1, 65, 6)])
 def test_tile_kernel_nested_levels_vs_oracle(ffi, ctx, d, ms, nd, K, E):
     """Delayed acceptance over an even number of surrogates at large dimension (ymc_tile_nested.hip): a
     hierarchy of 2 (E - 1) + 1 linear models, each with its own matrix, output count and data; ragged shapes, a
@@ -1225,13 +1230,14 @@ def test_tile_kernel_nested_levels_vs_oracle(ffi, ctx, d, ms, nd, K, E):
 
     models = [model(m, 1.0 - 0.03 * i) for i, m in enumerate(ms)]
     (lt, pt), surs = models[-1], models[:-1]
-    subs = [int(v) for v in rng.integers(1, 4, size=len(surs))]
+    subs = [int(v) for v in rng.integers(1, 4 if E <= 5 else 3, size=len(surs))]
     sigma = rng.uniform(0.02, 0.08, size=d)
     x0 = rng.normal(size=(K, d))
-    dev = _nested_device_run(ffi, ctx, lt, [l for l, _ in surs], subs, sigma, x0, 777, 24, splits=3, chain0=3000)
+    n = 24 if E <= 4 else 9
+    dev = _nested_device_run(ffi, ctx, lt, [l for l, _ in surs], subs, sigma, x0, 777, n, splits=3, chain0=3000)
     P, Q, steps = o.nested_levels([p for _, p in surs], subs, pt)
     e = o.NestedEnsemble(P, Q, steps, sigma, x0, 777, chain0=3000)
-    out = e.advance(24)
+    out = e.advance(n)
     _same_as_oracle(dev, e, out)
     assert np.array_equal(dev["level_acc"], e.level_acc)
     assert 0 < dev["acc"].mean() < 1

@@ -142,10 +142,12 @@ def _nested_from_fixture(g):
     return o.nested_levels(surs, [int(v) for v in g["sub_lengths"]], tgt)
 
 
-@pytest.mark.parametrize("name", ["f10_mlda_nested2.npz", "f11_mlda_nested4.npz"])
+@pytest.mark.parametrize("name", ["f10_mlda_nested2.npz", "f11_mlda_nested4.npz", "f23_mlda_nested8.npz",
+                                  "f23b_mlda_nested14.npz"])
 def test_f10_f11_even_surrogate_hierarchies_as_the_reference_runs_them(golden, name):
-    """example_mcmc_2d_hierarchical.py (2 surrogates) and test_mlda.py:189-256 (4 surrogates): only
-    every second level decides; chains, decisions and per-level accept counts == the reference's."""
+    """example_mcmc_2d_hierarchical.py (2 surrogates), test_mlda.py:189-256 (4 surrogates) and deeper than the
+    reference's own cases (8 and 14 surrogates: 5 and 8 effective levels): only every second level decides;
+    chains, decisions and per-level accept counts == the reference's."""
     g = golden(name)
     n = int(g["n_states"])
     P, Q, steps = _nested_from_fixture(g)
@@ -156,7 +158,7 @@ def test_f10_f11_even_surrogate_hierarchies_as_the_reference_runs_them(golden, n
     assert np.array_equal(e.level_acc, g["level_acc"])
     # resumable: two halves == one piece
     e2 = o.NestedEnsemble(P, Q, steps, g["sigma"], g["x0"], int(g["seed"]), nthreads=3)
-    a, b = e2.advance(100), e2.advance(n - 101)
+    a, b = e2.advance(n // 3), e2.advance(n - 1 - n // 3)
     assert np.array_equal(np.concatenate([a["traj"], b["traj"]]), out["traj"])
     assert np.array_equal(e2.level_acc, e.level_acc)
 
@@ -313,7 +315,8 @@ def test_f14_two_level_over_a_model_hierarchy_d128(golden):
     assert 0.5 < g["acc"].mean() < 0.95 and 0.2 < g["sub_acc"].mean() < 0.8   # both levels decide both ways
 
 
-@pytest.mark.parametrize("name", ["f18_mlda_nested2_linear_d128.npz", "f18b_mlda_nested4_linear_d24.npz"])
+@pytest.mark.parametrize("name", ["f18_mlda_nested2_linear_d128.npz", "f18b_mlda_nested4_linear_d24.npz",
+                                  "f18c_mlda_nested8_linear_d24.npz"])
 def test_f18_nested_levels_over_model_hierarchies_at_large_dimension(golden, name):
     """MLDABuilder.bayesModel = a hierarchy of three (d = 128) / five (d = 24) linear models: an even number of
     surrogates, run by the reference as a nest of effective levels (mlda.py:12-73,100-116,315-335).  The

@@ -22,7 +22,7 @@ OK, ERR_INVALID, ERR_DEVICE, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_COMM = 0, -1, -2
 GAUSS_WHITENED, GAUSS_ISO1D, POSTERIOR_LINEAR, POSTERIOR_LV = 1, 2, 3, 4
 # ymc_method / ymc_state_eq
 METHOD_MRW, METHOD_MLDA2, METHOD_PCN, METHOD_MLDA_NESTED, METHOD_AEM2 = 1, 2, 3, 4, 5
-MAX_LEVELS = 4
+MAX_LEVELS = 8
 EQ_EXACT, EQ_ISCLOSE = 0, 1
 # record flags
 RECORD_TRAJECTORY, RECORD_ACCEPT, RECORD_LOGPOST, RECORD_SUB_ACCEPT, RECORD_MOMENTS = 1, 2, 4, 8, 16

@@ -157,8 +157,8 @@ struct ymc_problem {
     /* MLDA_NESTED: P of levels 0..E-2 (level E-1's is tgt), Q of levels 1..E-1 (index 0 unused) */
     int E = 0;
     DensityHost lvlP[YMC_MAX_LEVELS], lvlQ[YMC_MAX_LEVELS];
-    int lvl_steps[YMC_MAX_LEVELS] = {0, 0, 0, 0};
-    uint64_t lvl_cost[YMC_MAX_LEVELS] = {0, 0, 0, 0}; /* transitions one step of level e spans */
+    int lvl_steps[YMC_MAX_LEVELS] = {};
+    uint64_t lvl_cost[YMC_MAX_LEVELS] = {}; /* transitions one step of level e spans */
     DeviceBuf lvlP_dev, lvlQ_dev;                     /* DensityDev<D>[E] each */
     DeviceBuf tile_levels;                            /* matrix-core path: TileLevel[2 E], P / Q of level l at 2 l, 2 l + 1 */
 };
@@ -704,7 +704,7 @@ int launch_advance_nested(ymc_run *r, uint64_t nsteps)
         YMC_HIP(hipEventCreate(&ev.second));
     }
     YMC_HIP(hipEventRecord(ev.first, r->ctx->stream));
-    hipError_t e = ymc_launch_nested<D>(p->kind, a, r->ctx->stream);
+    hipError_t e = a.E > 4 ? ymc_launch_nested_deep<D>(p->kind, a, r->ctx->stream) : ymc_launch_nested<D>(p->kind, a, r->ctx->stream);
     if (e != hipSuccess) {
         r->pool.push_back(ev);
         return fail(YMC_ERR_DEVICE, "nested chain kernel launch failed: %s", hipGetErrorString(e));
@@ -1086,6 +1086,10 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
             p->lvl_cost[e] = e == 0 ? 1 : (uint64_t)p->lvl_steps[e - 1] * p->lvl_cost[e - 1] + 1;
         }
         if (rc == YMC_OK) p->lvl_cost[E - 1] = (uint64_t)p->lvl_steps[E - 2] * p->lvl_cost[E - 2] + 1;
+        /* the transition index (64 bits) addresses the draws: a step of the recorded level may span 2^40 of them */
+        for (int e = 1; rc == YMC_OK && e < E; ++e)
+            if (p->lvl_cost[e] > (1ull << 40) || p->lvl_cost[e] < p->lvl_cost[e - 1])
+                rc = fail(YMC_ERR_UNSUPPORTED, "one step of level %d spans more than 2^40 transitions", e);
     }
     if (rc == YMC_OK) {
         /* MRWBuilder._validate_parameters, mrw.py:88-91 */

@@ -31,7 +31,10 @@ struct NestedArgs {
     double *lp_out;
 };
 
+/* nests of up to four effective levels / of more (the same file built with -DYMC_NESTED_DEEP) */
 template <int D>
 hipError_t ymc_launch_nested(int kind, const NestedArgs<D> &a, hipStream_t s);
+template <int D>
+hipError_t ymc_launch_nested_deep(int kind, const NestedArgs<D> &a, hipStream_t s);
 
 #endif /* YMC_NESTED_H */

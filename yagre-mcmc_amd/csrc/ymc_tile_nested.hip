@@ -42,15 +42,28 @@ constexpr int kNestThreads = 64 * kNestWaves;
  * values stay in registers (an indexed array went to scratch) */
 template <typename T>
 struct PerLevel {
-    T v0, v1, v2, v3;
-    static_assert(YMC_MAX_LEVELS == 4, "PerLevel holds four levels");
-    __device__ __forceinline__ T get(int l) const { return l == 0 ? v0 : l == 1 ? v1 : l == 2 ? v2 : v3; }
+    T v0, v1, v2, v3, v4, v5, v6, v7;
+    static_assert(YMC_MAX_LEVELS == 8, "PerLevel holds eight levels");
+    /* every member is read BEFORE the selects: a conditional over the members themselves becomes a load through a
+     * selected address, which at eight members leaves the whole struct in private memory */
+    __device__ __forceinline__ T get(int l) const
+    {
+        const T a0 = v0, a1 = v1, a2 = v2, a3 = v3, a4 = v4, a5 = v5, a6 = v6, a7 = v7;
+        const T lo = l == 0 ? a0 : l == 1 ? a1 : l == 2 ? a2 : a3;
+        const T hi = l == 4 ? a4 : l == 5 ? a5 : l == 6 ? a6 : a7;
+        return l < 4 ? lo : hi;
+    }
     __device__ __forceinline__ void set(int l, T x)
     {
-        v0 = l == 0 ? x : v0;
-        v1 = l == 1 ? x : v1;
-        v2 = l == 2 ? x : v2;
-        v3 = l == 3 ? x : v3;
+        const T a0 = v0, a1 = v1, a2 = v2, a3 = v3, a4 = v4, a5 = v5, a6 = v6, a7 = v7;
+        v0 = l == 0 ? x : a0;
+        v1 = l == 1 ? x : a1;
+        v2 = l == 2 ? x : a2;
+        v3 = l == 3 ? x : a3;
+        v4 = l == 4 ? x : a4;
+        v5 = l == 5 ? x : a5;
+        v6 = l == 6 ? x : a6;
+        v7 = l == 7 ? x : a7;
     }
 };
 
@@ -84,7 +97,7 @@ __global__ __launch_bounds__(kNestThreads) void linear_tile_nested_kernel(const 
     const uint32_t chain = (uint32_t)(a.chain0 + k);
     const int d = a.d, E = a.E;
     /* a local copy: indexing the argument block with a run-time level would put it in scratch */
-    const PerLevel<int> steps = {a.steps[0], a.steps[1], a.steps[2], a.steps[3]};
+    const PerLevel<int> steps = {a.steps[0], a.steps[1], a.steps[2], a.steps[3], a.steps[4], a.steps[5], a.steps[6], a.steps[7]};
     const uint32_t pair_of_g = (g == 0) ? 0u : (g == 1) ? 2u : (g == 2) ? 1u : 3u;
     /* parked state of level l >= 1: this lane's column */
     auto park = [&](int l) { return a.x_tiled + (((uint64_t)(l - 1) * nct + (wave_live ? tile : 0)) * KS) * 64 + lane; };
@@ -100,10 +113,10 @@ __global__ __launch_bounds__(kNestThreads) void linear_tile_nested_kernel(const 
 #pragma unroll
         for (int s = 0; s < KS; ++s) top[s * 64] = z[s];
     }
-    PerLevel<double> lpP = {0.0, 0.0, 0.0, 0.0}, lpQ = {0.0, 0.0, 0.0, 0.0};
+    PerLevel<double> lpP = {}, lpQ = {};
     lpP.set(E - 1, live ? a.lp[k] : 0.0);
     lpQ.set(E - 1, live ? a.lpc[k] : 0.0);
-    PerLevel<uint64_t> lacc = {0, 0, 0, 0};
+    PerLevel<uint64_t> lacc = {};
     for (int e = 0; e < E - 1; ++e)
         if (live) lacc.set(e, a.level_acc[(uint64_t)e * a.K + k]);
     uint64_t accepted = live ? a.acc_count[k] : 0;
@@ -178,7 +191,7 @@ __global__ __launch_bounds__(kNestThreads) void linear_tile_nested_kernel(const 
 #pragma unroll 1
     for (uint32_t n = 0; n < a.nsteps; ++n) {
         uint64_t t = (a.t0 + n) * a.cost_top;
-        PerLevel<int> cnt = {0, 0, 0, 0};
+        PerLevel<int> cnt = {};
         int from = E - 2; /* the levels below the top are entered afresh: MLDAProposal.generate_proposal, mlda.py:100-116 */
         bool acc_top = false;
 #pragma unroll 1
