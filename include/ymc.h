@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define YMC_ABI_VERSION 3
+#define YMC_ABI_VERSION 4
 
 typedef enum ymc_status {
     YMC_OK = 0,
@@ -50,7 +50,7 @@ typedef enum ymc_density_kind {
      * (statistics/gaussian.py:19-24); diagonal covariances */
     YMC_DENSITY_POSTERIOR_LINEAR = 3,
     /* the same over LotkaVolterraSolver (test/testSetup.py:61-141) with the
-     * ODE integrated by fixed-step RK4 */
+     * ODE integrated by fixed-step RK4 or, with lv_rtol > 0, adaptively */
     YMC_DENSITY_POSTERIOR_LV = 4
 } ymc_density_kind;
 
@@ -92,6 +92,14 @@ typedef struct ymc_density_desc {
      * prior. */
     const double *noise_chol_inv;
     const double *prior_chol_inv;
+    /* POSTERIOR_LV: lv_rtol > 0 integrates with the adaptive Dormand-Prince 5(4) pair (ymc_lv_dp45_solve,
+     * csrc/ymc_numerics.h; the reference hands its `rtol` to scipy's adaptive solve_ivp, testSetup.py:124-126) and
+     * rk4_steps is ignored: each component's local error within lv_atol + lv_rtol |y|.  0 = rk4_steps steps of
+     * classical RK4 (which overflows where the dynamics outrun its step, e.g. at the starting point of
+     * example_inference_lotkaVolterra_singleLevel.py:106).  A solve that fails counts as a non-finite forward
+     * value: the proposal is rejected and the chain flagged (YMC_CHAIN_NONFINITE). */
+    double lv_rtol;
+    double lv_atol;
 } ymc_density_desc;
 
 typedef enum ymc_method {

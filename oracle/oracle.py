@@ -37,6 +37,7 @@ class _Density(C.Structure):
         ("rk4_steps", C.c_int32), ("likelihood_only", C.c_int32),
         ("lin_dbar", _dp), ("lin_nprec", _dp), ("lin_const", C.c_double),
         ("noise_linv", _dp), ("prior_linv", _dp),
+        ("lv_rtol", C.c_double), ("lv_atol", C.c_double),
     ]
 
 
@@ -175,12 +176,13 @@ def posterior_linear(A, b, data, noise_precision, prior_mean, prior_precision):
 
 
 def posterior_lv(design, t_final, alpha, gamma, rk4_steps, data, noise_precision, prior_mean,
-                 prior_precision):
+                 prior_precision, rtol=0.0, atol=1e-6):
+    """rtol > 0: the adaptive integrator (ymc_lv_dp45_solve) instead of rk4_steps steps of RK4."""
     design = _f64(design)
     p = _posterior_common(POST_LV, 2, data, noise_precision, prior_mean, prior_precision)
     assert design.shape == (p["n_data"], 2) and p["data_dim"] == 2
     p.update(design=design, t_final=float(t_final), alpha=float(alpha), gamma=float(gamma),
-             rk4_steps=int(rk4_steps))
+             rk4_steps=int(rk4_steps), lv_rtol=float(rtol), lv_atol=float(atol) if rtol > 0 else 0.0)
     return p
 
 
@@ -201,7 +203,7 @@ def _lower(p):
             arr = _f64(p[name])
             keep.append(arr)
             setattr(d, name, _ptr(arr))
-    for name in ("log_norm", "variance", "t_final", "alpha", "gamma"):
+    for name in ("log_norm", "variance", "t_final", "alpha", "gamma", "lv_rtol", "lv_atol"):
         if name in p:
             setattr(d, name, p[name])
     for name in ("n_data", "data_dim", "rk4_steps", "likelihood_only"):

@@ -79,6 +79,8 @@ typedef struct ymo_density {
     /* dense noise / prior covariance (DenseCovarianceMatrix, covariance.py:69-94): the inverse of its lower
      * Cholesky factor, or NULL for the diagonal covariance above (ymc_whitened_norm_sq, ymc_numerics.h) */
     const double *noise_linv, *prior_linv;
+    /* POST_LV: lv_rtol > 0 = the adaptive integrator (ymc_lv_dp45_solve, ymc_numerics.h) instead of RK4 */
+    double lv_rtol, lv_atol;
 } ymo_density;
 
 /* ---------------------------------------------------------------------- */
@@ -204,8 +206,14 @@ static int ymo_forward_lv(const ymo_density *p, const double *theta, double *F)
     int bad = 0;
     for (int32_t n = 0; n < p->n_data; ++n) {
         double x = p->design[2 * n], y = p->design[2 * n + 1];
-        for (int32_t s = 0; s < p->rk4_steps; ++s) {
-            ymc_lv_rk4_step(&x, &y, alpha, beta, gamma, delta, h, h2, h6); /* ymc_numerics.h */
+        if (p->lv_rtol > 0.0) {
+            if (!ymc_lv_dp45_solve(&x, &y, alpha, beta, gamma, delta, p->t_final, p->lv_rtol, p->lv_atol,
+                                   YMC_LV_MAX_ATTEMPTS))
+                x = y = NAN;
+        } else {
+            for (int32_t s = 0; s < p->rk4_steps; ++s) {
+                ymc_lv_rk4_step(&x, &y, alpha, beta, gamma, delta, h, h2, h6); /* ymc_numerics.h */
+            }
         }
         F[2 * n] = x;
         F[2 * n + 1] = y;

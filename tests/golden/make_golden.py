@@ -473,6 +473,58 @@ def fixture_f4():
           "LSODA vs DOP853:", np.abs(f_ref - f_tight).max())
 
 
+def fixture_f24():
+    """example_inference_lotkaVolterra_singleLevel.py as shipped -- T = 10, ten design rows in [0.5, 1.5]^2, noise variance
+    0.04, prior N(0, 1.4 I), proposal variance 0.15 -- FROM ITS OWN STARTING POINT (-7, 2.8) (:106), where the predator
+    first grows at rate 16 and RK4 in 50 steps overflows: the reference's loop with the build's ADAPTIVE integrator
+    (ymc_lv_dp45_solve at the example's rtol 1e-4) as its solver plug-in; the forward map there and around the
+    posterior bulk against the reference's LSODA and a tight DOP853."""
+    cfg = {'T': 10., 'alpha': 0.8, 'gamma': 0.4, 'nData': 10, 'dataDim': 2, 'solver': 'LSODA', 'rtol': 1e-4}
+    _, uu = oracle.rng_fill(2424, 0, 20, 0, 1, 2)
+    design = 0.5 + uu[0, :20].reshape(10, 2)
+    ref_solver = LotkaVolterraSolver(design, cfg)
+    tight = LotkaVolterraSolver(design, dict(cfg, solver='DOP853', rtol=1e-12))
+    zz, _ = oracle.rng_fill(2425, 0, 24, 0, 1, 2, uniforms=False)
+    thetas = np.concatenate([np.log(np.array([0.4, 0.6])) + 0.3 * zz[0], [[-7.0, 2.8], [-6.5, 2.5], [-3.0, 3.0], [1.5, -2.0]]])
+    f_ref = np.empty((len(thetas), 10, 2))
+    f_tight = np.empty((len(thetas), 10, 2))
+    for i, th in enumerate(thetas):
+        prm = LotkaVolterraParameter.from_coefficient(th)
+        for s_, out in ((ref_solver, f_ref), (tight, f_tight)):
+            s_.interpolate(prm)
+            s_.invoke()
+            assert s_.status == EvaluationStatus.SUCCESS
+            out[i] = s_.evaluation
+    tight.interpolate(LotkaVolterraParameter.from_interpolation(np.array([0.4, 0.6])))
+    tight.invoke()
+    noise_var = 0.04
+    zn, _ = oracle.rng_fill(2426, 0, 10, 0, 1, 2, uniforms=False)
+    data = tight.evaluation + np.sqrt(noise_var) * zn[0]
+    prior_mean, prior_var = np.zeros(2), 1.4
+    rtol, atol = 1e-4, 1e-6
+    problem = oracle.posterior_lv(design, cfg['T'], cfg['alpha'], cfg['gamma'], 50, data,
+                                  np.reciprocal(np.full(2, noise_var)), prior_mean, np.reciprocal(np.full(2, prior_var)),
+                                  rtol=rtol, atol=atol)
+    like = AdditiveGaussianNoiseLikelihood(Data(data), ForwardModel(RK4LotkaVolterraSolver(problem)),
+                                           CentredGaussianNoise(IIDCovarianceMatrix(2, noise_var)))
+    prior = Gaussian(LotkaVolterraParameter.from_coefficient(prior_mean.copy()), IIDCovarianceMatrix(2, prior_var))
+    model = BayesianRegressionModel(like, prior)
+    seed, K, n = 20250124, 8, 500
+    prop_cov = IIDCovarianceMatrix(2, 0.15)
+    x0 = np.array([-7.0, 2.8])
+    traj, acc, lp = run_mrw_model(model, seed, K, n, prop_cov, x0, make_param=LotkaVolterraParameter.from_coefficient)
+    np.savez_compressed(
+        os.path.join(HERE, "f24_lotka_volterra_adaptive.npz"), seed=seed, n_states=n, design=design, t_final=cfg['T'],
+        alpha=cfg['alpha'], gamma=cfg['gamma'], rtol=rtol, atol=atol, data=data,
+        noise_precision=np.reciprocal(np.full(2, noise_var)), prior_mean=prior_mean,
+        prior_precision=np.reciprocal(np.full(2, prior_var)), sigma=sigma_of(prop_cov), x0=np.tile(x0, (K, 1)),
+        thetas=thetas, forward_lsoda_rtol1e4=f_ref, forward_dop853_rtol1e12=f_tight, traj=traj, acc=acc, logpost=lp)
+    f = oracle.forward(problem, thetas).reshape(-1, 10, 2)
+    print("F24", acc.mean(), "final states", traj[-1, :3], "adaptive vs DOP853 (rel):",
+          (np.abs(f - f_tight) / (1e-3 + np.abs(f_tight))).max(), "LSODA vs DOP853 (rel):",
+          (np.abs(f_ref - f_tight) / (1e-3 + np.abs(f_tight))).max())
+
+
 def fixture_f7():
     """Two-level delayed acceptance over a model hierarchy: the shipped linear example
     (example_inference_linearModel_twoLevel.py:24-177, vanilla MLDA, sub-chain length 5)."""
@@ -1143,7 +1195,7 @@ def fixture_f18(name="f18_mlda_nested2_linear_d128.npz", d=128, n_models=3, seed
 
 def main():
     which = sys.argv[1:] or ["f1", "f2", "f2b", "f3", "f3b", "f4", "f5", "f7", "f8", "f9", "f10", "f11", "f12", "f13",
-                             "f14", "f15", "f16", "f17", "f18", "f19", "f20", "f21", "f22", "f23"]
+                             "f14", "f15", "f16", "f17", "f18", "f19", "f20", "f21", "f22", "f23", "f24"]
     if "f1" in which:
         fixture_f1()
     if "f2" in which:
@@ -1197,6 +1249,8 @@ def main():
                     sub_lengths=(2, 2, 3, 2, 1, 2, 2, 2), perturb=0.015, prop_var=6e-3)
     if "f23" in which:
         fixture_f23()
+    if "f24" in which:
+        fixture_f24()
     if "f12" in which:
         fixture_f12()
         fixture_f12("f12b_aem_linear_noheuristic.npz", use_heuristic=False, seed=20250113, min_data=5, K=12,

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(ffi):
 def test_struct_layouts_match_the_header(ffi):
     import ctypes as C
     # sizes computed from the header's field lists (LP64)
-    assert C.sizeof(ffi.DensityDesc) == 8 + 2 * 8 + 16 + 8 + 7 * 8 + 24 + 8 + 2 * 8
+    assert C.sizeof(ffi.DensityDesc) == 8 + 2 * 8 + 16 + 8 + 7 * 8 + 24 + 8 + 2 * 8 + 2 * 8
     assert C.sizeof(ffi.ProblemDesc) == 8 + 2 * C.sizeof(ffi.DensityDesc) + 8 + 8 + 8 + 8 + 3 * 8 + 8
     assert C.sizeof(ffi.RunDesc) == 7 * 8
     assert C.sizeof(ffi.DeviceInfo) == 128 + 64 + 8 + 8

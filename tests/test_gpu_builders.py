@@ -325,6 +325,53 @@ def test_lotka_volterra_inference_through_the_builder(proposal):
     assert np.array_equal(states[1:], e.advance(999)["traj"])
 
 
+def test_lotka_volterra_example_from_its_own_start_with_the_adaptive_integrator_f24(golden):
+    """example_inference_lotkaVolterra_singleLevel.py:29-106 through the builders with 'adaptive': True in the solver's
+    config: from theta = (-7, 2.8) the chains are those of the reference's loop (fixture F24), no chain is flagged;
+    without it (RK4 in 50 steps) the start itself is a non-finite evaluation and every chain is flagged."""
+    import yagremcmc_amd.test.testSetup as setup
+    from yagremcmc_amd.chain.method.mrw import MRWBuilder
+    from yagremcmc_amd.model.forwardModel import ForwardModel
+    from yagremcmc_amd.statistics.bayesModel import BayesianRegressionModel
+    from yagremcmc_amd.statistics.covariance import IIDCovarianceMatrix
+    from yagremcmc_amd.statistics.data import Data
+    from yagremcmc_amd.statistics.gaussian import Gaussian
+    from yagremcmc_amd.statistics.likelihood import AdditiveGaussianNoiseLikelihood
+    from yagremcmc_amd.statistics.noise import CentredGaussianNoise
+    g = golden("f24_lotka_volterra_adaptive.npz")
+    n, K = int(g["n_states"]), g["x0"].shape[0]
+    config = {'T': 10., 'alpha': 0.8, 'gamma': 0.4, 'nData': 10, 'dataDim': 2, 'solver': 'LSODA', 'rtol': 1e-4}
+    with pytest.raises(ValueError, match="exclude"):
+        setup.LotkaVolterraSolver(np.asarray(g["design"]), dict(config, adaptive=True, rk4Steps=80))
+
+    def sampler(cfg):
+        solver = setup.LotkaVolterraSolver(np.asarray(g["design"]), cfg)
+        like = AdditiveGaussianNoiseLikelihood(Data(np.asarray(g["data"])), ForwardModel(solver),
+                                               CentredGaussianNoise(IIDCovarianceMatrix(2, 0.04)))
+        prior = Gaussian(setup.LotkaVolterraParameter.from_coefficient(np.zeros(2)), IIDCovarianceMatrix(2, 1.4))
+        b = MRWBuilder()
+        b.proposalCovariance = IIDCovarianceMatrix(2, 0.15)
+        b.bayesModel = BayesianRegressionModel(like, prior)
+        b.nChains, b.seed, b.recordLogPosterior = K, int(g["seed"]), True
+        return b.build_method(), solver
+
+    mc, solver = sampler(dict(config, adaptive=True))
+    init = setup.LotkaVolterraParameter.from_coefficient(np.array([-7.0, 2.8]))
+    mc.run(n, init, verbose=False)
+    assert np.array_equal(mc.chain.trajectory, g["traj"]) and np.array_equal(mc.accept_decisions, g["acc"])
+    assert np.abs(mc.log_posterior - g["logpost"]).max() <= 1e-12 * np.abs(g["logpost"]).max()
+    assert (mc.chain_status == 0).all()
+    # the forward map alone, and a trajectory for plotting (testSetup.py:142-162)
+    f = ForwardModel(solver).evaluate(init)
+    tight = g["forward_dop853_rtol1e12"][24]
+    assert np.array_equal(g["thetas"][24], [-7.0, 2.8]) and (np.abs(f - tight) / (1e-3 + np.abs(tight))).max() < 1e-2
+    t, y = solver.full_solution(init, np.asarray(g["design"])[0])
+    assert t.shape == (101,) and y.shape == (2, 101) and np.array_equal(y[:, -1], f[0]) and np.isfinite(y).all()
+    rk4, _ = sampler(config)
+    rk4.run(20, init, verbose=False)
+    assert (rk4.log_posterior[0] == -np.inf).all() and (rk4.chain_status != 0).any()
+
+
 def test_reference_style_objects_are_accepted_by_duck_typing():
     """A user who keeps the reference's own plug-in instances: recognised by class
     name + attributes (here: stand-ins with the reference's attribute names)."""

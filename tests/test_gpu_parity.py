@@ -215,6 +215,84 @@ def test_f4_lotka_volterra(ffi, ctx, golden):
     assert np.array_equal(lp, lpo) and np.array_equal(st, sto)
 
 
+def _f24_pair(ffi, g, rtol=None, steps=50):
+    rtol = float(g["rtol"]) if rtol is None else rtol
+    low = _posterior_low(ffi, ffi.POSTERIOR_LV, 2, g, design=np.asarray(g["design"]), t_final=float(g["t_final"]),
+                         alpha=float(g["alpha"]), gamma=float(g["gamma"]), rk4_steps=steps, lv_rtol=rtol,
+                         lv_atol=float(g["atol"]) if rtol > 0 else 0.0)
+    p = o.posterior_lv(g["design"], float(g["t_final"]), float(g["alpha"]), float(g["gamma"]), steps, g["data"],
+                       g["noise_precision"], g["prior_mean"], g["prior_precision"], rtol=rtol, atol=float(g["atol"]))
+    return low, p
+
+
+def test_f24_adaptive_lotka_volterra_from_the_examples_own_start(ffi, ctx, golden):
+    """The reference's Lotka-Volterra example from its own starting point (-7, 2.8), integrated adaptively
+    (ymc_lv_dp45_solve): chains == the reference's loop with that integrator plugged in == oracle, bit for bit; the
+    forward map == oracle's at every probe, including parameters where the solve gives up."""
+    from yagremcmc_amd import lowering
+    g = golden("f24_lotka_volterra_adaptive.npz")
+    n = int(g["n_states"])
+    low, p = _f24_pair(ffi, g)
+    dev = _device_run(ffi, ctx, low, g["sigma"], g["x0"], int(g["seed"]), n - 1, splits=3)
+    e = o.Ensemble(p, g["sigma"], g["x0"], int(g["seed"]))
+    _same_as_oracle(dev, e, e.advance(n - 1))
+    _same_as_reference(dev, g)
+    prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, g["sigma"])
+    probes = np.concatenate([g["thetas"], [[40.0, 40.0], [-30.0, 5.0], [5.0, -30.0]]])
+    assert np.array_equal(prob.forward(probes), o.forward(p, probes), equal_nan=True)
+    lp, st = prob.logdensity(probes)
+    lpo, sto = o.logdensity(p, probes)
+    assert np.array_equal(lp, lpo) and np.array_equal(st, sto) and st[-3] != 0 and (st[:len(g["thetas"])] == 0).all()
+    for rtol in (1e-2, 1e-7, 1e-11):
+        low2, p2 = _f24_pair(ffi, g, rtol)
+        prob2 = lowering.make_problem(ctx, ffi.METHOD_MRW, low2, g["sigma"])
+        assert np.array_equal(prob2.forward(g["thetas"]), o.forward(p2, g["thetas"]))
+
+
+@pytest.mark.parametrize("method", ["mlda2", "nested", "pcn"])
+def test_adaptive_lotka_volterra_levels_vs_oracle(ffi, ctx, golden, method):
+    """Levels that differ in the tolerance of the adaptive integrator (the reference's two-level example separates its
+    levels by scipy's rtol alone), and one adaptive level under a fixed-step one; pCN on the adaptive likelihood."""
+    from yagremcmc_amd import lowering
+    g = golden("f24_lotka_volterra_adaptive.npz")
+    K = 80
+    rng = np.random.default_rng(24)
+    x0 = np.log([0.4, 0.6]) + 0.2 * rng.normal(size=(K, 2))
+    sigma = np.array([0.08, 0.06])
+    if method == "mlda2":
+        (lf, pf), (lc, pc) = _f24_pair(ffi, g, 1e-6), _f24_pair(ffi, g, 1e-2)
+        prob = lowering.make_problem(ctx, ffi.METHOD_MLDA2, lf, sigma, surrogate=lc, sub_chain_length=3)
+        run = ffi.Run(prob, 5, K, x0, 30, ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT | ffi.RECORD_LOGPOST, chain_offset=3)
+        run.advance(13)
+        run.advance(17)
+        e = o.Ensemble(pf, sigma, x0, 5, chain0=3, surrogate=pc, sub_chain_length=3)
+        out = e.advance(30)
+        assert np.array_equal(run.trajectory(), out["traj"]) and np.array_equal(run.accept(), out["acc"])
+        assert np.array_equal(run.logpost(), out["logpost"]) and 0.05 < out["acc"].mean() < 0.95
+    elif method == "nested":
+        lows = [_f24_pair(ffi, g, 1e-2), _f24_pair(ffi, g, 0.0, steps=12), _f24_pair(ffi, g, 1e-4), _f24_pair(ffi, g, 1e-3),
+                _f24_pair(ffi, g, 1e-7)]
+        subs = [2, 3, 2, 2]
+        dev = _nested_device_run(ffi, ctx, lows[-1][0], [l for l, _ in lows[:-1]], subs, sigma, x0, 99, 12, splits=2, chain0=5)
+        P, Q, steps = o.nested_levels([q for _, q in lows[:-1]], subs, lows[-1][1])
+        e = o.NestedEnsemble(P, Q, steps, sigma, x0, 99, chain0=5)
+        out = e.advance(12)
+        _same_as_oracle(dev, e, out)
+        assert np.array_equal(dev["level_acc"], e.level_acc)
+    else:
+        low, p = _f24_pair(ffi, g, 1e-5)
+        low.desc.likelihood_only = 1
+        p["likelihood_only"] = 1
+        psig = 1.0 / np.sqrt(np.asarray(g["prior_precision"]))
+        x0 = x0 * 0.3
+        prob = lowering.make_problem(ctx, ffi.METHOD_PCN, low, psig, pcn_step_size=0.02)
+        run = ffi.Run(prob, 8, K, x0, 40, ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT, chain_offset=0)
+        run.advance(40)
+        e = o.Ensemble(p, psig, x0, 8, pcn_step_size=0.02)
+        out = e.advance(40)
+        assert np.array_equal(run.trajectory(), out["traj"]) and np.array_equal(run.accept(), out["acc"])
+
+
 def test_f5_two_level(ffi, ctx, golden):
     g = golden("f5_mlda2_2d.npz")
     n, S = int(g["n_states"]), int(g["S"])

@@ -124,6 +124,50 @@ def test_f4_nonfinite_forward_is_rejected_and_flagged(golden):
     assert st[0] & o.STATUS_NONFINITE and lp[0] == -np.inf
 
 
+def _f24_problem(g, rtol=None):
+    return o.posterior_lv(g["design"], float(g["t_final"]), float(g["alpha"]), float(g["gamma"]), 50, g["data"],
+                          g["noise_precision"], g["prior_mean"], g["prior_precision"],
+                          rtol=float(g["rtol"]) if rtol is None else rtol, atol=float(g["atol"]))
+
+
+def test_f24_adaptive_lotka_volterra_from_the_examples_own_start(golden):
+    """example_inference_lotkaVolterra_singleLevel.py:29-106 as shipped, from theta = (-7, 2.8): the adaptive
+    integrator (ymc_lv_dp45_solve at the example's rtol 1e-4) is as close to a tight DOP853 solution as the
+    reference's LSODA at that rtol -- also at the start, where RK4 in 50 steps overflows --, and the reference's LOOP
+    run with it as its solver plug-in is reproduced decision for decision; no chain is flagged and all of them reach
+    the posterior bulk."""
+    g = golden("f24_lotka_volterra_adaptive.npz")
+    n = int(g["n_states"])
+    p = _f24_problem(g)
+    f = o.forward(p, g["thetas"]).reshape(-1, 10, 2)
+    tight, lsoda = g["forward_dop853_rtol1e12"], g["forward_lsoda_rtol1e4"]
+    rel = lambda a: (np.abs(a - tight) / (1e-3 + np.abs(tight))).max()
+    assert rel(f) < 1e-2 and rel(f) < 1.5 * rel(lsoda)
+    # error follows the tolerance (down to atol = 1e-6 on the small components)
+    assert rel(o.forward(_f24_problem(g, 1e-7), g["thetas"]).reshape(-1, 10, 2)) < 1e-3 * 1.0
+    assert rel(o.forward(_f24_problem(g, 1e-10), g["thetas"]).reshape(-1, 10, 2)) < 1e-3
+    e = o.Ensemble(p, g["sigma"], g["x0"], int(g["seed"]))
+    out = e.advance(n - 1)
+    _check(out, g, n)
+    assert (e.status == 0).all()
+    assert np.abs(out["traj"][-1] - np.log([0.4, 0.6])).max() < 0.5
+    # the fixed-step integrator at the same start: non-finite, flagged
+    rk4 = o.posterior_lv(g["design"], 10.0, 0.8, 0.4, 50, g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+    lp, st = o.logdensity(rk4, g["x0"][:1])
+    assert st[0] & o.STATUS_NONFINITE and lp[0] == -np.inf
+
+
+def test_adaptive_lotka_volterra_gives_up_loudly():
+    """A right-hand side the step cannot follow (rates of e^40) ends the solve: NaN forward values, the density
+    -inf and the evaluation flagged -- never a silently wrong number, never an endless loop."""
+    design = np.array([[1.0, 1.0], [0.5, 1.5]])
+    p = o.posterior_lv(design, 10.0, 0.8, 0.4, 50, np.ones((2, 2)), np.ones(2), np.zeros(2), np.ones(2), rtol=1e-6)
+    f = o.forward(p, np.array([[40.0, 40.0]]))
+    assert np.isnan(f).all()
+    lp, st = o.logdensity(p, np.array([[40.0, 40.0], [0.0, 0.0]]))
+    assert lp[0] == -np.inf and st[0] & o.STATUS_NONFINITE and np.isfinite(lp[1]) and st[1] == 0
+
+
 def test_f5_two_level_delayed_acceptance(golden):
     g = golden("f5_mlda2_2d.npz")
     n, S = int(g["n_states"]), int(g["S"])

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # YMC_LIBRARY: another build of the same library (the host-sanitizer build of tests/test_sanitizers.py)
 LIB_PATH = os.environ.get("YMC_LIBRARY") or os.path.join(_HERE, "libymc.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # ymc_status
 OK, ERR_INVALID, ERR_DEVICE, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_COMM = 0, -1, -2, -3, -4, -5
@@ -55,6 +55,7 @@ class DensityDesc(C.Structure):
         ("t_final", C.c_double), ("alpha", C.c_double), ("gamma", C.c_double),
         ("rk4_steps", C.c_int32), ("likelihood_only", C.c_int32),
         ("noise_chol_inv", _dp), ("prior_chol_inv", _dp),
+        ("lv_rtol", C.c_double), ("lv_atol", C.c_double),
     ]
 
 

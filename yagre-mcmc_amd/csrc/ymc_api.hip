@@ -338,7 +338,12 @@ int lower_density(ymc_ctx *ctx, const ymc_density_desc &in, DensityHost &out, in
             }
         } else {
             if (d != 2 || m != 2) return fail(YMC_ERR_INVALID, "Lotka-Volterra needs dim 2 and data_dim 2");
-            if (in.rk4_steps < 1) return fail(YMC_ERR_INVALID, "rk4_steps must be positive");
+            if (in.lv_rtol < 0.0 || !std::isfinite(in.lv_rtol) || (in.lv_rtol > 0.0 && !(in.lv_atol >= 0.0)) ||
+                !std::isfinite(in.lv_atol))
+                return fail(YMC_ERR_INVALID, "lv_rtol and lv_atol must be finite and not negative");
+            if (in.lv_rtol > 0.0 && in.lv_rtol < 1e-13)
+                return fail(YMC_ERR_INVALID, "lv_rtol %g is below what double precision resolves (1e-13)", in.lv_rtol);
+            if (in.lv_rtol == 0.0 && in.rk4_steps < 1) return fail(YMC_ERR_INVALID, "rk4_steps must be positive");
             if (!std::isfinite(in.t_final) || !std::isfinite(in.alpha) || !std::isfinite(in.gamma))
                 return fail(YMC_ERR_INVALID, "Lotka-Volterra constants must be finite");
             YMC_TRY(copy_array(out.design, in.design, nd * 2, "design"));
@@ -384,6 +389,8 @@ DensityDev<D> device_view(const DensityHost &h)
     v.n_data = h.d.n_data;
     v.data_dim = h.d.data_dim;
     v.rk4_steps = h.d.rk4_steps;
+    v.lv_rtol = h.d.lv_rtol;
+    v.lv_atol = h.d.lv_rtol > 0.0 ? h.d.lv_atol : 0.0;
     v.likelihood_only = h.d.likelihood_only;
     const double *base = h.dev.as<double>();
     if (base) {
@@ -467,6 +474,7 @@ int choose_lv_rows(const ymc_run *r)
     if (p->kind != YMC_DENSITY_POSTERIOR_LV || p->method != YMC_METHOD_MRW) return 0;
     const int nd = p->tgt.d.n_data;
     if (nd < 2 || nd > 64) return 0;
+    if (p->tgt.d.lv_rtol > 0.0) return 0; /* the adaptive integrator runs in the lane-per-chain kernel only */
     if (const char *env = std::getenv("YMC_LV_ROWS")) return env[0] == '1';
     const uint64_t simds = 4ull * (uint64_t)r->ctx->prop.multiProcessorCount;
     return (r->K + 63) / 64 < simds; /* measured: 2.5x at 16 384 chains, break-even near 65 536 */

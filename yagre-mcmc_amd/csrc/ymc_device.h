@@ -40,6 +40,8 @@ struct DensityDev {
     double lik_const;
     /* dense noise / prior covariance: inverse Cholesky factors (null: diagonal), ymc_whitened_norm_sq */
     const double *noise_linv, *prior_linv;
+    /* POSTERIOR_LV: lv_rtol > 0 = the adaptive integrator (ymc_lv_dp45_solve) instead of rk4_steps steps of RK4 */
+    double lv_rtol, lv_atol;
 };
 
 /* ymc_whitened_norm_sq for a register-resident residual (same operations in the same order) */
@@ -169,8 +171,16 @@ struct Density<YMC_DENSITY_POSTERIOR_LINEAR, D> {
     }
 };
 
+/* one design row of the Lotka-Volterra forward map by the adaptive integrator; a failed solve reads as NaN */
+__device__ __forceinline__ void ymc_lv_solve_adaptive(double &x, double &y, double alpha, double beta, double gamma,
+                                                      double delta, double t_final, double rtol, double atol)
+{
+    if (!ymc_lv_dp45_solve(&x, &y, alpha, beta, gamma, delta, t_final, rtol, atol, YMC_LV_MAX_ATTEMPTS))
+        x = y = __builtin_nan("");
+}
+
 /* the same with the Lotka-Volterra forward map (testSetup.py:101-141),
- * integrated by rk4_steps steps of classical RK4 per design row */
+ * integrated by rk4_steps steps of classical RK4 per design row, or adaptively (lv_rtol > 0) */
 template <int D>
 struct Density<YMC_DENSITY_POSTERIOR_LV, D> {
     static __device__ __forceinline__ double eval(const DensityDev<D> &p, const double (&th)[D], uint32_t &st)
@@ -186,14 +196,18 @@ struct Density<YMC_DENSITY_POSTERIOR_LV, D> {
         bool bad = false;
         for (int n = 0; n < p.n_data; ++n) {
             double x = p.design[2 * n], y = p.design[2 * n + 1];
-            int s = 0;
+            if (p.lv_rtol > 0.0) {
+                ymc_lv_solve_adaptive(x, y, alpha, beta, gamma, delta, p.t_final, p.lv_rtol, p.lv_atol);
+            } else {
+                int s = 0;
 #pragma unroll 1
-            for (; s + 5 <= p.rk4_steps; s += 5) { /* five steps per iteration: the loop branch is a visible bubble */
+                for (; s + 5 <= p.rk4_steps; s += 5) { /* five steps per iteration: the loop branch is a visible bubble */
 #pragma unroll
-                for (int r = 0; r < 5; ++r) ymc_lv_rk4_step(&x, &y, alpha, beta, gamma, delta, h, h2, h6);
-            }
+                    for (int r = 0; r < 5; ++r) ymc_lv_rk4_step(&x, &y, alpha, beta, gamma, delta, h, h2, h6);
+                }
 #pragma unroll 1
-            for (; s < p.rk4_steps; ++s) ymc_lv_rk4_step(&x, &y, alpha, beta, gamma, delta, h, h2, h6);
+                for (; s < p.rk4_steps; ++s) ymc_lv_rk4_step(&x, &y, alpha, beta, gamma, delta, h, h2, h6);
+            }
             bad = bad || !ymc_finite(x) || !ymc_finite(y);
             double r[2] = {x - p.data[2 * n], y - p.data[2 * n + 1]};
             total = total + (p.noise_linv ? ymc_whitened_norm_sq_reg<2>(p.noise_linv, r, 2)

@@ -670,8 +670,12 @@ __global__ __launch_bounds__(kBlock) void forward_lv_kernel(const DensityDev<2> 
     const double h = p.t_final / (double)p.rk4_steps, h2 = 0.5 * h, h6 = h / 6.0;
     for (int r = 0; r < p.n_data; ++r) {
         double x = p.design[2 * r], y = p.design[2 * r + 1];
-        for (int s = 0; s < p.rk4_steps; ++s) {
-            ymc_lv_rk4_step(&x, &y, p.alpha, beta, p.gamma, delta, h, h2, h6);
+        if (p.lv_rtol > 0.0) {
+            ymc_lv_solve_adaptive(x, y, p.alpha, beta, p.gamma, delta, p.t_final, p.lv_rtol, p.lv_atol);
+        } else {
+            for (int s = 0; s < p.rk4_steps; ++s) {
+                ymc_lv_rk4_step(&x, &y, p.alpha, beta, p.gamma, delta, h, h2, h6);
+            }
         }
         out[(i * p.n_data + r) * 2] = x;
         out[(i * p.n_data + r) * 2 + 1] = y;

@@ -587,4 +587,72 @@ YMC_FN void ymc_lv_rk4_step(double *x, double *y, double alpha, double beta, dou
     *y = ymc_fma(h6, ymc_fma(2.0, k2y, k1y) + ymc_fma(2.0, k3y, k4y), *y);
 }
 
+/* The same flow integrated adaptively over [0, T]: the Dormand-Prince 5(4) pair (the tableau of scipy's RK45;
+ * the reference's LotkaVolterraSolver hands `method` and `rtol` to scipy.integrate.solve_ivp, testSetup.py:118-141)
+ * with first-same-as-last and a controller that only halves and doubles the step -- every quantity an IEEE sum,
+ * product or fma in a fixed order, so that device and checker agree to the bit.  A step is accepted when every
+ * component's error estimate is within atol + rtol max(|y|, |y_new|); it doubles after a step whose estimate is within
+ * 1/64 of that bound (the estimate scales with h^5: x 32), halves after a rejected one (to a quarter beyond 32 x the
+ * bound).  Returns false -- state unspecified -- when the step has shrunk below T 2^-40 (a singular right-hand side
+ * or a non-finite state) or after max_attempts steps.  Classical RK4 in 50 steps overflows at the reference
+ * example's own starting point, theta = (-7, 2.8), where the predator first grows at rate 16 (h lambda = 3.3). */
+#define YMC_LV_MAX_ATTEMPTS 100000 /* steps, accepted or not, one solve may take */
+
+YMC_FN int ymc_lv_dp45_solve(double *x, double *y, double alpha, double beta, double gamma, double delta, double T,
+                             double rtol, double atol, int max_attempts)
+{
+    const double a21 = 1.0 / 5.0;
+    const double a31 = 3.0 / 40.0, a32 = 9.0 / 40.0;
+    const double a41 = 44.0 / 45.0, a42 = -56.0 / 15.0, a43 = 32.0 / 9.0;
+    const double a51 = 19372.0 / 6561.0, a52 = -25360.0 / 2187.0, a53 = 64448.0 / 6561.0, a54 = -212.0 / 729.0;
+    const double a61 = 9017.0 / 3168.0, a62 = -355.0 / 33.0, a63 = 46732.0 / 5247.0, a64 = 49.0 / 176.0,
+                 a65 = -5103.0 / 18656.0;
+    const double b1 = 35.0 / 384.0, b3 = 500.0 / 1113.0, b4 = 125.0 / 192.0, b5 = -2187.0 / 6784.0, b6 = 11.0 / 84.0;
+    const double e1 = 71.0 / 57600.0, e3 = -71.0 / 16695.0, e4 = 71.0 / 1920.0, e5 = -17253.0 / 339200.0,
+                 e6 = 22.0 / 525.0, e7 = -1.0 / 40.0;
+    const double h_min = T * 0x1p-40, huge = 1.79769313486231570815e308;
+    double u = *x, v = *y, t = 0.0, h = T * 0x1p-7;
+    double k1u, k1v;
+    ymc_lv_flow(u, v, alpha, beta, gamma, delta, &k1u, &k1v);
+    for (int attempt = 0; attempt < max_attempts; ++attempt) {
+        const double left = T - t;
+        const int last = !(h < left);
+        const double hs = last ? left : h;
+        double k2u, k2v, k3u, k3v, k4u, k4v, k5u, k5v, k6u, k6v, k7u, k7v;
+        ymc_lv_flow(ymc_fma(hs, a21 * k1u, u), ymc_fma(hs, a21 * k1v, v), alpha, beta, gamma, delta, &k2u, &k2v);
+        ymc_lv_flow(ymc_fma(hs, ymc_fma(a32, k2u, a31 * k1u), u), ymc_fma(hs, ymc_fma(a32, k2v, a31 * k1v), v), alpha, beta,
+                    gamma, delta, &k3u, &k3v);
+        ymc_lv_flow(ymc_fma(hs, ymc_fma(a43, k3u, ymc_fma(a42, k2u, a41 * k1u)), u),
+                    ymc_fma(hs, ymc_fma(a43, k3v, ymc_fma(a42, k2v, a41 * k1v)), v), alpha, beta, gamma, delta, &k4u, &k4v);
+        ymc_lv_flow(ymc_fma(hs, ymc_fma(a54, k4u, ymc_fma(a53, k3u, ymc_fma(a52, k2u, a51 * k1u))), u),
+                    ymc_fma(hs, ymc_fma(a54, k4v, ymc_fma(a53, k3v, ymc_fma(a52, k2v, a51 * k1v))), v), alpha, beta, gamma,
+                    delta, &k5u, &k5v);
+        ymc_lv_flow(ymc_fma(hs, ymc_fma(a65, k5u, ymc_fma(a64, k4u, ymc_fma(a63, k3u, ymc_fma(a62, k2u, a61 * k1u)))), u),
+                    ymc_fma(hs, ymc_fma(a65, k5v, ymc_fma(a64, k4v, ymc_fma(a63, k3v, ymc_fma(a62, k2v, a61 * k1v)))), v),
+                    alpha, beta, gamma, delta, &k6u, &k6v);
+        const double un = ymc_fma(hs, ymc_fma(b6, k6u, ymc_fma(b5, k5u, ymc_fma(b4, k4u, ymc_fma(b3, k3u, b1 * k1u)))), u);
+        const double vn = ymc_fma(hs, ymc_fma(b6, k6v, ymc_fma(b5, k5v, ymc_fma(b4, k4v, ymc_fma(b3, k3v, b1 * k1v)))), v);
+        ymc_lv_flow(un, vn, alpha, beta, gamma, delta, &k7u, &k7v);
+        const double eu = __builtin_fabs(
+            hs * ymc_fma(e7, k7u, ymc_fma(e6, k6u, ymc_fma(e5, k5u, ymc_fma(e4, k4u, ymc_fma(e3, k3u, e1 * k1u))))));
+        const double ev = __builtin_fabs(
+            hs * ymc_fma(e7, k7v, ymc_fma(e6, k6v, ymc_fma(e5, k5v, ymc_fma(e4, k4v, ymc_fma(e3, k3v, e1 * k1v))))));
+        const double au = __builtin_fabs(u), aun = __builtin_fabs(un), av = __builtin_fabs(v), avn = __builtin_fabs(vn);
+        const double su = ymc_fma(rtol, aun > au ? aun : au, atol), sv = ymc_fma(rtol, avn > av ? avn : av, atol);
+        if (eu <= su && ev <= sv && su <= huge && sv <= huge) { /* false for a NaN or an overflow anywhere */
+            u = un, v = vn, k1u = k7u, k1v = k7v;
+            if (last) {
+                *x = u, *y = v;
+                return 1;
+            }
+            t = t + hs;
+            if (64.0 * eu <= su && 64.0 * ev <= sv) h = 2.0 * h;
+        } else {
+            h = (eu <= 32.0 * su && ev <= 32.0 * sv) ? 0.5 * hs : 0.25 * hs;
+            if (!(h >= h_min)) return 0;
+        }
+    }
+    return 0;
+}
+
 #endif /* YMC_NUMERICS_H */

@@ -176,6 +176,13 @@ def lower_solver(solver, low, rk4_steps=None):
         low.desc.alpha = float(solver.fixedParam_[0])
         low.desc.gamma = float(solver.fixedParam_[1])
         low.desc.rk4_steps = _lv_steps(solver, rk4_steps)
+        if getattr(solver, "adaptive_", False) and not rk4_steps:
+            # the adaptive integrator at the reference's own `rtol` (ymc_lv_dp45_solve; include/ymc.h, lv_rtol)
+            rtol = getattr(solver, "_solverRTol", None)
+            low.desc.lv_rtol = 1e-4 if rtol is None else float(rtol)
+            low.desc.lv_atol = float(getattr(solver, "atol_", 1e-6))
+            if not (low.desc.lv_rtol > 0.0):
+                raise ValueError(f"rtol must be positive, got {low.desc.lv_rtol}")
         return 2, 2
     raise UnsupportedPlugin(
         f"solver {n} has no device lowering (known: ExampleLinearModelSolver, LotkaVolterraSolver); "

@@ -309,11 +309,16 @@ class ExampleLinearModelSolver(_DeviceSolver):
 
 class LotkaVolterraSolver(_DeviceSolver):
     """test/testSetup.py:61-141.  `config` takes the reference's keys (T, alpha, gamma, nData, dataDim,
-    solver, rtol) plus the optional 'rk4Steps': the ensemble integrates with fixed-step classical RK4
-    instead of scipy's adaptive solve_ivp.  Without 'rk4Steps' the step count follows from 'rtol'
+    solver, rtol) plus the optional 'rk4Steps' and 'adaptive': the ensemble integrates with fixed-step classical
+    RK4 instead of scipy's adaptive solve_ivp.  Without 'rk4Steps' the step count follows from 'rtol'
     (lowering.rk4_steps_for_rtol: 50 steps at the reference's default 1e-4, fewer for a looser, more for a
     tighter tolerance), so levels that differ only in 'rtol' stay different; 'solver' (the name of a scipy
-    method) has no counterpart and is recorded only."""
+    method) has no counterpart and is recorded only.
+
+    'adaptive': True integrates with the device's adaptive Dormand-Prince 5(4) pair at the configured 'rtol'
+    (and 'atol', scipy's default 1e-6) instead: the choice for chains that visit parameters whose dynamics outrun
+    a fixed step -- at the starting point of the reference's example, exp(theta) = (9e-4, 16.4), RK4 in 50 steps
+    overflows (the chain would be flagged and every proposal compared with a non-finite value)."""
 
     def __init__(self, design, config):
         super().__init__()
@@ -323,6 +328,10 @@ class LotkaVolterraSolver(_DeviceSolver):
         self.dataShape_ = (int(config['nData']), int(config['dataDim']))
         self._solverMethod = config.get('solver')
         self._solverRTol = config.get('rtol')
+        self.adaptive_ = bool(config.get('adaptive', False))
+        self.atol_ = float(config.get('atol', 1e-6))
+        if self.adaptive_ and config.get('rk4Steps'):
+            raise ValueError("'adaptive' and 'rk4Steps' exclude each other")
         if config.get('rk4Steps'):
             self.rk4Steps_ = int(config['rk4Steps'])
         else:
@@ -361,15 +370,18 @@ class LotkaVolterraSolver(_DeviceSolver):
 
     def full_solution(self, parameter, y0):
         """testSetup.py:142-162: the trajectory from y0 under `parameter`, here on the integrator's own
-        grid t_i = i T / rk4Steps; every state is a forward solve on the device up to t_i.
-        Returns (t (n+1,), y (2, n+1))."""
-        n = self.rk4Steps_
+        grid t_i = i T / rk4Steps (100 points with the adaptive integrator); every state is a forward solve on
+        the device up to t_i.  Returns (t (n+1,), y (2, n+1))."""
+        n = 100 if self.adaptive_ else self.rk4Steps_
         T = self.tBoundary_[1]
         t = np.linspace(0.0, T, n + 1)
         y = np.empty((2, n + 1))
         y[:, 0] = np.asarray(y0, dtype=float)
-        cfg = {'alpha': self.fixedParam_[0], 'gamma': self.fixedParam_[1], 'nData': 1, 'dataDim': 2,
-               'rk4Steps': self.rk4Steps_}
+        cfg = {'alpha': self.fixedParam_[0], 'gamma': self.fixedParam_[1], 'nData': 1, 'dataDim': 2}
+        if self.adaptive_:
+            cfg.update(adaptive=True, rtol=self._solverRTol, atol=self.atol_)
+        else:
+            cfg['rk4Steps'] = self.rk4Steps_
         for i in range(1, n + 1):
             probe = LotkaVolterraSolver(np.asarray(y0, dtype=float).reshape(1, 2), dict(cfg, T=float(t[i])))
             probe.interpolate(parameter)
