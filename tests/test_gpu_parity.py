@@ -225,11 +225,14 @@ def _f24_pair(ffi, g, rtol=None, steps=50):
     return low, p
 
 
-def test_f24_adaptive_lotka_volterra_from_the_examples_own_start(ffi, ctx, golden):
+@pytest.mark.parametrize("rows", ["0", "1"])
+def test_f24_adaptive_lotka_volterra_from_the_examples_own_start(ffi, ctx, golden, monkeypatch, rows):
     """The reference's Lotka-Volterra example from its own starting point (-7, 2.8), integrated adaptively
-    (ymc_lv_dp45_solve): chains == the reference's loop with that integrator plugged in == oracle, bit for bit; the
-    forward map == oracle's at every probe, including parameters where the solve gives up."""
+    (ymc_lv_dp45_solve), one lane per chain and one lane per design row: chains == the reference's loop with that
+    integrator plugged in == oracle, bit for bit; the forward map == oracle's at every probe, including parameters
+    where the solve gives up."""
     from yagremcmc_amd import lowering
+    monkeypatch.setenv("YMC_LV_ROWS", rows)
     g = golden("f24_lotka_volterra_adaptive.npz")
     n = int(g["n_states"])
     low, p = _f24_pair(ffi, g)

@@ -474,7 +474,6 @@ int choose_lv_rows(const ymc_run *r)
     if (p->kind != YMC_DENSITY_POSTERIOR_LV || p->method != YMC_METHOD_MRW) return 0;
     const int nd = p->tgt.d.n_data;
     if (nd < 2 || nd > 64) return 0;
-    if (p->tgt.d.lv_rtol > 0.0) return 0; /* the adaptive integrator runs in the lane-per-chain kernel only */
     if (const char *env = std::getenv("YMC_LV_ROWS")) return env[0] == '1';
     const uint64_t simds = 4ull * (uint64_t)r->ctx->prop.multiProcessorCount;
     return (r->K + 63) / 64 < simds; /* measured: 2.5x at 16 384 chains, break-even near 65 536 */
@@ -515,7 +514,7 @@ int launch_advance(ymc_run *r, uint64_t nsteps)
     a.S = p->S;
     a.lv_rows = choose_lv_rows(r);
     if constexpr (D == 2) {
-        if (a.lv_rows && p->eq_mode == YMC_EQ_EXACT && !p->tgt.d.likelihood_only && !p->chol.p) {
+        if (a.lv_rows && p->eq_mode == YMC_EQ_EXACT && !p->tgt.d.likelihood_only && !p->chol.p && !(p->tgt.d.lv_rtol > 0.0)) {
             /* a number of chain waves that is not a multiple of the SIMD count leaves CUs idle for the tail of the
              * launch: cut it into a whole number of equal pieces per SIMD (mrw_lv_rows_balanced_kernel).  Pieces
              * start on draw rounds; identical results; YMC_LV_PIECES=n forces n pieces (0: never), the tests do */

@@ -435,7 +435,9 @@ __global__ __launch_bounds__(kBlock) void mlda2_kernel(const ChainArgs<D> a)
  */
 /* transitions [n_begin, n_end) of this launch for the cpw chains of chain wave `cwave` (state loaded from and
  * stored to the run's arrays, so a chain wave's launch can be cut into segments run by different waves) */
-template <unsigned REC>
+/* ADAPT: the lane's solve by the adaptive integrator (lv_rtol > 0) -- its own instantiation, the fixed-step kernel's
+ * registers and loop are what configs[3] is measured on */
+template <unsigned REC, bool ADAPT = false>
 __device__ __forceinline__ void lv_rows_segment(const ChainArgs<2> &a, uint64_t cwave, uint32_t n_begin, uint32_t n_end,
                                                 double (*slots)[3])
 {
@@ -497,14 +499,18 @@ __device__ __forceinline__ void lv_rows_segment(const ChainArgs<2> &a, uint64_t 
         double sx = dx0, sy = dy0;
         /* five steps per loop iteration: at ~2.7 waves per SIMD the loop branch of a 30-instruction body is a
          * visible bubble (north_star's 50 steps divide evenly; any other count finishes in the remainder loop) */
-        int s = 0;
+        if constexpr (ADAPT) {
+            ymc_lv_solve_adaptive(sx, sy, alpha, beta, gamma, delta, p.t_final, p.lv_rtol, p.lv_atol);
+        } else {
+            int s = 0;
 #pragma unroll 1
-        for (; s + 5 <= p.rk4_steps; s += 5) {
+            for (; s + 5 <= p.rk4_steps; s += 5) {
 #pragma unroll
-            for (int r = 0; r < 5; ++r) ymc_lv_rk4_step(&sx, &sy, alpha, beta, gamma, delta, h, h2, h6);
-        }
+                for (int r = 0; r < 5; ++r) ymc_lv_rk4_step(&sx, &sy, alpha, beta, gamma, delta, h, h2, h6);
+            }
 #pragma unroll 1
-        for (; s < p.rk4_steps; ++s) ymc_lv_rk4_step(&sx, &sy, alpha, beta, gamma, delta, h, h2, h6);
+            for (; s < p.rk4_steps; ++s) ymc_lv_rk4_step(&sx, &sy, alpha, beta, gamma, delta, h, h2, h6);
+        }
         const int bad_l = (!ymc_finite(sx) || !ymc_finite(sy)) ? 1 : 0;
         const double res[2] = {sx - obs0, sy - obs1};
         const double term = p.noise_linv ? ymc_whitened_norm_sq_reg<2>(p.noise_linv, res, 2)
@@ -550,13 +556,13 @@ __device__ __forceinline__ void lv_rows_segment(const ChainArgs<2> &a, uint64_t 
     }
 }
 
-template <unsigned REC>
+template <unsigned REC, bool ADAPT = false>
 __global__ __launch_bounds__(kBlock) void mrw_lv_rows_kernel(const ChainArgs<2> a)
 {
     ymc_stage_tables();
     __shared__ double draw_slots[kBlock / 64][64][3]; /* per wave and lane: sigma_0 z_0, sigma_1 z_1, u */
     const uint64_t wave = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-    lv_rows_segment<REC>(a, wave, 0u, a.nsteps, draw_slots[threadIdx.x >> 6]);
+    lv_rows_segment<REC, ADAPT>(a, wave, 0u, a.nsteps, draw_slots[threadIdx.x >> 6]);
 }
 
 /*
@@ -857,7 +863,10 @@ hipError_t ymc_launch_chain(int kind, int method, const ChainArgs<D> &a, hipStre
                 /* small ensemble: n_data lanes per chain */
                 const int cpw = 64 / a.tgt.n_data;
                 const uint64_t waves = (a.K + cpw - 1) / cpw;
-                if (a.lv_pieces > 0) /* a whole number of waves per SIMD, equal pieces of the ribbon (see the kernel) */
+                if (a.tgt.lv_rtol > 0.0) /* solves of uneven length: no equal pieces to cut */
+                    hipLaunchKernelGGL((mrw_lv_rows_kernel<kRuntimeRec, true>), dim3((unsigned)((waves * 64 + kBlock - 1) / kBlock)),
+                                       dim3(kBlock), 0, s, a);
+                else if (a.lv_pieces > 0) /* a whole number of waves per SIMD, equal pieces of the ribbon (see the kernel) */
                     hipLaunchKernelGGL((mrw_lv_rows_balanced_kernel<kRuntimeRec>),
                                        dim3((unsigned)(((uint64_t)a.lv_pieces * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, a);
                 else
