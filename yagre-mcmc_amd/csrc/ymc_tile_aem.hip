@@ -192,6 +192,9 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
             const double *rows = ROWBLOCKS ? data_c + (size_t)r0 * m_pad : data_c;
             const int nr = ROWBLOCKS && n_data - r0 >= kAemRows ? kAemRows : n_data - r0;
             d4 SA = {0.0, 0.0, 0.0, 0.0}, SB = {0.0, 0.0, 0.0, 0.0};
+            int row_off[kAemRows];
+#pragma unroll
+            for (int i = 0; i < kAemRows; ++i) row_off[i] = (i < nr ? i : nr - 1) * m_pad;
 #pragma unroll 1
             for (int mt = 0; mt < MT; mt += 2) {
                 d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
@@ -211,24 +214,36 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
                     acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0[s * 64], v[s], acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1[s * 64], v[s], acc1, 0, 0, 0);
                 }
+                /* the pair's eight outputs against the block's rows, all eight row sums whatever the row count (a sum
+                 * beyond the last row repeats that row and is never read): as a conditional per row the compiler chained a
+                 * branch, an LDS read and its wait per row and output -- 160 serial round trips per evaluation, 46.8 k
+                 * cycles around a 17 k matrix product; here an output's eight reads are in flight together.  Without the
+                 * error mean res + 0.0 is res (a -0.0 becomes +0.0; its square is +0.0 either way) */
+                double gate = 0.0, gate_next = 0.0;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int m = 16 * (mt + h) + 4 * r + g;
                         const double F = (h ? acc1[r] : acc0[r]) + bias_c[m];
-                        const double mean = em_v[4 * h + r];
+                        const double mean = shift ? em_v[4 * h + r] : 0.0;
                         const double pe = has_prec ? ep_v[4 * h + r] : nprec_c[m];
+                        double dv[kAemRows];
+                        int mo = m;
+                        /* this output's reads wait for the sums of the one before the previous: two outputs' values in
+                         * registers at most, everything else free to move */
+                        asm volatile("" : "+v"(mo) : "v"(gate));
+#pragma unroll
+                        for (int i = 0; i < kAemRows; ++i) dv[i] = rows[row_off[i] + mo];
 #pragma unroll
                         for (int i = 0; i < kAemRows; ++i) {
-                            if (i < nr) {
-                                double res = F - rows[i * m_pad + m];
-                                res = shift ? res + mean : res;
-                                const double px = pe * res;
-                                if (i < 4) SA[i & 3] = SA[i & 3] + res * px;
-                                else SB[i & 3] = SB[i & 3] + res * px;
-                            }
+                            const double res = (F - dv[i]) + mean;
+                            const double px = pe * res;
+                            if (i < 4) SA[i & 3] = SA[i & 3] + res * px;
+                            else SB[i & 3] = SB[i & 3] + res * px;
                         }
+                        gate = gate_next;
+                        gate_next = SA[0];
                     }
                 }
             }
