@@ -845,6 +845,7 @@ static double ymo_aem_query(ymo_aem *a, const double *theta)
 static void ymo_aem_update(ymo_aem *a, const ymo_density *fine, const double *y)
 {
     double Ff[YMO_MMAX], Fc[YMO_MMAX], err[YMO_MMAX];
+    if (a->m < 1) return; /* (a model without outputs has no error to learn; also tells the compiler err is written) */
     ymo_forward_linear(fine, y, Ff);
     ymo_forward_linear(a->coarse, y, Fc);
     for (int32_t j = 0; j < a->m; ++j) err[j] = Ff[j] - Fc[j];
