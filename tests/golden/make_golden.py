@@ -828,18 +828,19 @@ def fixture_f13():
     print("F13", acc.mean())
 
 
-def fixture_f14():
+def fixture_f14(name="f14_mlda2_linear_d128.npz", d=128, seed=20250114, K=8, n=201, S=5, prop_var=1.1e-3):
     """Two-level delayed acceptance over a model hierarchy at d = 128 (the matrix-core kernel's size): two
     C3-shaped linear models (mlda.py:315-335, modelHierarchy.py:6-53), the coarse one a perturbation of the
-    fine one; 8 chains x 200 fine steps, sub-chain length 5; decisions of both levels."""
+    fine one; 8 chains x 200 fine steps, sub-chain length 5; decisions of both levels.  F14b: d = 192 (both
+    matrices beyond the LDS: streamed), 4 chains x 80 fine steps, sub-chain length 3."""
     from yagremcmc.statistics.modelHierarchy import BayesianRegressionModelHierarchy
     from yagremcmc.utility.hierarchy import Hierarchy, SharedComponent
-    d, n_data, seed, K, n, S = 128, 5, 20250114, 8, 201, 5
+    n_data = 5
     A_f, b_f, data, noise_var = linear_problem(d, n_data, 7)
     z, _ = oracle.rng_fill(99, 0, d + 1, 0, 1, d, uniforms=False)
     A_c = A_f + 0.02 * z[0][:d] / np.sqrt(d)          # a surrogate close enough to be useful, different enough to reject
     b_c = b_f + 0.05 * z[0][d]
-    prior_mean, prior_var, prop_var = np.zeros(d), 5.0, 1.1e-3
+    prior_mean, prior_var = np.zeros(d), 5.0
     prior = Gaussian(ParameterVector(prior_mean.copy()), IIDCovarianceMatrix(d, prior_var))
     noise = CentredGaussianNoise(IIDCovarianceMatrix(d, noise_var))
     lik_c = AdditiveGaussianNoiseLikelihood(Data(data), ForwardModel(ExampleLinearModelSolver(A_c, b_c)), noise)
@@ -866,11 +867,11 @@ def fixture_f14():
         sub[:, :, k] = np.array(mc.surrogate(0).diagnostics._decisions, dtype=np.uint8).reshape(n - 1, S)
         lp[:, k] = eval_log_along(mc.target, traj[:, k, :], lambda s_: ParameterVector(np.array(s_)))
     np.savez_compressed(
-        os.path.join(HERE, "f14_mlda2_linear_d128.npz"), seed=seed, n_states=n, S=S, A_fine=A_f, b_fine=b_f,
+        os.path.join(HERE, name), seed=seed, n_states=n, S=S, A_fine=A_f, b_fine=b_f,
         A_coarse=A_c, b_coarse=b_c, data=data, noise_precision=np.reciprocal(np.full(d, noise_var)),
         prior_mean=prior_mean, prior_precision=np.reciprocal(np.full(d, prior_var)), sigma=sigma_of(cov),
         x0=np.zeros((K, d)), traj_head=traj[:, :2, :], traj_sha256=sha(traj), acc=acc, sub_acc=sub, logpost=lp)
-    print("F14", acc.mean(), sub.mean())
+    print(name, acc.mean(), sub.mean())
 
 
 def fixture_f16(name="f16_aem_linear_d128.npz", use_heuristic=True, seed=20250116, min_data=6, K=8, n=161, S=4):
@@ -1229,6 +1230,7 @@ def main():
         fixture_f13()
     if "f14" in which:
         fixture_f14()
+        fixture_f14("f14b_mlda2_linear_d192.npz", d=192, seed=20250126, K=4, n=81, S=3, prop_var=7e-4)
     if "f15" in which:
         fixture_f15()
     if "f16" in which:

@@ -647,9 +647,11 @@ def test_two_level_lotka_volterra_model_hierarchy_vs_oracle():
     assert 0.05 < out["acc"].mean() < 0.999 and not np.array_equal(out["acc"], out["sub_acc"][:, -1, :])
 
 
-def test_two_level_over_a_model_hierarchy_d128_f14(golden):
-    """MLDABuilder.bayesModel = BayesianRegressionModelHierarchy of two d = 128 linear models (mlda.py:315-335):
-    through the builders the chains are the live reference's (fixture F14), on the matrix-core kernel."""
+@pytest.mark.parametrize("name,prop_var", [("f14_mlda2_linear_d128.npz", 1.1e-3), ("f14b_mlda2_linear_d192.npz", 7e-4)])
+def test_two_level_over_a_model_hierarchy_d128_f14(golden, name, prop_var):
+    """MLDABuilder.bayesModel = BayesianRegressionModelHierarchy of two d = 128 / d = 192 linear models
+    (mlda.py:315-335): through the builders the chains are the live reference's (fixtures F14 / F14b), on the
+    matrix-core kernel."""
     import hashlib
     from yagremcmc_amd.chain.diagnostics import AcceptanceRateDiagnostics
     from yagremcmc_amd.chain.method.mlda import MLDABuilder
@@ -663,15 +665,15 @@ def test_two_level_over_a_model_hierarchy_d128_f14(golden):
     from yagremcmc_amd.statistics.modelHierarchy import BayesianRegressionModelHierarchy
     from yagremcmc_amd.statistics.noise import CentredGaussianNoise
     from yagremcmc_amd.utility.hierarchy import Hierarchy, SharedComponent
-    g = golden("f14_mlda2_linear_d128.npz")
-    d, n, S, K = 128, int(g["n_states"]), int(g["S"]), g["x0"].shape[0]
+    g = golden(name)
+    d, n, S, K = g["A_fine"].shape[1], int(g["n_states"]), int(g["S"]), g["x0"].shape[0]
     prior = Gaussian(ParameterVector(np.array(g["prior_mean"])), IIDCovarianceMatrix(d, 5.0))
     noise = CentredGaussianNoise(IIDCovarianceMatrix(d, 0.3))
     liks = [AdditiveGaussianNoiseLikelihood(Data(g["data"]), ForwardModel(ExampleLinearModelSolver(g[f"A_{lv}"], g[f"b_{lv}"])), noise)
             for lv in ("coarse", "fine")]
     b = MLDABuilder()
     b.bayesModel = BayesianRegressionModelHierarchy(Hierarchy(liks), SharedComponent(prior, 2))
-    b.baseProposalCovariance = IIDCovarianceMatrix(d, 1.1e-3)
+    b.baseProposalCovariance = IIDCovarianceMatrix(d, prop_var)
     b.subChainLengths = [S]
     b.surrogateDiagnostics = [AcceptanceRateDiagnostics()]
     b.nChains, b.seed, b.recordSubChain = K, int(g["seed"]), True

@@ -1142,9 +1142,11 @@ def test_tile_kernel_dense_prior_limits(ffi, ctx):
         return _dense_low(ffi, ffi.POSTERIOR_LINEAR, d, g, None, B @ B.T + np.eye(d), fwd_matrix=rng.normal(size=(m, d)),
                           fwd_shift=np.zeros(m), likelihood_only=likelihood_only)
 
-    # two-level samplers keep their coarse matrix in LDS: (128 + 128) outputs x 128 do not fit
+    # the two-level sampler streams what does not fit the LDS ((128 + 128) outputs x 128 per level); the nest keeps its
+    # base level resident
+    lowering.make_problem(ctx, ffi.METHOD_MLDA2, low(128, 128), np.ones(128), surrogate=low(128, 128), sub_chain_length=2)
     with pytest.raises(ffi.YmcError, match="dense prior") as err:
-        lowering.make_problem(ctx, ffi.METHOD_MLDA2, low(128, 128), np.ones(128), surrogate=low(128, 128), sub_chain_length=2)
+        _nested_device_run(ffi, ctx, low(128, 128), [low(128, 128), low(128, 128)], [2, 2], np.ones(128), np.zeros((4, 128)), 1, 2)
     assert err.value.code == ffi.ERR_UNSUPPORTED
     lowering.make_problem(ctx, ffi.METHOD_MRW, low(96, 16), np.ones(96))        # (16 + 96) outputs x 96 fit
     # the random walk streams its matrix: a dense prior at d = 128 (and beyond) == oracle
@@ -1210,12 +1212,14 @@ def test_tile_kernel_dense_proposal_other_shapes(ffi, ctx, d, m, nd, K):
     _same_as_oracle(dev, e, out)
 
 
-def test_f14_two_level_d128_matrix_cores(ffi, ctx, golden):
-    """Two-level delayed acceptance over two d = 128 linear models (linear_tile_mlda2_kernel): the LIVE
-    reference's decisions at both levels, its chains (sha256 of all states) and log-posteriors; == oracle."""
+@pytest.mark.parametrize("name", ["f14_mlda2_linear_d128.npz", "f14b_mlda2_linear_d192.npz"])
+def test_f14_two_level_d128_matrix_cores(ffi, ctx, golden, name):
+    """Two-level delayed acceptance over two d = 128 (coarse matrix in LDS) / d = 192 (both streamed, one wave per SIMD)
+    linear models (linear_tile_mlda2_kernel): the LIVE reference's decisions at both levels, its chains (sha256 of all
+    states) and log-posteriors; == oracle."""
     import hashlib
-    g = golden("f14_mlda2_linear_d128.npz")
-    n, S, d = int(g["n_states"]), int(g["S"]), 128
+    g = golden(name)
+    n, S, d = int(g["n_states"]), int(g["S"]), g["A_fine"].shape[1]
     common = dict(data=g["data"], noise_precision=g["noise_precision"], prior_mean=g["prior_mean"],
                   prior_precision=g["prior_precision"])
     fine = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, common, fwd_matrix=g["A_fine"], fwd_shift=g["b_fine"])
@@ -1378,7 +1382,7 @@ def test_tile_kernels_with_and_without_the_shared_matrix_stream(ffi, ctx, monkey
     _same_error_model(dev, e)
 
 
-@pytest.mark.parametrize("mode", ["mem", "regs", "lds", "plain"])
+@pytest.mark.parametrize("mode", ["mem", "regs", "lds", "plain", "stream"])
 @pytest.mark.parametrize("d,mc,mf,K,S", [(128, 128, 128, 150, 5), (128, 96, 112, 37, 2), (96, 64, 80, 200, 3), (20, 24, 17, 130, 4),
                                           (7, 5, 9, 300, 1)])
 def test_tile_mlda2_builds_agree_with_the_oracle(ffi, ctx, monkeypatch, mode, d, mc, mf, K, S):
@@ -1408,6 +1412,39 @@ def test_tile_mlda2_builds_agree_with_the_oracle(ffi, ctx, monkeypatch, mode, d,
     assert 0 < dev["acc"].mean() < 1
 
 
+@pytest.mark.parametrize("d,mc,mf,K,S,dense", [(192, 40, 160, 40, 3, False), (128, 256, 64, 70, 2, False), (256, 16, 48, 33, 4, False),
+                                                (130, 130, 130, 17, 2, False), (128, 128, 96, 36, 3, True), (144, 20, 30, 20, 2, True)])
+def test_tile_mlda2_beyond_the_lds_and_d128_vs_oracle(ffi, ctx, d, mc, mf, K, S, dense):
+    """Two-level delayed acceptance where the coarse matrix does not fit the LDS (256 outputs x 128; a dense prior's d more
+    outputs per level) and at parameter dimensions up to 256 (one wave per SIMD, both matrices streamed through the shared
+    double buffer, the fine state in memory): chains, both levels' decisions, log-posteriors, moments == oracle."""
+    rng = np.random.default_rng(500 + d + mc)
+    nd = 2
+
+    def model(m, scale):
+        g = dict(data=rng.normal(size=(nd, m)), noise_precision=rng.uniform(0.5, 3, size=m), prior_mean=rng.normal(size=d) * 0.1,
+                 prior_precision=rng.uniform(0.1, 2, size=d))
+        A, b = scale * rng.normal(size=(m, d)) / np.sqrt(d), rng.normal(size=m)
+        if not dense:
+            return (_posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, g, fwd_matrix=A, fwd_shift=b),
+                    o.posterior_linear(A, b, g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"]))
+        B = rng.normal(size=(d, d)) / np.sqrt(d)
+        pc = B @ B.T + np.eye(d)
+        g["prior_precision"] = np.ones(d)
+        return (_dense_low(ffi, ffi.POSTERIOR_LINEAR, d, g, None, pc, fwd_matrix=A, fwd_shift=b),
+                o.dense_covariances(o.posterior_linear(A, b, g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"]),
+                                    prior_cov=pc))
+
+    (lf, pf), (lc, pc_) = model(mf, 1.0), model(mc, 0.95)
+    sigma, x0 = rng.uniform(0.02, 0.05, size=d), rng.normal(size=(K, d)) * 0.5
+    dev = _device_run(ffi, ctx, lf, sigma, x0, 993, 14, method=ffi.METHOD_MLDA2, sur=lc, S=S, chain0=600, splits=3)
+    e = o.Ensemble(pf, sigma, x0, 993, chain0=600, surrogate=pc_, sub_chain_length=S)
+    out = e.advance(14, want_sub=True)
+    _same_as_oracle(dev, e, out)
+    assert np.array_equal(dev["sub_acc"], out["sub_acc"])
+    assert 0 < dev["sub_acc"].mean() < 1
+
+
 def test_tile_kernel_limits(ffi, ctx):
     from yagremcmc_amd import lowering
     rng = np.random.default_rng(1)
@@ -1430,11 +1467,17 @@ def test_tile_kernel_limits(ffi, ctx):
     with pytest.raises(ffi.YmcError, match="exceeds the matrix-core kernels' 256") as err:
         lowering.make_problem(ctx, ffi.METHOD_MRW, lin(257, 4), np.ones(257))
     assert err.value.code == ffi.ERR_UNSUPPORTED
-    with pytest.raises(ffi.YmcError, match="exceeds the matrix-core kernels' 128") as err:   # two-level: d <= 128
-        lowering.make_problem(ctx, ffi.METHOD_MLDA2, lin(200, 4), np.ones(200), surrogate=lin(200, 4), sub_chain_length=2)
+    lowering.make_problem(ctx, ffi.METHOD_MLDA2, lin(256, 4), np.ones(256), surrogate=lin(256, 4), sub_chain_length=2)
+    with pytest.raises(ffi.YmcError, match="exceeds the matrix-core kernels' 256") as err:
+        lowering.make_problem(ctx, ffi.METHOD_MLDA2, lin(260, 4), np.ones(260), surrogate=lin(260, 4), sub_chain_length=2)
     assert err.value.code == ffi.ERR_UNSUPPORTED
-    with pytest.raises(ffi.YmcError, match="does not fit the 160 KB LDS") as err:             # nor a matrix beyond the LDS
-        lowering.make_problem(ctx, ffi.METHOD_MLDA2, lin(128, 400), np.ones(128), surrogate=lin(128, 400), sub_chain_length=2)
+    lowering.make_problem(ctx, ffi.METHOD_MLDA2, lin(128, 400), np.ones(128), surrogate=lin(128, 400), sub_chain_length=2)
+    with pytest.raises(ffi.YmcError, match="exceeds the matrix-core kernels' 128") as err:   # adaptive error model, nest: d <= 128
+        lowering.make_problem(ctx, ffi.METHOD_AEM2, lin(200, 4), np.ones(200), surrogate=lin(200, 4), sub_chain_length=2, aem=(5, 0))
+    assert err.value.code == ffi.ERR_UNSUPPORTED
+    with pytest.raises(ffi.YmcError, match="not fit the 160 KB LDS") as err:                  # ... and an LDS-resident coarse matrix
+        lowering.make_problem(ctx, ffi.METHOD_AEM2, lin(128, 400), np.ones(128), surrogate=lin(128, 400), sub_chain_length=2,
+                              aem=(5, 0))
     assert err.value.code == ffi.ERR_UNSUPPORTED
     with pytest.raises(ffi.YmcError, match="too many outputs") as err:                        # constants alone beyond the LDS
         lowering.make_problem(ctx, ffi.METHOD_MRW, lin(64, 8000), np.ones(64))

@@ -340,10 +340,11 @@ def test_f7_two_level_over_a_model_hierarchy(golden):
     assert np.array_equal(out["sub_acc"], g["sub_acc"])
 
 
-def test_f14_two_level_over_a_model_hierarchy_d128(golden):
-    """mlda.py:315-335 with two d = 128 linear models (the matrix-core kernel's size): the reference's
-    decisions at both levels, its chains (sha256 of all 201 x 8 x 128 states) and log-posteriors"""
-    g = golden("f14_mlda2_linear_d128.npz")
+@pytest.mark.parametrize("name", ["f14_mlda2_linear_d128.npz", "f14b_mlda2_linear_d192.npz"])
+def test_f14_two_level_over_a_model_hierarchy_d128(golden, name):
+    """mlda.py:315-335 with two d = 128 / d = 192 linear models (the matrix-core kernels' sizes): the reference's
+    decisions at both levels, its chains (sha256 of all states) and log-posteriors"""
+    g = golden(name)
     n, S = int(g["n_states"]), int(g["S"])
     common = (g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
     fine = o.posterior_linear(g["A_fine"], g["b_fine"], *common)

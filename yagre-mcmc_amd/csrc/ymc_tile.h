@@ -82,6 +82,7 @@ struct BigLinearArgs {
 size_t ymc_tile_lds_bytes(int KS, int MT);
 size_t ymc_tile_stream_lds_bytes(int KS, int MT); /* the forward matrix streamed from L2: constants + double buffer */
 size_t ymc_tile_mlda2_lds_bytes(int KS, int MT_coarse, int MT_fine);
+size_t ymc_tile_mlda2_stream_lds_bytes(int KS, int MT_coarse, int MT_fine); /* both matrices streamed: constants + double buffer */
 hipError_t ymc_launch_linear_tile(int KS, const TileArgs &a, hipStream_t s);
 hipError_t ymc_launch_linear_tile_mlda2(int KS, const TileArgs &a, hipStream_t s);
 size_t ymc_tile_aem2_lds_bytes(int KS, int MT, int n_data);

@@ -262,21 +262,23 @@ __global__ __launch_bounds__(64 * WAVES) void linear_tile_kernel(const TileArgs 
  * measured 5.7 x the cost of an LDS-fed GEMV.  Waves past the last tile stay in the loop for the barriers and
  * touch no memory.  The plain form remains for shapes whose constants leave no room for the buffer.
  */
-enum { kXRegs = 0, kXLds = 1, kXMem = 2 };   /* where the fine state x lives between fine steps */
+/* where the fine state x lives between fine steps; kXLds and kXMemC take the COARSE matrix from L2 too (through the
+ * shared double buffer, as the fine one) */
+enum { kXRegs = 0, kXLds = 1, kXMem = 2, kXMemC = 3 };
 
 template <int KS, bool STAGED, int WAVES, int XM>
 __global__ __launch_bounds__(64 * WAVES) void linear_tile_mlda2_kernel(const TileArgs a)
 {
-    constexpr bool XLDS = XM == kXLds, XMEM = XM == kXMem;
-    static_assert(!XLDS || STAGED, "the fine state lives in LDS only where both matrices stream");
+    constexpr bool XLDS = XM == kXLds, XMEM = XM == kXMem || XM == kXMemC, CSTREAM = XM == kXLds || XM == kXMemC;
+    static_assert(!CSTREAM || STAGED, "a streamed coarse matrix shares the fine one's double buffer");
     constexpr int kThreads = 64 * WAVES;
     ymc_stage_tables();
     extern __shared__ double lds[];
     const int MTc = a.MT, MTf = a.MT_f, m_pad_c = 16 * MTc, m_pad_f = 16 * MTf, d_pad = 4 * KS;
-    /* coarse level: [A fragments, unless XLDS] | bias | n * noise_prec | row mean | prior mean | prior prec | sigma */
+    /* coarse level: [A fragments, unless CSTREAM] | bias | n * noise_prec | row mean | prior mean | prior prec | sigma */
     const size_t frag_c = (size_t)MTc * KS * 64, consts_c = (size_t)m_pad_c * 3 + 3 * (size_t)d_pad;
-    const double *Ac = XLDS ? a.blob : lds;
-    double *bias_c = lds + (XLDS ? 0 : frag_c);
+    const double *Ac = CSTREAM ? a.blob : lds;
+    double *bias_c = lds + (CSTREAM ? 0 : frag_c);
     double *nprec_c = bias_c + m_pad_c;
     double *dbar_c = nprec_c + m_pad_c;
     double *pmean_c = dbar_c + m_pad_c;
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(64 * WAVES) void linear_tile_mlda2_kernel(const Til
     double *stage = bias_f + consts_f;                           /* STAGED: the stream's double buffer (ymc_tile_dev.h) */
 
     const int tid = threadIdx.x;
-    if constexpr (XLDS) {
+    if constexpr (CSTREAM) {
         for (size_t i = tid; i < consts_c; i += kThreads) bias_c[i] = a.blob[frag_c + i];
     } else {
         ymc_stage_block<kThreads>(lds, a.blob, (frag_c + consts_c) / 2, tid);
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(64 * WAVES) void linear_tile_mlda2_kernel(const Til
             YMC_PROF(0);
             YMC_PHASE_MAP();
             double llc;
-            if constexpr (XLDS) llc = loglik_staged(Ac, MTc, bias_c, nprec_c, dbar_c, a.lik_const, y);
+            if constexpr (CSTREAM) llc = loglik_staged(Ac, MTc, bias_c, nprec_c, dbar_c, a.lik_const, y);
             else llc = loglik(Ac, MTc, bias_c, nprec_c, dbar_c, a.lik_const, y);
                 YMC_PROF(1);
             const double lpcy = llc + logprior(pmean_c, pprec_c, y);
@@ -617,14 +619,16 @@ size_t ymc_tile_mlda2_lds_bytes(int KS, int MT_coarse, int MT_fine)
  *          z and y in 128 of their 256 registers) -- KS = 32 when the constants leave the room
  *   regs   the coarse matrix resident in LDS, the fine one streamed, the fine state in registers; 4 waves at
  *          KS = 32 (one per SIMD, 512 registers), 8 below
- *   plain  as regs, every wave reading the fine matrix from L2 itself (no room for the double buffer) */
+ *   plain  as regs, every wave reading the fine matrix from L2 itself (no room for the double buffer)
+ *   stream both matrices stream, the fine state in memory as in mem; 4 waves at KS >= 32: what runs where the coarse
+ *          matrix does not fit the LDS, and at KS = 64 (d <= 256: z and y alone are 256 registers) */
 template <int KS>
 constexpr int mlda2_waves() { return KS >= 32 ? 4 : 8; }
 
 template <int KS, bool STAGED, int XM>
 static hipError_t launch_tile_mlda2_as(const TileArgs &a, size_t lds, hipStream_t s)
 {
-    constexpr int W = XM == kXRegs ? mlda2_waves<KS>() : 8;
+    constexpr int W = (XM == kXRegs || XM == kXMemC) ? mlda2_waves<KS>() : 8;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_tile_mlda2_kernel<KS, STAGED, W, XM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -640,16 +644,26 @@ static hipError_t launch_tile_mlda2(const TileArgs &a, hipStream_t s)
     const size_t unit2 = 2 * (size_t)ymc_stream_unit<KS, 4>() * sizeof(double);
     const size_t consts = ymc_tile_mlda2_lds_bytes(KS, a.MT, a.MT_f) - (size_t)a.MT * KS * 64 * sizeof(double);
     const size_t plain = ymc_tile_mlda2_lds_bytes(KS, a.MT, a.MT_f), staged = plain + unit2;
-    const size_t xlds = consts + unit2 + (size_t)8 * KS * 64 * sizeof(double);
-    bool stage = staged <= kTileLdsLimit;
-    if (const char *env = std::getenv("YMC_TILE_STAGE")) stage = stage && env[0] != '0';
-    char mode = 'r';
-    if (const char *env = std::getenv("YMC_TILE_MLDA2")) mode = env[0];
-    if (mode == 'p') stage = false;
-    if (mode == 'l' && stage && xlds <= kTileLdsLimit) return launch_tile_mlda2_as<KS, true, kXLds>(a, xlds, s);
-    if (mode == 'm')
-        return stage ? launch_tile_mlda2_as<KS, true, kXMem>(a, staged, s) : launch_tile_mlda2_as<KS, false, kXMem>(a, plain, s);
-    return stage ? launch_tile_mlda2_as<KS, true, kXRegs>(a, staged, s) : launch_tile_mlda2_as<KS, false, kXRegs>(a, plain, s);
+    {
+        const char *env = std::getenv("YMC_TILE_MLDA2");
+        if (KS >= 64 || plain > kTileLdsLimit || (env && env[0] == 's')) {
+            if (consts + unit2 > kTileLdsLimit) return hipErrorInvalidValue;
+            return launch_tile_mlda2_as<KS, true, kXMemC>(a, consts + unit2, s);
+        }
+    }
+    if constexpr (KS < 64) {
+        const size_t xlds = consts + unit2 + (size_t)8 * KS * 64 * sizeof(double);
+        bool stage = staged <= kTileLdsLimit;
+        if (const char *env = std::getenv("YMC_TILE_STAGE")) stage = stage && env[0] != '0';
+        char mode = 'r';
+        if (const char *env = std::getenv("YMC_TILE_MLDA2")) mode = env[0];
+        if (mode == 'p') stage = false;
+        if (mode == 'l' && stage && xlds <= kTileLdsLimit) return launch_tile_mlda2_as<KS, true, kXLds>(a, xlds, s);
+        if (mode == 'm')
+            return stage ? launch_tile_mlda2_as<KS, true, kXMem>(a, staged, s) : launch_tile_mlda2_as<KS, false, kXMem>(a, plain, s);
+        return stage ? launch_tile_mlda2_as<KS, true, kXRegs>(a, staged, s) : launch_tile_mlda2_as<KS, false, kXRegs>(a, plain, s);
+    }
+    return hipErrorInvalidValue;
 }
 
 #ifdef YMC_TILE_PROFILE
@@ -666,8 +680,15 @@ hipError_t ymc_launch_linear_tile_mlda2(int KS, const TileArgs &a, hipStream_t s
     case 8: return launch_tile_mlda2<8>(a, s);
     case 16: return launch_tile_mlda2<16>(a, s);
     case 32: return launch_tile_mlda2<32>(a, s);
+    case 64: return launch_tile_mlda2<64>(a, s);
     default: return hipErrorInvalidValue;
     }
+}
+
+size_t ymc_tile_mlda2_stream_lds_bytes(int KS, int MT_coarse, int MT_fine)
+{
+    const size_t unit2 = 2 * (size_t)2 * (KS / 4) * 64 * sizeof(double);     /* 2 ymc_stream_unit<KS, 4>() */
+    return ymc_tile_mlda2_lds_bytes(KS, MT_coarse, MT_fine) - (size_t)MT_coarse * KS * 64 * sizeof(double) + unit2;
 }
 
 template <int KS>
