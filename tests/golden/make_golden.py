@@ -1249,6 +1249,8 @@ def main():
                     sub_lengths=(2, 3, 2, 2), perturb=0.03, prop_var=6e-3)
         fixture_f18("f18c_mlda_nested8_linear_d24.npz", d=24, n_models=9, seed=20250125, K=4, n=25,
                     sub_lengths=(2, 2, 3, 2, 1, 2, 2, 2), perturb=0.015, prop_var=6e-3)
+        fixture_f18("f18d_mlda_nested2_linear_d192.npz", d=192, n_models=3, seed=20250127, K=4, n=41, sub_lengths=(2, 3),
+                    perturb=0.02, prop_var=7e-4)
     if "f23" in which:
         fixture_f23()
     if "f24" in which:

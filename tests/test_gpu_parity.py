@@ -1142,12 +1142,9 @@ def test_tile_kernel_dense_prior_limits(ffi, ctx):
         return _dense_low(ffi, ffi.POSTERIOR_LINEAR, d, g, None, B @ B.T + np.eye(d), fwd_matrix=rng.normal(size=(m, d)),
                           fwd_shift=np.zeros(m), likelihood_only=likelihood_only)
 
-    # the two-level sampler streams what does not fit the LDS ((128 + 128) outputs x 128 per level); the nest keeps its
-    # base level resident
+    # delayed acceptance (two-level and nested) streams what does not fit the LDS ((128 + 128) outputs x 128 per level)
     lowering.make_problem(ctx, ffi.METHOD_MLDA2, low(128, 128), np.ones(128), surrogate=low(128, 128), sub_chain_length=2)
-    with pytest.raises(ffi.YmcError, match="dense prior") as err:
-        _nested_device_run(ffi, ctx, low(128, 128), [low(128, 128), low(128, 128)], [2, 2], np.ones(128), np.zeros((4, 128)), 1, 2)
-    assert err.value.code == ffi.ERR_UNSUPPORTED
+    _nested_device_run(ffi, ctx, low(128, 128), [low(128, 128), low(128, 128)], [2, 2], np.full(128, 0.01), np.zeros((4, 128)), 1, 2)
     lowering.make_problem(ctx, ffi.METHOD_MRW, low(96, 16), np.ones(96))        # (16 + 96) outputs x 96 fit
     # the random walk streams its matrix: a dense prior at d = 128 (and beyond) == oracle
     for d, m, K in ((128, 128, 40), (160, 30, 33)):
@@ -1265,7 +1262,7 @@ def test_tile_kernel_two_level_other_shapes(ffi, ctx, d, mf, mc, nd, K, S):
 
 
 @pytest.mark.parametrize("name", ["f18_mlda_nested2_linear_d128.npz", "f18b_mlda_nested4_linear_d24.npz",
-                                  "f18c_mlda_nested8_linear_d24.npz"])
+                                  "f18c_mlda_nested8_linear_d24.npz", "f18d_mlda_nested2_linear_d192.npz"])
 def test_f18_nested_levels_matrix_cores(ffi, ctx, golden, name):
     """Hierarchies of three (d = 128), five and nine (d = 24) linear models (linear_tile_nested_kernel): the LIVE
     reference's top-level decisions, accepted counts of the lower levels, chains (sha256) and log-posteriors;
@@ -1296,11 +1293,14 @@ def test_f18_nested_levels_matrix_cores(ffi, ctx, golden, name):
                                          (24, (16, 40, 8, 30, 12), 2, 70, 3), (64, (64, 30, 64, 10, 48), 4, 17, 3),
                                          (9, (3, 3, 4, 2, 5, 3, 6), 1, 129, 4), (5, (30, 12, 6), 2, 20, 2),
                                          (20, (12, 9, 16, 5, 20, 7, 11, 18, 10), 2, 40, 5),
-                                         (128, (16,) * 14 + (128,), 3, 20, 8), (10, (3, 9) * 5 + (12,), 1, 65, 6)])
+                                         (128, (16,) * 14 + (128,), 3, 20, 8), (10, (3, 9) * 5 + (12,), 1, 65, 6),
+                                         (128, (256, 40, 300), 2, 36, 2), (192, (30, 64, 20, 50, 160), 3, 20, 3),
+                                         (256, (16, 32, 16), 2, 17, 2)])
 def test_tile_kernel_nested_levels_vs_oracle(ffi, ctx, d, ms, nd, K, E):
     """Delayed acceptance over an even number of surrogates at large dimension (ymc_tile_nested.hip): a
     hierarchy of 2 (E - 1) + 1 linear models, each with its own matrix, output count and data; ragged shapes, a
-    partly filled last wave, a hierarchy one of whose models alone would fit the lane kernels.  Everything the
+    partly filled last wave, a hierarchy one of whose models alone would fit the lane kernels; a base level whose
+    matrix does not fit the LDS (256 x 128: streamed like the upper levels') and parameter dimensions up to 256.  Everything the
     lane kernel's test compares: chains, decisions of the recorded level, accepted counts of the lower levels,
     log-posteriors, Welford moments, carried state -- across three launches."""
     rng = np.random.default_rng(900 + d + sum(ms))
@@ -1326,6 +1326,33 @@ def test_tile_kernel_nested_levels_vs_oracle(ffi, ctx, d, ms, nd, K, E):
     _same_as_oracle(dev, e, out)
     assert np.array_equal(dev["level_acc"], e.level_acc)
     assert 0 < dev["acc"].mean() < 1
+
+
+@pytest.mark.parametrize("d,ms,K,E", [(128, (128, 128, 128), 40, 2), (24, (16, 40, 8, 30, 12), 70, 3), (9, (3, 3, 4, 2, 5, 3, 6), 129, 4)])
+def test_tile_kernel_nested_base_level_streamed_agrees(ffi, ctx, monkeypatch, d, ms, K, E):
+    """YMC_TILE_NESTED=stream: level 0's matrix through the shared double buffer at shapes that would fit the LDS == the
+    resident build == oracle."""
+    rng = np.random.default_rng(950 + d + sum(ms))
+
+    def model(m, scale):
+        g = dict(data=rng.normal(size=(2, m)), noise_precision=rng.uniform(0.5, 3, size=m), prior_mean=rng.normal(size=d) * 0.1,
+                 prior_precision=rng.uniform(0.1, 2, size=d))
+        A, b = scale * rng.normal(size=(m, d)) / np.sqrt(d), rng.normal(size=m)
+        return (_posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, g, fwd_matrix=A, fwd_shift=b),
+                o.posterior_linear(A, b, g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"]))
+
+    models = [model(m, 1.0 - 0.03 * i) for i, m in enumerate(ms)]
+    (lt, pt), surs = models[-1], models[:-1]
+    subs = [int(v) for v in rng.integers(1, 4, size=len(surs))]
+    sigma, x0 = rng.uniform(0.02, 0.08, size=d), rng.normal(size=(K, d))
+    P, Q, steps = o.nested_levels([p for _, p in surs], subs, pt)
+    e = o.NestedEnsemble(P, Q, steps, sigma, x0, 778, chain0=10)
+    out = e.advance(15)
+    for mode in ("stream", "resident"):
+        monkeypatch.setenv("YMC_TILE_NESTED", mode)
+        dev = _nested_device_run(ffi, ctx, lt, [l for l, _ in surs], subs, sigma, x0, 778, 15, splits=2, chain0=10)
+        _same_as_oracle(dev, e, out)
+        assert np.array_equal(dev["level_acc"], e.level_acc)
 
 
 @pytest.mark.parametrize("stage", ["0", "1"])
@@ -1472,7 +1499,7 @@ def test_tile_kernel_limits(ffi, ctx):
         lowering.make_problem(ctx, ffi.METHOD_MLDA2, lin(260, 4), np.ones(260), surrogate=lin(260, 4), sub_chain_length=2)
     assert err.value.code == ffi.ERR_UNSUPPORTED
     lowering.make_problem(ctx, ffi.METHOD_MLDA2, lin(128, 400), np.ones(128), surrogate=lin(128, 400), sub_chain_length=2)
-    with pytest.raises(ffi.YmcError, match="exceeds the matrix-core kernels' 128") as err:   # adaptive error model, nest: d <= 128
+    with pytest.raises(ffi.YmcError, match="exceeds the matrix-core kernels' 128") as err:   # adaptive error model: d <= 128
         lowering.make_problem(ctx, ffi.METHOD_AEM2, lin(200, 4), np.ones(200), surrogate=lin(200, 4), sub_chain_length=2, aem=(5, 0))
     assert err.value.code == ffi.ERR_UNSUPPORTED
     with pytest.raises(ffi.YmcError, match="not fit the 160 KB LDS") as err:                  # ... and an LDS-resident coarse matrix

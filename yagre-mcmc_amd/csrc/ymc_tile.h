@@ -88,6 +88,7 @@ hipError_t ymc_launch_linear_tile_mlda2(int KS, const TileArgs &a, hipStream_t s
 size_t ymc_tile_aem2_lds_bytes(int KS, int MT, int n_data);
 int ymc_tile_aem2_max_rows(void);
 hipError_t ymc_launch_linear_tile_aem2(int KS, const TileArgs &a, hipStream_t s);
+size_t ymc_tile_nested_stream_lds_bytes(int KS, int MT); /* level 0's matrix streamed as the upper ones */
 hipError_t ymc_launch_linear_tile_nested(int KS, const TileArgs &a, hipStream_t s);
 hipError_t ymc_launch_untile(const double *tiled, uint64_t row0, uint64_t rows, uint64_t K, int d, int KS,
                              double *out, hipStream_t s);

@@ -67,24 +67,32 @@ struct PerLevel {
     }
 };
 
-template <int KS, bool STAGED>
+/* BSTREAM: level 0's matrix streams through the shared double buffer too (its constants stay in LDS): where it does not
+ * fit the LDS, and at KS = 64 (d <= 256) */
+template <int KS, bool STAGED, bool BSTREAM = false>
 __global__ __launch_bounds__(kNestThreads) void linear_tile_nested_kernel(const TileArgs a)
 {
+    static_assert(!BSTREAM || STAGED, "a streamed base matrix shares the upper levels' double buffer");
     ymc_stage_tables();
     extern __shared__ double lds[];
     const int MT0 = a.MT, m_pad0 = 16 * MT0, d_pad = 4 * KS;
-    double *A0 = lds;
-    double *bias0 = A0 + (size_t)MT0 * KS * 64;
+    const size_t frag0 = (size_t)MT0 * KS * 64;
+    const double *A0 = BSTREAM ? a.blob : lds;
+    double *bias0 = lds + (BSTREAM ? 0 : frag0);
     double *nprec0 = bias0 + m_pad0;
     double *dbar0 = nprec0 + m_pad0;
     double *pmean0 = dbar0 + m_pad0;
     double *pprec0 = pmean0 + d_pad;
     double *sigma = pprec0 + d_pad;
-    const size_t blob0 = (size_t)MT0 * KS * 64 + (size_t)m_pad0 * 3 + 3 * (size_t)d_pad;
-    double *stage = lds + blob0;                                 /* STAGED: the stream's double buffer (ymc_tile_dev.h) */
+    const size_t consts0 = (size_t)m_pad0 * 3 + 3 * (size_t)d_pad, blob0 = frag0 + consts0;
+    double *stage = bias0 + consts0;                             /* STAGED: the stream's double buffer (ymc_tile_dev.h) */
 
     const int tid = threadIdx.x;
-    ymc_stage_block<kNestThreads>(lds, a.blob, blob0 / 2, tid);
+    if constexpr (BSTREAM) {
+        for (size_t i = tid; i < consts0; i += kNestThreads) bias0[i] = a.blob[frag0 + i];
+    } else {
+        ymc_stage_block<kNestThreads>(lds, a.blob, blob0 / 2, tid);
+    }
     __syncthreads();
 
     const int lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
@@ -133,9 +141,6 @@ __global__ __launch_bounds__(kNestThreads) void linear_tile_nested_kernel(const 
         const double logl = -0.5 * (combine4(ymc_tile_residual_sum<KS>(A, MT, bias, nprec, dbar, lane, g, v)) + lik_const);
         return logl + ymc_tile_logprior<KS>(pmean, pprec, g, v);
     };
-    auto logpost0 = [&](const double (&v)[KS]) {
-        return logpost(A0, MT0, bias0, nprec0, dbar0, pmean0, pprec0, a.lik_const, v);
-    };
     /* P[l] (which = 0) or Q[l] (which = 1) of a level above the base: everything from global memory */
     /* STAGED: the same value over the workgroup's shared stream of the matrix (ymc_stream_tile_pairs,
      * ymc_tile_dev.h); every wave of the workgroup evaluates the same level at the same point of the walk */
@@ -147,6 +152,10 @@ __global__ __launch_bounds__(kNestThreads) void linear_tile_nested_kernel(const 
         });
         const double logl = -0.5 * (combine4(Ssum) + lik_const);
         return logl + ymc_tile_logprior<KS>(pmean, pprec, g, v);
+    };
+    auto logpost0 = [&](const double (&v)[KS]) {
+        if constexpr (BSTREAM) return logpost_staged(A0, MT0, bias0, nprec0, dbar0, pmean0, pprec0, a.lik_const, v);
+        else return logpost(A0, MT0, bias0, nprec0, dbar0, pmean0, pprec0, a.lik_const, v);
     };
     auto logpost_of = [&](int l, int which, const double (&v)[KS]) {
         const TileLevel L = a.levels[2 * l + which];
@@ -287,15 +296,15 @@ __global__ __launch_bounds__(kNestThreads) void linear_tile_nested_kernel(const 
     }
 }
 
-template <int KS, bool STAGED>
+template <int KS, bool STAGED, bool BSTREAM = false>
 hipError_t launch_staged_or_not(const TileArgs &a, size_t lds, hipStream_t s)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_tile_nested_kernel<KS, STAGED>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_tile_nested_kernel<KS, STAGED, BSTREAM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const uint64_t nct = (a.K + 15) / 16;
     const unsigned grid = (unsigned)((nct + kNestWaves - 1) / kNestWaves);
-    hipLaunchKernelGGL((linear_tile_nested_kernel<KS, STAGED>), dim3(grid), dim3(kNestThreads), lds, s, a);
+    hipLaunchKernelGGL((linear_tile_nested_kernel<KS, STAGED, BSTREAM>), dim3(grid), dim3(kNestThreads), lds, s, a);
     return hipGetLastError();
 }
 
@@ -305,13 +314,28 @@ hipError_t launch_as(const TileArgs &a, hipStream_t s)
     /* the upper levels' matrices through a shared double buffer when the LDS has room beside level 0's block
      * (identical results; YMC_TILE_STAGE=0|1 overrides, the tests run both) */
     const size_t plain = ymc_tile_lds_bytes(KS, a.MT);
-    const size_t staged = plain + 2 * (size_t)ymc_stream_unit<KS, 4>() * sizeof(double);
-    bool stage = staged <= kTileLdsLimit;
-    if (const char *env = std::getenv("YMC_TILE_STAGE")) stage = stage && env[0] != '0';
-    return stage ? launch_staged_or_not<KS, true>(a, staged, s) : launch_staged_or_not<KS, false>(a, plain, s);
+    const size_t unit2 = 2 * (size_t)ymc_stream_unit<KS, 4>() * sizeof(double), staged = plain + unit2;
+    /* level 0's matrix streamed where it does not fit (YMC_TILE_NESTED=stream forces it: the tests compare) */
+    const char *mode = std::getenv("YMC_TILE_NESTED");
+    if (KS >= 64 || plain > kTileLdsLimit || (mode && mode[0] == 's')) {
+        const size_t lds = ymc_tile_nested_stream_lds_bytes(KS, a.MT);
+        if (lds > kTileLdsLimit) return hipErrorInvalidValue;
+        return launch_staged_or_not<KS, true, true>(a, lds, s);
+    }
+    if constexpr (KS < 64) {
+        bool stage = staged <= kTileLdsLimit;
+        if (const char *env = std::getenv("YMC_TILE_STAGE")) stage = stage && env[0] != '0';
+        return stage ? launch_staged_or_not<KS, true>(a, staged, s) : launch_staged_or_not<KS, false>(a, plain, s);
+    }
+    return hipErrorInvalidValue;
 }
 
 }  // namespace
+
+size_t ymc_tile_nested_stream_lds_bytes(int KS, int MT)
+{
+    return ymc_tile_stream_lds_bytes(KS, MT); /* level 0's constants + the double buffer */
+}
 
 hipError_t ymc_launch_linear_tile_nested(int KS, const TileArgs &a, hipStream_t s)
 {
@@ -321,6 +345,7 @@ hipError_t ymc_launch_linear_tile_nested(int KS, const TileArgs &a, hipStream_t 
     case 8: return launch_as<8>(a, s);
     case 16: return launch_as<16>(a, s);
     case 32: return launch_as<32>(a, s);
+    case 64: return launch_as<64>(a, s);
     default: return hipErrorInvalidValue;
     }
 }
