@@ -1191,8 +1191,11 @@ def test_f17_dense_proposal_d16_matrix_cores(ffi, ctx, golden):
     assert np.array_equal(dev["acc"], g["acc"]) and np.abs(dev["traj"] - g["traj"][1:]).max() <= 1e-12
 
 
-@pytest.mark.parametrize("d,m,nd,K", [(128, 128, 2, 40), (9, 3, 2, 33), (20, 40, 1, 64), (100, 20, 4, 129)])
+@pytest.mark.parametrize("d,m,nd,K", [(128, 128, 2, 40), (9, 3, 2, 33), (20, 40, 1, 64), (100, 20, 4, 129),
+                                      (128, 400, 2, 36), (192, 60, 2, 33), (256, 16, 1, 20), (40, 1000, 1, 17)])
 def test_tile_kernel_dense_proposal_other_shapes(ffi, ctx, d, m, nd, K):
+    """(the last four: a forward matrix beyond the LDS / d beyond 128 -- the proposal's factor and the forward matrix both
+    through the shared double buffer, one after the other)"""
     rng = np.random.default_rng(600 + d + m)
     g = dict(A=rng.normal(size=(m, d)) / np.sqrt(d), b=rng.normal(size=m), data=rng.normal(size=(nd, m)),
              noise_precision=rng.uniform(0.5, 3, size=m), prior_mean=rng.normal(size=d) * 0.1,

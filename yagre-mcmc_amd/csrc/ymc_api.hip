@@ -273,7 +273,7 @@ int lower_density(ymc_ctx *ctx, const ymc_density_desc &in, DensityHost &out, in
                 const int d_max = may_stream ? 256 : 128;
                 if (d > d_max)
                     return fail(YMC_ERR_UNSUPPORTED, "parameter dimension %d exceeds the matrix-core kernels' %d%s", d, d_max,
-                                may_stream ? "" : " for this sampler (the random walk with a diagonal proposal, pCN and delayed acceptance take 256)");
+                                may_stream ? "" : " for this sampler (the random walk, pCN and delayed acceptance take 256)");
                 const int ks_need = (d + 3) / 4;
                 out.KS = ks_need <= 4 ? 4 : ks_need <= 8 ? 8 : ks_need <= 16 ? 16 : ks_need <= 32 ? 32 : 64;
                 /* a dense prior covariance adds d pseudo-observations to the forward map (below) */
@@ -285,7 +285,7 @@ int lower_density(ymc_ctx *ctx, const ymc_density_desc &in, DensityHost &out, in
                     return fail(YMC_ERR_UNSUPPORTED, "forward map %zu x %d%s does not fit the 160 KB LDS%s", m, d,
                                 out.prior_linv.empty() ? "" : " plus the dense prior's d x d factor",
                                 may_stream ? " (nor do its constants alone: too many outputs)"
-                                           : "; only the random walk with a diagonal proposal, pCN and delayed acceptance stream it from L2");
+                                           : "; only the random walk, pCN and delayed acceptance stream it from L2");
                 out.tile = true;
             }
             YMC_TRY(copy_array(out.A, in.fwd_matrix, m * d, "fwd_matrix"));
@@ -1020,10 +1020,10 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
         for (int e = 0; e < desc->n_levels - 1; ++e)
             joint_tile = joint_tile || needs_tile(desc->level_target[e]) || needs_tile(desc->level_correction[e]);
     }
-    /* the random walk with a diagonal proposal, pCN and delayed acceptance (two-level or nested) stream a forward matrix
-     * that does not fit the LDS from L2 (d <= 256) */
-    const bool may_stream = (desc->method == YMC_METHOD_MRW || desc->method == YMC_METHOD_PCN || desc->method == YMC_METHOD_MLDA2 ||
-                             desc->method == YMC_METHOD_MLDA_NESTED) && !desc->proposal_chol;
+    /* the random walk, pCN and delayed acceptance (two-level or nested) stream a forward matrix that does not fit the
+     * LDS from L2 (d <= 256) */
+    const bool may_stream = desc->method == YMC_METHOD_MRW || desc->method == YMC_METHOD_PCN || desc->method == YMC_METHOD_MLDA2 ||
+                            desc->method == YMC_METHOD_MLDA_NESTED;
     int rc = lower_density(ctx, desc->target, p->tgt, 0, joint_tile, may_stream);
     if (rc == YMC_OK) {
         p->D = desc->target.dim;

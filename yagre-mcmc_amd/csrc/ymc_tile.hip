@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64 * WAVES) void linear_tile_kernel(const TileArgs 
     constexpr bool PCN = PROP == kPropPcn, DENSE = PROP == kPropDense || PROP == kPropDenseStaged;
     constexpr bool STAGED = PROP == kPropDenseStaged || ASTREAM;
     constexpr int kThreads = 64 * WAVES;
-    static_assert(!(ASTREAM && DENSE), "one matrix stream per kernel");
+    static_assert(!(ASTREAM && PROP == kPropDense), "a streamed forward matrix takes the proposal's factor through the same buffer");
     ymc_stage_tables();
     extern __shared__ double lds[];
     const int MT = a.MT, m_pad = 16 * MT, d_pad = 4 * KS;
@@ -697,10 +697,11 @@ static hipError_t launch_tile(const TileArgs &a, hipStream_t s)
     /* the forward matrix streamed from L2 where it does not fit the LDS (YMC_TILE_ASTREAM=1 forces it: the tests
      * compare both forms); one wave per SIMD at KS = 64 */
     bool astream = KS >= 64 || ymc_tile_lds_bytes(KS, a.MT) > kTileLdsLimit;
-    if (const char *env = std::getenv("YMC_TILE_ASTREAM")) astream = astream || (env[0] == '1' && !a.chol_frag);
+    if (const char *env = std::getenv("YMC_TILE_ASTREAM")) astream = astream || env[0] == '1';
     if (astream) {
-        if (a.chol_frag) return hipErrorInvalidValue;
         constexpr int W = KS >= 64 ? 4 : kTileWaves;
+        if (a.chol_frag) /* the proposal's factor, then the forward matrix, through the one double buffer */
+            return a.pcn ? hipErrorInvalidValue : launch_tile_as<KS, kPropDenseStaged, W, true>(a, s);
         return a.pcn ? launch_tile_as<KS, kPropPcn, W, true>(a, s) : launch_tile_as<KS, kPropDiag, W, true>(a, s);
     }
     if constexpr (KS < 64) {
