@@ -156,7 +156,7 @@ typedef struct ymc_problem_desc {
     /* MRW with a DenseCovarianceMatrix proposal (covariance.py:69-94): its lower Cholesky factor
      * [d][d], row-major; NULL = the diagonal covariance of proposal_sigma.  Row i of L xi is summed left to
      * right with separate multiplies and adds by the lane kernels (d <= 8 and at most 8 forward outputs) and as
-     * one k-ordered fma chain on the matrix cores beyond (linear posteriors up to d = 128). */
+     * one k-ordered fma chain on the matrix cores beyond (linear posteriors up to d = 256). */
     const double *proposal_chol;
 } ymc_problem_desc;
 
