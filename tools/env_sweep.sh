@@ -1,3 +1,8 @@
-for e in "YMC_TILE_MLDA2=mem" "YMC_TILE_MLDA2=lds" "YMC_TILE_MLDA2=plain" "YMC_TILE_ASTREAM=1" "YMC_TILE_STAGE=0" "YMC_LV_ROWS=1 YMC_LV_PIECES=7" "YMC_LV_ROWS=0" "YMC_SPLIT=0" "YMC_SPLIT=1 YMC_SPLIT_NP=2"; do
+#!/bin/bash
+# The whole GPU suite under every build-selection override (the kernels must agree with the oracle whichever build runs):
+#   tools/env_sweep.sh            (on the GPU box; about half a minute per setting)
+cd "$(dirname "$0")/.." || exit 1
+for e in "YMC_TILE_MLDA2=mem" "YMC_TILE_MLDA2=lds" "YMC_TILE_MLDA2=plain" "YMC_TILE_MLDA2=stream" "YMC_TILE_NESTED=stream" \
+         "YMC_TILE_ASTREAM=1" "YMC_TILE_STAGE=0" "YMC_LV_ROWS=1 YMC_LV_PIECES=7" "YMC_LV_ROWS=0" "YMC_SPLIT=0" "YMC_SPLIT=1 YMC_SPLIT_NP=2"; do
   echo "== $e"; env $e timeout -k 10 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -1
 done
