@@ -874,7 +874,8 @@ def fixture_f14(name="f14_mlda2_linear_d128.npz", d=128, seed=20250114, K=8, n=2
     print(name, acc.mean(), sub.mean())
 
 
-def fixture_f16(name="f16_aem_linear_d128.npz", use_heuristic=True, seed=20250116, min_data=6, K=8, n=161, S=4):
+def fixture_f16(name="f16_aem_linear_d128.npz", use_heuristic=True, seed=20250116, min_data=6, K=8, n=161, S=4, d=128, n_data=5,
+                prop_var=1.1e-3):
     """The adaptive error model over two d = 128 linear models (the matrix-core kernel's size): AEMBuilder
     (aem.py:61-82) with AEMLikelihoods on both levels, fresh likelihood objects per chain; chains, decisions of
     both levels, and what every chain's coarse likelihood learned (error count, mean, variance, inflated
@@ -884,12 +885,11 @@ def fixture_f16(name="f16_aem_linear_d128.npz", use_heuristic=True, seed=2025011
     from yagremcmc.statistics.likelihood import AEMLikelihood
     from yagremcmc.statistics.modelHierarchy import BayesianRegressionModelHierarchy
     from yagremcmc.utility.hierarchy import Hierarchy, SharedComponent
-    d, n_data = 128, 5
     A_f, b_f, data, noise_var = linear_problem(d, n_data, 7)
     z, _ = oracle.rng_fill(99, 0, d + 1, 0, 1, d, uniforms=False)
     A_c = A_f + 0.02 * z[0][:d] / np.sqrt(d)
     b_c = b_f + 0.05 * z[0][d]
-    prior_mean, prior_var, prop_var = np.zeros(d), 5.0, 1.1e-3
+    prior_mean, prior_var = np.zeros(d), 5.0
     cov = IIDCovarianceMatrix(d, prop_var)
     traj = np.empty((n, K, d))
     acc = np.empty((n - 1, K), dtype=np.uint8)
@@ -1068,11 +1068,11 @@ def fixture_f19():
     print("F19", acc.mean(), acc2.mean(), sub2.mean())
 
 
-def fixture_f20():
+def fixture_f20(name="f20_dense_prior_noise_d20.npz", d=20, n_data=4, seed=20250120, K=8, n=301, prop_var=6e-3):
     """Dense PRIOR and dense NOISE covariance beyond the lane kernels' sizes (d = 20 parameters, 20 outputs, 4
     data rows; Gaussian / CentredGaussianNoise over DenseCovarianceMatrix, gaussian.py:19-24, noise.py:21-22,
-    covariance.py:69-94), prior mean away from zero: a random walk.  Decisions, chains, log-posteriors."""
-    d, n_data = 20, 4
+    covariance.py:69-94), prior mean away from zero: a random walk.  Decisions, chains, log-posteriors.
+    F20b: d = 128 (the prior's 128 more outputs take the forward map beyond the LDS: streamed)."""
     A, b, _, _ = linear_problem(d, n_data, 20)
     z, _ = oracle.rng_fill(2020, 0, 3 * d + 8, 0, 1, d, uniforms=False)
     z = z[0]
@@ -1086,13 +1086,12 @@ def fixture_f20():
     prior = Gaussian(ParameterVector(prior_mean.copy()), DenseCovarianceMatrix(prior_cov))
     noise = CentredGaussianNoise(DenseCovarianceMatrix(noise_cov))
     lik = AdditiveGaussianNoiseLikelihood(Data(data), ForwardModel(ExampleLinearModelSolver(A, b)), noise)
-    cov = IIDCovarianceMatrix(d, 6e-3)
-    seed, K, n = 20250120, 8, 301
+    cov = IIDCovarianceMatrix(d, prop_var)
     traj, acc, lp = run_mrw_model(BayesianRegressionModel(lik, prior), seed, K, n, cov, np.zeros(d))
-    np.savez_compressed(os.path.join(HERE, "f20_dense_prior_noise_d20.npz"), seed=seed, n_states=n, A=A, b=b, data=data,
+    np.savez_compressed(os.path.join(HERE, name), seed=seed, n_states=n, A=A, b=b, data=data,
                         noise_cov=noise_cov, prior_cov=prior_cov, prior_mean=prior_mean, sigma=sigma_of(cov),
                         x0=np.zeros((K, d)), traj=traj, acc=acc, logpost=lp)
-    print("F20", acc.mean())
+    print(name, acc.mean())
 
 
 def fixture_f21():
@@ -1235,12 +1234,14 @@ def main():
         fixture_f15()
     if "f16" in which:
         fixture_f16()
+        fixture_f16("f16b_aem_linear_d48_rows12.npz", seed=20250128, min_data=5, K=6, n=121, S=3, d=48, n_data=12, prop_var=4e-3)
     if "f17" in which:
         fixture_f17()
     if "f19" in which:
         fixture_f19()
     if "f20" in which:
         fixture_f20()
+        fixture_f20("f20b_dense_prior_noise_d128.npz", d=128, n_data=3, seed=20250129, K=4, n=121, prop_var=1.2e-3)
     if "f21" in which:
         fixture_f21()
     if "f18" in which:

@@ -522,12 +522,14 @@ def test_aem_with_a_dense_prior_at_lane_sizes_vs_oracle(ffi, ctx):
     _same_error_model(dev, e)
 
 
-def test_f16_adaptive_error_model_d128_matrix_cores(ffi, ctx, golden):
+@pytest.mark.parametrize("name", ["f16_aem_linear_d128.npz", "f16b_aem_linear_d48_rows12.npz"])
+def test_f16_adaptive_error_model_d128_matrix_cores(ffi, ctx, golden, name):
     """The adaptive error model on the matrix-core kernel (linear_tile_aem2_kernel: per-output error-model
     arrays in the tiled layout, cache keyed by the identity of the points): the live reference's chains at
-    d = 128 (sha256), decisions of both levels, what every chain learned; == oracle bit for bit."""
+    d = 128 (sha256) and at d = 48 with TWELVE data rows (two passes of eight rows over the coarse map), decisions of
+    both levels, what every chain learned; == oracle bit for bit."""
     import hashlib
-    g = golden("f16_aem_linear_d128.npz")
+    g = golden(name)
     n, S = int(g["n_states"]), int(g["S"])
     common = dict(data=g["data"], noise_precision=g["noise_precision"], prior_mean=g["prior_mean"],
                   prior_precision=g["prior_precision"])
@@ -1063,13 +1065,14 @@ def test_tile_kernel_dense_noise_other_shapes(ffi, ctx, d, m, nd, K, method):
         assert np.array_equal(dev["level_acc"], e.level_acc)
 
 
-def test_f20_dense_prior_and_noise_d20_matrix_cores(ffi, ctx, golden):
-    """Dense prior and noise covariances on the matrix-core path (the prior as 20 more outputs of the forward
-    map): the LIVE reference's decisions and chains, log-posteriors to rounding, == oracle bit for bit;
-    ymc_forward_eval returns the model's own 20 outputs."""
+@pytest.mark.parametrize("name", ["f20_dense_prior_noise_d20.npz", "f20b_dense_prior_noise_d128.npz"])
+def test_f20_dense_prior_and_noise_d20_matrix_cores(ffi, ctx, golden, name):
+    """Dense prior and noise covariances on the matrix-core path (the prior as d more outputs of the forward
+    map; at d = 128 that takes the map beyond the LDS: streamed): the LIVE reference's decisions and chains,
+    log-posteriors to rounding, == oracle bit for bit; ymc_forward_eval returns the model's own outputs."""
     from yagremcmc_amd import lowering
-    g = golden("f20_dense_prior_noise_d20.npz")
-    d = 20
+    g = golden(name)
+    d = g["A"].shape[1]
     common = dict(data=g["data"], noise_precision=np.ones(d), prior_mean=g["prior_mean"], prior_precision=np.ones(d))
     low = _dense_low(ffi, ffi.POSTERIOR_LINEAR, d, common, g["noise_cov"], g["prior_cov"], fwd_matrix=g["A"], fwd_shift=g["b"])
     p = o.dense_covariances(o.posterior_linear(g["A"], g["b"], g["data"], np.ones(d), g["prior_mean"], np.ones(d)),

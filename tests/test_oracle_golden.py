@@ -264,10 +264,12 @@ def test_f17_dense_proposal_covariance_d16(golden):
     assert np.abs(out["logpost"] - want).max() <= 1e-12 * np.abs(want).max()
 
 
-def test_f16_adaptive_error_model_d128(golden):
-    """aem.py over two d = 128 linear models (the matrix-core kernel's size): chains (sha256 of all states),
-    decisions at both levels and the learned error model == the live reference's."""
-    g = golden("f16_aem_linear_d128.npz")
+@pytest.mark.parametrize("name", ["f16_aem_linear_d128.npz", "f16b_aem_linear_d48_rows12.npz"])
+def test_f16_adaptive_error_model_d128(golden, name):
+    """aem.py over two d = 128 linear models (the matrix-core kernel's size) and over two d = 48 models with twelve
+    data rows: chains (sha256 of all states), decisions at both levels and the learned error model == the live
+    reference's."""
+    g = golden(name)
     n = int(g["n_states"])
     e = _aem_from_fixture(g)
     out = e.advance(n - 1, want_sub=True)
@@ -453,12 +455,13 @@ def test_f19_dense_noise_covariance_beyond_the_lane_sizes(golden):
     assert np.allclose(got, want, rtol=1e-11, atol=0)
 
 
-def test_f20_dense_prior_and_noise_beyond_the_lane_sizes(golden):
-    """Gaussian prior AND noise over DenseCovarianceMatrix at d = 20: the noise is whitened away, the prior becomes
-    20 more outputs of the forward map (oracle.dense_covariances, as the product's lowering).  The live
+@pytest.mark.parametrize("name", ["f20_dense_prior_noise_d20.npz", "f20b_dense_prior_noise_d128.npz"])
+def test_f20_dense_prior_and_noise_beyond_the_lane_sizes(golden, name):
+    """Gaussian prior AND noise over DenseCovarianceMatrix at d = 20 and d = 128: the noise is whitened away, the prior
+    becomes d more outputs of the forward map (oracle.dense_covariances, as the product's lowering).  The live
     reference's decisions and chains; log-posteriors to rounding; against NumPy on random points."""
-    g = golden("f20_dense_prior_noise_d20.npz")
-    d = 20
+    g = golden(name)
+    d = g["A"].shape[1]
     p = o.dense_covariances(o.posterior_linear(g["A"], g["b"], g["data"], np.ones(d), g["prior_mean"], np.ones(d)),
                             noise_cov=g["noise_cov"], prior_cov=g["prior_cov"])
     assert p["data_dim"] == 2 * d and not p["prior_precision"].any() and "lin_tail" in p
