@@ -297,7 +297,7 @@ def test_random_adaptive_error_model_matches_oracle(case):
         assert np.array_equal(s["wf_mean"], e.wf_mean) and np.array_equal(s["wf_m2"], e.wf_m2)
 
 
-@pytest.mark.parametrize("case", range(36))
+@pytest.mark.parametrize("case", range(96))
 def test_random_matrix_core_configuration_matches_oracle(case):
     """The samplers of the matrix-core path (random walk with a diagonal or dense proposal, pCN, two-level, nested)
     over random shapes -- parameter dimension 9..128 or a small one with many outputs, per-level output counts,
@@ -402,3 +402,186 @@ def test_random_matrix_core_configuration_matches_oracle(case):
         assert np.array_equal(s["wf_mean"], e.wf_mean) and np.array_equal(s["wf_m2"], e.wf_m2)
     if sampler == "nested":
         assert np.array_equal(run.level_accept()[0], e.level_acc)
+
+
+def _linear_pair(ffi, d, m, nd, rng, dense_prior=False, scale=1.0):
+    from scipy.linalg import solve_triangular
+    from yagremcmc_amd import lowering
+    g = dict(A=scale * rng.normal(size=(m, d)) / np.sqrt(d), b=rng.normal(size=m), data=rng.normal(size=(nd, m)),
+             noise_precision=rng.uniform(0.5, 3, size=m), prior_mean=rng.normal(size=d) * 0.1,
+             prior_precision=np.ones(d) if dense_prior else rng.uniform(0.1, 2, size=d))
+    p = o.posterior_linear(g["A"], g["b"], g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+    low = lowering.Lowered(ffi.POSTERIOR_LINEAR, d)
+    low.desc.n_data, low.desc.data_dim = nd, m
+    for k, v in (("data", g["data"]), ("noise_precision", g["noise_precision"]), ("prior_mean", g["prior_mean"]),
+                 ("prior_precision", g["prior_precision"]), ("fwd_matrix", g["A"]), ("fwd_shift", g["b"])):
+        low.set_array(k, v)
+    if dense_prior:
+        B = rng.normal(size=(d, d)) / np.sqrt(d)
+        pc = B @ B.T + np.eye(d)
+        L = np.linalg.cholesky(pc)
+        low.set_array("prior_chol_inv", np.tril(solve_triangular(L, np.eye(d), lower=True)))
+        p = o.dense_covariances(p, prior_cov=pc)
+    return low, p
+
+
+class _Pre:
+    def __init__(self, low):
+        self.low = low
+
+
+@pytest.mark.parametrize("case", range(96))
+def test_random_round3_features_match_oracle(case, monkeypatch):
+    """Round 3's paths, fuzzed against the oracle: nests of up to eight effective levels (lane and matrix-core kernels),
+    Lotka-Volterra levels integrated adaptively (lane per chain and lane per design row, two-level, nested), the
+    adaptive error model with more than eight data rows, and the streamed builds of the matrix-core samplers (a base /
+    coarse / forward matrix beyond the LDS, parameter dimensions beyond 128, dense proposals and priors there)."""
+    from yagremcmc_amd import _ffi as ffi, lowering
+    ctx = ffi.default_context(0)
+    rng = np.random.default_rng(11000 + case)
+    feature = ["deep_nest", "lv_adaptive", "aem_rows", "stream_mlda2", "stream_nested", "stream_dense"][case % 6]
+    K = int(rng.choice([5, 16, 33, 70]))
+    seed, chain0 = int(rng.integers(0, 2**62)), int(rng.choice([0, 17, 2**31 + 5]))
+    real = lowering.lower_density
+    monkeypatch.setattr(lowering, "lower_density", lambda dd, rk4_steps=None: dd.low if isinstance(dd, _Pre) else real(dd, rk4_steps))
+
+    def nested(models, subs, sigma, x0, n):
+        (lt, pt), surs = models[-1], models[:-1]
+        prob = lowering.make_nested_problem(ctx, _Pre(lt), [_Pre(l) for l, _ in surs], subs, sigma)
+        run = ffi.Run(prob, seed, K, x0, n, ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT | ffi.RECORD_LOGPOST | ffi.RECORD_MOMENTS, chain0)
+        cut = int(rng.integers(0, n + 1))
+        run.advance(cut)
+        run.advance(n - cut)
+        P, Q, steps = o.nested_levels([q for _, q in surs], subs, pt)
+        e = o.NestedEnsemble(P, Q, steps, sigma, x0, seed, chain0=chain0)
+        out = e.advance(n)
+        assert np.array_equal(run.accept(), out["acc"]) and np.array_equal(run.trajectory(), out["traj"])
+        assert np.array_equal(run.logpost(), out["logpost"])
+        acc, _ = run.level_accept()
+        assert np.array_equal(acc, e.level_acc)
+        s = run.summary()
+        assert np.array_equal(s["wf_mean"], e.wf_mean) and np.array_equal(s["wf_m2"], e.wf_m2)
+
+    def two_level(lf, pf, lc, pc, sigma, x0, n, S):
+        prob = lowering.make_problem(ctx, ffi.METHOD_MLDA2, lf, sigma, surrogate=lc, sub_chain_length=S)
+        run = ffi.Run(prob, seed, K, x0, n, ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT | ffi.RECORD_SUB_ACCEPT | ffi.RECORD_LOGPOST, chain0)
+        cut = int(rng.integers(0, n + 1))
+        run.advance(cut)
+        run.advance(n - cut)
+        e = o.Ensemble(pf, sigma, x0, seed, chain0=chain0, surrogate=pc, sub_chain_length=S)
+        out = e.advance(n, want_sub=True)
+        assert np.array_equal(run.accept(), out["acc"]) and np.array_equal(run.sub_accept(), out["sub_acc"])
+        assert np.array_equal(run.trajectory(), out["traj"]) and np.array_equal(run.logpost(), out["logpost"])
+
+    def lv(rtol):
+        nd = int(rng.integers(2, 11))
+        design = rng.uniform(0.5, 1.5, size=(nd, 2))
+        g = dict(data=rng.uniform(0.2, 2.0, size=(nd, 2)), noise_precision=rng.uniform(5, 30, size=2), prior_mean=np.zeros(2),
+                 prior_precision=rng.uniform(0.5, 2, size=2))
+        lv.shape = lv.shape if hasattr(lv, "shape") else (design, g, float(rng.uniform(2, 9)))
+        design, g, T = lv.shape
+        steps = int(rng.integers(10, 40))
+        p = o.posterior_lv(design, T, 0.8, 0.4, steps, g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"],
+                           rtol=rtol)
+        low = lowering.Lowered(ffi.POSTERIOR_LV, 2)
+        low.desc.n_data, low.desc.data_dim = design.shape[0], 2
+        for k, v in (("data", g["data"]), ("noise_precision", g["noise_precision"]), ("prior_mean", g["prior_mean"]),
+                     ("prior_precision", g["prior_precision"]), ("design", design)):
+            low.set_array(k, v)
+        low.desc.t_final, low.desc.alpha, low.desc.gamma, low.desc.rk4_steps = T, 0.8, 0.4, steps
+        low.desc.lv_rtol, low.desc.lv_atol = rtol, 1e-6 if rtol > 0 else 0.0
+        return low, p
+
+    if feature == "deep_nest":
+        E = int(rng.integers(5, 9))
+        tile = bool(case % 12 >= 6)
+        d = int(rng.integers(9, 40)) if tile else int(rng.integers(1, 9))
+        if tile:
+            models = [_linear_pair(ffi, d, int(rng.integers(1, 40)), int(rng.integers(1, 4)), rng, scale=1.0 - 0.02 * i)
+                      for i in range(2 * (E - 1) + 1)]
+            sigma = rng.uniform(0.03, 0.1, size=d)
+        else:
+            models = [_lowered(ffi, "gauss", d, rng) for _ in range(2 * (E - 1) + 1)]
+            sigma = rng.uniform(0.4, 1.0, size=d)
+        subs = [int(v) for v in rng.integers(1, 3, size=2 * (E - 1))]
+        nested(models, subs, sigma, rng.normal(size=(K, d)) * 0.5, int(rng.integers(2, 7)))
+    elif feature == "lv_adaptive":
+        monkeypatch.setenv("YMC_LV_ROWS", str((case // 6) % 2))
+        rt = [1e-2, 1e-4, 1e-7]
+        x0 = rng.normal(size=(K, 2)) * 0.25 - np.array([0.6, 0.3])
+        sigma = rng.uniform(0.05, 0.3, size=2)
+        mode = (case // 6) % 3
+        if mode == 0:
+            low, p = lv(rt[case % 3])
+            prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, sigma)
+            n = int(rng.integers(3, 40))
+            run = ffi.Run(prob, seed, K, x0, n, ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT | ffi.RECORD_LOGPOST, chain0)
+            run.advance(n)
+            out = o.Ensemble(p, sigma, x0, seed, chain0=chain0).advance(n)
+            assert np.array_equal(run.accept(), out["acc"]) and np.array_equal(run.trajectory(), out["traj"])
+            assert np.array_equal(run.logpost(), out["logpost"], equal_nan=True)
+        elif mode == 1:
+            (lf, pf), (lc, pc) = lv(1e-6), lv(float(rng.choice([1e-2, 0.0])))
+            two_level(lf, pf, lc, pc, sigma, x0, int(rng.integers(3, 20)), int(rng.integers(1, 4)))
+        else:
+            models = [lv(float(r)) for r in rng.choice([1e-2, 1e-3, 0.0, 1e-5], size=5)]
+            nested(models, [2, 1, 2, 2], sigma, x0, int(rng.integers(2, 8)))
+    elif feature == "aem_rows":
+        d, m, nd = int(rng.integers(9, 50)), int(rng.integers(3, 60)), int(rng.integers(9, 30))
+        A, b = rng.normal(size=(m, d)) / np.sqrt(d), rng.normal(size=m) * 0.3
+        As, bs = A + 0.05 * rng.normal(size=(m, d)), b + 0.1 * rng.normal(size=m)
+        data = np.array([A @ rng.normal(size=d) * 0.2 + b + 0.5 * rng.normal(size=m) for _ in range(nd)])
+        common = dict(data=data, noise_precision=rng.uniform(3, 5, size=m), prior_mean=np.zeros(d), prior_precision=np.full(d, 0.25))
+
+        def low(A_, b_):
+            l = lowering.Lowered(ffi.POSTERIOR_LINEAR, d)
+            l.desc.n_data, l.desc.data_dim = nd, m
+            for k, v in (("fwd_matrix", A_), ("fwd_shift", b_)) + tuple(common.items()):
+                l.set_array(k, v)
+            return l
+        S, mind, heur = int(rng.integers(1, 4)), int(rng.integers(2, 6)), int(case % 2)
+        sigma, x0 = np.full(d, 0.5 / np.sqrt(d)), rng.normal(size=(K, d)) * 0.3
+        prob = lowering.make_problem(ctx, ffi.METHOD_AEM2, low(A, b), sigma, surrogate=low(As, bs), sub_chain_length=S, aem=(mind, heur))
+        n = int(rng.integers(10, 40))
+        run = ffi.Run(prob, seed, K, x0, n, ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT | ffi.RECORD_SUB_ACCEPT, chain0)
+        cut = int(rng.integers(0, n + 1))
+        run.advance(cut)
+        run.advance(n - cut)
+        e = o.AemEnsemble(o.posterior_linear(A, b, **common), o.posterior_linear(As, bs, **common), sigma, x0, seed, S, mind, heur,
+                          chain0=chain0)
+        out = e.advance(n, want_sub=True)
+        assert np.array_equal(run.accept(), out["acc"]) and np.array_equal(run.sub_accept(), out["sub_acc"])
+        assert np.array_equal(run.trajectory(), out["traj"])
+        err = run.error_model()
+        assert np.array_equal(err["n"], e.aem_n) and np.array_equal(err["mean"], e.aem_mean) and np.array_equal(err["m2"], e.aem_m2)
+    elif feature == "stream_mlda2":
+        d = int(rng.choice([100, 128, 130, 200, 256]))
+        mc, mf = int(rng.integers(10, 300)), int(rng.integers(10, 200))
+        dense = bool(case % 12 >= 6) and d <= 160
+        (lf, pf), (lc, pc) = _linear_pair(ffi, d, mf, 2, rng, dense), _linear_pair(ffi, d, mc, 2, rng, dense, scale=0.95)
+        if case % 4 == 0:
+            monkeypatch.setenv("YMC_TILE_MLDA2", "stream")
+        two_level(lf, pf, lc, pc, rng.uniform(0.02, 0.05, size=d), rng.normal(size=(K, d)) * 0.5, int(rng.integers(3, 12)),
+                  int(rng.integers(1, 4)))
+    elif feature == "stream_nested":
+        d = int(rng.choice([64, 128, 140, 256]))
+        E = int(rng.integers(2, 5))
+        ms = [int(rng.integers(8, 280 if i == 0 else 80)) for i in range(2 * (E - 1) + 1)]
+        models = [_linear_pair(ffi, d, m, 2, rng, scale=1.0 - 0.02 * i) for i, m in enumerate(ms)]
+        if case % 4 == 0:
+            monkeypatch.setenv("YMC_TILE_NESTED", "stream")
+        nested(models, [int(v) for v in rng.integers(1, 3, size=2 * (E - 1))], rng.uniform(0.02, 0.06, size=d),
+               rng.normal(size=(K, d)) * 0.5, int(rng.integers(2, 8)))
+    else:
+        d, m = int(rng.choice([40, 128, 150, 256])), int(rng.choice([20, 200, 600]))
+        low, p = _linear_pair(ffi, d, m, 2, rng, dense_prior=bool(case % 12 >= 6) and d <= 150)
+        B = rng.normal(size=(d, d)) * 0.02 / np.sqrt(d)
+        L = np.linalg.cholesky(B @ B.T + 0.002 * np.eye(d))
+        x0 = rng.normal(size=(K, d)) * 0.5
+        prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, np.ones(d), chol=np.tril(L))
+        n = int(rng.integers(3, 30))
+        run = ffi.Run(prob, seed, K, x0, n, ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT | ffi.RECORD_LOGPOST, chain0)
+        run.advance(n)
+        out = o.Ensemble(p, np.ones(d), x0, seed, chain0=chain0, chol=L).advance(n)
+        assert np.array_equal(run.accept(), out["acc"]) and np.array_equal(run.trajectory(), out["traj"])
+        assert np.array_equal(run.logpost(), out["logpost"])
