@@ -14,10 +14,11 @@ CASES = [("example_mcmc_1d.py", []), ("example_mcmc_2d_singleLevel.py", ["256", 
          ("example_mcmc_2d_twoLevel.py", ["256", "800"]), ("example_mcmc_2d_hierarchical.py", ["256", "600"]),
          ("example_inference_linearModel_twoLevel.py", ["128", "600"]),
          ("example_inference_lotkaVolterra_singleLevel.py", ["256", "400"]),
+         ("example_inference_lotkaVolterra_singleLevel.py", ["256", "600", "adaptive"]),   # from the reference's own start
          ("example_inference_lotkaVolterra_twoLevel.py", ["256", "300"])]
 
 
-@pytest.mark.parametrize("script,args", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("script,args", CASES, ids=["-".join([c[0]] + c[1][2:]) for c in CASES])
 def test_example_runs(script, args):
     env = dict(os.environ, MPLBACKEND="Agg", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", script), *args], env=env, cwd=ROOT,
@@ -25,3 +26,5 @@ def test_example_runs(script, args):
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     out = r.stdout.lower()
     assert "acceptance rate" in out and "nan" not in out, r.stdout[-1500:]
+    if "adaptive" in args:
+        assert "chains flagged non-finite: 0" in out, r.stdout[-1500:]
