@@ -15,7 +15,8 @@ CASES = [("example_mcmc_1d.py", []), ("example_mcmc_2d_singleLevel.py", ["256", 
          ("example_inference_linearModel_twoLevel.py", ["128", "600"]),
          ("example_inference_lotkaVolterra_singleLevel.py", ["256", "400"]),
          ("example_inference_lotkaVolterra_singleLevel.py", ["256", "600", "adaptive"]),   # from the reference's own start
-         ("example_inference_lotkaVolterra_twoLevel.py", ["256", "300"])]
+         ("example_inference_lotkaVolterra_twoLevel.py", ["256", "300"]),
+         ("example_inference_lotkaVolterra_twoLevel.py", ["256", "400", "adaptive"])]
 
 
 @pytest.mark.parametrize("script,args", CASES, ids=["-".join([c[0]] + c[1][2:]) for c in CASES])

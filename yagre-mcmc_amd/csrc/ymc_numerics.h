@@ -591,7 +591,7 @@ YMC_FN void ymc_lv_rk4_step(double *x, double *y, double alpha, double beta, dou
  * the reference's LotkaVolterraSolver hands `method` and `rtol` to scipy.integrate.solve_ivp, testSetup.py:118-141)
  * with first-same-as-last and a controller that only halves and doubles the step -- every quantity an IEEE sum,
  * product or fma in a fixed order, so that device and checker agree to the bit.  A step is accepted when every
- * component's error estimate is within atol + rtol max(|y|, |y_new|); it doubles after a step whose estimate is within
+ * component's error estimate is within atol + rtol |y|; it doubles after a step whose estimate is within
  * 1/64 of that bound (the estimate scales with h^5: x 32), halves after a rejected one (to a quarter beyond 32 x the
  * bound).  Returns false -- state unspecified -- when the step has shrunk below T 2^-40 (a singular right-hand side
  * or a non-finite state) or after max_attempts steps.  Classical RK4 in 50 steps overflows at the reference
@@ -637,9 +637,14 @@ YMC_FN int ymc_lv_dp45_solve(double *x, double *y, double alpha, double beta, do
             hs * ymc_fma(e7, k7u, ymc_fma(e6, k6u, ymc_fma(e5, k5u, ymc_fma(e4, k4u, ymc_fma(e3, k3u, e1 * k1u))))));
         const double ev = __builtin_fabs(
             hs * ymc_fma(e7, k7v, ymc_fma(e6, k6v, ymc_fma(e5, k5v, ymc_fma(e4, k4v, ymc_fma(e3, k3v, e1 * k1v))))));
-        const double au = __builtin_fabs(u), aun = __builtin_fabs(un), av = __builtin_fabs(v), avn = __builtin_fabs(vn);
-        const double su = ymc_fma(rtol, aun > au ? aun : au, atol), sv = ymc_fma(rtol, avn > av ? avn : av, atol);
-        if (eu <= su && ev <= sv && su <= huge && sv <= huge) { /* false for a NaN or an overflow anywhere */
+        /* the bound is relative to the state the step STARTS from: with max(|y|, |y_new|) -- scipy's choice -- a step that
+         * explodes inflates its own tolerance (at rtol 1e-2 one in eighty solves around theta = (-7, 2.8) accepted a jump to
+         * 1e10 and a negative population that way) */
+        const double su = ymc_fma(rtol, __builtin_fabs(u), atol), sv = ymc_fma(rtol, __builtin_fabs(v), atol);
+        const double aun = __builtin_fabs(un), avn = __builtin_fabs(vn);
+        /* (a population does not change sign: the exact flow keeps the axes invariant) */
+        const int keeps_sign = !(u > 0.0 && un < 0.0) && !(v > 0.0 && vn < 0.0) && !(u < 0.0 && un > 0.0) && !(v < 0.0 && vn > 0.0);
+        if (eu <= su && ev <= sv && aun <= huge && avn <= huge && keeps_sign) { /* false for a NaN or an overflow anywhere */
             u = un, v = vn, k1u = k7u, k1v = k7v;
             if (last) {
                 *x = u, *y = v;
