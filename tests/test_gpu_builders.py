@@ -102,6 +102,34 @@ def test_two_level_builder_and_perfect_surrogate():
     assert abs(mc2.diagnostics.global_acceptance_rate() - 1.0) < 1e-3
 
 
+def test_two_level_surrogate_diagnostics_come_from_the_sub_chain_record():
+    """mcmc.surrogate(0).diagnostics of a one-surrogate run (mlda.py:84-89: the coarse chain's own diagnostics): counted
+    from the record of the sub-chain decisions -- without that record the request is refused, not answered with 0."""
+    m = _imports()
+    mean = np.array([1.0, 1.5])
+    cov = np.array([[2.4, -0.5], [-0.5, 0.7]])
+    fine = m["GaussianTargetDensity2d"](m["ParameterVector"](mean), cov)
+    coarse = m["GaussianTargetDensity2d"](m["ParameterVector"](mean + np.array([0.15, -0.2])), 2.0 * cov)
+    b = m["MLDABuilder"]()
+    b.explicitTarget, b.surrogateTargets = fine, [coarse]
+    b.baseProposalCovariance = m["IIDCovarianceMatrix"](2, 1.0)
+    b.subChainLengths = [4]
+    b.nChains, b.seed = 128, 21
+    mc = b.build_method()
+    mc.run(200, m["ParameterVector"](np.array([-8.0, -7.0])), verbose=False)
+    with pytest.raises(RuntimeError, match="recordSubChain"):
+        mc.surrogate(0).diagnostics
+    b.recordSubChain = True
+    ms = b.build_method()
+    ms.run(200, m["ParameterVector"](np.array([-8.0, -7.0])), verbose=False)
+    assert np.array_equal(ms.accept_decisions, mc.accept_decisions)
+    sub = ms.sub_chain_decisions
+    assert sub.shape == (199, 4, 128) and 0.05 < sub.mean() < 0.95
+    assert ms.surrogate(0).diagnostics.global_acceptance_rate() == sub.mean()
+    assert np.array_equal(ms.surrogate(0).diagnostics.per_chain_acceptance_rate(), sub.mean(axis=(0, 1)))
+    assert ms.surrogate(0).target is coarse
+
+
 def _mlda_test_data(m):
     """test_mlda.py:14-43"""
     mean = np.array([1.0, 1.5])

@@ -344,8 +344,15 @@ class MLDA(MetropolisHastingsEnsemble):
     def _level_diagnostics(self, index):
         """Surrogate i of an even hierarchy decides iff i is even (it is level i/2 of the nest)."""
         n = self.nSurrogates
-        if n == 1 or self._run is None or index % 2 == 1:
+        if self._run is None or (n > 1 and index % 2 == 1):
             return LevelAcceptance(np.zeros(self.nChains, dtype=np.uint64), 0)
+        if n == 1:
+            # one surrogate: the coarse decisions are counted from the sub-chain record (the kernels keep no counter)
+            if not self.recordSubChain:
+                raise RuntimeError("the surrogate's acceptance statistics of a two-level run come from the record of its "
+                                   "sub-chain decisions: set recordSubChain = True on the builder")
+            sub = self.sub_chain_decisions
+            return LevelAcceptance(sub.sum(axis=(0, 1), dtype=np.uint64), sub.shape[0] * sub.shape[1])
         acc, made = self._run.level_accept()
         return LevelAcceptance(acc[index // 2], made[index // 2])
 
