@@ -128,6 +128,12 @@ def test_two_level_surrogate_diagnostics_come_from_the_sub_chain_record():
     assert ms.surrogate(0).diagnostics.global_acceptance_rate() == sub.mean()
     assert np.array_equal(ms.surrogate(0).diagnostics.per_chain_acceptance_rate(), sub.mean(axis=(0, 1)))
     assert ms.surrogate(0).target is coarse
+    # diagnostics handed in for the surrogate (the reference's way) switch the record on by themselves
+    b.recordSubChain = False
+    b.surrogateDiagnostics = [m["AcceptanceRateDiagnostics"]()]
+    md = b.build_method()
+    md.run(200, m["ParameterVector"](np.array([-8.0, -7.0])), verbose=False)
+    assert md.surrogate(0).diagnostics.global_acceptance_rate() == sub.mean()
 
 
 def _mlda_test_data(m):

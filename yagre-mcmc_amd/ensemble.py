@@ -313,6 +313,10 @@ class MLDA(MetropolisHastingsEnsemble):
         self._nSteps = [int(v) for v in nSteps]
         self._surrogateDiagnostics = surrogateDiagnosticsList
         self.recordSubChain = bool(recordSubChain)
+        # diagnostics handed in for the one surrogate (mlda.py:84-89 reads them after the run) need its decisions
+        if (surrogateDiagnosticsList is not None and len(self._surrogates) == 1 and self.recordStride == 1
+                and self.recordTrajectory):
+            self.recordSubChain = True
         if self.recordSubChain and len(self._surrogates) != 1:
             raise lowering.UnsupportedPlugin("sub-chain decisions are recorded for one surrogate only")
         if self.recordSubChain and self.recordStride > 1:
