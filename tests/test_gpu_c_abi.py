@@ -166,3 +166,75 @@ def test_invalid_descriptions_are_refused_with_messages():
     assert rc == _ffi.ERR_INVALID and b"burn-in" in _ffi.lib().ymc_last_error()
     buf = np.zeros((2, 8, 2))
     assert _ffi.lib().ymc_run_fetch_trajectory(full.raw, 5, (1 << 64) - 3, _ffi.vptr(buf), buf.nbytes) == _ffi.ERR_INVALID
+
+
+@pytest.mark.gpu
+def test_device_memory_returns_when_problems_and_runs_are_destroyed():
+    """Every sampler's problem and run, created, advanced and destroyed forty times over: the device's free memory
+    comes back (hipMemGetInfo before and after; the context keeps a few scratch buffers, bounded)."""
+    import ctypes as C
+    from yagremcmc_amd import _ffi, lowering
+    hip = C.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        free, total = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        return free.value
+
+    ctx = _ffi.default_context(0)
+    rng = np.random.default_rng(3)
+
+    def lin(d, m, nd=2):
+        low = lowering.Lowered(_ffi.POSTERIOR_LINEAR, d)
+        low.desc.n_data, low.desc.data_dim = nd, m
+        for k, v in dict(data=rng.normal(size=(nd, m)), noise_precision=np.ones(m), prior_mean=np.zeros(d), prior_precision=np.ones(d),
+                         fwd_matrix=rng.normal(size=(m, d)) / np.sqrt(d), fwd_shift=np.zeros(m)).items():
+            low.set_array(k, v)
+        return low
+
+    def gauss(d=2):
+        low = lowering.Lowered(_ffi.GAUSS_WHITENED, d)
+        low.set_array("mean", np.zeros(d))
+        low.set_array("whiten", np.eye(d))
+        return low
+
+    class Pre:
+        def __init__(self, low):
+            self.low = low
+
+    real = lowering.lower_density
+    lowering.lower_density = lambda dd, rk4_steps=None: dd.low if isinstance(dd, Pre) else real(dd, rk4_steps)
+    flags = _ffi.RECORD_TRAJECTORY | _ffi.RECORD_ACCEPT | _ffi.RECORD_MOMENTS
+    K = 4096
+
+    def cycle():
+        made = [
+            (lowering.make_problem(ctx, _ffi.METHOD_MRW, gauss(), np.ones(2)), 2),
+            (lowering.make_problem(ctx, _ffi.METHOD_MRW, lin(64, 64), np.full(64, 0.05)), 64),
+            (lowering.make_problem(ctx, _ffi.METHOD_MRW, lin(200, 300), np.full(200, 0.03)), 200),
+            (lowering.make_problem(ctx, _ffi.METHOD_MLDA2, lin(128, 200), np.full(128, 0.03), surrogate=lin(128, 200), sub_chain_length=2), 128),
+            (lowering.make_problem(ctx, _ffi.METHOD_AEM2, lin(32, 40, 11), np.full(32, 0.05), surrogate=lin(32, 40, 11), sub_chain_length=2,
+                                   aem=(4, 1)), 32),
+            (lowering.make_nested_problem(ctx, Pre(lin(48, 20)), [Pre(lin(48, 30)), Pre(lin(48, 16))], [2, 2], np.full(48, 0.05)), 48),
+            (lowering.make_nested_problem(ctx, Pre(gauss()), [Pre(gauss())] * 10, [1] * 10, np.ones(2)), 2),
+        ]
+        for prob, d in made:
+            run = _ffi.Run(prob, 1, K, np.zeros((K, d)), 6, flags)
+            run.advance(6)
+            run.trajectory()
+            run.summary()
+            run.close()
+            prob.close()
+
+    import warnings
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            cycle()                                  # the context's own scratch buffers are in place after one cycle
+            before = free_bytes()
+            for _ in range(40):
+                cycle()
+            after = free_bytes()
+    finally:
+        lowering.lower_density = real
+    assert before - after < 64 << 20, f"{(before - after) / 2**20:.1f} MiB of device memory did not come back"
