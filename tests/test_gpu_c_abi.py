@@ -238,3 +238,12 @@ def test_device_memory_returns_when_problems_and_runs_are_destroyed():
     finally:
         lowering.lower_density = real
     assert before - after < 64 << 20, f"{(before - after) / 2**20:.1f} MiB of device memory did not come back"
+    # a record beyond the card's memory: refused with the runtime's message, and what had been allocated is released
+    prob = lowering.make_problem(ctx, _ffi.METHOD_MRW, gauss(), np.ones(2))
+    with pytest.raises(_ffi.YmcError, match="(?i)memory") as err:
+        _ffi.Run(prob, 1, 1 << 24, np.zeros((1, 2)), 2000, _ffi.RECORD_TRAJECTORY | _ffi.RECORD_ACCEPT)
+    assert err.value.code == _ffi.ERR_DEVICE
+    assert after - free_bytes() < 64 << 20
+    run = _ffi.Run(prob, 1, 1024, np.zeros((1, 2)), 10, _ffi.RECORD_TRAJECTORY)      # the context is still usable
+    run.advance(10)
+    assert np.isfinite(run.trajectory()).all()

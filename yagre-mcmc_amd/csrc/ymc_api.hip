@@ -36,12 +36,17 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
+/* a failed runtime call also leaves its code in the runtime's "last error", where the next launch check
+ * (hipGetLastError after a kernel launch) would find it and blame the launch: an allocation refused for lack of memory
+ * made every later launch on the context fail with "out of memory".  Reading the last error resets it. */
 #define YMC_HIP(call)                                                                          \
     do {                                                                                       \
         hipError_t e_ = (call);                                                                \
-        if (e_ != hipSuccess)                                                                  \
+        if (e_ != hipSuccess) {                                                                \
+            (void)hipGetLastError();                                                           \
             return fail(YMC_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
                         __FILE__, __LINE__);                                                   \
+        }                                                                                      \
     } while (0)
 
 #define YMC_TRY(call)          \
