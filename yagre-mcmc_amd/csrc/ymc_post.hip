@@ -203,29 +203,38 @@ __global__ __launch_bounds__(64) void iat_wave_kernel(const double *__restrict__
         const bool near = l0 <= (uint64_t)kIatNear;
         const double *Bt = near ? tileA : tileB;        /* the shifted factors: Bt[iat_pad(bo + q)] = x[T0 + l0 + q] */
         const int bo = near ? (int)l0 : 0;
+        /* a tile's elements: requested (issue) and, centred, written to LDS (commit) separately, so that the NEXT tile's loads
+         * are in flight while this one is multiplied (+3.5 %: the kernel re-reads its series once per block of lags and runs
+         * at 3.7 TB/s of such reads -- it is the passes that cost, not their latency) */
+        constexpr int kStage = (TB + kIatNear + L + 63) / 64;
+        auto issue = [&](double (&v)[kStage], uint64_t base, int count) {
+#pragma unroll
+            for (int j = 0; j < kStage; ++j) {
+                const int q = lane + 64 * j;
+                const uint64_t t = base + (uint64_t)q;
+                v[j] = (q < count && t < N) ? x[t] : mean;      /* past the end: x - mean = 0 */
+            }
+        };
+        auto commit = [&](double *dst, const double (&v)[kStage], int count) {
+#pragma unroll
+            for (int j = 0; j < kStage; ++j) {
+                const int q = lane + 64 * j;
+                if (q < count) dst[iat_pad(q)] = v[j] - mean;
+            }
+        };
+        const int na = near ? TB + (int)l0 + L : TB;
+        double va[kStage];
+        issue(va, 0, na);
         for (uint64_t T0 = 0; T0 + l0 < N; T0 += TB) { /* tiles whose elements still have a partner at lag l0 */
             __syncthreads();
-            const int na = near ? TB + (int)l0 + L : TB;
-            /* stage a tile with all its loads in flight together: up to kStage = 10 elements per lane
-             * (TB + kIatNear + L = 640 = 10 x 64) */
-            auto stage_tile = [&](double *dst, uint64_t base, int count) {
-                constexpr int kStage = (TB + kIatNear + L + 63) / 64;
-                double v[kStage];
-#pragma unroll
-                for (int j = 0; j < kStage; ++j) {
-                    const int q = lane + 64 * j;
-                    const uint64_t t = base + (uint64_t)q;
-                    v[j] = (q < count && t < N) ? x[t] : mean;      /* past the end: x - mean = 0 */
-                }
-#pragma unroll
-                for (int j = 0; j < kStage; ++j) {
-                    const int q = lane + 64 * j;
-                    if (q < count) dst[iat_pad(q)] = v[j] - mean;
-                }
-            };
-            stage_tile(tileA, T0, na);
-            if (!near) stage_tile(tileB, T0 + l0, TB + L);
+            commit(tileA, va, na);
+            if (!near) {
+                double vb[kStage];
+                issue(vb, T0 + l0, TB + L);
+                commit(tileB, vb, TB + L);
+            }
             __syncthreads();
+            if (T0 + TB + l0 < N) issue(va, T0 + TB, na);
             double a[P], w[L];
 #pragma unroll
             for (int j = 0; j < P; ++j) a[j] = tileA[iat_pad(P * lane + j)];
