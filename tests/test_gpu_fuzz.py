@@ -6,6 +6,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+# YMC_FUZZ_SHIFT=n moves every case to another seed (a hunt beyond the fixed cases: tools/fuzz_hunt.sh)
+_SEED_SHIFT = 100003 * int(__import__("os").environ.get("YMC_FUZZ_SHIFT", "0"))
+
 from oracle import oracle as o  # noqa: E402
 
 
@@ -56,7 +59,7 @@ def _lowered(ffi, kind, d, rng):
 def test_random_configuration_matches_oracle(case, monkeypatch):
     from yagremcmc_amd import _ffi as ffi, lowering
     ctx = ffi.default_context(0)
-    rng = np.random.default_rng(5000 + case)
+    rng = np.random.default_rng(5000 + case + _SEED_SHIFT)
     kind = ["gauss", "gauss", "linear", "lv", "iso1d", "gauss"][case % 6]
     d = {"iso1d": 1, "lv": 2}.get(kind, int(rng.integers(1, 9)))
     low, p = _lowered(ffi, kind, d, rng)
@@ -78,7 +81,7 @@ def test_random_configuration_matches_oracle(case, monkeypatch):
     kwargs = {}
     if method == "mlda":
         S = int(rng.integers(1, 5))
-        low2, p2 = _lowered(ffi, kind, d, np.random.default_rng(9000 + case)) if kind in ("gauss", "iso1d") else (low, p)
+        low2, p2 = _lowered(ffi, kind, d, np.random.default_rng(9000 + case + _SEED_SHIFT)) if kind in ("gauss", "iso1d") else (low, p)
         prob = lowering.make_problem(ctx, ffi.METHOD_MLDA2, low, sigma, eq, surrogate=low2, sub_chain_length=S)
         e = o.Ensemble(p, sigma, x0, seed, chain0=chain0, eq_mode=eq, surrogate=p2, sub_chain_length=S)
         flags |= int(rng.choice([0, ffi.RECORD_SUB_ACCEPT]))
@@ -121,7 +124,7 @@ def test_random_round2_features_match_oracle(case, monkeypatch):
     from scipy.linalg import solve_triangular
     from yagremcmc_amd import _ffi as ffi, lowering
     ctx = ffi.default_context(0)
-    rng = np.random.default_rng(7000 + case)
+    rng = np.random.default_rng(7000 + case + _SEED_SHIFT)
     kind = ["gauss", "linear", "gauss", "lv", "linear"][case % 5]
     d = 2 if kind == "lv" else int(rng.choice([1, 2, 2, 3, 5]))
     low, p = _lowered(ffi, kind, d, rng)
@@ -153,7 +156,7 @@ def test_random_round2_features_match_oracle(case, monkeypatch):
     kwargs = {}
     if method == "mlda":
         S = int(rng.choice([1, 2, 3, 4, 6, 7]))        # 2, 3, 4, 6 have compile-time kernels at d <= 2
-        low2, p2 = _lowered(ffi, kind, d, np.random.default_rng(9500 + case)) if kind == "gauss" else (low, p)
+        low2, p2 = _lowered(ffi, kind, d, np.random.default_rng(9500 + case + _SEED_SHIFT)) if kind == "gauss" else (low, p)
         with np.errstate(all="ignore"):
             import warnings
             with warnings.catch_warnings():
@@ -209,7 +212,7 @@ def test_random_nested_hierarchy_matches_oracle(case):
     """MLDA over 2, 4 or 6 surrogates of every density kind (the nest of csrc/ymc_nested.hip)."""
     from yagremcmc_amd import _ffi as ffi, lowering
     ctx = ffi.default_context(0)
-    rng = np.random.default_rng(7000 + case)
+    rng = np.random.default_rng(7000 + case + _SEED_SHIFT)
     kind = ["gauss", "linear", "lv", "iso1d"][case % 4]
     d = {"iso1d": 1, "lv": 2}.get(kind, int(rng.integers(1, 9)))
     E = int(rng.integers(2, 5))
@@ -254,7 +257,7 @@ def test_random_nested_hierarchy_matches_oracle(case):
 def test_random_adaptive_error_model_matches_oracle(case):
     from yagremcmc_amd import _ffi as ffi, lowering
     ctx = ffi.default_context(0)
-    rng = np.random.default_rng(11000 + case)
+    rng = np.random.default_rng(11000 + case + _SEED_SHIFT)
     d, m, nd = int(rng.integers(1, 9)), int(rng.integers(1, 9)), int(rng.integers(1, 7))
     A = rng.normal(size=(m, d)) / np.sqrt(d)
     b = rng.normal(size=m) * 0.3
@@ -306,7 +309,7 @@ def test_random_matrix_core_configuration_matches_oracle(case):
     from scipy.linalg import solve_triangular
     from yagremcmc_amd import _ffi as ffi, lowering
     ctx = ffi.default_context(0)
-    rng = np.random.default_rng(9000 + case)
+    rng = np.random.default_rng(9000 + case + _SEED_SHIFT)
     sampler = ["mrw", "pcn", "mlda2", "nested", "mrw_chol", "mrw"][case % 6]
     d = int(rng.choice([5, 9, 12, 16, 17, 33, 64, 100, 128]))
     small = d <= 8
@@ -438,7 +441,7 @@ def test_random_round3_features_match_oracle(case, monkeypatch):
     coarse / forward matrix beyond the LDS, parameter dimensions beyond 128, dense proposals and priors there)."""
     from yagremcmc_amd import _ffi as ffi, lowering
     ctx = ffi.default_context(0)
-    rng = np.random.default_rng(11000 + case)
+    rng = np.random.default_rng(11000 + case + _SEED_SHIFT)
     feature = ["deep_nest", "lv_adaptive", "aem_rows", "stream_mlda2", "stream_nested", "stream_dense"][case % 6]
     K = int(rng.choice([5, 16, 33, 70]))
     seed, chain0 = int(rng.integers(0, 2**62)), int(rng.choice([0, 17, 2**31 + 5]))
