@@ -181,6 +181,7 @@ struct ymc_run {
     DeviceBuf x_tiled;   /* two-level tile kernel: the carried state in the record's tiled layout */
     DeviceBuf w_tiled;   /* dense proposal on the tile kernel: L xi in the record's tiled layout */
     DeviceBuf err_n, err_mean, err_m2, aem_prec, aem_flags, cache_key, cache_val; /* AEM2 */
+    DeviceBuf err_mean_alt, err_m2_alt; /* AEM2 on the matrix cores: the kernel's second copy of mean / M2 (scratch) */
     /* egress (ymc_run_egress_*): a copy stream, two slots of page-locked staging */
     struct EgressSlot {
         PinnedBuf traj, acc, lp;
@@ -819,6 +820,8 @@ int launch_advance_tile(ymc_run *r, uint64_t nsteps)
         a.err_n = r->err_n.as<uint64_t>();
         a.err_mean_t = r->err_mean.as<double>();
         a.err_m2_t = r->err_m2.as<double>();
+        a.err_mean_alt_t = r->err_mean_alt.as<double>();
+        a.err_m2_alt_t = r->err_m2_alt.as<double>();
         a.prec_t = r->aem_prec.as<double>();
         a.aem_flags = r->aem_flags.as<int32_t>();
         a.cache_id = r->cache_key.as<uint64_t>();
@@ -1294,6 +1297,8 @@ int ymc_run_create(ymc_ctx *ctx, const ymc_problem *problem, const ymc_run_desc 
         if (problem->method == YMC_METHOD_AEM2 && problem->tile) {
             /* per-output arrays in the kernel's tiled layout [ceil(K/16)][4 MT][64]; ids of the cached points */
             const uint64_t per_out = ((K + 15) / 16) * 4ull * (uint64_t)problem->sur.MT * 64ull;
+            YMC_TRY(r->err_mean_alt.alloc(per_out * sizeof(double)));
+            YMC_TRY(r->err_m2_alt.alloc(per_out * sizeof(double)));
             DeviceBuf *bufs[] = {&r->err_n, &r->err_mean, &r->err_m2, &r->aem_prec, &r->aem_flags, &r->cache_key,
                                  &r->cache_val};
             const size_t sizes[] = {K * sizeof(uint64_t), per_out * sizeof(double), per_out * sizeof(double),

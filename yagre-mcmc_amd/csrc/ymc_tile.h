@@ -61,6 +61,7 @@ struct TileArgs {
     const double *aem_rows;  /* noise precision [m_pad] | data rows [n_data][m_pad] of the coarse level */
     uint64_t *err_n;         /* [K] accepted fine proposals */
     double *err_mean_t, *err_m2_t, *prec_t;
+    double *err_mean_alt_t, *err_m2_alt_t; /* the second copy of mean / M2 (the kernel updates into the copy a chain is not reading) */
     int32_t *aem_flags;      /* [K][2] {precision set, cache fill} */
     uint64_t *cache_id;      /* [K][4]: the three cached points' ids (oldest first) and the carried state's id */
     double *cache_val;       /* [K][3] */

@@ -147,8 +147,12 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
     const uint32_t pair_of_g = (g == 0) ? 0u : (g == 1) ? 2u : (g == 2) ? 1u : 3u;
     double *xt = a.x_tiled + (tile * KS) * 64 + lane;
     /* this lane's column of the per-output error-model arrays: slot q = 4 mt + r <-> output 16 mt + 4 r + g */
-    double *em = a.err_mean_t + (tile * Q) * 64 + lane;
-    double *e2 = a.err_m2_t + (tile * Q) * 64 + lane;
+    /* mean / M2 of the chain's error model: the copy it reads (em, e2) and the one the fine pass writes the updated
+     * values into before the decision is known (em_o, e2_o); an accepting chain swaps them.  The run's arrays are the
+     * first copy: a chain that ends a launch on the second one copies it back */
+    double *const em_run = a.err_mean_t + (tile * Q) * 64 + lane, *const e2_run = a.err_m2_t + (tile * Q) * 64 + lane;
+    double *em = em_run, *e2 = e2_run;
+    double *em_o = a.err_mean_alt_t + (tile * Q) * 64 + lane, *e2_o = a.err_m2_alt_t + (tile * Q) * 64 + lane;
     double *ep = a.prec_t + (tile * Q) * 64 + lane;
 
     double z[KS], y[KS];
@@ -275,14 +279,6 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
             }
         }
     };
-    /* the fine model's plain likelihood through the row-mean identity */
-    auto loglik_fine = [&](const double (&v)[KS]) {
-        double Ssum = 0.0;
-        fine_pairs(v, [&](int mt, const d4 &acc0, const d4 &acc1) {
-            ymc_tile_add_residuals(mt, acc0, acc1, bias_f, nprec_f, dbar_f, g, Ssum);
-        });
-        return -0.5 * (combine4(Ssum) + a.lik_const_f);
-    };
     auto logprior = [&](const double *pmean, const double *pprec, const double (&v)[KS]) {
         return ymc_tile_logprior<KS>(pmean, pprec, g, v);
     };
@@ -296,15 +292,20 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
         if (__builtin_amdgcn_ballot_w64(miss) != 0) fresh = now(v);
         return active ? cache.take(id, hit, fresh) : 0.0;
     };
-    /* update_error_estimate(F_fine(v) - F_coarse(v)) for the chains with `mine` (aem.py:44-56,
-     * likelihood.py:142-150, noise.py:41-54) */
-    auto update = [&](const double (&v)[KS], bool mine) {
+    /* The fine accept step in ONE pass over the fine matrix: the plain fine likelihood of v (for the decision) and
+     * update_error_estimate(F_fine(v) - F_coarse(v)) (aem.py:44-56, likelihood.py:142-150, estimation.py:36-53) prepared for
+     * every chain -- the updated mean / M2 go to the copy the chain is not reading, the range of the marginal variances
+     * is kept -- so that an accepting chain only swaps its copies (commit_error_model).  The two used to be two passes:
+     * the second one, after the decision, streamed the fine matrix again for the same F_fine. */
+    double upd_lo = 0.0, upd_hi = 0.0;
+    bool upd_first = true;
+    auto fine_likelihood_and_error = [&](const double (&v)[KS]) {
         const uint64_t n_new = n_err + 1;
         const double dn = (double)n_new, nm1 = (double)(n_new - 1);
-        const bool inflate = n_new > (uint64_t)a.min_data;
-        double lo = 0.0, hi = 0.0;
+        double lo = 0.0, hi = 0.0, Ssum = 0.0;
         bool first = true;
         fine_pairs(v, [&](int mt, const d4 &f0, const d4 &f1) {
+            ymc_tile_add_residuals(mt, f0, f1, bias_f, nprec_f, dbar_f, g, Ssum);
             d4 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0};
             const double *C0 = Ac + (size_t)mt * KS * 64 + lane, *C1 = C0 + (size_t)KS * 64;
             double em_v[8], e2_v[8];        /* requested before the coarse MFMAs, as in now() */
@@ -331,9 +332,9 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
                     mean = mean + delta / dn;
                     const double delta2 = e - mean;
                     m2 = m2 + delta * delta2;
-                    if (mine && m < m_real) {
-                        em[q * 64] = mean;
-                        e2[q * 64] = m2;
+                    if (wave_live && m < m_real) {
+                        em_o[q * 64] = mean;
+                        e2_o[q * 64] = m2;
                         const double mvar = m2 / nm1;
                         lo = (first || mvar < lo) ? mvar : lo;
                         hi = (first || mvar > hi) ? mvar : hi;
@@ -342,6 +343,22 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
                 }
             }
         });
+        upd_lo = lo, upd_hi = hi, upd_first = first;
+        return -0.5 * (combine4(Ssum) + a.lik_const_f);
+    };
+    /* the chains with `mine` take the prepared update: their copies swap; beyond minDataSize the precision is inflated
+     * from the new variances (noise.py:41-54) */
+    auto commit_error_model = [&](bool mine) {
+        const uint64_t n_new = n_err + 1;
+        const double nm1 = (double)(n_new - 1);
+        const bool inflate = n_new > (uint64_t)a.min_data;
+        double lo = upd_lo, hi = upd_hi;
+        bool first = upd_first;
+        {
+            double *t0 = mine ? em_o : em, *t1 = mine ? e2_o : e2;
+            em_o = mine ? em : em_o, e2_o = mine ? e2 : e2_o;
+            em = t0, e2 = t1;
+        }
         if (__builtin_amdgcn_ballot_w64(mine && inflate) != 0) {
             /* min / max of the marginal variances over ALL outputs of the chain: the four lanes' ranges joined
              * (a lane without a real output holds none) */
@@ -424,15 +441,15 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
         const double u = ymc_uniform_cached(uc, a.seed, chain, tbase + (uint64_t)S);
         const bool moved = any_differs(z, y);
         YMC_PROF(4);
-        const double lpfy = loglik_fine(z) + logprior(pmean_f, pprec_f, z);
+        const double lpfy = fine_likelihood_and_error(z) + logprior(pmean_f, pprec_f, z);
         YMC_PROF(5);
         const double cx = query(x_id, y, moved) + logprior(pmean_c, pprec_c, y);
         const double cy = query(z_id, z, moved) + logprior(pmean_c, pprec_c, z);
         YMC_PROF(6);
         const double log_ratio = ((lpfy + cx) - cy) - lpf;
         const bool acc = wave_live && moved && ymc_accept(log_ratio, true, ymc_finite(lpfy) && ymc_finite(cy), u, st);
-        /* aem.py:26-56, before the chain moves; STAGED: by every wave (the shared stream), else by the waves with an accepted chain */
-        if (STAGED || __builtin_amdgcn_ballot_w64(acc) != 0) update(z, acc);
+        /* aem.py:26-56, before the chain moves */
+        if (__builtin_amdgcn_ballot_w64(acc) != 0) commit_error_model(acc);
         YMC_PROF(7);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -458,6 +475,13 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
     }
     YMC_PROF_FLUSH();
 
+    if (wave_live && em != em_run) { /* the run's arrays are the first copy */
+#pragma unroll 1
+        for (int q = 0; q < Q; ++q) {
+            em_run[q * 64] = em[q * 64];
+            e2_run[q * 64] = e2[q * 64];
+        }
+    }
     if (live) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
