@@ -186,7 +186,7 @@ def posterior_lv(design, t_final, alpha, gamma, rk4_steps, data, noise_precision
     return p
 
 
-DMAX, MMAX = 256, 8192     # YMO_DMAX, YMO_MMAX of ymc_oracle.c (its work arrays live on the stack)
+DMAX, MMAX = 2048, 8192     # YMO_DMAX, YMO_MMAX of ymc_oracle.c (its work arrays live on the stack)
 
 
 def _lower(p):

@@ -35,7 +35,7 @@
 #include <omp.h>
 #endif
 
-#define YMO_DMAX 256  /* largest parameter dimension the oracle handles */
+#define YMO_DMAX 2048  /* largest parameter dimension the oracle handles */
 #define YMO_MMAX 8192 /* largest forward-map output dimension (stack arrays: 64 KB each) */
 
 enum {

@@ -338,10 +338,11 @@ def fixture_f3():
     print("F3", acc.mean())
 
 
-def fixture_f22():
+def fixture_f22(name="f22_linear_d192_m160.npz", d=192, m=160, seed=20250122, K=8, n=200, prop_var=8e-4):
     """Beyond the LDS-resident shapes: d = 192 parameters, m = 160 outputs (a 240 KB forward matrix), the reference's
-    shape-agnostic linear model (exampleSetup.py:42-52, likelihood.py:74-84) under a random walk, 8 chains x 200 states."""
-    d, m, n_data, seed, K, n = 192, 160, 4, 20250122, 8, 200
+    shape-agnostic linear model (exampleSetup.py:42-52, likelihood.py:74-84) under a random walk, 8 chains x 200 states.
+    F22b: d = 320, m = 48 (beyond the matrix-core kernels' 256 parameters: the wide path), 4 chains x 120 states."""
+    n_data = 4
     z, _ = oracle.rng_fill(22, 0, m + 3 + n_data, 0, 1, d, uniforms=False)
     z = z[0]
     A = z[:m] / np.sqrt(d)
@@ -349,16 +350,16 @@ def fixture_f22():
     theta_true = z[m + 1]
     noise_var = 0.3
     data = np.array([A @ theta_true + b + np.sqrt(noise_var) * z[m + 3 + i][:m] for i in range(n_data)])
-    prior_mean, prior_var, prop_var = np.zeros(d), 5.0, 8e-4
+    prior_mean, prior_var = np.zeros(d), 5.0
     model = build_linear_reference(A, b, data, noise_var, prior_mean, prior_var)
     prop_cov = IIDCovarianceMatrix(d, prop_var)
     traj, acc, lp = run_mrw_model(model, seed, K, n, prop_cov, np.zeros(d))
     np.savez_compressed(
-        os.path.join(HERE, "f22_linear_d192_m160.npz"), seed=seed, n_states=n, A=A, b=b, data=data,
+        os.path.join(HERE, name), seed=seed, n_states=n, A=A, b=b, data=data,
         noise_precision=np.reciprocal(np.full(m, noise_var)), prior_mean=prior_mean,
         prior_precision=np.reciprocal(np.full(d, prior_var)), sigma=sigma_of(prop_cov),
         x0=np.zeros((K, d)), traj_head=traj[:, :2, :], traj_sha256=sha(traj), acc=acc, logpost=lp)
-    print("F22", acc.mean())
+    print(name, acc.mean())
 
 
 def fixture_f3b():
@@ -1211,6 +1212,7 @@ def main():
         fixture_f3b()
     if "f22" in which:
         fixture_f22()
+        fixture_f22("f22b_linear_d320_m48.npz", d=320, m=48, seed=20250130, K=4, n=120, prop_var=5e-4)
     if "f4" in which:
         fixture_f4()
     if "f5" in which:

@@ -839,10 +839,11 @@ def test_dense_noise_beyond_the_lane_sizes_through_the_builders_f19(golden):
     assert np.array_equal(mc.chain.ensemble_trajectory, g["ml_traj"])
 
 
-def test_linear_model_d192_through_the_builder_f22(golden):
-    """MRWBuilder over the reference's shape-agnostic linear model at d = 192, m = 160 (exampleSetup.py:42-52,
-    likelihood.py:74-84; fixture F22 = the live reference's chains): the forward matrix streams from L2, one wave per
-    SIMD holds 192 components per chain."""
+@pytest.mark.parametrize("name,prop_var", [("f22_linear_d192_m160.npz", 8e-4), ("f22b_linear_d320_m48.npz", 5e-4)])
+def test_linear_model_d192_through_the_builder_f22(golden, name, prop_var):
+    """MRWBuilder over the reference's shape-agnostic linear model at d = 192, m = 160 and at d = 320, m = 48
+    (exampleSetup.py:42-52, likelihood.py:74-84; fixtures F22 / F22b = the live reference's chains): the forward matrix
+    streams from L2, one wave per SIMD holds 192 components per chain; 320 components take the wide path."""
     import hashlib
     from yagremcmc_amd.chain.method.mrw import MRWBuilder
     from yagremcmc_amd.exampleSetup import ExampleLinearModelSolver
@@ -854,13 +855,13 @@ def test_linear_model_d192_through_the_builder_f22(golden):
     from yagremcmc_amd.statistics.gaussian import Gaussian
     from yagremcmc_amd.statistics.likelihood import AdditiveGaussianNoiseLikelihood
     from yagremcmc_amd.statistics.noise import CentredGaussianNoise
-    g = golden("f22_linear_d192_m160.npz")
-    d, m = 192, 160
+    g = golden(name)
+    m, d = g["A"].shape
     like = AdditiveGaussianNoiseLikelihood(Data(g["data"]), ForwardModel(ExampleLinearModelSolver(g["A"], g["b"])),
                                            CentredGaussianNoise(IIDCovarianceMatrix(m, 0.3)))
     b = MRWBuilder()
     b.bayesModel = BayesianRegressionModel(like, Gaussian(ParameterVector(np.zeros(d)), IIDCovarianceMatrix(d, 5.0)))
-    b.proposalCovariance = IIDCovarianceMatrix(d, 8e-4)
+    b.proposalCovariance = IIDCovarianceMatrix(d, prop_var)
     b.nChains, b.seed, b.recordLogPosterior = g["x0"].shape[0], int(g["seed"]), True
     mc = b.build_method()
     mc.run(int(g["n_states"]), ParameterVector(np.zeros(d)), verbose=False)
@@ -869,7 +870,7 @@ def test_linear_model_d192_through_the_builder_f22(golden):
     assert np.array_equal(traj[:, :2, :], g["traj_head"])
     assert hashlib.sha256(np.ascontiguousarray(traj).tobytes()).hexdigest() == str(g["traj_sha256"])
     assert np.abs(mc.log_posterior - g["logpost"]).max() <= 1e-12 * np.abs(g["logpost"]).max()
-    assert mc.integrated_autocorrelation("mean", 20).shape == (8,)
+    assert mc.integrated_autocorrelation("mean", 20).shape == (g["x0"].shape[0],)
 
 
 def test_iat_of_a_stuck_chain_is_reported_not_invented():

@@ -767,14 +767,16 @@ def test_f3_linear_d128_matrix_cores(ffi, ctx, golden):
     assert np.array_equal(prob.forward(xs), o.forward(p, xs))
 
 
-def test_f22_linear_d192_m160_streamed_matrix(ffi, ctx, golden):
+@pytest.mark.parametrize("name", ["f22_linear_d192_m160.npz", "f22b_linear_d320_m48.npz"])
+def test_f22_linear_d192_m160_streamed_matrix(ffi, ctx, golden, name):
     """The forward matrix streamed from L2 (it does not fit the LDS) and 192 parameter components per chain (KS = 64,
-    one wave per SIMD): device == oracle == the live reference's chains (fixture F22, exampleSetup.py:42-52,
-    likelihood.py:74-84), the IAT of the d = 192 record included ('mean' sums 192 components in NumPy's pairwise order)."""
+    one wave per SIMD); 320 components on the wide path: device == oracle == the live reference's chains (fixtures F22 /
+    F22b, exampleSetup.py:42-52, likelihood.py:74-84), the IAT of the record included ('mean' sums the components in
+    NumPy's pairwise order)."""
     import hashlib
-    g = golden("f22_linear_d192_m160.npz")
+    g = golden(name)
     n = int(g["n_states"])
-    low = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, 192, g, fwd_matrix=np.asarray(g["A"]), fwd_shift=np.asarray(g["b"]))
+    low = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, g["A"].shape[1], g, fwd_matrix=np.asarray(g["A"]), fwd_shift=np.asarray(g["b"]))
     dev = _device_run(ffi, ctx, low, g["sigma"], g["x0"], int(g["seed"]), n - 1, moments=True, splits=3)
     p = o.posterior_linear(g["A"], g["b"], g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
     e = o.Ensemble(p, g["sigma"], g["x0"], int(g["seed"]))
@@ -790,7 +792,7 @@ def test_f22_linear_d192_m160_streamed_matrix(ffi, ctx, golden):
     assert np.array_equal(prob.logdensity(xs)[0], o.logdensity(p, xs)[0])
     assert np.array_equal(prob.forward(xs), o.forward(p, xs))
     # post-processing on the d = 192 record, read in place in the tiled layout
-    run = ffi.Run(prob, int(g["seed"]), 8, g["x0"], n - 1, ffi.RECORD_TRAJECTORY)
+    run = ffi.Run(prob, int(g["seed"]), g["x0"].shape[0], g["x0"], n - 1, ffi.RECORD_TRAJECTORY)
     run.advance(n - 1)
     states = run.trajectory()
     for method in (0, 1):
@@ -1478,6 +1480,61 @@ def test_tile_mlda2_beyond_the_lds_and_d128_vs_oracle(ffi, ctx, d, mc, mf, K, S,
     assert 0 < dev["sub_acc"].mean() < 1
 
 
+@pytest.mark.parametrize("d,m,nd,K,method,stride", [(300, 40, 2, 70, "mrw", 1), (257, 1, 1, 33, "mrw", 1), (513, 700, 3, 20, "pcn", 1),
+                                                    (1000, 64, 2, 17, "mrw", 4), (384, 384, 2, 40, "pcn", 3), (300, 20, 2, 30, "dense", 1)])
+def test_linear_posteriors_beyond_256_parameters_vs_oracle(ffi, ctx, d, m, nd, K, method, stride):
+    """Beyond the matrix-core kernels' 256 parameters the random walk (diagonal proposal) and pCN run as a sequence of plain
+    kernels per transition (launch_advance_wide): chains, decisions, log-posteriors, moments, carried state == oracle at any
+    d and m; thinned records; dense noise and prior covariances folded in as at smaller sizes; the IAT of such records."""
+    from yagremcmc_amd import lowering
+    rng = np.random.default_rng(3000 + d + m)
+    g = dict(data=rng.normal(size=(nd, m)), noise_precision=rng.uniform(0.5, 3, size=m), prior_mean=rng.normal(size=d) * 0.1,
+             prior_precision=rng.uniform(0.1, 2, size=d))
+    A, b = rng.normal(size=(m, d)) / np.sqrt(d), rng.normal(size=m)
+    p = o.posterior_linear(A, b, g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+    if method == "dense":
+        B = rng.normal(size=(m, m)) / np.sqrt(m)
+        nc = B @ B.T + np.eye(m)
+        Bp = rng.normal(size=(d, d)) / np.sqrt(d)
+        pc = Bp @ Bp.T + np.eye(d)
+        g["noise_precision"], g["prior_precision"] = np.ones(m), np.ones(d)
+        low = _dense_low(ffi, ffi.POSTERIOR_LINEAR, d, g, nc, pc, fwd_matrix=A, fwd_shift=b)
+        p = o.dense_covariances(o.posterior_linear(A, b, g["data"], np.ones(m), g["prior_mean"], np.ones(d)), noise_cov=nc, prior_cov=pc)
+    else:
+        low = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, g, fwd_matrix=A, fwd_shift=b)
+    x0 = rng.normal(size=(K, d)) * 0.3
+    n = 24
+    flags = ffi.RECORD_TRAJECTORY | ffi.RECORD_LOGPOST | ffi.RECORD_MOMENTS | (ffi.RECORD_ACCEPT if stride == 1 else 0)
+    if method == "pcn":
+        g["prior_mean"] = np.zeros(d)
+        low = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, g, fwd_matrix=A, fwd_shift=b)
+        low.desc.likelihood_only = 1
+        p = dict(o.posterior_linear(A, b, g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"]), likelihood_only=1)
+        sigma = 1.0 / np.sqrt(g["prior_precision"])
+        prob = lowering.make_problem(ctx, ffi.METHOD_PCN, low, sigma, pcn_step_size=0.01)
+        e = o.Ensemble(p, sigma, x0, 17, chain0=40, pcn_step_size=0.01)
+    else:
+        sigma = rng.uniform(0.01, 0.04, size=d)
+        prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, sigma)
+        e = o.Ensemble(p, sigma, x0, 17, chain0=40)
+    run = ffi.Run(prob, 17, K, x0, n, flags, 40, record_stride=stride)
+    run.advance(7)
+    run.advance(n - 7)
+    out = e.advance(n)
+    rows = slice(stride - 1, None, stride)
+    assert np.array_equal(run.trajectory(), out["traj"][rows]) and np.array_equal(run.logpost(), out["logpost"][rows])
+    if stride == 1:
+        assert np.array_equal(run.accept(), out["acc"]) and 0 < out["acc"].mean() < 1
+    x, lp = run.state()
+    assert np.array_equal(x, e.x) and np.array_equal(lp, e.lp)
+    s_ = run.summary()
+    assert np.array_equal(s_["accepted"], e.acc_count) and np.array_equal(s_["status"], e.status)
+    assert np.array_equal(s_["wf_mean"], e.wf_mean) and np.array_equal(s_["wf_m2"], e.wf_m2)
+    probe = rng.normal(size=(9, d))
+    assert np.array_equal(prob.logdensity(probe)[0], o.logdensity(p, probe)[0])
+    assert np.array_equal(prob.forward(probe), o.forward(p, probe))
+
+
 def test_tile_kernel_limits(ffi, ctx):
     from yagremcmc_amd import lowering
     rng = np.random.default_rng(1)
@@ -1497,9 +1554,7 @@ def test_tile_kernel_limits(ffi, ctx):
         gg = dict(data=rng.normal(size=(2, m)), noise_precision=np.ones(m), prior_mean=np.zeros(d), prior_precision=np.ones(d))
         return _posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, gg, fwd_matrix=rng.normal(size=(m, d)), fwd_shift=np.zeros(m))
     lowering.make_problem(ctx, ffi.METHOD_MRW, lin(256, 4), np.ones(256))
-    with pytest.raises(ffi.YmcError, match="exceeds the matrix-core kernels' 256") as err:
-        lowering.make_problem(ctx, ffi.METHOD_MRW, lin(257, 4), np.ones(257))
-    assert err.value.code == ffi.ERR_UNSUPPORTED
+    lowering.make_problem(ctx, ffi.METHOD_MRW, lin(257, 4), np.ones(257))     # beyond 256: the wide path (random walk, pCN)
     lowering.make_problem(ctx, ffi.METHOD_MLDA2, lin(256, 4), np.ones(256), surrogate=lin(256, 4), sub_chain_length=2)
     with pytest.raises(ffi.YmcError, match="exceeds the matrix-core kernels' 256") as err:
         lowering.make_problem(ctx, ffi.METHOD_MLDA2, lin(260, 4), np.ones(260), surrogate=lin(260, 4), sub_chain_length=2)

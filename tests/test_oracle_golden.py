@@ -71,10 +71,11 @@ def test_f3_linear_d128(golden):
     assert hashlib.sha256(np.ascontiguousarray(full).tobytes()).hexdigest() == str(g["traj_sha256"])
 
 
-def test_f22_linear_d192_m160(golden):
-    """d = 192, m = 160: beyond what one wave's registers and the LDS held up to round 2 (the reference is
-    shape-agnostic, exampleSetup.py:42-52)."""
-    g = golden("f22_linear_d192_m160.npz")
+@pytest.mark.parametrize("name", ["f22_linear_d192_m160.npz", "f22b_linear_d320_m48.npz"])
+def test_f22_linear_d192_m160(golden, name):
+    """d = 192, m = 160: beyond what one wave's registers and the LDS held up to round 2; d = 320: beyond the matrix-core
+    kernels (the reference is shape-agnostic, exampleSetup.py:42-52)."""
+    g = golden(name)
     n = int(g["n_states"])
     p = o.posterior_linear(g["A"], g["b"], g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
     e = o.Ensemble(p, g["sigma"], g["x0"], int(g["seed"]))

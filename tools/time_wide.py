@@ -40,12 +40,14 @@ def timed(label, prob, d, n, flop_per_step):
     run.advance(n); run.sync()
     ms, _ = run.kernel_time_ms()
     rate = K * n / ms * 1e3
-    print("%-58s %8.2f ms / %d steps -> %.3g steps/s, MFMA %.2f" % (label, ms, n, rate, rate * flop_per_step / PEAK))
+    print("%-58s %8.2f ms / %d steps -> %.3g steps/s, fp64 %.2f" % (label, ms, n, rate, rate * flop_per_step / PEAK))
     run.close()
 
 
 for d, m in ((128, 128), (128, 512), (192, 192), (256, 256)):
     timed(f"random walk d={d} m={m}", lowering.make_problem(ctx, ffi.METHOD_MRW, low(d, m), np.full(d, 0.03)), d, 20, 2.0 * m * d)
+for d, m in ((320, 64), (512, 512), (1024, 256)):   # beyond 256: the wide path (five plain launches per transition)
+    timed(f"random walk d={d} m={m} (wide path)", lowering.make_problem(ctx, ffi.METHOD_MRW, low(d, m), np.full(d, 0.02)), d, 6, 2.0 * m * d)
 for d, m in ((128, 128), (256, 256)):
     B = rng.normal(size=(d, d)) * 0.02 / np.sqrt(d)
     L = np.linalg.cholesky(B @ B.T + 0.001 * np.eye(d))

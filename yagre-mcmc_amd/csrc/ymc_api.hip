@@ -120,6 +120,7 @@ struct DensityHost {
            off_dbar = 0, off_nprec = 0;
     /* large-dimension linear posterior (ymc_tile.hip): KS k-steps of 4, MT output tiles of 16 */
     bool tile = false;
+    bool wide = false; /* beyond the matrix-core kernels' 256 parameters: the composed wide path (WideArgs, ymc_tile.h) */
     int KS = 0, MT = 0;
     DeviceBuf tile_blob;
     DeviceBuf aem_rows; /* tile adaptive error model: noise precision [m_pad] | data rows [n_data][m_pad] */
@@ -158,6 +159,8 @@ struct ymc_problem {
     std::vector<double> sigma;
     DeviceBuf chol; /* dense proposal covariance: lower Cholesky factor [D][D] */
     DeviceBuf chol_frag; /* the same as MFMA A-operand fragments [MT_L][KS][64] (matrix-core kernel) */
+    bool wide = false;   /* d > 256: the composed wide path */
+    DeviceBuf wide_consts; /* sigma[d] | prior mean[d] on the device */
     int MT_L = 0;
     /* MLDA_NESTED: P of levels 0..E-2 (level E-1's is tgt), Q of levels 1..E-1 (index 0 unused) */
     int E = 0;
@@ -182,6 +185,7 @@ struct ymc_run {
     DeviceBuf w_tiled;   /* dense proposal on the tile kernel: L xi in the record's tiled layout */
     DeviceBuf err_n, err_mean, err_m2, aem_prec, aem_flags, cache_key, cache_val; /* AEM2 */
     DeviceBuf err_mean_alt, err_m2_alt; /* AEM2 on the matrix cores: the kernel's second copy of mean / M2 (scratch) */
+    DeviceBuf wide_xi, wide_u, wide_y, wide_yt, wide_lpy, wide_flag; /* the wide path's per-transition scratch */
     /* egress (ymc_run_egress_*): a copy stream, two slots of page-locked staging */
     struct EgressSlot {
         PinnedBuf traj, acc, lp;
@@ -223,7 +227,7 @@ bool needs_tile(const ymc_density_desc &in)
  * (linear_tile_kernel<.., ASTREAM>: random walk with a diagonal proposal, pCN): any number of outputs whose
  * constants fit the LDS, parameter dimensions up to 256 */
 int lower_density(ymc_ctx *ctx, const ymc_density_desc &in, DensityHost &out, int expect_dim, bool force_tile = false,
-                  bool may_stream = false)
+                  bool may_stream = false, bool may_wide = false)
 {
     (void)ctx;
     out.d = in;
@@ -277,22 +281,30 @@ int lower_density(ymc_ctx *ctx, const ymc_density_desc &in, DensityHost &out, in
                 /* the matrix-core tile kernels: d <= 128 with A staged in LDS; the single-level samplers also stream
                  * A from L2 (d <= 256, any m whose constants fit) */
                 const int d_max = may_stream ? 256 : 128;
-                if (d > d_max)
+                if (d > d_max && may_wide) {
+                    out.wide = true; /* any dimension, any number of outputs (dense covariances are folded in below as ever) */
+                    out.KS = 4 * ((d + 15) / 16);
+                    const size_t m_wide = m + (out.prior_linv.empty() ? 0 : (size_t)d);
+                    out.MT = (int)((m_wide + 15) / 16);
+                    out.MT += out.MT & 1;
+                } else if (d > d_max)
                     return fail(YMC_ERR_UNSUPPORTED, "parameter dimension %d exceeds the matrix-core kernels' %d%s", d, d_max,
                                 may_stream ? "" : " for this sampler (the random walk, pCN and delayed acceptance take 256)");
-                const int ks_need = (d + 3) / 4;
-                out.KS = ks_need <= 4 ? 4 : ks_need <= 8 ? 8 : ks_need <= 16 ? 16 : ks_need <= 32 ? 32 : 64;
-                /* a dense prior covariance adds d pseudo-observations to the forward map (below) */
-                const size_t m_all = m + (out.prior_linv.empty() ? 0 : (size_t)d);
-                out.MT = (int)((m_all + 15) / 16);
-                out.MT += out.MT & 1;
-                const bool fits = out.KS <= 32 && ymc_tile_lds_bytes(out.KS, out.MT) <= kTileLdsLimit;
-                if (!fits && !(may_stream && ymc_tile_stream_lds_bytes(out.KS, out.MT) <= kTileLdsLimit))
-                    return fail(YMC_ERR_UNSUPPORTED, "forward map %zu x %d%s does not fit the 160 KB LDS%s", m, d,
-                                out.prior_linv.empty() ? "" : " plus the dense prior's d x d factor",
-                                may_stream ? " (nor do its constants alone: too many outputs)"
-                                           : "; only the random walk, pCN and delayed acceptance stream it from L2");
-                out.tile = true;
+                if (!out.wide) {
+                    const int ks_need = (d + 3) / 4;
+                    out.KS = ks_need <= 4 ? 4 : ks_need <= 8 ? 8 : ks_need <= 16 ? 16 : ks_need <= 32 ? 32 : 64;
+                    /* a dense prior covariance adds d pseudo-observations to the forward map (below) */
+                    const size_t m_all = m + (out.prior_linv.empty() ? 0 : (size_t)d);
+                    out.MT = (int)((m_all + 15) / 16);
+                    out.MT += out.MT & 1;
+                    const bool fits = out.KS <= 32 && ymc_tile_lds_bytes(out.KS, out.MT) <= kTileLdsLimit;
+                    if (!fits && !(may_stream && ymc_tile_stream_lds_bytes(out.KS, out.MT) <= kTileLdsLimit))
+                        return fail(YMC_ERR_UNSUPPORTED, "forward map %zu x %d%s does not fit the 160 KB LDS%s", m, d,
+                                    out.prior_linv.empty() ? "" : " plus the dense prior's d x d factor",
+                                    may_stream ? " (nor do its constants alone: too many outputs)"
+                                               : "; only the random walk, pCN and delayed acceptance stream it from L2");
+                    out.tile = true;
+                }
             }
             YMC_TRY(copy_array(out.A, in.fwd_matrix, m * d, "fwd_matrix"));
             YMC_TRY(copy_array(out.b, in.fwd_shift, m, "fwd_shift"));
@@ -462,7 +474,7 @@ BigLinearArgs big_view(const DensityHost &h, bool raw_forward = false)
 int eval_logdensity(ymc_ctx *ctx, const ymc_problem *p, const DensityHost &h, uint64_t n, const double *x_dev,
                     double *out_dev, uint32_t *status_dev)
 {
-    if (h.tile) {
+    if (h.tile || h.wide) {
         if (status_dev) YMC_HIP(hipMemsetAsync(status_dev, 0, n * sizeof(uint32_t), ctx->stream));
         YMC_HIP(ymc_launch_linear_big_eval(big_view(h), n, x_dev, out_dev, nullptr, ctx->stream));
         return YMC_OK;
@@ -775,6 +787,71 @@ uint64_t tiled_row_doubles(const ymc_run *r)
     return ((r->K + 15) / 16) * (uint64_t)r->problem->tgt.KS * 64;
 }
 
+/* Beyond 256 parameters (random walk with a diagonal proposal, pCN over a linear model): a transition is five plain
+ * launches over [K][d] arrays -- the draws, the proposal, the canonical-order evaluation (linear_big_eval_kernel, the
+ * kernel behind evaluate_log at these sizes), the decision per chain, the move with record and moments.  The same
+ * arithmetic in the same order as the matrix-core kernels (which are bit-identical to the checker), at any d and m. */
+int launch_advance_wide(ymc_run *r, uint64_t nsteps)
+{
+    const ymc_problem *p = r->problem;
+    hipStream_t s = r->ctx->stream;
+    const uint64_t K = r->K, d = (uint64_t)p->D;
+    WideArgs a{};
+    a.K = K;
+    a.d = p->D;
+    a.pcn = p->method == YMC_METHOD_PCN;
+    a.pcn_c1 = p->pcn_c1;
+    a.pcn_c2 = p->pcn_c2;
+    a.sigma = p->wide_consts.as<double>();
+    a.pmean = a.sigma + d;
+    a.xi = r->wide_xi.as<double>();
+    a.u = r->wide_u.as<double>();
+    a.x = r->x.as<double>();
+    a.y = r->wide_y.as<double>();
+    a.y_tiled = r->wide_yt.as<double>();
+    a.KS = p->tgt.KS;
+    a.lp = r->lp.as<double>();
+    a.lpy = r->wide_lpy.as<double>();
+    a.acc_count = r->acc_count.as<uint64_t>();
+    a.status = r->status.as<uint32_t>();
+    a.accflag = r->wide_flag.as<uint8_t>();
+
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (!r->pool.empty()) {
+        ev = r->pool.back();
+        r->pool.pop_back();
+    } else {
+        YMC_HIP(hipEventCreate(&ev.first));
+        YMC_HIP(hipEventCreate(&ev.second));
+    }
+    YMC_HIP(hipEventRecord(ev.first, s));
+    uint64_t rows = 0;
+    for (uint64_t n = 0; n < nsteps; ++n) {
+        const uint64_t t = r->steps_done + n;
+        const bool due = (t + 1) % r->stride == 0;
+        const uint64_t row = r->recorded + rows;
+        a.acc_row = (r->flags & YMC_RECORD_ACCEPT) ? r->acc.as<uint8_t>() + row * K : nullptr; /* stride 1 when recorded */
+        a.traj_row = (due && (r->flags & YMC_RECORD_TRAJECTORY)) ? r->traj.as<double>() + row * K * d : nullptr;
+        a.lp_row = (due && (r->flags & YMC_RECORD_LOGPOST)) ? r->lp_out.as<double>() + row * K : nullptr;
+        if (r->flags & YMC_RECORD_MOMENTS) {
+            a.wf_mean = r->wf_mean.as<double>();
+            a.wf_m2 = r->wf_m2.as<double>();
+            a.wf_dn = (double)(t + 1);
+            a.wf_rdn = 1.0 / a.wf_dn;
+        }
+        YMC_HIP(ymc_launch_rng_fill(r->seed, r->chain0, K, t, 1, p->D, r->wide_xi.as<double>(), r->wide_u.as<double>(), s));
+        YMC_HIP(ymc_launch_wide_propose(a, s));
+        YMC_HIP(ymc_launch_wide_eval(p->tgt.tile_blob.as<double>(), p->tgt.KS, p->tgt.MT, p->tgt.lik_const,
+                                     p->tgt.d.likelihood_only, a.y_tiled, K, r->wide_lpy.as<double>(), s));
+        YMC_HIP(ymc_launch_wide_decide(a, s));
+        YMC_HIP(ymc_launch_wide_apply(a, s));
+        if (due) ++rows;
+    }
+    YMC_HIP(hipEventRecord(ev.second, s));
+    r->timed.push_back(ev);
+    return YMC_OK;
+}
+
 int launch_advance_tile(ymc_run *r, uint64_t nsteps)
 {
     const ymc_problem *p = r->problem;
@@ -1032,8 +1109,12 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
      * LDS from L2 (d <= 256) */
     const bool may_stream = desc->method == YMC_METHOD_MRW || desc->method == YMC_METHOD_PCN || desc->method == YMC_METHOD_MLDA2 ||
                             desc->method == YMC_METHOD_MLDA_NESTED;
-    int rc = lower_density(ctx, desc->target, p->tgt, 0, joint_tile, may_stream);
+    /* beyond 256 parameters the random walk with a diagonal proposal and pCN run as a sequence of plain kernels per
+     * transition (launch_advance_wide) */
+    const bool may_wide = (desc->method == YMC_METHOD_MRW && !desc->proposal_chol) || desc->method == YMC_METHOD_PCN;
+    int rc = lower_density(ctx, desc->target, p->tgt, 0, joint_tile, may_stream, may_wide);
     if (rc == YMC_OK) {
+        p->wide = p->tgt.wide;
         p->D = desc->target.dim;
         p->kind = desc->target.kind;
         if (p->eq_mode == YMC_EQ_ISCLOSE && p->D != 1)
@@ -1160,6 +1241,18 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
             p->pcn_c1 = std::sqrt(1.0 - t);
             p->pcn_c2 = std::sqrt(t);
         }
+    }
+    if (rc == YMC_OK && p->wide) {
+        auto up = [&]() -> int {
+            std::vector<double> c(p->sigma);
+            c.insert(c.end(), p->tgt.prior_mean.begin(), p->tgt.prior_mean.end());
+            c.resize(2 * (size_t)p->D, 0.0);
+            YMC_TRY(p->wide_consts.alloc(c.size() * sizeof(double)));
+            YMC_HIP(hipMemcpy(p->wide_consts.p, c.data(), c.size() * sizeof(double), hipMemcpyHostToDevice));
+            YMC_TRY(build_tile_blob(p, p->tgt)); /* the matrix-core layout of the model for linear_wide_eval_kernel */
+            return YMC_OK;
+        };
+        rc = up();
     }
     if (rc == YMC_OK && p->tgt.tile) {
         const bool two = p->method == YMC_METHOD_MLDA2 || p->method == YMC_METHOD_AEM2;
@@ -1294,6 +1387,15 @@ int ymc_run_create(ymc_ctx *ctx, const ymc_problem *problem, const ymc_run_desc 
         if (problem->tile && problem->method == YMC_METHOD_MLDA_NESTED) /* the parked states of levels 1 .. E-1 */
             YMC_TRY(r->x_tiled.alloc((uint64_t)(problem->E - 1) * tiled_row_doubles(r) * sizeof(double)));
         if (problem->tile && problem->chol_frag.p) YMC_TRY(r->w_tiled.alloc(tiled_row_doubles(r) * sizeof(double)));
+        if (problem->wide) {
+            YMC_TRY(r->wide_xi.alloc(K * D * sizeof(double)));
+            YMC_TRY(r->wide_y.alloc(K * D * sizeof(double)));
+            YMC_TRY(r->wide_yt.alloc(((K + 15) / 16) * (uint64_t)problem->tgt.KS * 64 * sizeof(double)));
+            YMC_HIP(hipMemsetAsync(r->wide_yt.p, 0, r->wide_yt.bytes, ctx->stream)); /* the padding stays zero */
+            YMC_TRY(r->wide_u.alloc(K * sizeof(double)));
+            YMC_TRY(r->wide_lpy.alloc(K * sizeof(double)));
+            YMC_TRY(r->wide_flag.alloc(K));
+        }
         if (problem->method == YMC_METHOD_AEM2 && problem->tile) {
             /* per-output arrays in the kernel's tiled layout [ceil(K/16)][4 MT][64]; ids of the cached points */
             const uint64_t per_out = ((K + 15) / 16) * 4ull * (uint64_t)problem->sur.MT * 64ull;
@@ -1387,6 +1489,8 @@ int ymc_run_advance(ymc_run *run, uint64_t nsteps)
         const uint64_t chunk = nsteps < chunk_max ? nsteps : chunk_max;
         if (run->problem->tile) {
             YMC_TRY(launch_advance_tile(run, chunk));
+        } else if (run->problem->wide) {
+            YMC_TRY(launch_advance_wide(run, chunk));
         } else if (run->problem->method == YMC_METHOD_MLDA_NESTED) {
             YMC_DISPATCH_D(run->problem->D, YMC_TRY(launch_advance_nested<DD>(run, chunk)));
         } else if (run->problem->method == YMC_METHOD_AEM2) {
@@ -1705,7 +1809,7 @@ int ymc_forward_eval(ymc_ctx *ctx, const ymc_problem *problem, int which, uint64
     YMC_TRY(xd.alloc(n * D * sizeof(double)));
     YMC_TRY(od.alloc(n * m * sizeof(double)));
     YMC_HIP(hipMemcpyAsync(xd.p, x, xd.bytes, hipMemcpyHostToDevice, ctx->stream));
-    if (h.tile) {
+    if (h.tile || h.wide) {
         YMC_HIP(ymc_launch_linear_big_eval(big_view(h, true), n, xd.as<double>(), nullptr, od.as<double>(), ctx->stream));
     } else {
         YMC_DISPATCH_D(D, YMC_HIP(ymc_launch_forward<DD>(problem->kind, device_view<DD>(h), n, xd.as<double>(),

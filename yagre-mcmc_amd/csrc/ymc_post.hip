@@ -66,8 +66,7 @@ struct RecordView {
 /* np.mean(seq, axis=1) (autocorrelation.py:126-129) in NumPy's own summation order for a contiguous axis
  * (pairwise_sum): a block of fewer than 8 terms left to right; a block of up to 128 as eight interleaved partial
  * sums combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), the remainder added one by one; a longer one split at
- * n/2 rounded down to a multiple of 8, each half summed the same way (one split covers d <= 256, the matrix-core
- * kernels' limit); then a division by d. */
+ * n/2 rounded down to a multiple of 8, each half summed the same way; then a division by d. */
 __device__ __forceinline__ double numpy_block_sum(const RecordView &v, uint64_t n, uint64_t k, int j0, int len)
 {
     double res;
@@ -95,10 +94,41 @@ __device__ __forceinline__ double numpy_row_mean(const RecordView &v, uint64_t n
     double res;
     if (d <= 128) {
         res = numpy_block_sum(v, n, k, 0, d);
-    } else {
+    } else if (d <= 256) {
         int n2 = d / 2;
         n2 -= n2 % 8;
         res = numpy_block_sum(v, n, k, 0, n2) + numpy_block_sum(v, n, k, n2, d - n2);
+    } else {
+        /* the general recursion (beyond 256 components: the wide path's records), unrolled into a loop over frames:
+         * phase 0 = not started, 1 = left half running, 2 = right half running */
+        struct Frame { int start, len, n2, phase; double left; } fr[24];
+        int depth = 0;
+        fr[0] = {0, d, 0, 0, 0.0};
+        double ret = 0.0;
+        while (depth >= 0) {
+            Frame &f = fr[depth];
+            if (f.phase == 0) {
+                if (f.len <= 128) {
+                    ret = numpy_block_sum(v, n, k, f.start, f.len);
+                    --depth;
+                } else {
+                    f.n2 = f.len / 2;
+                    f.n2 -= f.n2 % 8;
+                    f.phase = 1;
+                    fr[depth + 1] = {f.start, f.n2, 0, 0, 0.0};
+                    ++depth;
+                }
+            } else if (f.phase == 1) {
+                f.left = ret;
+                f.phase = 2;
+                fr[depth + 1] = {f.start + f.n2, f.len - f.n2, 0, 0, 0.0};
+                ++depth;
+            } else {
+                ret = f.left + ret;
+                --depth;
+            }
+        }
+        res = ret;
     }
     return res / (double)d;
 }

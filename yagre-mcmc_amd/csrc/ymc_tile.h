@@ -80,6 +80,37 @@ struct BigLinearArgs {
     int32_t d, m, pad0_, likelihood_only;
 };
 
+/* Linear posteriors beyond the matrix-core kernels' 256 parameters (random walk with a diagonal proposal, pCN): one
+ * transition as a sequence of plain kernels over [K][d] arrays -- draws (ymc_launch_rng_fill), proposal, the canonical-order
+ * evaluation (ymc_launch_linear_big_eval), decision, move + record + moments.  Any d, any number of outputs; the record is
+ * in the lane kernels' plain layout. */
+struct WideArgs {
+    uint64_t K;
+    int32_t d, pcn;
+    double pcn_c1, pcn_c2;
+    const double *sigma, *pmean;   /* [d] */
+    const double *xi, *u;          /* the transition's draws: [K][d], [K] */
+    double *x, *y;                 /* [K][d]: state, proposal */
+    double *y_tiled;               /* the proposal once more in the matrix-core layout [ceil(K/16)][KS][64] (padding zero) */
+    int32_t KS, pad_;
+    double *lp;                    /* [K] */
+    const double *lpy;             /* [K]: log-density of the proposals */
+    uint64_t *acc_count;
+    uint32_t *status;
+    uint8_t *accflag;              /* [K]: this transition's decisions */
+    uint8_t *acc_row;              /* record rows of this transition (null: not recorded / not due) */
+    double *traj_row, *lp_row;
+    double *wf_mean, *wf_m2;       /* [K][d] (null: no moments) */
+    double wf_dn, wf_rdn;          /* the moments' sample count after this transition and RN(1 / count) */
+};
+hipError_t ymc_launch_wide_propose(const WideArgs &a, hipStream_t s);
+/* log-densities of the K points of y_tiled on the matrix cores: `blob` as TileArgs::blob with KS k-steps (any number) and MT
+ * output tiles, everything read from global memory */
+hipError_t ymc_launch_wide_eval(const double *blob, int KS, int MT, double lik_const, int likelihood_only, const double *y_tiled,
+                                uint64_t K, double *lp_out, hipStream_t s);
+hipError_t ymc_launch_wide_decide(const WideArgs &a, hipStream_t s);
+hipError_t ymc_launch_wide_apply(const WideArgs &a, hipStream_t s);
+
 size_t ymc_tile_lds_bytes(int KS, int MT);
 size_t ymc_tile_stream_lds_bytes(int KS, int MT); /* the forward matrix streamed from L2: constants + double buffer */
 size_t ymc_tile_mlda2_lds_bytes(int KS, int MT_coarse, int MT_fine);

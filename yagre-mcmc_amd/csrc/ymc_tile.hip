@@ -578,7 +578,140 @@ __global__ __launch_bounds__(256) void linear_big_eval_kernel(const BigLinearArg
     lp_out[i] = p.likelihood_only ? -0.5 * total : -0.5 * total + (-0.5 * ((P[0] + P[1]) + (P[2] + P[3])));
 }
 
+/* the wide path's elementwise kernels (WideArgs, ymc_tile.h) */
+__global__ __launch_bounds__(256) void wide_propose_kernel(const WideArgs a)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.K * (uint64_t)a.d) return;
+    const int j = (int)(i % (uint64_t)a.d);
+    const double x = a.x[i], xi = a.xi[i];
+    double y;
+    if (a.pcn) { /* pcn.py:27-36 as linear_tile_kernel: xi ~ prior, y = sqrt(1 - 2h) x + sqrt(2h) xi */
+        const double p0 = a.pmean[j] + a.sigma[j] * xi;
+        y = a.pcn_c1 * x + a.pcn_c2 * p0;
+    } else {
+        y = x + a.sigma[j] * xi; /* mrw.py:32-38 */
+    }
+    a.y[i] = y;
+    const uint64_t k = i / (uint64_t)a.d;
+    a.y_tiled[((k / 16) * (uint64_t)a.KS + (uint64_t)(j / 4)) * 64 + (uint64_t)(j % 4) * 16 + k % 16] = y;
+}
+
+/* The linear posterior of 16 points per wave at ANY parameter dimension: the matrix-core kernels' evaluation (lane (g, c)
+ * owns components 4 s + g of point c; k ascending per accumulator; the residual sums and the prior in the canonical four
+ * partial sums) with the point read from its tiled array instead of registers and the matrix's fragments from global
+ * memory -- two 8-byte loads per MFMA and lane, L2-bound. */
+__global__ __launch_bounds__(512) void linear_wide_eval_kernel(const double *__restrict__ blob, int KS, int MT, double lik_const,
+                                                               int likelihood_only, const double *__restrict__ y_tiled,
+                                                               uint64_t K, double *__restrict__ lp_out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const uint64_t nct = (K + 15) / 16, tile = (uint64_t)blockIdx.x * 8 + wave;
+    if (tile >= nct) return;
+    const int m_pad = 16 * MT, d_pad = 4 * KS;
+    const double *bias = blob + (size_t)MT * KS * 64, *nprec = bias + m_pad, *dbar = nprec + m_pad;
+    const double *pmean = dbar + m_pad, *pprec = pmean + d_pad;
+    const double *yt = y_tiled + (tile * (uint64_t)KS) * 64 + lane;
+    double Ssum = 0.0;
+#pragma unroll 1
+    for (int mt = 0; mt < MT; mt += 2) {
+        d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        const double *A0 = blob + (size_t)mt * KS * 64 + lane, *A1 = A0 + (size_t)KS * 64;
+#pragma unroll 1
+        for (int s0 = 0; s0 < KS; s0 += 4) { /* KS is a multiple of 4 here: four steps' loads in flight together */
+            double v[4], f0[4], f1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = yt[(s0 + q) * 64], f0[q] = A0[(s0 + q) * 64], f1[q] = A1[(s0 + q) * 64];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0[q], v[q], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1[q], v[q], acc1, 0, 0, 0);
+            }
+        }
+        ymc_tile_add_residuals(mt, acc0, acc1, bias, nprec, dbar, g, Ssum);
+    }
+    const double logl = -0.5 * (combine4(Ssum) + lik_const);
+    double P = 0.0;
+    for (int s = 0; s < KS; ++s) {
+        const int j = 4 * s + g;
+        const double dx = yt[s * 64] - pmean[j];
+        const double px = pprec[j] * dx;
+        P = P + dx * px;
+    }
+    const double lp = likelihood_only ? logl : logl + (-0.5 * combine4(P));
+    const uint64_t k = tile * 16 + c;
+    if (g == 0 && k < K) lp_out[k] = lp;
+}
+
+__global__ __launch_bounds__(256) void wide_decide_kernel(const WideArgs a)
+{
+    ymc_stage_tables();
+    const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= a.K) return;
+    const double *x = a.x + k * (uint64_t)a.d, *y = a.y + k * (uint64_t)a.d;
+    bool moved = false;
+    for (int j = 0; j < a.d; ++j) moved = moved || !(y[j] == x[j]); /* metropolisHastings.py:60-61 */
+    uint32_t st = a.status[k];
+    const double lpy = a.lpy[k], lp = a.lp[k];
+    const bool acc = ymc_accept(lpy - lp, moved, ymc_finite(lpy), a.u[k], st); /* mrw.py:51-57 */
+    a.accflag[k] = acc ? 1 : 0;
+    a.lp[k] = acc ? lpy : lp;
+    a.acc_count[k] += acc ? 1u : 0u;
+    a.status[k] = st;
+    if (a.acc_row) a.acc_row[k] = acc ? 1 : 0;
+    if (a.lp_row) a.lp_row[k] = acc ? lpy : lp;
+}
+
+__global__ __launch_bounds__(256) void wide_apply_kernel(const WideArgs a)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.K * (uint64_t)a.d) return;
+    const uint64_t k = i / (uint64_t)a.d;
+    double x = a.x[i];
+    if (a.wf_mean) { /* the state BEFORE the move, as the lane kernels (estimation.py:36-53) */
+        double mean = a.wf_mean[i], m2 = a.wf_m2[i];
+        const double delta = x - mean;
+        mean = mean + ymc_div_by_recip(delta, a.wf_dn, a.wf_rdn);
+        const double delta2 = x - mean;
+        m2 = m2 + delta * delta2;
+        a.wf_mean[i] = mean;
+        a.wf_m2[i] = m2;
+    }
+    x = a.accflag[k] ? a.y[i] : x;
+    a.x[i] = x;
+    if (a.traj_row) a.traj_row[i] = x;
+}
+
 }  // namespace
+
+hipError_t ymc_launch_wide_propose(const WideArgs &a, hipStream_t s)
+{
+    const uint64_t n = a.K * (uint64_t)a.d;
+    hipLaunchKernelGGL(wide_propose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t ymc_launch_wide_eval(const double *blob, int KS, int MT, double lik_const, int likelihood_only, const double *y_tiled,
+                                uint64_t K, double *lp_out, hipStream_t s)
+{
+    const uint64_t nct = (K + 15) / 16;
+    hipLaunchKernelGGL(linear_wide_eval_kernel, dim3((unsigned)((nct + 7) / 8)), dim3(512), 0, s, blob, KS, MT, lik_const,
+                       likelihood_only, y_tiled, K, lp_out);
+    return hipGetLastError();
+}
+
+hipError_t ymc_launch_wide_decide(const WideArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(wide_decide_kernel, dim3((unsigned)((a.K + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t ymc_launch_wide_apply(const WideArgs &a, hipStream_t s)
+{
+    const uint64_t n = a.K * (uint64_t)a.d;
+    hipLaunchKernelGGL(wide_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
 
 size_t ymc_tile_lds_bytes(int KS, int MT)
 {
