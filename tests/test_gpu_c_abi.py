@@ -212,6 +212,7 @@ def test_device_memory_returns_when_problems_and_runs_are_destroyed():
             (lowering.make_problem(ctx, _ffi.METHOD_MRW, gauss(), np.ones(2)), 2),
             (lowering.make_problem(ctx, _ffi.METHOD_MRW, lin(64, 64), np.full(64, 0.05)), 64),
             (lowering.make_problem(ctx, _ffi.METHOD_MRW, lin(200, 300), np.full(200, 0.03)), 200),
+            (lowering.make_problem(ctx, _ffi.METHOD_MRW, lin(300, 24), np.full(300, 0.03)), 300),        # the wide path
             (lowering.make_problem(ctx, _ffi.METHOD_MLDA2, lin(128, 200), np.full(128, 0.03), surrogate=lin(128, 200), sub_chain_length=2), 128),
             (lowering.make_problem(ctx, _ffi.METHOD_AEM2, lin(32, 40, 11), np.full(32, 0.05), surrogate=lin(32, 40, 11), sub_chain_length=2,
                                    aem=(4, 1)), 32),
