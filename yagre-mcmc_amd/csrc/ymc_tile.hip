@@ -605,42 +605,54 @@ __global__ __launch_bounds__(512) void linear_wide_eval_kernel(const double *__r
                                                                int likelihood_only, const double *__restrict__ y_tiled,
                                                                uint64_t K, double *__restrict__ lp_out)
 {
+    /* TWO tiles of 16 points per wave: a fragment of the matrix feeds two MFMAs (the matrix is what a wave reads most of) */
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-    const uint64_t nct = (K + 15) / 16, tile = (uint64_t)blockIdx.x * 8 + wave;
-    if (tile >= nct) return;
+    const uint64_t nct = (K + 15) / 16, tile0 = ((uint64_t)blockIdx.x * 8 + wave) * 2;
+    if (tile0 >= nct) return;
+    const bool two = tile0 + 1 < nct;
     const int m_pad = 16 * MT, d_pad = 4 * KS;
     const double *bias = blob + (size_t)MT * KS * 64, *nprec = bias + m_pad, *dbar = nprec + m_pad;
     const double *pmean = dbar + m_pad, *pprec = pmean + d_pad;
-    const double *yt = y_tiled + (tile * (uint64_t)KS) * 64 + lane;
-    double Ssum = 0.0;
+    const double *ya = y_tiled + (tile0 * (uint64_t)KS) * 64 + lane;
+    const double *yb = two ? ya + (size_t)KS * 64 : ya; /* a last odd tile is evaluated twice and written once */
+    double Sa = 0.0, Sb = 0.0;
 #pragma unroll 1
     for (int mt = 0; mt < MT; mt += 2) {
-        d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        d4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0}, b0 = {0.0, 0.0, 0.0, 0.0}, b1 = {0.0, 0.0, 0.0, 0.0};
         const double *A0 = blob + (size_t)mt * KS * 64 + lane, *A1 = A0 + (size_t)KS * 64;
 #pragma unroll 1
         for (int s0 = 0; s0 < KS; s0 += 4) { /* KS is a multiple of 4 here: four steps' loads in flight together */
-            double v[4], f0[4], f1[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = yt[(s0 + q) * 64], f0[q] = A0[(s0 + q) * 64], f1[q] = A1[(s0 + q) * 64];
+            double va[4], vb[4], f0[4], f1[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0[q], v[q], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1[q], v[q], acc1, 0, 0, 0);
+                va[q] = ya[(s0 + q) * 64], vb[q] = yb[(s0 + q) * 64];
+                f0[q] = A0[(s0 + q) * 64], f1[q] = A1[(s0 + q) * 64];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0[q], va[q], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1[q], va[q], a1, 0, 0, 0);
+                b0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0[q], vb[q], b0, 0, 0, 0);
+                b1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1[q], vb[q], b1, 0, 0, 0);
             }
         }
-        ymc_tile_add_residuals(mt, acc0, acc1, bias, nprec, dbar, g, Ssum);
+        ymc_tile_add_residuals(mt, a0, a1, bias, nprec, dbar, g, Sa);
+        ymc_tile_add_residuals(mt, b0, b1, bias, nprec, dbar, g, Sb);
     }
-    const double logl = -0.5 * (combine4(Ssum) + lik_const);
-    double P = 0.0;
+    const double logl_a = -0.5 * (combine4(Sa) + lik_const), logl_b = -0.5 * (combine4(Sb) + lik_const);
+    double Pa = 0.0, Pb = 0.0;
     for (int s = 0; s < KS; ++s) {
         const int j = 4 * s + g;
-        const double dx = yt[s * 64] - pmean[j];
-        const double px = pprec[j] * dx;
-        P = P + dx * px;
+        const double pm = pmean[j], pp = pprec[j];
+        const double dxa = ya[s * 64] - pm, dxb = yb[s * 64] - pm;
+        Pa = Pa + dxa * (pp * dxa);
+        Pb = Pb + dxb * (pp * dxb);
     }
-    const double lp = likelihood_only ? logl : logl + (-0.5 * combine4(P));
-    const uint64_t k = tile * 16 + c;
-    if (g == 0 && k < K) lp_out[k] = lp;
+    const double lpa = likelihood_only ? logl_a : logl_a + (-0.5 * combine4(Pa));
+    const double lpb = likelihood_only ? logl_b : logl_b + (-0.5 * combine4(Pb));
+    const uint64_t ka = tile0 * 16 + c, kb = ka + 16;
+    if (g == 0 && ka < K) lp_out[ka] = lpa;
+    if (g == 0 && two && kb < K) lp_out[kb] = lpb;
 }
 
 __global__ __launch_bounds__(256) void wide_decide_kernel(const WideArgs a)
@@ -695,7 +707,7 @@ hipError_t ymc_launch_wide_eval(const double *blob, int KS, int MT, double lik_c
                                 uint64_t K, double *lp_out, hipStream_t s)
 {
     const uint64_t nct = (K + 15) / 16;
-    hipLaunchKernelGGL(linear_wide_eval_kernel, dim3((unsigned)((nct + 7) / 8)), dim3(512), 0, s, blob, KS, MT, lik_const,
+    hipLaunchKernelGGL(linear_wide_eval_kernel, dim3((unsigned)((nct + 15) / 16)), dim3(512), 0, s, blob, KS, MT, lik_const,
                        likelihood_only, y_tiled, K, lp_out);
     return hipGetLastError();
 }
