@@ -1232,6 +1232,7 @@ def main():
     if "f14" in which:
         fixture_f14()
         fixture_f14("f14b_mlda2_linear_d192.npz", d=192, seed=20250126, K=4, n=81, S=3, prop_var=7e-4)
+        fixture_f14("f14c_mlda2_linear_d300.npz", d=300, seed=20250131, K=4, n=41, S=3, prop_var=4e-4)
     if "f15" in which:
         fixture_f15()
     if "f16" in which:

@@ -681,7 +681,8 @@ def test_two_level_lotka_volterra_model_hierarchy_vs_oracle():
     assert 0.05 < out["acc"].mean() < 0.999 and not np.array_equal(out["acc"], out["sub_acc"][:, -1, :])
 
 
-@pytest.mark.parametrize("name,prop_var", [("f14_mlda2_linear_d128.npz", 1.1e-3), ("f14b_mlda2_linear_d192.npz", 7e-4)])
+@pytest.mark.parametrize("name,prop_var", [("f14_mlda2_linear_d128.npz", 1.1e-3), ("f14b_mlda2_linear_d192.npz", 7e-4),
+                                           ("f14c_mlda2_linear_d300.npz", 4e-4)])
 def test_two_level_over_a_model_hierarchy_d128_f14(golden, name, prop_var):
     """MLDABuilder.bayesModel = BayesianRegressionModelHierarchy of two d = 128 / d = 192 linear models
     (mlda.py:315-335): through the builders the chains are the live reference's (fixtures F14 / F14b), on the

@@ -1217,7 +1217,7 @@ def test_tile_kernel_dense_proposal_other_shapes(ffi, ctx, d, m, nd, K):
     _same_as_oracle(dev, e, out)
 
 
-@pytest.mark.parametrize("name", ["f14_mlda2_linear_d128.npz", "f14b_mlda2_linear_d192.npz"])
+@pytest.mark.parametrize("name", ["f14_mlda2_linear_d128.npz", "f14b_mlda2_linear_d192.npz", "f14c_mlda2_linear_d300.npz"])
 def test_f14_two_level_d128_matrix_cores(ffi, ctx, golden, name):
     """Two-level delayed acceptance over two d = 128 (coarse matrix in LDS) / d = 192 (both streamed, one wave per SIMD)
     linear models (linear_tile_mlda2_kernel): the LIVE reference's decisions at both levels, its chains (sha256 of all
@@ -1535,6 +1535,38 @@ def test_linear_posteriors_beyond_256_parameters_vs_oracle(ffi, ctx, d, m, nd, K
     assert np.array_equal(prob.forward(probe), o.forward(p, probe))
 
 
+@pytest.mark.parametrize("d,mc,mf,K,S,dense", [(300, 20, 40, 40, 3, False), (513, 64, 700, 17, 2, False), (260, 30, 30, 70, 4, True)])
+def test_two_level_beyond_256_parameters_vs_oracle(ffi, ctx, d, mc, mf, K, S, dense):
+    """Two-level delayed acceptance beyond 256 parameters (the wide path: every sub-step and the fine decision as plain
+    kernels, both levels evaluated on the matrix cores from global memory): chains, both levels' decisions, log-posteriors,
+    moments, carried state == oracle."""
+    from yagremcmc_amd import lowering
+    rng = np.random.default_rng(3100 + d + mc)
+
+    def model(m, scale):
+        g = dict(data=rng.normal(size=(2, m)), noise_precision=rng.uniform(0.5, 3, size=m), prior_mean=rng.normal(size=d) * 0.1,
+                 prior_precision=rng.uniform(0.1, 2, size=d))
+        A, b = scale * rng.normal(size=(m, d)) / np.sqrt(d), rng.normal(size=m)
+        if not dense:
+            return (_posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, g, fwd_matrix=A, fwd_shift=b),
+                    o.posterior_linear(A, b, g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"]))
+        B = rng.normal(size=(d, d)) / np.sqrt(d)
+        pc = B @ B.T + np.eye(d)
+        g["prior_precision"] = np.ones(d)
+        return (_dense_low(ffi, ffi.POSTERIOR_LINEAR, d, g, None, pc, fwd_matrix=A, fwd_shift=b),
+                o.dense_covariances(o.posterior_linear(A, b, g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"]),
+                                    prior_cov=pc))
+
+    (lf, pf), (lc, pc_) = model(mf, 1.0), model(mc, 0.95)
+    sigma, x0 = rng.uniform(0.01, 0.03, size=d), rng.normal(size=(K, d)) * 0.3
+    dev = _device_run(ffi, ctx, lf, sigma, x0, 995, 12, method=ffi.METHOD_MLDA2, sur=lc, S=S, chain0=700, splits=3)
+    e = o.Ensemble(pf, sigma, x0, 995, chain0=700, surrogate=pc_, sub_chain_length=S)
+    out = e.advance(12, want_sub=True)
+    _same_as_oracle(dev, e, out)
+    assert np.array_equal(dev["sub_acc"], out["sub_acc"])
+    assert 0 < dev["sub_acc"].mean() < 1 and 0 < dev["acc"].mean()
+
+
 def test_tile_kernel_limits(ffi, ctx):
     from yagremcmc_amd import lowering
     rng = np.random.default_rng(1)
@@ -1556,9 +1588,7 @@ def test_tile_kernel_limits(ffi, ctx):
     lowering.make_problem(ctx, ffi.METHOD_MRW, lin(256, 4), np.ones(256))
     lowering.make_problem(ctx, ffi.METHOD_MRW, lin(257, 4), np.ones(257))     # beyond 256: the wide path (random walk, pCN)
     lowering.make_problem(ctx, ffi.METHOD_MLDA2, lin(256, 4), np.ones(256), surrogate=lin(256, 4), sub_chain_length=2)
-    with pytest.raises(ffi.YmcError, match="exceeds the matrix-core kernels' 256") as err:
-        lowering.make_problem(ctx, ffi.METHOD_MLDA2, lin(260, 4), np.ones(260), surrogate=lin(260, 4), sub_chain_length=2)
-    assert err.value.code == ffi.ERR_UNSUPPORTED
+    lowering.make_problem(ctx, ffi.METHOD_MLDA2, lin(260, 4), np.ones(260), surrogate=lin(260, 4), sub_chain_length=2)  # the wide path
     lowering.make_problem(ctx, ffi.METHOD_MLDA2, lin(128, 400), np.ones(128), surrogate=lin(128, 400), sub_chain_length=2)
     with pytest.raises(ffi.YmcError, match="exceeds the matrix-core kernels' 128") as err:   # adaptive error model: d <= 128
         lowering.make_problem(ctx, ffi.METHOD_AEM2, lin(200, 4), np.ones(200), surrogate=lin(200, 4), sub_chain_length=2, aem=(5, 0))

@@ -343,7 +343,7 @@ def test_f7_two_level_over_a_model_hierarchy(golden):
     assert np.array_equal(out["sub_acc"], g["sub_acc"])
 
 
-@pytest.mark.parametrize("name", ["f14_mlda2_linear_d128.npz", "f14b_mlda2_linear_d192.npz"])
+@pytest.mark.parametrize("name", ["f14_mlda2_linear_d128.npz", "f14b_mlda2_linear_d192.npz", "f14c_mlda2_linear_d300.npz"])
 def test_f14_two_level_over_a_model_hierarchy_d128(golden, name):
     """mlda.py:315-335 with two d = 128 / d = 192 linear models (the matrix-core kernels' sizes): the reference's
     decisions at both levels, its chains (sha256 of all states) and log-posteriors"""
@@ -360,7 +360,7 @@ def test_f14_two_level_over_a_model_hierarchy_d128(golden, name):
     assert hashlib.sha256(np.ascontiguousarray(full).tobytes()).hexdigest() == str(g["traj_sha256"])
     want = g["logpost"][1:]
     assert np.abs(out["logpost"] - want).max() <= LP_RTOL * np.abs(want).max()
-    assert 0.5 < g["acc"].mean() < 0.95 and 0.2 < g["sub_acc"].mean() < 0.8   # both levels decide both ways
+    assert 0.4 < g["acc"].mean() < 0.95 and 0.2 < g["sub_acc"].mean() < 0.8   # both levels decide both ways
 
 
 @pytest.mark.parametrize("name", ["f18_mlda_nested2_linear_d128.npz", "f18b_mlda_nested4_linear_d24.npz",

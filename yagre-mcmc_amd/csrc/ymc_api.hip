@@ -186,6 +186,7 @@ struct ymc_run {
     DeviceBuf err_n, err_mean, err_m2, aem_prec, aem_flags, cache_key, cache_val; /* AEM2 */
     DeviceBuf err_mean_alt, err_m2_alt; /* AEM2 on the matrix cores: the kernel's second copy of mean / M2 (scratch) */
     DeviceBuf wide_xi, wide_u, wide_y, wide_yt, wide_lpy, wide_flag; /* the wide path's per-transition scratch */
+    DeviceBuf wide_z, wide_zt, wide_lpcz;                            /* ... and the two-level sampler's sub-chain state */
     /* egress (ymc_run_egress_*): a copy stream, two slots of page-locked staging */
     struct EgressSlot {
         PinnedBuf traj, acc, lp;
@@ -796,6 +797,8 @@ int launch_advance_wide(ymc_run *r, uint64_t nsteps)
     const ymc_problem *p = r->problem;
     hipStream_t s = r->ctx->stream;
     const uint64_t K = r->K, d = (uint64_t)p->D;
+    const bool two = p->method == YMC_METHOD_MLDA2;
+    const uint64_t S = two ? (uint64_t)p->S : 0;
     WideArgs a{};
     a.K = K;
     a.d = p->D;
@@ -815,6 +818,10 @@ int launch_advance_wide(ymc_run *r, uint64_t nsteps)
     a.acc_count = r->acc_count.as<uint64_t>();
     a.status = r->status.as<uint32_t>();
     a.accflag = r->wide_flag.as<uint8_t>();
+    auto eval = [&](const DensityHost &h, const double *tiled, double *out) -> int {
+        YMC_HIP(ymc_launch_wide_eval(h.tile_blob.as<double>(), h.KS, h.MT, h.lik_const, h.d.likelihood_only, tiled, K, out, s));
+        return YMC_OK;
+    };
 
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (!r->pool.empty()) {
@@ -827,24 +834,52 @@ int launch_advance_wide(ymc_run *r, uint64_t nsteps)
     YMC_HIP(hipEventRecord(ev.first, s));
     uint64_t rows = 0;
     for (uint64_t n = 0; n < nsteps; ++n) {
-        const uint64_t t = r->steps_done + n;
-        const bool due = (t + 1) % r->stride == 0;
+        const uint64_t step = r->steps_done + n;
+        const bool due = (step + 1) % r->stride == 0;
         const uint64_t row = r->recorded + rows;
-        a.acc_row = (r->flags & YMC_RECORD_ACCEPT) ? r->acc.as<uint8_t>() + row * K : nullptr; /* stride 1 when recorded */
-        a.traj_row = (due && (r->flags & YMC_RECORD_TRAJECTORY)) ? r->traj.as<double>() + row * K * d : nullptr;
-        a.lp_row = (due && (r->flags & YMC_RECORD_LOGPOST)) ? r->lp_out.as<double>() + row * K : nullptr;
+        uint8_t *acc_row = (r->flags & YMC_RECORD_ACCEPT) ? r->acc.as<uint8_t>() + row * K : nullptr; /* stride 1 when recorded */
+        double *traj_row = (due && (r->flags & YMC_RECORD_TRAJECTORY)) ? r->traj.as<double>() + row * K * d : nullptr;
+        double *lp_row = (due && (r->flags & YMC_RECORD_LOGPOST)) ? r->lp_out.as<double>() + row * K : nullptr;
+        double *wf_mean = nullptr, *wf_m2 = nullptr;
         if (r->flags & YMC_RECORD_MOMENTS) {
-            a.wf_mean = r->wf_mean.as<double>();
-            a.wf_m2 = r->wf_m2.as<double>();
-            a.wf_dn = (double)(t + 1);
+            wf_mean = r->wf_mean.as<double>();
+            wf_m2 = r->wf_m2.as<double>();
+            a.wf_dn = (double)(step + 1);
             a.wf_rdn = 1.0 / a.wf_dn;
         }
-        YMC_HIP(ymc_launch_rng_fill(r->seed, r->chain0, K, t, 1, p->D, r->wide_xi.as<double>(), r->wide_u.as<double>(), s));
-        YMC_HIP(ymc_launch_wide_propose(a, s));
-        YMC_HIP(ymc_launch_wide_eval(p->tgt.tile_blob.as<double>(), p->tgt.KS, p->tgt.MT, p->tgt.lik_const,
-                                     p->tgt.d.likelihood_only, a.y_tiled, K, r->wide_lpy.as<double>(), s));
-        YMC_HIP(ymc_launch_wide_decide(a, s));
-        YMC_HIP(ymc_launch_wide_apply(a, s));
+        if (!two) { /* one transition of the random walk / pCN */
+            a.from = a.x, a.cur_lp = a.lp, a.dst = a.x, a.dst_tiled = nullptr, a.count = a.acc_count;
+            a.acc_row = acc_row, a.traj_row = traj_row, a.lp_row = lp_row, a.wf_mean = wf_mean, a.wf_m2 = wf_m2;
+            YMC_HIP(ymc_launch_rng_fill(r->seed, r->chain0, K, step, 1, p->D, r->wide_xi.as<double>(), r->wide_u.as<double>(), s));
+            YMC_HIP(ymc_launch_wide_propose(a, s));
+            YMC_TRY(eval(p->tgt, a.y_tiled, r->wide_lpy.as<double>()));
+            YMC_HIP(ymc_launch_wide_decide(a, s));
+            YMC_HIP(ymc_launch_wide_apply(a, s));
+        } else {
+            /* one fine step of two-level delayed acceptance (mlda.py:100-110,146-154, as mlda2_body): the sub-chain of S
+             * coarse random-walk transitions from z = x, then the fine decision; fine step n owns transitions n (S + 1) + s */
+            double *z = r->wide_z.as<double>(), *zt = r->wide_zt.as<double>(), *lpcz = r->wide_lpcz.as<double>();
+            const uint64_t tbase = step * (S + 1);
+            YMC_HIP(ymc_launch_wide_copy(a, a.x, z, zt, s));
+            YMC_HIP(hipMemcpyAsync(lpcz, r->lpc.p, K * sizeof(double), hipMemcpyDeviceToDevice, s));
+            a.from = z, a.cur_lp = lpcz, a.dst = z, a.dst_tiled = zt, a.count = nullptr;
+            a.traj_row = nullptr, a.lp_row = nullptr, a.wf_mean = nullptr, a.wf_m2 = nullptr;
+            for (uint64_t sub = 0; sub < S; ++sub) {
+                a.acc_row = (r->flags & YMC_RECORD_SUB_ACCEPT) ? r->sub_acc.as<uint8_t>() + (row * S + sub) * K : nullptr;
+                YMC_HIP(ymc_launch_rng_fill(r->seed, r->chain0, K, tbase + sub, 1, p->D, r->wide_xi.as<double>(),
+                                            r->wide_u.as<double>(), s));
+                YMC_HIP(ymc_launch_wide_propose(a, s));
+                YMC_TRY(eval(p->sur, a.y_tiled, r->wide_lpy.as<double>()));
+                YMC_HIP(ymc_launch_wide_decide(a, s));
+                YMC_HIP(ymc_launch_wide_apply(a, s));
+            }
+            YMC_HIP(ymc_launch_rng_fill(r->seed, r->chain0, K, tbase + S, 1, p->D, nullptr, r->wide_u.as<double>(), s));
+            YMC_TRY(eval(p->tgt, zt, r->wide_lpy.as<double>()));
+            a.z = z, a.lpfz = r->wide_lpy.as<double>(), a.lpc = r->lpc.as<double>(), a.lpcz = lpcz;
+            a.acc_row = acc_row, a.traj_row = traj_row, a.lp_row = lp_row, a.wf_mean = wf_mean, a.wf_m2 = wf_m2;
+            YMC_HIP(ymc_launch_wide_fine_decide(a, s));
+            YMC_HIP(ymc_launch_wide_fine_apply(a, s));
+        }
         if (due) ++rows;
     }
     YMC_HIP(hipEventRecord(ev.second, s));
@@ -1111,7 +1146,8 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
                             desc->method == YMC_METHOD_MLDA_NESTED;
     /* beyond 256 parameters the random walk with a diagonal proposal and pCN run as a sequence of plain kernels per
      * transition (launch_advance_wide) */
-    const bool may_wide = (desc->method == YMC_METHOD_MRW && !desc->proposal_chol) || desc->method == YMC_METHOD_PCN;
+    const bool may_wide = (desc->method == YMC_METHOD_MRW && !desc->proposal_chol) || desc->method == YMC_METHOD_PCN ||
+                          desc->method == YMC_METHOD_MLDA2;
     int rc = lower_density(ctx, desc->target, p->tgt, 0, joint_tile, may_stream, may_wide);
     if (rc == YMC_OK) {
         p->wide = p->tgt.wide;
@@ -1147,7 +1183,8 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
         if (rc == YMC_OK && desc->surrogate.kind != desc->target.kind)
             rc = fail(YMC_ERR_UNSUPPORTED, "surrogate density kind %d differs from target kind %d",
                       desc->surrogate.kind, desc->target.kind);
-        if (rc == YMC_OK) rc = lower_density(ctx, desc->surrogate, p->sur, p->D, joint_tile, may_stream);
+        if (rc == YMC_OK)
+            rc = lower_density(ctx, desc->surrogate, p->sur, p->D, joint_tile, may_stream, may_wide && desc->method == YMC_METHOD_MLDA2);
         /* both levels run in one kernel: on the lane path each holds at most YMC_LANE_MMAX forward outputs, on
          * the matrix-core path the coarse matrix and both levels' constants share the LDS */
         if (rc == YMC_OK && p->sur.tile != p->tgt.tile)
@@ -1250,6 +1287,7 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
             YMC_TRY(p->wide_consts.alloc(c.size() * sizeof(double)));
             YMC_HIP(hipMemcpy(p->wide_consts.p, c.data(), c.size() * sizeof(double), hipMemcpyHostToDevice));
             YMC_TRY(build_tile_blob(p, p->tgt)); /* the matrix-core layout of the model for linear_wide_eval_kernel */
+            if (p->method == YMC_METHOD_MLDA2) YMC_TRY(build_tile_blob(p, p->sur));
             return YMC_OK;
         };
         rc = up();
@@ -1392,6 +1430,12 @@ int ymc_run_create(ymc_ctx *ctx, const ymc_problem *problem, const ymc_run_desc 
             YMC_TRY(r->wide_y.alloc(K * D * sizeof(double)));
             YMC_TRY(r->wide_yt.alloc(((K + 15) / 16) * (uint64_t)problem->tgt.KS * 64 * sizeof(double)));
             YMC_HIP(hipMemsetAsync(r->wide_yt.p, 0, r->wide_yt.bytes, ctx->stream)); /* the padding stays zero */
+            if (problem->method == YMC_METHOD_MLDA2) {
+                YMC_TRY(r->wide_z.alloc(K * D * sizeof(double)));
+                YMC_TRY(r->wide_zt.alloc(r->wide_yt.bytes));
+                YMC_HIP(hipMemsetAsync(r->wide_zt.p, 0, r->wide_zt.bytes, ctx->stream));
+                YMC_TRY(r->wide_lpcz.alloc(K * sizeof(double)));
+            }
             YMC_TRY(r->wide_u.alloc(K * sizeof(double)));
             YMC_TRY(r->wide_lpy.alloc(K * sizeof(double)));
             YMC_TRY(r->wide_flag.alloc(K));

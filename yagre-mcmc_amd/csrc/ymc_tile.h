@@ -90,7 +90,17 @@ struct WideArgs {
     double pcn_c1, pcn_c2;
     const double *sigma, *pmean;   /* [d] */
     const double *xi, *u;          /* the transition's draws: [K][d], [K] */
-    double *x, *y;                 /* [K][d]: state, proposal */
+    double *x, *y;                 /* [K][d]: the recorded chain's state, the proposal */
+    /* what one decision works on (random walk: from = dst = x, cur_lp = lp, count = acc_count; a sub-step of the two-level
+     * sampler: from = dst = z, cur_lp = the coarse log-density of z, no count) */
+    const double *from;            /* the state the proposal starts from and is compared with */
+    double *cur_lp;                /* [K]: its log-density, replaced on acceptance */
+    double *dst, *dst_tiled;       /* the state that moves (and its copy in the matrix-core layout, or null) */
+    uint64_t *count;               /* accepted moves (or null) */
+    /* two-level delayed acceptance: the sub-chain's state z (from / dst above), the coarse log-densities of x and z, the
+     * fine log-density of z */
+    const double *z, *lpfz;
+    double *lpc, *lpcz;
     double *y_tiled;               /* the proposal once more in the matrix-core layout [ceil(K/16)][KS][64] (padding zero) */
     int32_t KS, pad_;
     double *lp;                    /* [K] */
@@ -110,6 +120,9 @@ hipError_t ymc_launch_wide_eval(const double *blob, int KS, int MT, double lik_c
                                 uint64_t K, double *lp_out, hipStream_t s);
 hipError_t ymc_launch_wide_decide(const WideArgs &a, hipStream_t s);
 hipError_t ymc_launch_wide_apply(const WideArgs &a, hipStream_t s);
+hipError_t ymc_launch_wide_copy(const WideArgs &a, const double *src, double *dst, double *dst_tiled, hipStream_t s);
+hipError_t ymc_launch_wide_fine_decide(const WideArgs &a, hipStream_t s); /* mlda.py:146-154: z against x */
+hipError_t ymc_launch_wide_fine_apply(const WideArgs &a, hipStream_t s);  /* x <- z where accepted; record, moments */
 
 size_t ymc_tile_lds_bytes(int KS, int MT);
 size_t ymc_tile_stream_lds_bytes(int KS, int MT); /* the forward matrix streamed from L2: constants + double buffer */

@@ -584,7 +584,7 @@ __global__ __launch_bounds__(256) void wide_propose_kernel(const WideArgs a)
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= a.K * (uint64_t)a.d) return;
     const int j = (int)(i % (uint64_t)a.d);
-    const double x = a.x[i], xi = a.xi[i];
+    const double x = a.from[i], xi = a.xi[i];
     double y;
     if (a.pcn) { /* pcn.py:27-36 as linear_tile_kernel: xi ~ prior, y = sqrt(1 - 2h) x + sqrt(2h) xi */
         const double p0 = a.pmean[j] + a.sigma[j] * xi;
@@ -660,15 +660,15 @@ __global__ __launch_bounds__(256) void wide_decide_kernel(const WideArgs a)
     ymc_stage_tables();
     const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= a.K) return;
-    const double *x = a.x + k * (uint64_t)a.d, *y = a.y + k * (uint64_t)a.d;
+    const double *x = a.from + k * (uint64_t)a.d, *y = a.y + k * (uint64_t)a.d;
     bool moved = false;
     for (int j = 0; j < a.d; ++j) moved = moved || !(y[j] == x[j]); /* metropolisHastings.py:60-61 */
     uint32_t st = a.status[k];
-    const double lpy = a.lpy[k], lp = a.lp[k];
+    const double lpy = a.lpy[k], lp = a.cur_lp[k];
     const bool acc = ymc_accept(lpy - lp, moved, ymc_finite(lpy), a.u[k], st); /* mrw.py:51-57 */
     a.accflag[k] = acc ? 1 : 0;
-    a.lp[k] = acc ? lpy : lp;
-    a.acc_count[k] += acc ? 1u : 0u;
+    a.cur_lp[k] = acc ? lpy : lp;
+    if (a.count) a.count[k] += acc ? 1u : 0u;
     a.status[k] = st;
     if (a.acc_row) a.acc_row[k] = acc ? 1 : 0;
     if (a.lp_row) a.lp_row[k] = acc ? lpy : lp;
@@ -679,7 +679,8 @@ __global__ __launch_bounds__(256) void wide_apply_kernel(const WideArgs a)
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= a.K * (uint64_t)a.d) return;
     const uint64_t k = i / (uint64_t)a.d;
-    double x = a.x[i];
+    const int j = (int)(i % (uint64_t)a.d);
+    double x = a.dst[i];
     if (a.wf_mean) { /* the state BEFORE the move, as the lane kernels (estimation.py:36-53) */
         double mean = a.wf_mean[i], m2 = a.wf_m2[i];
         const double delta = x - mean;
@@ -690,6 +691,63 @@ __global__ __launch_bounds__(256) void wide_apply_kernel(const WideArgs a)
         a.wf_m2[i] = m2;
     }
     x = a.accflag[k] ? a.y[i] : x;
+    a.dst[i] = x;
+    if (a.dst_tiled) a.dst_tiled[((k / 16) * (uint64_t)a.KS + (uint64_t)(j / 4)) * 64 + (uint64_t)(j % 4) * 16 + k % 16] = x;
+    if (a.traj_row) a.traj_row[i] = x;
+}
+
+/* dst (and its matrix-core copy) <- src, [K][d] */
+__global__ __launch_bounds__(256) void wide_copy_kernel(const WideArgs a, const double *__restrict__ src, double *__restrict__ dst,
+                                                        double *__restrict__ dst_tiled)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.K * (uint64_t)a.d) return;
+    const uint64_t k = i / (uint64_t)a.d;
+    const int j = (int)(i % (uint64_t)a.d);
+    const double v = src[i];
+    dst[i] = v;
+    if (dst_tiled) dst_tiled[((k / 16) * (uint64_t)a.KS + (uint64_t)(j / 4)) * 64 + (uint64_t)(j % 4) * 16 + k % 16] = v;
+}
+
+/* the fine accept / reject of two-level delayed acceptance (mlda.py:146-154, as mlda2_body): the sub-chain's end z against
+ * the fine state x with exp(P(z) + Q(x) - Q(z) - P(x)) */
+__global__ __launch_bounds__(256) void wide_fine_decide_kernel(const WideArgs a)
+{
+    ymc_stage_tables();
+    const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= a.K) return;
+    const double *x = a.x + k * (uint64_t)a.d, *z = a.z + k * (uint64_t)a.d;
+    bool moved = false;
+    for (int j = 0; j < a.d; ++j) moved = moved || !(z[j] == x[j]);
+    uint32_t st = a.status[k];
+    const double lpfy = a.lpfz[k], lpf = a.lp[k], lpc = a.lpc[k], lpcz = a.lpcz[k];
+    const double log_ratio = ((lpfy + lpc) - lpcz) - lpf;
+    const bool acc = ymc_accept(log_ratio, moved, ymc_finite(lpfy) && ymc_finite(lpcz), a.u[k], st);
+    a.accflag[k] = acc ? 1 : 0;
+    a.lp[k] = acc ? lpfy : lpf;
+    a.lpc[k] = acc ? lpcz : lpc;
+    a.acc_count[k] += acc ? 1u : 0u;
+    a.status[k] = st;
+    if (a.acc_row) a.acc_row[k] = acc ? 1 : 0;
+    if (a.lp_row) a.lp_row[k] = acc ? lpfy : lpf;
+}
+
+__global__ __launch_bounds__(256) void wide_fine_apply_kernel(const WideArgs a)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.K * (uint64_t)a.d) return;
+    const uint64_t k = i / (uint64_t)a.d;
+    double x = a.x[i];
+    if (a.wf_mean) {
+        double mean = a.wf_mean[i], m2 = a.wf_m2[i];
+        const double delta = x - mean;
+        mean = mean + ymc_div_by_recip(delta, a.wf_dn, a.wf_rdn);
+        const double delta2 = x - mean;
+        m2 = m2 + delta * delta2;
+        a.wf_mean[i] = mean;
+        a.wf_m2[i] = m2;
+    }
+    x = a.accflag[k] ? a.z[i] : x;
     a.x[i] = x;
     if (a.traj_row) a.traj_row[i] = x;
 }
@@ -700,6 +758,26 @@ hipError_t ymc_launch_wide_propose(const WideArgs &a, hipStream_t s)
 {
     const uint64_t n = a.K * (uint64_t)a.d;
     hipLaunchKernelGGL(wide_propose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t ymc_launch_wide_copy(const WideArgs &a, const double *src, double *dst, double *dst_tiled, hipStream_t s)
+{
+    const uint64_t n = a.K * (uint64_t)a.d;
+    hipLaunchKernelGGL(wide_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, src, dst, dst_tiled);
+    return hipGetLastError();
+}
+
+hipError_t ymc_launch_wide_fine_decide(const WideArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(wide_fine_decide_kernel, dim3((unsigned)((a.K + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t ymc_launch_wide_fine_apply(const WideArgs &a, hipStream_t s)
+{
+    const uint64_t n = a.K * (uint64_t)a.d;
+    hipLaunchKernelGGL(wide_fine_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
