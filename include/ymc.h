@@ -80,7 +80,8 @@ typedef struct ymc_density_desc {
      * (entries above the diagonal are ignored), so that |r|^2 in the covariance's norm is |L^-1 r|^2.  NULL = the
      * diagonal covariance of noise_precision / prior_precision.  At lane-kernel sizes (d, data_dim <= 8) the
      * kernels form the norm per evaluation; beyond (POSTERIOR_LINEAR on the matrix cores: any d for YMC_METHOD_MRW with a
-     * diagonal proposal, YMC_METHOD_PCN and YMC_METHOD_MLDA2 -- a sequence of plain kernels per transition beyond 256 --; d <= 256 and any number of
+     * diagonal proposal, YMC_METHOD_PCN, YMC_METHOD_MLDA2 and YMC_METHOD_MLDA_NESTED -- a sequence of plain kernels per transition
+     * beyond 256 --; d <= 256 and any number of
      * outputs for YMC_METHOD_MRW, YMC_METHOD_PCN, YMC_METHOD_MLDA2 and YMC_METHOD_MLDA_NESTED, whose
      * forward matrices stream from L2 when they do not fit the LDS; d <= 128 and an LDS-resident coarse matrix for AEM2) a dense NOISE
      * covariance is whitened away when the problem is created -- A, b and the data rows are multiplied by L^-1
@@ -118,7 +119,7 @@ typedef enum ymc_method {
      *                with exp(P(y) + Q(x) - Q(y) - P(x)), P = surrogateTargets[2e], Q = [2e-1]
      *   level E-1    the recorded chain: P = the target, Q = surrogateTargets[n-1]
      * (An odd n >= 3 raises AttributeError in the reference; the Python layer raises the same.)
-     * Lane kernels up to d = 8; hierarchies of POSTERIOR_LINEAR models up to d = 256 on the matrix cores. */
+     * Lane kernels up to d = 8; hierarchies of POSTERIOR_LINEAR models of any d on the matrix cores. */
     YMC_METHOD_MLDA_NESTED = 4,
     /* AdaptiveErrorModel with one surrogate (chain/method/aem.py:6-58): MLDA2 whose coarse
      * AEMLikelihood (statistics/likelihood.py:90-155, noise.py:25-61) learns the model error

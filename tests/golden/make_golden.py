@@ -1255,6 +1255,8 @@ def main():
                     sub_lengths=(2, 2, 3, 2, 1, 2, 2, 2), perturb=0.015, prop_var=6e-3)
         fixture_f18("f18d_mlda_nested2_linear_d192.npz", d=192, n_models=3, seed=20250127, K=4, n=41, sub_lengths=(2, 3),
                     perturb=0.02, prop_var=7e-4)
+        fixture_f18("f18e_mlda_nested2_linear_d300.npz", d=300, n_models=3, seed=20250132, K=4, n=31, sub_lengths=(2, 3),
+                    perturb=0.02, prop_var=4e-4)
     if "f23" in which:
         fixture_f23()
     if "f24" in which:

@@ -723,7 +723,8 @@ def test_two_level_over_a_model_hierarchy_d128_f14(golden, name, prop_var):
 @pytest.mark.parametrize("name,prior_var,noise_var,prop_var", [("f18_mlda_nested2_linear_d128.npz", 5.0, 0.3, 1.1e-3),
                                                                ("f18b_mlda_nested4_linear_d24.npz", 5.0, 0.3, 6e-3),
                                                                ("f18c_mlda_nested8_linear_d24.npz", 5.0, 0.3, 6e-3),
-                                                               ("f18d_mlda_nested2_linear_d192.npz", 5.0, 0.3, 7e-4)])
+                                                               ("f18d_mlda_nested2_linear_d192.npz", 5.0, 0.3, 7e-4),
+                                                               ("f18e_mlda_nested2_linear_d300.npz", 5.0, 0.3, 4e-4)])
 def test_nested_levels_over_model_hierarchies_f18(golden, name, prior_var, noise_var, prop_var):
     """MLDABuilder.bayesModel = a hierarchy of three (d = 128) / five / nine (d = 24) linear models, i.e. an even number
     of surrogates: through the builders the chains are the live reference's (fixtures F18), on the matrix cores."""

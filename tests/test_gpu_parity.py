@@ -1270,7 +1270,8 @@ def test_tile_kernel_two_level_other_shapes(ffi, ctx, d, mf, mc, nd, K, S):
 
 
 @pytest.mark.parametrize("name", ["f18_mlda_nested2_linear_d128.npz", "f18b_mlda_nested4_linear_d24.npz",
-                                  "f18c_mlda_nested8_linear_d24.npz", "f18d_mlda_nested2_linear_d192.npz"])
+                                  "f18c_mlda_nested8_linear_d24.npz", "f18d_mlda_nested2_linear_d192.npz",
+                                  "f18e_mlda_nested2_linear_d300.npz"])
 def test_f18_nested_levels_matrix_cores(ffi, ctx, golden, name):
     """Hierarchies of three (d = 128), five and nine (d = 24) linear models (linear_tile_nested_kernel): the LIVE
     reference's top-level decisions, accepted counts of the lower levels, chains (sha256) and log-posteriors;
@@ -1565,6 +1566,32 @@ def test_two_level_beyond_256_parameters_vs_oracle(ffi, ctx, d, mc, mf, K, S, de
     _same_as_oracle(dev, e, out)
     assert np.array_equal(dev["sub_acc"], out["sub_acc"])
     assert 0 < dev["sub_acc"].mean() < 1 and 0 < dev["acc"].mean()
+
+
+@pytest.mark.parametrize("d,ms,K,E", [(300, (20, 30, 40), 33, 2), (260, (16, 8, 24, 12, 40), 20, 3), (400, (8,) * 8 + (16,), 17, 5)])
+def test_nested_levels_beyond_256_parameters_vs_oracle(ffi, ctx, d, ms, K, E):
+    """The nest of levels beyond 256 parameters (the wide path: the walk as host recursion over plain kernels, every level
+    evaluated on the matrix cores from global memory): chains, top-level decisions, per-level accept counts, log-posteriors,
+    moments == oracle."""
+    rng = np.random.default_rng(3200 + d + sum(ms))
+
+    def model(m, scale):
+        g = dict(data=rng.normal(size=(2, m)), noise_precision=rng.uniform(0.5, 3, size=m), prior_mean=rng.normal(size=d) * 0.1,
+                 prior_precision=rng.uniform(0.1, 2, size=d))
+        A, b = scale * rng.normal(size=(m, d)) / np.sqrt(d), rng.normal(size=m)
+        return (_posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, g, fwd_matrix=A, fwd_shift=b),
+                o.posterior_linear(A, b, g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"]))
+
+    models = [model(m, 1.0 - 0.02 * i) for i, m in enumerate(ms)]
+    (lt, pt), surs = models[-1], models[:-1]
+    subs = [int(v) for v in rng.integers(1, 3, size=len(surs))]
+    sigma, x0 = rng.uniform(0.01, 0.03, size=d), rng.normal(size=(K, d)) * 0.3
+    dev = _nested_device_run(ffi, ctx, lt, [l for l, _ in surs], subs, sigma, x0, 779, 8, splits=2, chain0=60)
+    P, Q, steps = o.nested_levels([q for _, q in surs], subs, pt)
+    e = o.NestedEnsemble(P, Q, steps, sigma, x0, 779, chain0=60)
+    out = e.advance(8)
+    _same_as_oracle(dev, e, out)
+    assert np.array_equal(dev["level_acc"], e.level_acc)
 
 
 def test_tile_kernel_limits(ffi, ctx):

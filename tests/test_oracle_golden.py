@@ -364,7 +364,8 @@ def test_f14_two_level_over_a_model_hierarchy_d128(golden, name):
 
 
 @pytest.mark.parametrize("name", ["f18_mlda_nested2_linear_d128.npz", "f18b_mlda_nested4_linear_d24.npz",
-                                  "f18c_mlda_nested8_linear_d24.npz", "f18d_mlda_nested2_linear_d192.npz"])
+                                  "f18c_mlda_nested8_linear_d24.npz", "f18d_mlda_nested2_linear_d192.npz",
+                                  "f18e_mlda_nested2_linear_d300.npz"])
 def test_f18_nested_levels_over_model_hierarchies_at_large_dimension(golden, name):
     """MLDABuilder.bayesModel = a hierarchy of three (d = 128) / five (d = 24) linear models: an even number of
     surrogates, run by the reference as a nest of effective levels (mlda.py:12-73,100-116,315-335).  The

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "ymc_aem.h"
@@ -187,6 +188,7 @@ struct ymc_run {
     DeviceBuf err_mean_alt, err_m2_alt; /* AEM2 on the matrix cores: the kernel's second copy of mean / M2 (scratch) */
     DeviceBuf wide_xi, wide_u, wide_y, wide_yt, wide_lpy, wide_flag; /* the wide path's per-transition scratch */
     DeviceBuf wide_z, wide_zt, wide_lpcz;                            /* ... and the two-level sampler's sub-chain state */
+    DeviceBuf wide_lvl_x, wide_lvl_lp; /* the nest on the wide path: states (plain | tiled) and P | Q of levels 0 .. E-2 */
     /* egress (ymc_run_egress_*): a copy stream, two slots of page-locked staging */
     struct EgressSlot {
         PinnedBuf traj, acc, lp;
@@ -877,9 +879,120 @@ int launch_advance_wide(ymc_run *r, uint64_t nsteps)
             YMC_TRY(eval(p->tgt, zt, r->wide_lpy.as<double>()));
             a.z = z, a.lpfz = r->wide_lpy.as<double>(), a.lpc = r->lpc.as<double>(), a.lpcz = lpcz;
             a.acc_row = acc_row, a.traj_row = traj_row, a.lp_row = lp_row, a.wf_mean = wf_mean, a.wf_m2 = wf_m2;
+            a.dst_tiled = nullptr;
             YMC_HIP(ymc_launch_wide_fine_decide(a, s));
             YMC_HIP(ymc_launch_wide_fine_apply(a, s));
         }
+        if (due) ++rows;
+    }
+    YMC_HIP(hipEventRecord(ev.second, s));
+    r->timed.push_back(ev);
+    return YMC_OK;
+}
+
+/* The nest of levels (YMC_METHOD_MLDA_NESTED) beyond 256 parameters: the walk of ymc_nested.hip / the checker's
+ * ymo_nest_run as host recursion over the wide path's kernels.  Level l < E - 1 keeps the state of its run in
+ * wide_lvl_x[l] (plain and matrix-core layout) and P / Q of that state in wide_lvl_lp; every decision takes the next
+ * transition index in execution order. */
+int launch_advance_wide_nested(ymc_run *r, uint64_t nsteps)
+{
+    const ymc_problem *p = r->problem;
+    hipStream_t s = r->ctx->stream;
+    const uint64_t K = r->K, d = (uint64_t)p->D;
+    const int E = p->E;
+    WideArgs a{};
+    a.K = K;
+    a.d = p->D;
+    a.sigma = p->wide_consts.as<double>();
+    a.pmean = a.sigma + d;
+    a.xi = r->wide_xi.as<double>();
+    a.u = r->wide_u.as<double>();
+    a.y = r->wide_y.as<double>();
+    a.y_tiled = r->wide_yt.as<double>();
+    a.KS = p->tgt.KS;
+    a.lpy = r->wide_lpy.as<double>();
+    a.status = r->status.as<uint32_t>();
+    a.accflag = r->wide_flag.as<uint8_t>();
+    const uint64_t tiled = ((K + 15) / 16) * (uint64_t)p->tgt.KS * 64;
+    auto X = [&](int l) { return r->wide_lvl_x.as<double>() + (uint64_t)l * (K * d + tiled); };
+    auto Xt = [&](int l) { return X(l) + K * d; };
+    auto lpP = [&](int l) { return r->wide_lvl_lp.as<double>() + (uint64_t)(2 * l) * K; };
+    auto lpQ = [&](int l) { return r->wide_lvl_lp.as<double>() + (uint64_t)(2 * l + 1) * K; };
+    double *tmpQ = r->wide_lpcz.as<double>();
+    auto eval = [&](const DensityHost &h, const double *pts, double *out) -> int {
+        YMC_HIP(ymc_launch_wide_eval(h.tile_blob.as<double>(), h.KS, h.MT, h.lik_const, h.d.likelihood_only, pts, K, out, s));
+        return YMC_OK;
+    };
+    auto Pof = [&](int l) -> const DensityHost & { return l == E - 1 ? p->tgt : p->lvlP[l]; };
+    uint64_t t = 0;
+    /* _accept_reject of level l >= 1 (mlda.py:35-43; the top's: :146-154): the proposal Y against the level's state */
+    auto decide = [&](int l, double *x, double *xt, const double *Y, const double *Yt, double *P, double *Q, uint64_t *count) -> int {
+        YMC_HIP(ymc_launch_rng_fill(r->seed, r->chain0, K, t, 1, p->D, nullptr, r->wide_u.as<double>(), s));
+        YMC_TRY(eval(Pof(l), Yt, r->wide_lpy.as<double>()));
+        YMC_TRY(eval(p->lvlQ[l], Yt, tmpQ));
+        a.x = x, a.z = Y, a.lpfz = r->wide_lpy.as<double>(), a.lpcz = tmpQ, a.lp = P, a.lpc = Q, a.acc_count = count;
+        a.dst_tiled = xt;
+        YMC_HIP(ymc_launch_wide_fine_decide(a, s));
+        YMC_HIP(ymc_launch_wide_fine_apply(a, s));
+        ++t;
+        return YMC_OK;
+    };
+    /* MetropolisHastings.run of level l from the state in X(l) */
+    std::function<int(int)> run_level = [&](int l) -> int {
+        a.acc_row = nullptr, a.traj_row = nullptr, a.lp_row = nullptr, a.wf_mean = nullptr, a.wf_m2 = nullptr;
+        if (l == 0) {
+            YMC_TRY(eval(p->lvlP[0], Xt(0), lpP(0)));
+            for (int st = 0; st < p->lvl_steps[0]; ++st) {
+                a.from = X(0), a.cur_lp = lpP(0), a.dst = X(0), a.dst_tiled = Xt(0), a.count = r->level_acc.as<uint64_t>();
+                YMC_HIP(ymc_launch_rng_fill(r->seed, r->chain0, K, t, 1, p->D, r->wide_xi.as<double>(), r->wide_u.as<double>(), s));
+                YMC_HIP(ymc_launch_wide_propose(a, s));
+                YMC_TRY(eval(p->lvlP[0], a.y_tiled, r->wide_lpy.as<double>()));
+                YMC_HIP(ymc_launch_wide_decide(a, s));
+                YMC_HIP(ymc_launch_wide_apply(a, s));
+                ++t;
+            }
+            return YMC_OK;
+        }
+        YMC_TRY(eval(p->lvlP[l], Xt(l), lpP(l)));
+        YMC_TRY(eval(p->lvlQ[l], Xt(l), lpQ(l)));
+        for (int st = 0; st < p->lvl_steps[l]; ++st) {
+            YMC_HIP(ymc_launch_wide_copy(a, X(l), X(l - 1), Xt(l - 1), s));
+            YMC_TRY(run_level(l - 1));
+            a.acc_row = nullptr, a.traj_row = nullptr, a.lp_row = nullptr, a.wf_mean = nullptr, a.wf_m2 = nullptr;
+            YMC_TRY(decide(l, X(l), Xt(l), X(l - 1), Xt(l - 1), lpP(l), lpQ(l), r->level_acc.as<uint64_t>() + (uint64_t)l * K));
+        }
+        return YMC_OK;
+    };
+
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (!r->pool.empty()) {
+        ev = r->pool.back();
+        r->pool.pop_back();
+    } else {
+        YMC_HIP(hipEventCreate(&ev.first));
+        YMC_HIP(hipEventCreate(&ev.second));
+    }
+    YMC_HIP(hipEventRecord(ev.first, s));
+    uint64_t rows = 0;
+    for (uint64_t n = 0; n < nsteps; ++n) {
+        const uint64_t step = r->steps_done + n;
+        const bool due = (step + 1) % r->stride == 0;
+        const uint64_t row = r->recorded + rows;
+        t = step * p->lvl_cost[E - 1];
+        YMC_HIP(ymc_launch_wide_copy(a, r->x.as<double>(), X(E - 2), Xt(E - 2), s));
+        YMC_TRY(run_level(E - 2));                                                   /* mlda.py:100-116 */
+        a.acc_row = (r->flags & YMC_RECORD_ACCEPT) ? r->acc.as<uint8_t>() + row * K : nullptr;
+        a.traj_row = (due && (r->flags & YMC_RECORD_TRAJECTORY)) ? r->traj.as<double>() + row * K * d : nullptr;
+        a.lp_row = (due && (r->flags & YMC_RECORD_LOGPOST)) ? r->lp_out.as<double>() + row * K : nullptr;
+        a.wf_mean = nullptr, a.wf_m2 = nullptr;
+        if (r->flags & YMC_RECORD_MOMENTS) {
+            a.wf_mean = r->wf_mean.as<double>();
+            a.wf_m2 = r->wf_m2.as<double>();
+            a.wf_dn = (double)(step + 1);
+            a.wf_rdn = 1.0 / a.wf_dn;
+        }
+        YMC_TRY(decide(E - 1, r->x.as<double>(), nullptr, X(E - 2), Xt(E - 2), r->lp.as<double>(), r->lpc.as<double>(),
+                       r->acc_count.as<uint64_t>()));                                /* mlda.py:146-154 */
         if (due) ++rows;
     }
     YMC_HIP(hipEventRecord(ev.second, s));
@@ -1147,7 +1260,7 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
     /* beyond 256 parameters the random walk with a diagonal proposal and pCN run as a sequence of plain kernels per
      * transition (launch_advance_wide) */
     const bool may_wide = (desc->method == YMC_METHOD_MRW && !desc->proposal_chol) || desc->method == YMC_METHOD_PCN ||
-                          desc->method == YMC_METHOD_MLDA2;
+                          desc->method == YMC_METHOD_MLDA2 || desc->method == YMC_METHOD_MLDA_NESTED;
     int rc = lower_density(ctx, desc->target, p->tgt, 0, joint_tile, may_stream, may_wide);
     if (rc == YMC_OK) {
         p->wide = p->tgt.wide;
@@ -1214,8 +1327,8 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
             if (rc == YMC_OK && (P.kind != desc->target.kind || Q.kind != desc->target.kind))
                 rc = fail(YMC_ERR_UNSUPPORTED, "surrogate density kinds %d / %d differ from target kind %d", P.kind,
                           Q.kind, desc->target.kind);
-            if (rc == YMC_OK) rc = lower_density(ctx, P, p->lvlP[e], p->D, joint_tile, may_stream);
-            if (rc == YMC_OK) rc = lower_density(ctx, Q, p->lvlQ[e + 1], p->D, joint_tile, may_stream);
+            if (rc == YMC_OK) rc = lower_density(ctx, P, p->lvlP[e], p->D, joint_tile, may_stream, may_wide);
+            if (rc == YMC_OK) rc = lower_density(ctx, Q, p->lvlQ[e + 1], p->D, joint_tile, may_stream, may_wide);
             if (rc == YMC_OK && (p->lvlP[e].tile != p->tgt.tile || p->lvlQ[e + 1].tile != p->tgt.tile))
                 rc = fail(YMC_ERR_UNSUPPORTED, "the levels do not fit one kernel (mixed forward-map sizes)");
             p->lvl_steps[e] = desc->level_steps[e];
@@ -1288,6 +1401,11 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
             YMC_HIP(hipMemcpy(p->wide_consts.p, c.data(), c.size() * sizeof(double), hipMemcpyHostToDevice));
             YMC_TRY(build_tile_blob(p, p->tgt)); /* the matrix-core layout of the model for linear_wide_eval_kernel */
             if (p->method == YMC_METHOD_MLDA2) YMC_TRY(build_tile_blob(p, p->sur));
+            if (p->method == YMC_METHOD_MLDA_NESTED)
+                for (int e = 0; e < p->E - 1; ++e) {
+                    YMC_TRY(build_tile_blob(p, p->lvlP[e]));
+                    YMC_TRY(build_tile_blob(p, p->lvlQ[e + 1]));
+                }
             return YMC_OK;
         };
         rc = up();
@@ -1319,7 +1437,7 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
         }
         p->tile = true;
     }
-    if (rc == YMC_OK && p->method == YMC_METHOD_MLDA_NESTED && !p->tile) {
+    if (rc == YMC_OK && p->method == YMC_METHOD_MLDA_NESTED && !p->tile && !p->wide) {
         auto up = [&]() -> int {
             YMC_DISPATCH_D(p->D, return upload_levels<DD>(p));
             return YMC_OK;
@@ -1430,6 +1548,13 @@ int ymc_run_create(ymc_ctx *ctx, const ymc_problem *problem, const ymc_run_desc 
             YMC_TRY(r->wide_y.alloc(K * D * sizeof(double)));
             YMC_TRY(r->wide_yt.alloc(((K + 15) / 16) * (uint64_t)problem->tgt.KS * 64 * sizeof(double)));
             YMC_HIP(hipMemsetAsync(r->wide_yt.p, 0, r->wide_yt.bytes, ctx->stream)); /* the padding stays zero */
+            if (problem->method == YMC_METHOD_MLDA_NESTED) {
+                const uint64_t per = K * D * sizeof(double) + r->wide_yt.bytes;
+                YMC_TRY(r->wide_lvl_x.alloc((uint64_t)(problem->E - 1) * per));
+                YMC_HIP(hipMemsetAsync(r->wide_lvl_x.p, 0, r->wide_lvl_x.bytes, ctx->stream)); /* tiled padding zero */
+                YMC_TRY(r->wide_lvl_lp.alloc((uint64_t)(problem->E - 1) * 2 * K * sizeof(double)));
+                YMC_TRY(r->wide_lpcz.alloc(K * sizeof(double)));
+            }
             if (problem->method == YMC_METHOD_MLDA2) {
                 YMC_TRY(r->wide_z.alloc(K * D * sizeof(double)));
                 YMC_TRY(r->wide_zt.alloc(r->wide_yt.bytes));
@@ -1533,6 +1658,8 @@ int ymc_run_advance(ymc_run *run, uint64_t nsteps)
         const uint64_t chunk = nsteps < chunk_max ? nsteps : chunk_max;
         if (run->problem->tile) {
             YMC_TRY(launch_advance_tile(run, chunk));
+        } else if (run->problem->wide && run->problem->method == YMC_METHOD_MLDA_NESTED) {
+            YMC_TRY(launch_advance_wide_nested(run, chunk));
         } else if (run->problem->wide) {
             YMC_TRY(launch_advance_wide(run, chunk));
         } else if (run->problem->method == YMC_METHOD_MLDA_NESTED) {

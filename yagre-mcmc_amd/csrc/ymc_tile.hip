@@ -749,6 +749,10 @@ __global__ __launch_bounds__(256) void wide_fine_apply_kernel(const WideArgs a)
     }
     x = a.accflag[k] ? a.z[i] : x;
     a.x[i] = x;
+    if (a.dst_tiled) {
+        const int j = (int)(i % (uint64_t)a.d);
+        a.dst_tiled[((k / 16) * (uint64_t)a.KS + (uint64_t)(j / 4)) * 64 + (uint64_t)(j % 4) * 16 + k % 16] = x;
+    }
     if (a.traj_row) a.traj_row[i] = x;
 }
 
