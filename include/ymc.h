@@ -79,8 +79,8 @@ typedef struct ymc_density_desc {
      * (gaussian.py:19-24): the INVERSE of its lower Cholesky factor, [data_dim][data_dim] / [d][d] row-major
      * (entries above the diagonal are ignored), so that |r|^2 in the covariance's norm is |L^-1 r|^2.  NULL = the
      * diagonal covariance of noise_precision / prior_precision.  At lane-kernel sizes (d, data_dim <= 8) the
-     * kernels form the norm per evaluation; beyond (POSTERIOR_LINEAR on the matrix cores: any d for YMC_METHOD_MRW with a
-     * diagonal proposal, YMC_METHOD_PCN, YMC_METHOD_MLDA2 and YMC_METHOD_MLDA_NESTED -- a sequence of plain kernels per transition
+     * kernels form the norm per evaluation; beyond (POSTERIOR_LINEAR on the matrix cores: any d for YMC_METHOD_MRW,
+     * YMC_METHOD_PCN, YMC_METHOD_MLDA2 and YMC_METHOD_MLDA_NESTED -- a sequence of plain kernels per transition
      * beyond 256 --; d <= 256 and any number of
      * outputs for YMC_METHOD_MRW, YMC_METHOD_PCN, YMC_METHOD_MLDA2 and YMC_METHOD_MLDA_NESTED, whose
      * forward matrices stream from L2 when they do not fit the LDS; d <= 128 and an LDS-resident coarse matrix for AEM2) a dense NOISE
@@ -158,7 +158,7 @@ typedef struct ymc_problem_desc {
     /* MRW with a DenseCovarianceMatrix proposal (covariance.py:69-94): its lower Cholesky factor
      * [d][d], row-major; NULL = the diagonal covariance of proposal_sigma.  Row i of L xi is summed left to
      * right with separate multiplies and adds by the lane kernels (d <= 8 and at most 8 forward outputs) and as
-     * one k-ordered fma chain on the matrix cores beyond (linear posteriors up to d = 256). */
+     * one k-ordered fma chain on the matrix cores beyond (linear posteriors of any d). */
     const double *proposal_chol;
 } ymc_problem_desc;
 

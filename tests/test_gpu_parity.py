@@ -1197,10 +1197,11 @@ def test_f17_dense_proposal_d16_matrix_cores(ffi, ctx, golden):
 
 
 @pytest.mark.parametrize("d,m,nd,K", [(128, 128, 2, 40), (9, 3, 2, 33), (20, 40, 1, 64), (100, 20, 4, 129),
-                                      (128, 400, 2, 36), (192, 60, 2, 33), (256, 16, 1, 20), (40, 1000, 1, 17)])
+                                      (128, 400, 2, 36), (192, 60, 2, 33), (256, 16, 1, 20), (40, 1000, 1, 17),
+                                      (300, 24, 2, 33), (513, 100, 1, 17)])
 def test_tile_kernel_dense_proposal_other_shapes(ffi, ctx, d, m, nd, K):
-    """(the last four: a forward matrix beyond the LDS / d beyond 128 -- the proposal's factor and the forward matrix both
-    through the shared double buffer, one after the other)"""
+    """(shapes five to eight: a forward matrix beyond the LDS / d beyond 128 -- the proposal's factor and the forward matrix
+    both through the shared double buffer, one after the other; the last two: beyond 256 parameters, the wide path)"""
     rng = np.random.default_rng(600 + d + m)
     g = dict(A=rng.normal(size=(m, d)) / np.sqrt(d), b=rng.normal(size=m), data=rng.normal(size=(nd, m)),
              noise_precision=rng.uniform(0.5, 3, size=m), prior_mean=rng.normal(size=d) * 0.1,

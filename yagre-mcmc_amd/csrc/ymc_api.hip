@@ -853,6 +853,12 @@ int launch_advance_wide(ymc_run *r, uint64_t nsteps)
             a.from = a.x, a.cur_lp = a.lp, a.dst = a.x, a.dst_tiled = nullptr, a.count = a.acc_count;
             a.acc_row = acc_row, a.traj_row = traj_row, a.lp_row = lp_row, a.wf_mean = wf_mean, a.wf_m2 = wf_m2;
             YMC_HIP(ymc_launch_rng_fill(r->seed, r->chain0, K, step, 1, p->D, r->wide_xi.as<double>(), r->wide_u.as<double>(), s));
+            if (p->chol_frag.p) {
+                /* dense proposal covariance (covariance.py:91-92): xi <- L xi on the matrix cores, then y = x + 1 * (L xi) */
+                YMC_HIP(ymc_launch_wide_copy(a, r->wide_xi.as<double>(), r->wide_y.as<double>(), r->wide_yt.as<double>(), s));
+                YMC_HIP(ymc_launch_wide_rows(p->chol_frag.as<double>(), p->tgt.KS, p->MT_L, p->D, r->wide_yt.as<double>(), K,
+                                             r->wide_xi.as<double>(), s));
+            }
             YMC_HIP(ymc_launch_wide_propose(a, s));
             YMC_TRY(eval(p->tgt, a.y_tiled, r->wide_lpy.as<double>()));
             YMC_HIP(ymc_launch_wide_decide(a, s));
@@ -1259,7 +1265,7 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
                             desc->method == YMC_METHOD_MLDA_NESTED;
     /* beyond 256 parameters the random walk with a diagonal proposal and pCN run as a sequence of plain kernels per
      * transition (launch_advance_wide) */
-    const bool may_wide = (desc->method == YMC_METHOD_MRW && !desc->proposal_chol) || desc->method == YMC_METHOD_PCN ||
+    const bool may_wide = desc->method == YMC_METHOD_MRW || desc->method == YMC_METHOD_PCN ||
                           desc->method == YMC_METHOD_MLDA2 || desc->method == YMC_METHOD_MLDA_NESTED;
     int rc = lower_density(ctx, desc->target, p->tgt, 0, joint_tile, may_stream, may_wide);
     if (rc == YMC_OK) {
@@ -1359,7 +1365,7 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
             auto up = [&]() -> int {
                 YMC_TRY(p->chol.alloc(L.size() * sizeof(double)));
                 YMC_HIP(hipMemcpy(p->chol.p, L.data(), p->chol.bytes, hipMemcpyHostToDevice));
-                if (p->tgt.tile) { /* fragments for the matrix cores: rows = components, padded to whole tile pairs */
+                if (p->tgt.tile || p->wide) { /* fragments for the matrix cores: rows = components, padded to whole tile pairs */
                     const int KS = p->tgt.KS, d = p->D;
                     p->MT_L = (d + 15) / 16;
                     p->MT_L += p->MT_L & 1;
@@ -1395,6 +1401,7 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
     if (rc == YMC_OK && p->wide) {
         auto up = [&]() -> int {
             std::vector<double> c(p->sigma);
+            if (p->chol.p) std::fill(c.begin(), c.end(), 1.0); /* dense proposal: the increment is L xi itself */
             c.insert(c.end(), p->tgt.prior_mean.begin(), p->tgt.prior_mean.end());
             c.resize(2 * (size_t)p->D, 0.0);
             YMC_TRY(p->wide_consts.alloc(c.size() * sizeof(double)));

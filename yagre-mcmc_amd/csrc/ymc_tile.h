@@ -89,7 +89,7 @@ struct WideArgs {
     int32_t d, pcn;
     double pcn_c1, pcn_c2;
     const double *sigma, *pmean;   /* [d] */
-    const double *xi, *u;          /* the transition's draws: [K][d], [K] */
+    const double *xi, *u;          /* the transition's draws: [K][d], [K] (dense proposal: xi holds L xi, sigma ones) */
     double *x, *y;                 /* [K][d]: the recorded chain's state, the proposal */
     /* what one decision works on (random walk: from = dst = x, cur_lp = lp, count = acc_count; a sub-step of the two-level
      * sampler: from = dst = z, cur_lp = the coarse log-density of z, no count) */
@@ -118,6 +118,10 @@ hipError_t ymc_launch_wide_propose(const WideArgs &a, hipStream_t s);
  * output tiles, everything read from global memory */
 hipError_t ymc_launch_wide_eval(const double *blob, int KS, int MT, double lik_const, int likelihood_only, const double *y_tiled,
                                 uint64_t K, double *lp_out, hipStream_t s);
+/* out[K][d] = L in_tiled: the rows of a d x d factor (MFMA fragments [MT_L][KS][64]) times the 16 points of a tile, row i one
+ * k-ordered fma chain (the dense proposal's L xi, as linear_tile_kernel) */
+hipError_t ymc_launch_wide_rows(const double *frag, int KS, int MT_L, int d, const double *in_tiled, uint64_t K, double *out,
+                                hipStream_t s);
 hipError_t ymc_launch_wide_decide(const WideArgs &a, hipStream_t s);
 hipError_t ymc_launch_wide_apply(const WideArgs &a, hipStream_t s);
 hipError_t ymc_launch_wide_copy(const WideArgs &a, const double *src, double *dst, double *dst_tiled, hipStream_t s);

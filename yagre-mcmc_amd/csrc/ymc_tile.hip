@@ -655,6 +655,42 @@ __global__ __launch_bounds__(512) void linear_wide_eval_kernel(const double *__r
     if (g == 0 && two && kb < K) lp_out[kb] = lpb;
 }
 
+/* out[k][i] = sum_j L[i][j] in[k][j], the 16 points of a tile per wave (ymc_launch_wide_rows) */
+__global__ __launch_bounds__(512) void linear_wide_rows_kernel(const double *__restrict__ frag, int KS, int MT_L, int d,
+                                                               const double *__restrict__ in_tiled, uint64_t K,
+                                                               double *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const uint64_t nct = (K + 15) / 16, tile = (uint64_t)blockIdx.x * 8 + wave;
+    if (tile >= nct) return;
+    const double *v = in_tiled + (tile * (uint64_t)KS) * 64 + lane;
+    const uint64_t k = tile * 16 + c;
+#pragma unroll 1
+    for (int mt = 0; mt < MT_L; mt += 2) {
+        d4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
+        const double *L0 = frag + (size_t)mt * KS * 64 + lane, *L1 = L0 + (size_t)KS * 64;
+#pragma unroll 1
+        for (int s0 = 0; s0 < KS; s0 += 4) {
+            double vv[4], f0[4], f1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vv[q] = v[(s0 + q) * 64], f0[q] = L0[(s0 + q) * 64], f1[q] = L1[(s0 + q) * 64];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0[q], vv[q], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1[q], vv[q], a1, 0, 0, 0);
+            }
+        }
+        if (k < K) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i0 = 16 * mt + 4 * r + g, i1 = i0 + 16;
+                if (i0 < d) out[k * (uint64_t)d + i0] = a0[r];
+                if (i1 < d) out[k * (uint64_t)d + i1] = a1[r];
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void wide_decide_kernel(const WideArgs a)
 {
     ymc_stage_tables();
@@ -791,6 +827,14 @@ hipError_t ymc_launch_wide_eval(const double *blob, int KS, int MT, double lik_c
     const uint64_t nct = (K + 15) / 16;
     hipLaunchKernelGGL(linear_wide_eval_kernel, dim3((unsigned)((nct + 15) / 16)), dim3(512), 0, s, blob, KS, MT, lik_const,
                        likelihood_only, y_tiled, K, lp_out);
+    return hipGetLastError();
+}
+
+hipError_t ymc_launch_wide_rows(const double *frag, int KS, int MT_L, int d, const double *in_tiled, uint64_t K, double *out,
+                                hipStream_t s)
+{
+    const uint64_t nct = (K + 15) / 16;
+    hipLaunchKernelGGL(linear_wide_rows_kernel, dim3((unsigned)((nct + 7) / 8)), dim3(512), 0, s, frag, KS, MT_L, d, in_tiled, K, out);
     return hipGetLastError();
 }
 
