@@ -588,3 +588,82 @@ def test_random_round3_features_match_oracle(case, monkeypatch):
         out = o.Ensemble(p, np.ones(d), x0, seed, chain0=chain0, chol=L).advance(n)
         assert np.array_equal(run.accept(), out["acc"]) and np.array_equal(run.trajectory(), out["traj"])
         assert np.array_equal(run.logpost(), out["logpost"])
+
+
+@pytest.mark.parametrize("case", range(30))
+def test_random_wide_path_matches_oracle(case, monkeypatch):
+    """The wide path (more than 256 parameters), fuzzed against the oracle: random walk with a diagonal or dense proposal, pCN,
+    two-level and nested delayed acceptance; ragged ensembles, chain offsets, thinned records, launches cut at random."""
+    from yagremcmc_amd import _ffi as ffi, lowering
+    ctx = ffi.default_context(0)
+    rng = np.random.default_rng(13000 + case + _SEED_SHIFT)
+    method = ["mrw", "pcn", "mlda2", "nested", "dense"][case % 5]
+    d = int(rng.integers(257, 700))
+    K = int(rng.choice([1, 15, 16, 33, 70]))
+    seed, chain0 = int(rng.integers(0, 2**62)), int(rng.choice([0, 9, 2**31 + 7]))
+    n = int(rng.integers(2, 12))
+    cut = int(rng.integers(0, n + 1))
+    real = lowering.lower_density
+    monkeypatch.setattr(lowering, "lower_density", lambda dd, rk4_steps=None: dd.low if isinstance(dd, _Pre) else real(dd, rk4_steps))
+    x0 = rng.normal(size=(K, d)) * 0.3
+    sigma = rng.uniform(0.01, 0.03, size=d)
+    if method in ("mrw", "pcn", "dense"):
+        low, p = _linear_pair(ffi, d, int(rng.integers(1, 300)), int(rng.integers(1, 4)), rng, dense_prior=(method == "mrw" and case % 2 == 1))
+        stride = int(rng.choice([1, 1, 3]))
+        flags = ffi.RECORD_TRAJECTORY | ffi.RECORD_LOGPOST | ffi.RECORD_MOMENTS | (ffi.RECORD_ACCEPT if stride == 1 else 0)
+        if method == "pcn":
+            low.set_array("prior_mean", np.zeros(d))
+            low.desc.likelihood_only = 1
+            p = dict(p, prior_mean=np.zeros(d), likelihood_only=1)
+            sigma = 1.0 / np.sqrt(p["prior_precision"])
+            h = float(rng.uniform(0.005, 0.05))
+            prob = lowering.make_problem(ctx, ffi.METHOD_PCN, low, sigma, pcn_step_size=h)
+            e = o.Ensemble(p, sigma, x0, seed, chain0=chain0, pcn_step_size=h)
+        elif method == "dense":
+            B = rng.normal(size=(d, d)) * 0.02 / np.sqrt(d)
+            L = np.linalg.cholesky(B @ B.T + 0.0005 * np.eye(d))
+            prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, np.ones(d), chol=np.tril(L))
+            e = o.Ensemble(p, np.ones(d), x0, seed, chain0=chain0, chol=L)
+        else:
+            prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, sigma)
+            e = o.Ensemble(p, sigma, x0, seed, chain0=chain0)
+        run = ffi.Run(prob, seed, K, x0, n, flags, chain0, record_stride=stride)
+        run.advance(cut)
+        run.advance(n - cut)
+        out = e.advance(n)
+        rows = slice(stride - 1, None, stride)
+        assert np.array_equal(run.trajectory(), out["traj"][rows]) and np.array_equal(run.logpost(), out["logpost"][rows])
+        if stride == 1:
+            assert np.array_equal(run.accept(), out["acc"])
+        s_ = run.summary()
+        assert np.array_equal(s_["wf_mean"], e.wf_mean) and np.array_equal(s_["wf_m2"], e.wf_m2)
+        assert np.array_equal(s_["accepted"], e.acc_count)
+    elif method == "mlda2":
+        (lf, pf), (lc, pc) = _linear_pair(ffi, d, int(rng.integers(1, 200)), 2, rng), _linear_pair(ffi, d, int(rng.integers(1, 100)), 2, rng, scale=0.95)
+        S = int(rng.integers(1, 4))
+        prob = lowering.make_problem(ctx, ffi.METHOD_MLDA2, lf, sigma, surrogate=lc, sub_chain_length=S)
+        run = ffi.Run(prob, seed, K, x0, n, ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT | ffi.RECORD_SUB_ACCEPT | ffi.RECORD_LOGPOST, chain0)
+        run.advance(cut)
+        run.advance(n - cut)
+        e = o.Ensemble(pf, sigma, x0, seed, chain0=chain0, surrogate=pc, sub_chain_length=S)
+        out = e.advance(n, want_sub=True)
+        assert np.array_equal(run.accept(), out["acc"]) and np.array_equal(run.sub_accept(), out["sub_acc"])
+        assert np.array_equal(run.trajectory(), out["traj"]) and np.array_equal(run.logpost(), out["logpost"])
+    else:
+        E = int(rng.integers(2, 5))
+        models = [_linear_pair(ffi, d, int(rng.integers(1, 60)), 2, rng, scale=1.0 - 0.02 * i) for i in range(2 * (E - 1) + 1)]
+        (lt, pt), surs = models[-1], models[:-1]
+        subs = [int(v) for v in rng.integers(1, 3, size=len(surs))]
+        prob = lowering.make_nested_problem(ctx, _Pre(lt), [_Pre(l) for l, _ in surs], subs, sigma)
+        run = ffi.Run(prob, seed, K, x0, n, ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT | ffi.RECORD_LOGPOST | ffi.RECORD_MOMENTS, chain0)
+        run.advance(cut)
+        run.advance(n - cut)
+        P, Q, steps = o.nested_levels([q for _, q in surs], subs, pt)
+        e = o.NestedEnsemble(P, Q, steps, sigma, x0, seed, chain0=chain0)
+        out = e.advance(n)
+        assert np.array_equal(run.accept(), out["acc"]) and np.array_equal(run.trajectory(), out["traj"])
+        assert np.array_equal(run.logpost(), out["logpost"])
+        acc, _ = run.level_accept()
+        assert np.array_equal(acc, e.level_acc)
+    x, lp = run.state()
+    assert np.array_equal(x, e.x) and np.array_equal(lp, e.lp)
