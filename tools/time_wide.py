@@ -48,11 +48,21 @@ for d, m in ((128, 128), (128, 512), (192, 192), (256, 256)):
     timed(f"random walk d={d} m={m}", lowering.make_problem(ctx, ffi.METHOD_MRW, low(d, m), np.full(d, 0.03)), d, 20, 2.0 * m * d)
 for d, m in ((320, 64), (512, 512), (1024, 256)):   # beyond 256: the wide path (five plain launches per transition)
     timed(f"random walk d={d} m={m} (wide path)", lowering.make_problem(ctx, ffi.METHOD_MRW, low(d, m), np.full(d, 0.02)), d, 6, 2.0 * m * d)
+timed("two-level d=512 coarse 64 fine 512 S=5 (wide path)",
+      lowering.make_problem(ctx, ffi.METHOD_MLDA2, low(512, 512), np.full(512, 0.02), surrogate=low(512, 64), sub_chain_length=5), 512, 4,
+      2.0 * 512 * (5 * 64 + 512))
+timed("nested (2 surrogates, 4 base steps) d=512 outputs (64, 128, 512) (wide path)",
+      lowering.make_nested_problem(ctx, Pre(low(512, 512)), [Pre(low(512, 64)), Pre(low(512, 128))], [3, 4], np.full(512, 0.02)), 512, 4,
+      2.0 * 512 * (4 * 64 + 2 * (128 + 512)))
 for d, m in ((128, 128), (256, 256)):
     B = rng.normal(size=(d, d)) * 0.02 / np.sqrt(d)
     L = np.linalg.cholesky(B @ B.T + 0.001 * np.eye(d))
     timed(f"random walk, dense proposal d={d} m={m}", lowering.make_problem(ctx, ffi.METHOD_MRW, low(d, m), np.ones(d), chol=L), d, 20,
           2.0 * (m + d) * d)
+B = rng.normal(size=(512, 512)) * 0.02 / np.sqrt(512)
+timed("random walk, dense proposal d=512 m=128 (wide path)",
+      lowering.make_problem(ctx, ffi.METHOD_MRW, low(512, 128), np.ones(512), chol=np.linalg.cholesky(B @ B.T + 0.001 * np.eye(512))), 512, 6,
+      2.0 * (128 + 512) * 512)
 for d, mc, mf, S in ((128, 128, 128, 5), (128, 256, 256, 5), (256, 64, 256, 5), (256, 256, 256, 5)):
     timed(f"two-level d={d} coarse {mc} fine {mf} S={S}",
           lowering.make_problem(ctx, ffi.METHOD_MLDA2, low(d, mf), np.full(d, 0.03), surrogate=low(d, mc), sub_chain_length=S), d, 10,
