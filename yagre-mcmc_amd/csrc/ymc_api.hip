@@ -852,14 +852,15 @@ int launch_advance_wide(ymc_run *r, uint64_t nsteps)
         if (!two) { /* one transition of the random walk / pCN */
             a.from = a.x, a.cur_lp = a.lp, a.dst = a.x, a.dst_tiled = nullptr, a.count = a.acc_count;
             a.acc_row = acc_row, a.traj_row = traj_row, a.lp_row = lp_row, a.wf_mean = wf_mean, a.wf_m2 = wf_m2;
-            YMC_HIP(ymc_launch_rng_fill(r->seed, r->chain0, K, step, 1, p->D, r->wide_xi.as<double>(), r->wide_u.as<double>(), s));
             if (p->chol_frag.p) {
                 /* dense proposal covariance (covariance.py:91-92): xi <- L xi on the matrix cores, then y = x + 1 * (L xi) */
-                YMC_HIP(ymc_launch_wide_copy(a, r->wide_xi.as<double>(), r->wide_y.as<double>(), r->wide_yt.as<double>(), s));
+                YMC_HIP(ymc_launch_wide_draws(a, r->seed, r->chain0, step, r->wide_yt.as<double>(), s));
                 YMC_HIP(ymc_launch_wide_rows(p->chol_frag.as<double>(), p->tgt.KS, p->MT_L, p->D, r->wide_yt.as<double>(), K,
                                              r->wide_xi.as<double>(), s));
+                YMC_HIP(ymc_launch_wide_propose(a, s));
+            } else {
+                YMC_HIP(ymc_launch_wide_draw_propose(a, r->seed, r->chain0, step, s));
             }
-            YMC_HIP(ymc_launch_wide_propose(a, s));
             YMC_TRY(eval(p->tgt, a.y_tiled, r->wide_lpy.as<double>()));
             YMC_HIP(ymc_launch_wide_decide(a, s));
             YMC_HIP(ymc_launch_wide_apply(a, s));
@@ -874,9 +875,7 @@ int launch_advance_wide(ymc_run *r, uint64_t nsteps)
             a.traj_row = nullptr, a.lp_row = nullptr, a.wf_mean = nullptr, a.wf_m2 = nullptr;
             for (uint64_t sub = 0; sub < S; ++sub) {
                 a.acc_row = (r->flags & YMC_RECORD_SUB_ACCEPT) ? r->sub_acc.as<uint8_t>() + (row * S + sub) * K : nullptr;
-                YMC_HIP(ymc_launch_rng_fill(r->seed, r->chain0, K, tbase + sub, 1, p->D, r->wide_xi.as<double>(),
-                                            r->wide_u.as<double>(), s));
-                YMC_HIP(ymc_launch_wide_propose(a, s));
+                YMC_HIP(ymc_launch_wide_draw_propose(a, r->seed, r->chain0, tbase + sub, s));
                 YMC_TRY(eval(p->sur, a.y_tiled, r->wide_lpy.as<double>()));
                 YMC_HIP(ymc_launch_wide_decide(a, s));
                 YMC_HIP(ymc_launch_wide_apply(a, s));
@@ -950,8 +949,7 @@ int launch_advance_wide_nested(ymc_run *r, uint64_t nsteps)
             YMC_TRY(eval(p->lvlP[0], Xt(0), lpP(0)));
             for (int st = 0; st < p->lvl_steps[0]; ++st) {
                 a.from = X(0), a.cur_lp = lpP(0), a.dst = X(0), a.dst_tiled = Xt(0), a.count = r->level_acc.as<uint64_t>();
-                YMC_HIP(ymc_launch_rng_fill(r->seed, r->chain0, K, t, 1, p->D, r->wide_xi.as<double>(), r->wide_u.as<double>(), s));
-                YMC_HIP(ymc_launch_wide_propose(a, s));
+                YMC_HIP(ymc_launch_wide_draw_propose(a, r->seed, r->chain0, t, s));
                 YMC_TRY(eval(p->lvlP[0], a.y_tiled, r->wide_lpy.as<double>()));
                 YMC_HIP(ymc_launch_wide_decide(a, s));
                 YMC_HIP(ymc_launch_wide_apply(a, s));
@@ -1551,7 +1549,7 @@ int ymc_run_create(ymc_ctx *ctx, const ymc_problem *problem, const ymc_run_desc 
             YMC_TRY(r->x_tiled.alloc((uint64_t)(problem->E - 1) * tiled_row_doubles(r) * sizeof(double)));
         if (problem->tile && problem->chol_frag.p) YMC_TRY(r->w_tiled.alloc(tiled_row_doubles(r) * sizeof(double)));
         if (problem->wide) {
-            YMC_TRY(r->wide_xi.alloc(K * D * sizeof(double)));
+            if (problem->chol_frag.p) YMC_TRY(r->wide_xi.alloc(K * D * sizeof(double))); /* L xi of the dense proposal */
             YMC_TRY(r->wide_y.alloc(K * D * sizeof(double)));
             YMC_TRY(r->wide_yt.alloc(((K + 15) / 16) * (uint64_t)problem->tgt.KS * 64 * sizeof(double)));
             YMC_HIP(hipMemsetAsync(r->wide_yt.p, 0, r->wide_yt.bytes, ctx->stream)); /* the padding stays zero */

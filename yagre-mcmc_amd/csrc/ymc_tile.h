@@ -114,6 +114,10 @@ struct WideArgs {
     double wf_dn, wf_rdn;          /* the moments' sample count after this transition and RN(1 / count) */
 };
 hipError_t ymc_launch_wide_propose(const WideArgs &a, hipStream_t s);
+/* the normals of transition t in the matrix-core layout (xi_tiled) and the accept uniforms (a.u): the dense proposal's input */
+hipError_t ymc_launch_wide_draws(const WideArgs &a, uint64_t seed, uint64_t chain0, uint64_t t, double *xi_tiled, hipStream_t s);
+/* the draws of transition t AND the proposal in one launch (a thread per chain and pair of components; a.u is written) */
+hipError_t ymc_launch_wide_draw_propose(const WideArgs &a, uint64_t seed, uint64_t chain0, uint64_t t, hipStream_t s);
 /* log-densities of the K points of y_tiled on the matrix cores: `blob` as TileArgs::blob with KS k-steps (any number) and MT
  * output tiles, everything read from global memory */
 hipError_t ymc_launch_wide_eval(const double *blob, int KS, int MT, double lik_const, int likelihood_only, const double *y_tiled,

@@ -597,6 +597,59 @@ __global__ __launch_bounds__(256) void wide_propose_kernel(const WideArgs a)
     a.y_tiled[((k / 16) * (uint64_t)a.KS + (uint64_t)(j / 4)) * 64 + (uint64_t)(j % 4) * 16 + k % 16] = y;
 }
 
+/* rng_fill_kernel + wide_propose_kernel in one: thread (k, j) draws the normal pair j of chain k's transition t and writes
+ * components 2 j, 2 j + 1 of the proposal (plain and tiled); thread (k, 0) also draws the accept uniform */
+__global__ __launch_bounds__(256) void wide_draw_propose_kernel(const WideArgs a, uint64_t seed, uint64_t chain0, uint64_t t)
+{
+    ymc_stage_tables();
+    const uint64_t pairs = ((uint64_t)a.d + 1) / 2;
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.K * pairs) return;
+    const uint64_t k = i / pairs;
+    const int jp = (int)(i % pairs);
+    const uint32_t chain = (uint32_t)(chain0 + k);
+    double z[2];
+    ymc_draw_normal_pair(seed, chain, t, (uint32_t)jp, &z[0], &z[1]);
+    if (jp == 0) const_cast<double *>(a.u)[k] = ymc_draw_uniform(seed, chain, t);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int j = 2 * jp + e;
+        if (j < a.d) {
+            const uint64_t idx = k * (uint64_t)a.d + (uint64_t)j;
+            const double x = a.from[idx];
+            double y;
+            if (a.pcn) {
+                const double p0 = a.pmean[j] + a.sigma[j] * z[e];
+                y = a.pcn_c1 * x + a.pcn_c2 * p0;
+            } else {
+                y = x + a.sigma[j] * z[e];
+            }
+            a.y[idx] = y;
+            a.y_tiled[((k / 16) * (uint64_t)a.KS + (uint64_t)(j / 4)) * 64 + (uint64_t)(j % 4) * 16 + k % 16] = y;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wide_draws_kernel(const WideArgs a, uint64_t seed, uint64_t chain0, uint64_t t,
+                                                         double *__restrict__ xi_tiled)
+{
+    ymc_stage_tables();
+    const uint64_t pairs = ((uint64_t)a.d + 1) / 2;
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.K * pairs) return;
+    const uint64_t k = i / pairs;
+    const int jp = (int)(i % pairs);
+    const uint32_t chain = (uint32_t)(chain0 + k);
+    double z[2];
+    ymc_draw_normal_pair(seed, chain, t, (uint32_t)jp, &z[0], &z[1]);
+    if (jp == 0) const_cast<double *>(a.u)[k] = ymc_draw_uniform(seed, chain, t);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int j = 2 * jp + e;
+        if (j < a.d) xi_tiled[((k / 16) * (uint64_t)a.KS + (uint64_t)(j / 4)) * 64 + (uint64_t)(j % 4) * 16 + k % 16] = z[e];
+    }
+}
+
 /* The linear posterior of 16 points per wave at ANY parameter dimension: the matrix-core kernels' evaluation (lane (g, c)
  * owns components 4 s + g of point c; k ascending per accumulator; the residual sums and the prior in the canonical four
  * partial sums) with the point read from its tiled array instead of registers and the matrix's fragments from global
@@ -798,6 +851,20 @@ hipError_t ymc_launch_wide_propose(const WideArgs &a, hipStream_t s)
 {
     const uint64_t n = a.K * (uint64_t)a.d;
     hipLaunchKernelGGL(wide_propose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t ymc_launch_wide_draw_propose(const WideArgs &a, uint64_t seed, uint64_t chain0, uint64_t t, hipStream_t s)
+{
+    const uint64_t n = a.K * (((uint64_t)a.d + 1) / 2);
+    hipLaunchKernelGGL(wide_draw_propose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, seed, chain0, t);
+    return hipGetLastError();
+}
+
+hipError_t ymc_launch_wide_draws(const WideArgs &a, uint64_t seed, uint64_t chain0, uint64_t t, double *xi_tiled, hipStream_t s)
+{
+    const uint64_t n = a.K * (((uint64_t)a.d + 1) / 2);
+    hipLaunchKernelGGL(wide_draws_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, seed, chain0, t, xi_tiled);
     return hipGetLastError();
 }
 
