@@ -188,6 +188,7 @@ struct ymc_run {
     DeviceBuf err_mean_alt, err_m2_alt; /* AEM2 on the matrix cores: the kernel's second copy of mean / M2 (scratch) */
     DeviceBuf wide_xi, wide_u, wide_y, wide_yt, wide_lpy, wide_flag; /* the wide path's per-transition scratch */
     DeviceBuf wide_z, wide_zt, wide_lpcz;                            /* ... and the two-level sampler's sub-chain state */
+    DeviceBuf wide_differs;                                          /* [K] proposal-differs-from-state flags */
     DeviceBuf wide_lvl_x, wide_lvl_lp; /* the nest on the wide path: states (plain | tiled) and P | Q of levels 0 .. E-2 */
     /* egress (ymc_run_egress_*): a copy stream, two slots of page-locked staging */
     struct EgressSlot {
@@ -820,6 +821,7 @@ int launch_advance_wide(ymc_run *r, uint64_t nsteps)
     a.acc_count = r->acc_count.as<uint64_t>();
     a.status = r->status.as<uint32_t>();
     a.accflag = r->wide_flag.as<uint8_t>();
+    a.differs = r->wide_differs.as<uint32_t>();
     auto eval = [&](const DensityHost &h, const double *tiled, double *out) -> int {
         YMC_HIP(ymc_launch_wide_eval(h.tile_blob.as<double>(), h.KS, h.MT, h.lik_const, h.d.likelihood_only, tiled, K, out, s));
         return YMC_OK;
@@ -885,6 +887,7 @@ int launch_advance_wide(ymc_run *r, uint64_t nsteps)
             a.z = z, a.lpfz = r->wide_lpy.as<double>(), a.lpc = r->lpc.as<double>(), a.lpcz = lpcz;
             a.acc_row = acc_row, a.traj_row = traj_row, a.lp_row = lp_row, a.wf_mean = wf_mean, a.wf_m2 = wf_m2;
             a.dst_tiled = nullptr;
+            YMC_HIP(ymc_launch_wide_differs(a, z, a.x, s));
             YMC_HIP(ymc_launch_wide_fine_decide(a, s));
             YMC_HIP(ymc_launch_wide_fine_apply(a, s));
         }
@@ -918,6 +921,7 @@ int launch_advance_wide_nested(ymc_run *r, uint64_t nsteps)
     a.lpy = r->wide_lpy.as<double>();
     a.status = r->status.as<uint32_t>();
     a.accflag = r->wide_flag.as<uint8_t>();
+    a.differs = r->wide_differs.as<uint32_t>();
     const uint64_t tiled = ((K + 15) / 16) * (uint64_t)p->tgt.KS * 64;
     auto X = [&](int l) { return r->wide_lvl_x.as<double>() + (uint64_t)l * (K * d + tiled); };
     auto Xt = [&](int l) { return X(l) + K * d; };
@@ -937,6 +941,7 @@ int launch_advance_wide_nested(ymc_run *r, uint64_t nsteps)
         YMC_TRY(eval(p->lvlQ[l], Yt, tmpQ));
         a.x = x, a.z = Y, a.lpfz = r->wide_lpy.as<double>(), a.lpcz = tmpQ, a.lp = P, a.lpc = Q, a.acc_count = count;
         a.dst_tiled = xt;
+        YMC_HIP(ymc_launch_wide_differs(a, Y, x, s));
         YMC_HIP(ymc_launch_wide_fine_decide(a, s));
         YMC_HIP(ymc_launch_wide_fine_apply(a, s));
         ++t;
@@ -1569,6 +1574,8 @@ int ymc_run_create(ymc_ctx *ctx, const ymc_problem *problem, const ymc_run_desc 
             YMC_TRY(r->wide_u.alloc(K * sizeof(double)));
             YMC_TRY(r->wide_lpy.alloc(K * sizeof(double)));
             YMC_TRY(r->wide_flag.alloc(K));
+            YMC_TRY(r->wide_differs.alloc(K * sizeof(uint32_t)));
+            YMC_HIP(hipMemsetAsync(r->wide_differs.p, 0, r->wide_differs.bytes, ctx->stream));
         }
         if (problem->method == YMC_METHOD_AEM2 && problem->tile) {
             /* per-output arrays in the kernel's tiled layout [ceil(K/16)][4 MT][64]; ids of the cached points */

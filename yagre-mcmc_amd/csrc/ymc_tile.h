@@ -108,6 +108,8 @@ struct WideArgs {
     uint64_t *acc_count;
     uint32_t *status;
     uint8_t *accflag;              /* [K]: this transition's decisions */
+    uint32_t *differs;             /* [K]: set (by plain stores of 1) where the proposal differs from the state it is compared
+                                      with; the deciding kernel reads and clears it */
     uint8_t *acc_row;              /* record rows of this transition (null: not recorded / not due) */
     double *traj_row, *lp_row;
     double *wf_mean, *wf_m2;       /* [K][d] (null: no moments) */
@@ -129,6 +131,7 @@ hipError_t ymc_launch_wide_rows(const double *frag, int KS, int MT_L, int d, con
 hipError_t ymc_launch_wide_decide(const WideArgs &a, hipStream_t s);
 hipError_t ymc_launch_wide_apply(const WideArgs &a, hipStream_t s);
 hipError_t ymc_launch_wide_copy(const WideArgs &a, const double *src, double *dst, double *dst_tiled, hipStream_t s);
+hipError_t ymc_launch_wide_differs(const WideArgs &a, const double *p, const double *q, hipStream_t s); /* differs[k] = 1 where p != q */
 hipError_t ymc_launch_wide_fine_decide(const WideArgs &a, hipStream_t s); /* mlda.py:146-154: z against x */
 hipError_t ymc_launch_wide_fine_apply(const WideArgs &a, hipStream_t s);  /* x <- z where accepted; record, moments */
 

@@ -594,6 +594,7 @@ __global__ __launch_bounds__(256) void wide_propose_kernel(const WideArgs a)
     }
     a.y[i] = y;
     const uint64_t k = i / (uint64_t)a.d;
+    if (!(y == x)) a.differs[k] = 1u; /* metropolisHastings.py:60-61, gathered per chain: every writer stores the same 1 */
     a.y_tiled[((k / 16) * (uint64_t)a.KS + (uint64_t)(j / 4)) * 64 + (uint64_t)(j % 4) * 16 + k % 16] = y;
 }
 
@@ -625,6 +626,7 @@ __global__ __launch_bounds__(256) void wide_draw_propose_kernel(const WideArgs a
                 y = x + a.sigma[j] * z[e];
             }
             a.y[idx] = y;
+            if (!(y == x)) a.differs[k] = 1u;
             a.y_tiled[((k / 16) * (uint64_t)a.KS + (uint64_t)(j / 4)) * 64 + (uint64_t)(j % 4) * 16 + k % 16] = y;
         }
     }
@@ -749,9 +751,9 @@ __global__ __launch_bounds__(256) void wide_decide_kernel(const WideArgs a)
     ymc_stage_tables();
     const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= a.K) return;
-    const double *x = a.from + k * (uint64_t)a.d, *y = a.y + k * (uint64_t)a.d;
-    bool moved = false;
-    for (int j = 0; j < a.d; ++j) moved = moved || !(y[j] == x[j]); /* metropolisHastings.py:60-61 */
+    const bool moved = a.differs[k] != 0; /* set by the proposal kernel (a scan of the two rows here, one lane per chain,
+                                             touched a cache line per lane and component) */
+    a.differs[k] = 0;
     uint32_t st = a.status[k];
     const double lpy = a.lpy[k], lp = a.cur_lp[k];
     const bool acc = ymc_accept(lpy - lp, moved, ymc_finite(lpy), a.u[k], st); /* mrw.py:51-57 */
@@ -798,6 +800,13 @@ __global__ __launch_bounds__(256) void wide_copy_kernel(const WideArgs a, const 
     if (dst_tiled) dst_tiled[((k / 16) * (uint64_t)a.KS + (uint64_t)(j / 4)) * 64 + (uint64_t)(j % 4) * 16 + k % 16] = v;
 }
 
+__global__ __launch_bounds__(256) void wide_differs_kernel(const WideArgs a, const double *__restrict__ p, const double *__restrict__ q)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.K * (uint64_t)a.d) return;
+    if (!(p[i] == q[i])) a.differs[i / (uint64_t)a.d] = 1u;
+}
+
 /* the fine accept / reject of two-level delayed acceptance (mlda.py:146-154, as mlda2_body): the sub-chain's end z against
  * the fine state x with exp(P(z) + Q(x) - Q(z) - P(x)) */
 __global__ __launch_bounds__(256) void wide_fine_decide_kernel(const WideArgs a)
@@ -805,9 +814,8 @@ __global__ __launch_bounds__(256) void wide_fine_decide_kernel(const WideArgs a)
     ymc_stage_tables();
     const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= a.K) return;
-    const double *x = a.x + k * (uint64_t)a.d, *z = a.z + k * (uint64_t)a.d;
-    bool moved = false;
-    for (int j = 0; j < a.d; ++j) moved = moved || !(z[j] == x[j]);
+    const bool moved = a.differs[k] != 0; /* set by wide_differs_kernel (z against x) */
+    a.differs[k] = 0;
     uint32_t st = a.status[k];
     const double lpfy = a.lpfz[k], lpf = a.lp[k], lpc = a.lpc[k], lpcz = a.lpcz[k];
     const double log_ratio = ((lpfy + lpc) - lpcz) - lpf;
@@ -872,6 +880,13 @@ hipError_t ymc_launch_wide_copy(const WideArgs &a, const double *src, double *ds
 {
     const uint64_t n = a.K * (uint64_t)a.d;
     hipLaunchKernelGGL(wide_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, src, dst, dst_tiled);
+    return hipGetLastError();
+}
+
+hipError_t ymc_launch_wide_differs(const WideArgs &a, const double *p, const double *q, hipStream_t s)
+{
+    const uint64_t n = a.K * (uint64_t)a.d;
+    hipLaunchKernelGGL(wide_differs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, p, q);
     return hipGetLastError();
 }
 
