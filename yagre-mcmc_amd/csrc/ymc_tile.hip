@@ -656,15 +656,17 @@ __global__ __launch_bounds__(256) void wide_draws_kernel(const WideArgs a, uint6
  * owns components 4 s + g of point c; k ascending per accumulator; the residual sums and the prior in the canonical four
  * partial sums) with the point read from its tiled array instead of registers and the matrix's fragments from global
  * memory -- two 8-byte loads per MFMA and lane, L2-bound. */
+template <int TILES>
 __global__ __launch_bounds__(512) void linear_wide_eval_kernel(const double *__restrict__ blob, int KS, int MT, double lik_const,
                                                                int likelihood_only, const double *__restrict__ y_tiled,
                                                                uint64_t K, double *__restrict__ lp_out)
 {
-    /* TWO tiles of 16 points per wave: a fragment of the matrix feeds two MFMAs (the matrix is what a wave reads most of) */
+    /* TILES = 2 tiles of 16 points per wave: a fragment of the matrix feeds two MFMAs (the matrix is what a wave reads most
+     * of); TILES = 1 for small ensembles, where waves are what is short (the second tile is then the first again) */
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-    const uint64_t nct = (K + 15) / 16, tile0 = ((uint64_t)blockIdx.x * 8 + wave) * 2;
+    const uint64_t nct = (K + 15) / 16, tile0 = ((uint64_t)blockIdx.x * 8 + wave) * TILES;
     if (tile0 >= nct) return;
-    const bool two = tile0 + 1 < nct;
+    const bool two = TILES == 2 && tile0 + 1 < nct;
     const int m_pad = 16 * MT, d_pad = 4 * KS;
     const double *bias = blob + (size_t)MT * KS * 64, *nprec = bias + m_pad, *dbar = nprec + m_pad;
     const double *pmean = dbar + m_pad, *pprec = pmean + d_pad;
@@ -907,8 +909,12 @@ hipError_t ymc_launch_wide_eval(const double *blob, int KS, int MT, double lik_c
                                 uint64_t K, double *lp_out, hipStream_t s)
 {
     const uint64_t nct = (K + 15) / 16;
-    hipLaunchKernelGGL(linear_wide_eval_kernel, dim3((unsigned)((nct + 15) / 16)), dim3(512), 0, s, blob, KS, MT, lik_const,
-                       likelihood_only, y_tiled, K, lp_out);
+    if (nct >= 2048) /* two tiles per wave once every SIMD has a wave anyway */
+        hipLaunchKernelGGL(linear_wide_eval_kernel<2>, dim3((unsigned)((nct + 15) / 16)), dim3(512), 0, s, blob, KS, MT, lik_const,
+                           likelihood_only, y_tiled, K, lp_out);
+    else
+        hipLaunchKernelGGL(linear_wide_eval_kernel<1>, dim3((unsigned)((nct + 7) / 8)), dim3(512), 0, s, blob, KS, MT, lik_const,
+                           likelihood_only, y_tiled, K, lp_out);
     return hipGetLastError();
 }
 
