@@ -189,6 +189,7 @@ struct ymc_run {
     DeviceBuf wide_xi, wide_u, wide_y, wide_yt, wide_lpy, wide_flag; /* the wide path's per-transition scratch */
     DeviceBuf wide_z, wide_zt, wide_lpcz;                            /* ... and the two-level sampler's sub-chain state */
     DeviceBuf wide_differs;                                          /* [K] proposal-differs-from-state flags */
+    DeviceBuf wide_terms;                                            /* small ensembles: the evaluation's residual terms */
     DeviceBuf wide_lvl_x, wide_lvl_lp; /* the nest on the wide path: states (plain | tiled) and P | Q of levels 0 .. E-2 */
     /* egress (ymc_run_egress_*): a copy stream, two slots of page-locked staging */
     struct EgressSlot {
@@ -823,7 +824,8 @@ int launch_advance_wide(ymc_run *r, uint64_t nsteps)
     a.accflag = r->wide_flag.as<uint8_t>();
     a.differs = r->wide_differs.as<uint32_t>();
     auto eval = [&](const DensityHost &h, const double *tiled, double *out) -> int {
-        YMC_HIP(ymc_launch_wide_eval(h.tile_blob.as<double>(), h.KS, h.MT, h.lik_const, h.d.likelihood_only, tiled, K, out, s));
+        YMC_HIP(ymc_launch_wide_eval(h.tile_blob.as<double>(), h.KS, h.MT, h.lik_const, h.d.likelihood_only, tiled, K, out, s,
+                                     r->wide_terms.as<double>()));
         return YMC_OK;
     };
 
@@ -929,7 +931,8 @@ int launch_advance_wide_nested(ymc_run *r, uint64_t nsteps)
     auto lpQ = [&](int l) { return r->wide_lvl_lp.as<double>() + (uint64_t)(2 * l + 1) * K; };
     double *tmpQ = r->wide_lpcz.as<double>();
     auto eval = [&](const DensityHost &h, const double *pts, double *out) -> int {
-        YMC_HIP(ymc_launch_wide_eval(h.tile_blob.as<double>(), h.KS, h.MT, h.lik_const, h.d.likelihood_only, pts, K, out, s));
+        YMC_HIP(ymc_launch_wide_eval(h.tile_blob.as<double>(), h.KS, h.MT, h.lik_const, h.d.likelihood_only, pts, K, out, s,
+                                     r->wide_terms.as<double>()));
         return YMC_OK;
     };
     auto Pof = [&](int l) -> const DensityHost & { return l == E - 1 ? p->tgt : p->lvlP[l]; };
@@ -1574,6 +1577,14 @@ int ymc_run_create(ymc_ctx *ctx, const ymc_problem *problem, const ymc_run_desc 
             YMC_TRY(r->wide_u.alloc(K * sizeof(double)));
             YMC_TRY(r->wide_lpy.alloc(K * sizeof(double)));
             YMC_TRY(r->wide_flag.alloc(K));
+            {   /* the largest output count among the levels sizes the small-ensemble scratch */
+                int mt_max = problem->tgt.MT;
+                if (problem->method == YMC_METHOD_MLDA2) mt_max = std::max(mt_max, problem->sur.MT);
+                if (problem->method == YMC_METHOD_MLDA_NESTED)
+                    for (int e = 0; e < problem->E - 1; ++e) mt_max = std::max(mt_max, std::max(problem->lvlP[e].MT, problem->lvlQ[e + 1].MT));
+                const size_t terms = ymc_wide_eval_terms(mt_max, K);
+                if (terms) YMC_TRY(r->wide_terms.alloc(terms * sizeof(double)));
+            }
             YMC_TRY(r->wide_differs.alloc(K * sizeof(uint32_t)));
             YMC_HIP(hipMemsetAsync(r->wide_differs.p, 0, r->wide_differs.bytes, ctx->stream));
         }

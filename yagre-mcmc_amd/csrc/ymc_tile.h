@@ -123,7 +123,10 @@ hipError_t ymc_launch_wide_draw_propose(const WideArgs &a, uint64_t seed, uint64
 /* log-densities of the K points of y_tiled on the matrix cores: `blob` as TileArgs::blob with KS k-steps (any number) and MT
  * output tiles, everything read from global memory */
 hipError_t ymc_launch_wide_eval(const double *blob, int KS, int MT, double lik_const, int likelihood_only, const double *y_tiled,
-                                uint64_t K, double *lp_out, hipStream_t s);
+                                uint64_t K, double *lp_out, hipStream_t s, double *terms = nullptr);
+/* scratch doubles the evaluation of a FEW points wants (a wave per tile AND pair of output tiles, the residual terms summed
+ * in order by a second kernel); 0 for ensembles that fill the card with a wave per tile */
+size_t ymc_wide_eval_terms(int MT, uint64_t K);
 /* out[K][d] = L in_tiled: the rows of a d x d factor (MFMA fragments [MT_L][KS][64]) times the 16 points of a tile, row i one
  * k-ordered fma chain (the dense proposal's L xi, as linear_tile_kernel) */
 hipError_t ymc_launch_wide_rows(const double *frag, int KS, int MT_L, int d, const double *in_tiled, uint64_t K, double *out,

@@ -712,40 +712,106 @@ __global__ __launch_bounds__(512) void linear_wide_eval_kernel(const double *__r
     if (g == 0 && two && kb < K) lp_out[kb] = lpb;
 }
 
-/* out[k][i] = sum_j L[i][j] in[k][j], the 16 points of a tile per wave (ymc_launch_wide_rows) */
+/* out[k][i] = sum_j L[i][j] in[k][j]: a wave per tile of 16 points and pair of output tiles (ymc_launch_wide_rows) */
 __global__ __launch_bounds__(512) void linear_wide_rows_kernel(const double *__restrict__ frag, int KS, int MT_L, int d,
                                                                const double *__restrict__ in_tiled, uint64_t K,
                                                                double *__restrict__ out)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
-    const uint64_t nct = (K + 15) / 16, tile = (uint64_t)blockIdx.x * 8 + wave;
-    if (tile >= nct) return;
+    const uint64_t nct = (K + 15) / 16, pairs = (uint64_t)MT_L / 2, w = (uint64_t)blockIdx.x * 8 + wave;
+    if (w >= nct * pairs) return;
+    const uint64_t tile = w / pairs;
+    const int mt = 2 * (int)(w % pairs);
     const double *v = in_tiled + (tile * (uint64_t)KS) * 64 + lane;
     const uint64_t k = tile * 16 + c;
+    d4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
+    const double *L0 = frag + (size_t)mt * KS * 64 + lane, *L1 = L0 + (size_t)KS * 64;
 #pragma unroll 1
-    for (int mt = 0; mt < MT_L; mt += 2) {
-        d4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
-        const double *L0 = frag + (size_t)mt * KS * 64 + lane, *L1 = L0 + (size_t)KS * 64;
-#pragma unroll 1
-        for (int s0 = 0; s0 < KS; s0 += 4) {
-            double vv[4], f0[4], f1[4];
+    for (int s0 = 0; s0 < KS; s0 += 4) {
+        double vv[4], f0[4], f1[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) vv[q] = v[(s0 + q) * 64], f0[q] = L0[(s0 + q) * 64], f1[q] = L1[(s0 + q) * 64];
+        for (int q = 0; q < 4; ++q) vv[q] = v[(s0 + q) * 64], f0[q] = L0[(s0 + q) * 64], f1[q] = L1[(s0 + q) * 64];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0[q], vv[q], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1[q], vv[q], a1, 0, 0, 0);
-            }
-        }
-        if (k < K) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i0 = 16 * mt + 4 * r + g, i1 = i0 + 16;
-                if (i0 < d) out[k * (uint64_t)d + i0] = a0[r];
-                if (i1 < d) out[k * (uint64_t)d + i1] = a1[r];
-            }
+        for (int q = 0; q < 4; ++q) {
+            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0[q], vv[q], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1[q], vv[q], a1, 0, 0, 0);
         }
     }
+    if (k < K) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i0 = 16 * mt + 4 * r + g, i1 = i0 + 16;
+            if (i0 < d) out[k * (uint64_t)d + i0] = a0[r];
+            if (i1 < d) out[k * (uint64_t)d + i1] = a1[r];
+        }
+    }
+}
+
+/* Few points (a handful of tiles): a wave per tile AND pair of output tiles writes the pair's eight residual terms per lane,
+ * a second kernel adds them in the canonical order (the order linear_wide_eval_kernel adds them in: same bits) */
+__global__ __launch_bounds__(256) void linear_wide_terms_kernel(const double *__restrict__ blob, int KS, int MT,
+                                                                const double *__restrict__ y_tiled, uint64_t nct,
+                                                                double *__restrict__ terms)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const uint64_t pairs = (uint64_t)MT / 2, w = (uint64_t)blockIdx.x * 4 + wave;
+    if (w >= nct * pairs) return;
+    const uint64_t tile = w / pairs;
+    const int mt = 2 * (int)(w % pairs);
+    const int m_pad = 16 * MT;
+    const double *bias = blob + (size_t)MT * KS * 64, *nprec = bias + m_pad, *dbar = nprec + m_pad;
+    const double *yt = y_tiled + (tile * (uint64_t)KS) * 64 + lane;
+    d4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
+    const double *A0 = blob + (size_t)mt * KS * 64 + lane, *A1 = A0 + (size_t)KS * 64;
+#pragma unroll 1
+    for (int s0 = 0; s0 < KS; s0 += 4) {
+        double v[4], f0[4], f1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = yt[(s0 + q) * 64], f0[q] = A0[(s0 + q) * 64], f1[q] = A1[(s0 + q) * 64];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(f0[q], v[q], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(f1[q], v[q], a1, 0, 0, 0);
+        }
+    }
+    double *out = terms + (w * 8) * 64 + lane;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { /* ymc_tile_add_residuals' terms, one by one */
+            const int m = 16 * (mt + h) + 4 * r + g;
+            const double F = (h ? a1[r] : a0[r]) + bias[m];
+            const double res = F - dbar[m];
+            const double px = nprec[m] * res;
+            out[(4 * h + r) * 64] = res * px;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void linear_wide_sum_kernel(const double *__restrict__ blob, int KS, int MT, double lik_const,
+                                                              int likelihood_only, const double *__restrict__ y_tiled,
+                                                              const double *__restrict__ terms, uint64_t K,
+                                                              double *__restrict__ lp_out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const uint64_t nct = (K + 15) / 16, tile = (uint64_t)blockIdx.x * 4 + wave;
+    if (tile >= nct) return;
+    const int m_pad = 16 * MT, d_pad = 4 * KS;
+    const double *pmean = blob + (size_t)MT * KS * 64 + 3 * (size_t)m_pad, *pprec = pmean + d_pad;
+    const double *yt = y_tiled + (tile * (uint64_t)KS) * 64 + lane;
+    const double *tp = terms + (tile * ((uint64_t)MT / 2) * 8) * 64 + lane;
+    double Ssum = 0.0;
+    for (int i = 0; i < 4 * MT; ++i) Ssum = Ssum + tp[(size_t)i * 64];
+    const double logl = -0.5 * (combine4(Ssum) + lik_const);
+    double P = 0.0;
+    for (int s = 0; s < KS; ++s) {
+        const int j = 4 * s + g;
+        const double dx = yt[s * 64] - pmean[j];
+        P = P + dx * (pprec[j] * dx);
+    }
+    const double lp = likelihood_only ? logl : logl + (-0.5 * combine4(P));
+    const uint64_t k = tile * 16 + c;
+    if (g == 0 && k < K) lp_out[k] = lp;
 }
 
 __global__ __launch_bounds__(256) void wide_decide_kernel(const WideArgs a)
@@ -905,10 +971,25 @@ hipError_t ymc_launch_wide_fine_apply(const WideArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t ymc_launch_wide_eval(const double *blob, int KS, int MT, double lik_const, int likelihood_only, const double *y_tiled,
-                                uint64_t K, double *lp_out, hipStream_t s)
+constexpr uint64_t kWideSplitTiles = 128; /* fewer tiles than this: a wave per tile and pair of output tiles */
+
+size_t ymc_wide_eval_terms(int MT, uint64_t K)
 {
     const uint64_t nct = (K + 15) / 16;
+    return nct < kWideSplitTiles ? (size_t)(nct * ((uint64_t)MT / 2) * 8 * 64) : 0;
+}
+
+hipError_t ymc_launch_wide_eval(const double *blob, int KS, int MT, double lik_const, int likelihood_only, const double *y_tiled,
+                                uint64_t K, double *lp_out, hipStream_t s, double *terms)
+{
+    const uint64_t nct = (K + 15) / 16;
+    if (terms && nct < kWideSplitTiles) {
+        const uint64_t waves = nct * ((uint64_t)MT / 2);
+        hipLaunchKernelGGL(linear_wide_terms_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, blob, KS, MT, y_tiled, nct, terms);
+        hipLaunchKernelGGL(linear_wide_sum_kernel, dim3((unsigned)((nct + 3) / 4)), dim3(256), 0, s, blob, KS, MT, lik_const,
+                           likelihood_only, y_tiled, terms, K, lp_out);
+        return hipGetLastError();
+    }
     if (nct >= 2048) /* two tiles per wave once every SIMD has a wave anyway */
         hipLaunchKernelGGL(linear_wide_eval_kernel<2>, dim3((unsigned)((nct + 15) / 16)), dim3(512), 0, s, blob, KS, MT, lik_const,
                            likelihood_only, y_tiled, K, lp_out);
@@ -921,8 +1002,8 @@ hipError_t ymc_launch_wide_eval(const double *blob, int KS, int MT, double lik_c
 hipError_t ymc_launch_wide_rows(const double *frag, int KS, int MT_L, int d, const double *in_tiled, uint64_t K, double *out,
                                 hipStream_t s)
 {
-    const uint64_t nct = (K + 15) / 16;
-    hipLaunchKernelGGL(linear_wide_rows_kernel, dim3((unsigned)((nct + 7) / 8)), dim3(512), 0, s, frag, KS, MT_L, d, in_tiled, K, out);
+    const uint64_t waves = ((K + 15) / 16) * ((uint64_t)MT_L / 2);
+    hipLaunchKernelGGL(linear_wide_rows_kernel, dim3((unsigned)((waves + 7) / 8)), dim3(512), 0, s, frag, KS, MT_L, d, in_tiled, K, out);
     return hipGetLastError();
 }
 
