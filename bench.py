@@ -43,6 +43,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6  # AMD MI355X data sheet: FP64 vector = FP64 matrix = 78.6 TFLOP/s (the guide lists no f64 rate)
 STEP_TARGET_S = 0.5      # a bench step is sized to about this much device time
+# seconds of CPU work of a cpu_baseline leg: (all visible threads, 16 threads, 1 thread); YMC_BENCH_CPU_SCALE
+# shortens them for the launch tests
+_CPU_SCALE = float(os.environ.get("YMC_BENCH_CPU_SCALE", "1"))
+CPU_SECONDS = tuple(_CPU_SCALE * v for v in (8.0, 4.0, 4.0))
+LEG_CPU_SECONDS = tuple(_CPU_SCALE * v for v in (2.5, 2.5, 1.5))
 
 
 def parse():
@@ -58,6 +63,9 @@ def parse():
     ap.add_argument("--no-moments", action="store_true")
     ap.add_argument("--record-stride", type=int, default=1,
                     help="thinned record: keep every s-th state (drops the per-transition decision record)")
+    ap.add_argument("--legs", default="auto",
+                    help="workloads measured after the headline and reported under \"workloads\": auto (next to the "
+                         "default C2 headline: c3,c3m,c4,c5 on one GPU, c4,c5 on N > 1), none, or a comma list")
     return ap.parse_args()
 
 
@@ -184,10 +192,11 @@ def make_workload(name, ffi, ctx, lowering):
                                       prior_mean=prior_mean, prior_prec=prior_prec), sigma=sigma))
 
 
-def cpu_baseline(spec, x0):
+def cpu_baseline(spec, x0, seconds=CPU_SECONDS):
     """The oracle (CPU restatement, kind "port") timed on the host cores on a bounded sample of the same
-    workload: same target, same recording, fewer chains and transitions (~20 s of CPU work in all): all
-    hardware threads the process may use, 16 threads (one GPU's share of an 8-GPU host) and one thread."""
+    workload: same target, same recording, fewer chains and transitions (~16 s of CPU work for the headline,
+    ~6 s for a leg): all hardware threads the process may use, 16 threads (one GPU's share of an 8-GPU host)
+    and one thread."""
     from oracle import oracle  # the ONLY place the benchmark touches the checker
 
     def lower(s):
@@ -218,17 +227,17 @@ def cpu_baseline(spec, x0):
     heavy = spec["target"]["kind"] != "gauss"
     T = 50 if heavy else 500
     per_thread = 16 if heavy else 1024    # ~25 B of record per transition (d = 2)
-    rate_all, reps, dt = timed(per_thread * visible, T, visible, 8.0)
+    rate_all, reps, dt = timed(per_thread * visible, T, visible, seconds[0])
     n16 = min(16, visible)
-    rate16 = timed(per_thread * n16, T, n16, 4.0)[0] if n16 != visible else rate_all
-    rate1 = timed(per_thread, T, 1, 4.0)[0]
+    rate16 = timed(per_thread * n16, T, n16, seconds[1])[0] if n16 != visible else rate_all
+    rate1 = timed(per_thread, T, 1, seconds[2])[0]
     # the GPU box gives a one-GPU job a share of the host's CPU time: every visible hardware thread at once can
     # be SLOWER than 16 threads.  The headline is the better of the two, with the thread count that produced it.
     best, cores = (rate_all, visible) if rate_all >= rate16 else (rate16, n16)
     return {"value": best, "unit": "steps/s", "cores": cores, "kind": "port",
             "sample": f"{per_thread} chains per thread x {T} transitions of the same workload (trajectory, mask, "
-                      f"log-density and moments recorded, record buffers resident), passes repeated for 8 s "
-                      f"({visible} threads), 4 s (16 threads) and 4 s (1 thread)",
+                      f"log-density and moments recorded, record buffers resident), passes repeated for {seconds[0]:g} s "
+                      f"({visible} threads), {seconds[1]:g} s (16 threads) and {seconds[2]:g} s (1 thread)",
             "host_threads_visible": visible, "all_visible_threads_steps_per_s": rate_all,
             "threads_16_steps_per_s": rate16, "single_thread_steps_per_s": rate1,
             "reference_single_core_steps_per_s_survey_container": 2.2e4}
@@ -245,12 +254,12 @@ def profiled(workload, K, T):
     return rec or {}
 
 
-def roofline_block(args, wl, K, T, kernel_ms, launches, clock_mhz, info):
+def roofline_block(name, stride, wl, K, T, kernel_ms, launches, clock_mhz, info):
     d = wl["d"]
     ksec = kernel_ms * 1e-3
-    bytes_launch = K * T * (8 * d + 1) if args.record_stride <= 1 else K * (T // args.record_stride) * 8 * d
+    bytes_launch = K * T * (8 * d + 1) if stride <= 1 else K * (T // stride) * 8 * d
     hbm = bytes_launch / ksec / 1e9 if ksec > 0 else 0.0
-    rec = profiled(args.workload, K, T)
+    rec = profiled(name, K, T)
     traffic = rec.get("hbm_bytes_per_launch")
     common = {"traffic": traffic, "traffic_source": rec.get("source") if traffic else None,
               "kernel_ms_avg": kernel_ms, "launches_timed": launches,
@@ -260,7 +269,7 @@ def roofline_block(args, wl, K, T, kernel_ms, launches, clock_mhz, info):
     sq = rec.get("sq_per_launch") or {}
     valu = None
     if sq.get("SQ_INSTS_VALU") and clock_mhz and ksec > 0:
-        waves = math.ceil(K / (16 if args.workload in ("c3", "c3m", "c3a") else 64))   # waves' worth of chains
+        waves = math.ceil(K / (16 if name in ("c3", "c3m", "c3a") else 64))   # waves' worth of chains
         simds = 4 * info["compute_units"]
         avail = ksec * clock_mhz * 1e6 * simds          # SIMD issue cycles in one launch
         mfma = sq.get("SQ_INSTS_MFMA", 0.0)
@@ -276,7 +285,7 @@ def roofline_block(args, wl, K, T, kernel_ms, launches, clock_mhz, info):
                         "and a VALU instruction never execute together on gfx950: SQ_VALU_MFMA_COEXEC_CYCLES = 0); "
                         "instruction counts per wave of chains and transition",
                 "source": {"instr": rec.get("source"), "kernel_time_and_clock": "this run"}}
-    if args.workload in ("c3", "c3m", "c3a"):
+    if name in ("c3", "c3m", "c3a"):
         # c3m: S = 5 coarse + 1 fine forward map per fine step; c3a: S = 4 coarse + the fine matrix twice (likelihood, model error)
         maps = wl["spec"].get("fine_maps", 1) + wl["spec"].get("S", 0)
         flops = 2.0 * d * d * K * T * maps
@@ -285,7 +294,7 @@ def roofline_block(args, wl, K, T, kernel_ms, launches, clock_mhz, info):
                     algorithmic_flops_per_launch=flops, valu=valu,
                     note="per GPU (rank 0); v_mfma_f64_16x16x4_f64 GEMV (2 d m flop per transition); the 128 normal "
                          "draws per transition are VALU work on top of it -- DESIGN.md")
-    if args.workload == "c4":
+    if name == "c4":
         flops = 10 * 50 * 50.0 * K * T   # n_data x rk4_steps x 50 flop (30 fp64 instructions, 20 of them fma)
         tf = flops / ksec / 1e12 if ksec > 0 else 0.0
         return dict(common, bound="valu", achieved=tf, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / FP64_PEAK_TFLOPS,
@@ -294,7 +303,7 @@ def roofline_block(args, wl, K, T, kernel_ms, launches, clock_mhz, info):
                          "50 flop per transition) against the 78.6 TFLOP/s vector peak; HBM figures alongside")
     return dict(common, bound="hbm", achieved=hbm, peak=HBM_PEAK_GBPS, unit="GB/s", frac=hbm / HBM_PEAK_GBPS, valu=valu,
                 note="per GPU (rank 0); bytes = (8 d + 1) per transition per chain"
-                     + (" (per FINE step; every fine step also makes 6 coarse transitions)" if args.workload == "c5" else "")
+                     + (" (per FINE step; every fine step also makes 6 coarse transitions)" if name == "c5" else "")
                      + "; the kernel is VALU-issue bound (Philox + Box-Muller + exp per transition) -- see `valu` "
                        "and DESIGN.md")
 
@@ -332,6 +341,124 @@ def bench_iat(args, ffi, ctx, wl, K, info):
     print(json.dumps(out))
 
 
+# legs run after the headline: BASELINE.json's other configs at their own per-GPU sizes, ~3 s of device time each.
+# One GPU: all of them, each with its own bounded cpu_baseline.  N > 1: the two configs BASELINE defines as
+# sharded over the node (configs[3], configs[4]); the CPU leg stays on the N = 1 line.
+LEGS_ONE_GPU = ("c3", "c3m", "c4", "c5")
+LEGS_SHARDED = ("c4", "c5")
+LEG_STEPS, LEG_WARMUP = 6, 1
+INTERNAL_BITS = 2          # YMC_CHAIN_HANDOFF (include/ymc.h): an internal error, never a property of the problem
+
+
+def flagged_by_bit(status):
+    status = np.asarray(status)
+    return {"nonfinite": int(((status & 1) != 0).sum()), "internal": int(((status & INTERNAL_BITS) != 0).sum()),
+            "other": int(((status & ~np.uint32(3)) != 0).sum())}
+
+
+def measure(name, args, ffi, ctx, lowering, info, rank, world, comm, steps, warmup, headline):
+    """One workload on this rank's GPU: W warm-up steps, then exactly `steps` timed steps between barriers
+    (max over ranks), the kernel time from HIP events on the kernel's stream, the gather of the per-chain
+    summaries.  -> (result dict on rank 0 / None elsewhere, workload)"""
+    wl = make_workload(name, ffi, ctx, lowering)
+    K = (args.chains if headline else 0) or wl["K"]
+    T = (args.transitions if headline else 0) or wl["T"]
+    L = (args.launches_per_step if headline else 0) or wl["L"]
+    d, x0 = wl["d"], wl["x0"]
+    no_moments = args.no_moments or name in ("c3", "c3m", "c3a")   # the tile kernels keep no Welford state (the
+    #                                                                 reference's default diagnostics)
+    stride = max(args.record_stride, 1) if headline else 1
+    flags = ffi.RECORD_TRAJECTORY | (ffi.RECORD_ACCEPT if stride == 1 else 0) | (0 if no_moments else ffi.RECORD_MOMENTS)
+    # rows per launch: T // stride, or one more when the launch boundaries do not fall on multiples of the stride
+    run = ffi.Run(wl["problem"], 20250103, K, x0, T // stride + 1, flags, chain_offset=rank * K, record_stride=stride)
+
+    def step():
+        for _ in range(L):
+            run.rewind_record()
+            run.advance(T)
+
+    def barrier():
+        run.sync()
+        if comm is not None:
+            comm.barrier()
+
+    t_w = time.perf_counter()
+    for _ in range(warmup):
+        step()
+    run.sync()
+    warm_s = time.perf_counter() - t_w
+    run.kernel_time_ms()  # drop the warm-up launches from the kernel-time average
+
+    # the clock the chip holds DURING the timed region: a one-wave probe next to the chain kernels for
+    # ~80 % of the region's expected length (from the warm-up; without one, a calibration step)
+    if warmup > 0:
+        expect_s = warm_s / warmup * steps
+    else:
+        t_c = time.perf_counter()
+        step()
+        run.sync()
+        expect_s = (time.perf_counter() - t_c) * steps
+        run.kernel_time_ms()
+    probe_ms = min(max(0.8 * expect_s * 1e3, 1.0), 20000.0)
+
+    barrier()
+    t0 = time.perf_counter()
+    ctx.clock_probe_start(probe_ms)
+    for _ in range(steps):
+        step()
+    run.sync()
+    elapsed = time.perf_counter() - t0
+    if comm is not None:
+        elapsed = comm.allreduce_max(elapsed)
+    kernel_ms, launches = run.kernel_time_ms()
+    clock_mhz, probe_ran_ms = ctx.clock_probe_read()
+
+    # the single collective of a run: gather the per-chain summaries
+    gather_ms = None
+    if comm is not None:
+        tg = time.perf_counter()
+        packed = comm.allgather_summary(run)  # (world, K, 3d+5) u64
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        summary = distributed_mod().unpack_summaries(packed, d)
+    else:
+        summary = run.summary()
+    total_steps = run.steps_done()[0]
+    close = getattr(run, "close", None)
+    if close is not None:
+        close()            # the record (C3: 27 GB) goes back before the next workload allocates its own
+    if rank != 0:
+        return None, wl
+    pooled = distributed_mod().pooled_diagnostics(summary, total_steps)
+    value = float(world) * K * T * L * steps / elapsed
+    roofline = roofline_block(name, stride, wl, K, T, kernel_ms, launches, clock_mhz, info)
+    res = dict(value=value, elapsed=elapsed, K=K, T=T, L=L, d=d, stride=stride, no_moments=no_moments,
+               clock_mhz=clock_mhz, probe_ran_ms=probe_ran_ms, roofline=roofline, kernel_ms=kernel_ms,
+               pooled=pooled, gather_ms=gather_ms, flagged=flagged_by_bit(summary["status"]), steps=steps, warmup=warmup)
+    return res, wl
+
+
+def distributed_mod():
+    from yagremcmc_amd import distributed
+    return distributed
+
+
+def leg_block(name, res, wl, cpu):
+    """The compact record of a leg inside the one JSON line."""
+    r = res["roofline"]
+    out = {"metric": "MH steps/sec (whole node)", "value": res["value"], "unit": "steps/s",
+           "ms_per_step": res["elapsed"] / res["steps"] * 1e3, "steps": res["steps"], "warmup": res["warmup"],
+           "timed_region_s": res["elapsed"], "dtype": "f64",
+           "config": {"workload": wl["desc"], "chains_per_gpu": res["K"], "transitions_per_launch": res["T"],
+                      "launches_per_step": res["L"]},
+           "roofline": {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms_avg",
+                                              "launches_timed", "hbm_gb_per_s")},
+           "sustained_clock_mhz": res["clock_mhz"], "acceptance_rate": res["pooled"]["acceptance_rate"],
+           "chains_flagged": res["flagged"], "gather_ms": res["gather_ms"], "cpu_baseline": cpu}
+    if name == "c5":
+        out["coarse_sub_steps_per_s"] = res["value"] * 6
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -352,19 +479,9 @@ def main():
         device %= ffi.device_count()  # rehearsal of the N > 1 flow on a box with fewer GPUs than ranks
     ctx = ffi.Context(device)
     info = ctx.info()
-    wl = make_workload(args.workload, ffi, ctx, lowering)
-    K = args.chains or wl["K"]
     if args.workload == "iat":
-        return bench_iat(args, ffi, ctx, wl, K, info)
-    T = args.transitions or wl["T"]
-    L = args.launches_per_step or wl["L"]
-    d, x0 = wl["d"], wl["x0"]
-    if args.workload in ("c3", "c3m", "c3a"):
-        args.no_moments = True   # the reference's default diagnostics; the tile kernel keeps no Welford state
-    stride = max(args.record_stride, 1)
-    flags = ffi.RECORD_TRAJECTORY | (ffi.RECORD_ACCEPT if stride == 1 else 0) | (0 if args.no_moments else ffi.RECORD_MOMENTS)
-    # rows per launch: T // stride, or one more when the launch boundaries do not fall on multiples of the stride
-    run = ffi.Run(wl["problem"], 20250103, K, x0, T // stride + 1, flags, chain_offset=rank * K, record_stride=stride)
+        wl = make_workload("iat", ffi, ctx, lowering)
+        return bench_iat(args, ffi, ctx, wl, args.chains or wl["K"], info)
 
     # YMC_BENCH_FORCE_COMM=1 exercises the RCCL path with a single rank (1-GPU rehearsal of the N > 1 flow)
     use_comm = world > 1 or os.environ.get("YMC_BENCH_FORCE_COMM") == "1"
@@ -376,97 +493,74 @@ def main():
             print(f"bench.py: rank {rank}: {e}", file=sys.stderr, flush=True)
             sys.exit(1)
 
-    def step():
-        for _ in range(L):
-            run.rewind_record()
-            run.advance(T)
+    res, wl = measure(args.workload, args, ffi, ctx, lowering, info, rank, world, comm, args.steps, args.warmup, True)
+    want_cpu = world == 1 and not args.no_cpu_baseline
+    cpu = None
+    if rank == 0 and want_cpu and not wl["spec"].get("aem"):
+        cpu = cpu_baseline(wl["spec"], wl["x0"], CPU_SECONDS)
 
-    def barrier():
-        run.sync()
-        if comm is not None:
-            comm.barrier()
+    # the other BASELINE configs, driver-timed in the same line (only next to the default headline)
+    legs = {}
+    leg_names = ()
+    if args.legs == "auto":
+        untouched = args.workload == "c2" and not (args.chains or args.transitions or args.launches_per_step
+                                                   or args.record_stride > 1)
+        leg_names = (LEGS_ONE_GPU if world == 1 else LEGS_SHARDED) if untouched else ()
+    elif args.legs != "none":
+        leg_names = tuple(n for n in args.legs.split(",") if n)
+    for name in leg_names:
+        lres, lwl = measure(name, args, ffi, ctx, lowering, info, rank, world, comm, LEG_STEPS, LEG_WARMUP, False)
+        if rank == 0:
+            lcpu = cpu_baseline(lwl["spec"], lwl["x0"], LEG_CPU_SECONDS) if want_cpu and not lwl["spec"].get("aem") else None
+            legs[name] = leg_block(name, lres, lwl, lcpu)
 
-    t_w = time.perf_counter()
-    for _ in range(args.warmup):
-        step()
-    run.sync()
-    warm_s = time.perf_counter() - t_w
-    run.kernel_time_ms()  # drop the warm-up launches from the kernel-time average
-
-    # the clock the chip holds DURING the timed region: a one-wave probe next to the chain kernels for
-    # ~80 % of the region's expected length (from the warm-up; without one, a calibration step)
-    if args.warmup > 0:
-        expect_s = warm_s / args.warmup * args.steps
-    else:
-        t_c = time.perf_counter()
-        step()
-        run.sync()
-        expect_s = (time.perf_counter() - t_c) * args.steps
-        run.kernel_time_ms()
-    probe_ms = min(max(0.8 * expect_s * 1e3, 1.0), 20000.0)
-
-    barrier()
-    t0 = time.perf_counter()
-    ctx.clock_probe_start(probe_ms)
-    for _ in range(args.steps):
-        step()
-    run.sync()
-    elapsed = time.perf_counter() - t0
+    nranks_seen = backend = None
     if comm is not None:
-        elapsed = comm.allreduce_max(elapsed)
-    kernel_ms, launches = run.kernel_time_ms()
-    clock_mhz, probe_ran_ms = ctx.clock_probe_read()
-
-    # the single collective of the run: gather the per-chain summaries
-    gather_ms = nranks_seen = None
-    if comm is not None:
-        tg = time.perf_counter()
-        packed = comm.allgather_summary(run)  # (world, K, 3d+5) u64
-        gather_ms = (time.perf_counter() - tg) * 1e3
-        summary = distributed.unpack_summaries(packed, d)
-        nranks_seen = comm.count()
-        backend = comm.backend
+        nranks_seen, backend = comm.count(), comm.backend
         comm.close()
-    else:
-        summary = run.summary()
     if rank != 0:
         return
-    total_steps = run.steps_done()[0]
-    pooled = distributed.pooled_diagnostics(summary, total_steps)
 
-    transitions = float(world) * K * T * L * args.steps
-    value = transitions / elapsed
-    roofline = roofline_block(args, wl, K, T, kernel_ms, launches, clock_mhz, info)
+    roofline = res["roofline"]
+    K, T, L, stride = res["K"], res["T"], res["L"], res["stride"]
     out = {
-        "metric": "MH steps/sec (whole node)", "value": value, "unit": "steps/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "metric": "MH steps/sec (whole node)", "value": res["value"], "unit": "steps/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["elapsed"] / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": wl["desc"], "chains_per_gpu": K, "chains_total": world * K,
                    "transitions_per_launch": T, "launches_per_step": L, "transitions_per_step": T * L,
                    "record_stride": stride,
                    "record": "trajectory f64 [T][K][d] + accept u8 [T][K]"
-                   + ("" if args.no_moments else " + Welford moments") + ", refilled by every launch",
+                   + ("" if res["no_moments"] else " + Welford moments") + ", refilled by every launch",
                    "parallelism": f"chains sharded over {world} GPU(s)",
                    "rng": "Philox4x32-10, seed 20250103, keyed by global chain id"},
-        "timed_region_s": elapsed,
-        "sustained_clock_mhz": clock_mhz,
-        "clock_probe_ms": probe_ran_ms,
+        "timed_region_s": res["elapsed"],
+        "sustained_clock_mhz": res["clock_mhz"],
+        "clock_probe_ms": res["probe_ran_ms"],
         "roofline": roofline,
         "hbm_gb_per_s_whole_node": world * roofline["hbm_gb_per_s"],
-        "kernel_steps_per_s_per_gpu": K * T / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0,
-        "acceptance_rate": pooled["acceptance_rate"],
-        "pooled_mean": None if args.no_moments else [float(v) for v in pooled["mean"]],
-        "chains_flagged_nonfinite": pooled["flagged"],
-        "gather_ms": gather_ms,
-        "collective": None if comm is None else backend,
+        "kernel_steps_per_s_per_gpu": K * T / (res["kernel_ms"] * 1e-3) if res["kernel_ms"] > 0 else 0.0,
+        "acceptance_rate": res["pooled"]["acceptance_rate"],
+        "pooled_mean": None if res["no_moments"] else [float(v) for v in res["pooled"]["mean"]],
+        "chains_flagged_nonfinite": res["flagged"]["nonfinite"],
+        "chains_flagged": res["flagged"],
+        "gather_ms": res["gather_ms"],
+        "collective": backend,
         "nranks_seen": nranks_seen,
         "device": info,
     }
     if args.workload == "c5":
-        out["coarse_sub_steps_per_s"] = value * 6
-    if world == 1 and not args.no_cpu_baseline and not wl["spec"].get("aem"):
-        out["cpu_baseline"] = cpu_baseline(wl["spec"], x0)
+        out["coarse_sub_steps_per_s"] = res["value"] * 6
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+    if legs:
+        out["workloads"] = legs
     print(json.dumps(out))
+    internal = res["flagged"]["internal"] + sum(v["chains_flagged"]["internal"] for v in legs.values())
+    if internal:
+        print(f"bench.py: {internal} chains carry an internal device error (YMC_CHAIN_HANDOFF): the trajectories are "
+              f"incomplete", file=sys.stderr, flush=True)
+        sys.exit(1)
 
 
 if __name__ == "__main__":

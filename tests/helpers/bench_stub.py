@@ -66,7 +66,8 @@ class StubRun:
 
     def summary(self):
         e = self.e
-        return dict(accepted=e.acc_count, wf_n=e.wf_n, wf_mean=e.wf_mean, wf_m2=e.wf_m2, status=e.status)
+        status = e.status | np.uint32(int(os.environ.get("YMC_STUB_STATUS_BITS", "0")))
+        return dict(accepted=e.acc_count, wf_n=e.wf_n, wf_mean=e.wf_mean, wf_m2=e.wf_m2, status=status)
 
     def state(self):
         return self.e.x, self.e.lp
@@ -75,11 +76,12 @@ class StubRun:
 def stub_workload(name, ffi, ctx, lowering):
     U, c = bench.whitening(bench.TGT_MEAN, bench.TGT_COV)
     return dict(problem=oracle.gauss_whitened(bench.TGT_MEAN, U, c), x0=np.array([[-8.0, -7.0]]), K=32, T=40, L=1,
-                d=2, desc="stub: C2's target on the CPU checker", spec={})
+                d=2, desc=f"stub ({name}): C2's target on the CPU checker",
+                spec=dict(target=dict(kind="gauss", mean=bench.TGT_MEAN, whiten=U, log_norm=c), sigma=np.ones(2)))
 
 
 _ffi.Context, _ffi.Run, _ffi.device_count = StubContext, StubRun, lambda: 8
 bench.make_workload = stub_workload
-if "--no-cpu-baseline" not in sys.argv:
+if "--no-cpu-baseline" not in sys.argv and os.environ.get("YMC_STUB_CPU_BASELINE") != "1":
     sys.argv.append("--no-cpu-baseline")
 bench.main()

@@ -64,6 +64,56 @@ def test_one_gpu_needs_no_launch():
     assert out["n_gpus"] == 1 and out["collective"] is None and out["acceptance_rate"] == _expected(32, 120)
 
 
+LEG_KEYS = {"value", "ms_per_step", "roofline", "cpu_baseline", "config", "chains_flagged", "steps", "warmup",
+            "timed_region_s", "acceptance_rate"}
+
+
+def test_one_gpu_line_carries_every_baseline_config():
+    """after the unchanged C2 headline the one line holds a driver-timed block per other
+    BASELINE config, each with its roofline and its own bounded cpu_baseline."""
+    r = subprocess.run([sys.executable, STUB, "--gpus", "1", "--steps", "2", "--warmup", "1"],
+                       env=_env(YMC_STUB_CPU_BASELINE="1", YMC_BENCH_CPU_SCALE="0.02"), capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip())
+    assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
+    assert list(out["workloads"]) == ["c3", "c3m", "c4", "c5"]
+    for name, blk in out["workloads"].items():
+        assert LEG_KEYS <= set(blk), (name, sorted(blk))
+        assert blk["value"] > 0 and blk["steps"] == 6 and blk["warmup"] == 1
+        assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(blk["roofline"])
+        assert blk["cpu_baseline"]["value"] > 0 and blk["cpu_baseline"]["cores"] >= 1
+        assert blk["chains_flagged"] == {"nonfinite": 0, "internal": 0, "other": 0}
+    assert out["chains_flagged"] == {"nonfinite": 0, "internal": 0, "other": 0}
+    # a non-default headline is a kernel experiment: no legs ride along; --legs picks them by name
+    r = subprocess.run([sys.executable, STUB, "--gpus", "1", "--steps", "1", "--warmup", "0", "--chains", "16"], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "workloads" not in json.loads(r.stdout.strip())
+    r = subprocess.run([sys.executable, STUB, "--gpus", "1", "--steps", "1", "--warmup", "0", "--legs", "c5"], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and list(json.loads(r.stdout.strip())["workloads"]) == ["c5"]
+
+
+def test_sharded_launch_carries_the_node_wide_configs():
+    r = subprocess.run([sys.executable, STUB, "--gpus", "2", "--steps", "2", "--warmup", "1"], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _check_line(r.stdout, 2)
+    assert list(out["workloads"]) == ["c4", "c5"]
+    for blk in out["workloads"].values():
+        assert blk["value"] > 0 and blk["gather_ms"] is not None and blk["cpu_baseline"] is None
+        assert blk["acceptance_rate"] == _expected(64, 40 * 7)
+
+
+def test_an_internal_device_error_fails_the_bench():
+    """YMC_CHAIN_HANDOFF on any chain: the line says so by bit and the exit code is 1."""
+    r = subprocess.run([sys.executable, STUB, "--gpus", "1", "--steps", "1", "--warmup", "0", "--legs", "none"],
+                       env=_env(YMC_STUB_STATUS_BITS="2"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "internal device error" in r.stderr
+    out = json.loads(r.stdout.strip())
+    assert out["chains_flagged"]["internal"] == 32 and out["chains_flagged_nonfinite"] == 0
+
+
 def test_a_failing_rank_fails_the_launch():
     """Rank 1 dies before the rendezvous: rank 0 gives up at the store's timeout, the parent exits non-zero and
     prints no result line."""

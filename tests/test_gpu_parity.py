@@ -1954,6 +1954,48 @@ def test_lotka_volterra_launch_in_handover_pieces(ffi, ctx, monkeypatch, pieces,
     assert np.array_equal(thin.summary()["wf_mean"], e.wf_mean) and np.array_equal(thin.summary()["accepted"], e.acc_count)
 
 
+def test_an_abandoned_handover_fails_the_run(ffi, ctx, monkeypatch):
+    """a wave that gives up waiting for its predecessor's hand-over leaves transitions out of the
+    record -- an internal error, never data.  The poll limit is lowered through the test-only knob so that the give-up
+    path really runs: the chains carry YMC_CHAIN_HANDOFF, `ymc_run_sync` and every fetch of states return
+    YMC_ERR_DEVICE with a message (so `ensemble.run`, which syncs, raises), the summary (the status bits) stays
+    readable.  The reference aborts a chain whose evaluation failed with an exception (model/forwardModel.py:15-19)."""
+    monkeypatch.setenv("YMC_LV_ROWS", "1")
+    monkeypatch.setenv("YMC_LV_PIECES", "12")
+    monkeypatch.setenv("YMC_LV_POLL_LIMIT", "0")
+    from yagremcmc_amd import lowering
+    rng = np.random.default_rng(81)
+    design = rng.uniform(0.5, 1.5, size=(10, 2))
+    base = dict(noise_precision=np.array([25.0, 20.0]), prior_mean=np.array([0.1, -0.2]), prior_precision=np.array([0.7, 0.9]))
+    data = rng.uniform(0.2, 2.0, size=(10, 2))
+    low = _posterior_low(ffi, ffi.POSTERIOR_LV, 2, dict(base, data=data), design=design, t_final=10.0, alpha=0.8,
+                         gamma=0.4, rk4_steps=50)
+    K = 60
+    x0 = np.tile([[-0.6, -0.3]], (K, 1))
+    prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, np.array([0.4, 0.3]))
+    run = ffi.Run(prob, 17, K, x0, 300, _flags(ffi, True))
+    run.advance(300)
+    with pytest.raises(ffi.YmcError, match="internal device error.*YMC_CHAIN_HANDOFF") as err:
+        run.sync()
+    assert err.value.code == ffi.ERR_DEVICE
+    for fetch in (run.trajectory, run.accept, run.logpost, run.state):
+        with pytest.raises(ffi.YmcError, match="internal device error"):
+            fetch()
+    status = run.summary()["status"]
+    assert (status & ffi.CHAIN_HANDOFF).any() and not (status & ffi.CHAIN_NONFINITE).any()
+    # sticky: a later launch does not make the record whole again
+    monkeypatch.setenv("YMC_LV_POLL_LIMIT", str(1 << 22))
+    run.rewind_record()
+    run.advance(300)
+    with pytest.raises(ffi.YmcError, match="internal device error"):
+        run.sync()
+    # a fresh run of the same problem with the product's limit is fine
+    good = ffi.Run(prob, 17, K, x0, 300, _flags(ffi, True))
+    good.advance(300)
+    good.sync()
+    assert not good.summary()["status"].any()
+
+
 @pytest.mark.parametrize("rows", ["0", "1"])
 def test_lotka_volterra_row_parallel_variant(ffi, ctx, golden, monkeypatch, rows):
     """One lane per chain vs one lane per (chain, design row): a speed choice, same bits."""

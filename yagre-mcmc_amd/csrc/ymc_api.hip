@@ -182,6 +182,8 @@ struct ymc_run {
     DeviceBuf x, lp, lpc, acc_count, wf_mean, wf_m2, status, traj, acc, lp_out, sub_acc, summary, x_before, recip;
     DeviceBuf level_acc; /* MLDA_NESTED: [E-1][K] */
     DeviceBuf handoff;   /* Lotka-Volterra rows kernel in hand-over pieces: transitions published per chain wave */
+    PinnedBuf fault;     /* ... and the count of hand-overs a wave gave up on (YMC_CHAIN_HANDOFF): one word of page-locked
+                          * host memory the kernel adds to with a system-scope atomic, read by the host without a copy */
     DeviceBuf x_tiled;   /* two-level tile kernel: the carried state in the record's tiled layout */
     DeviceBuf w_tiled;   /* dense proposal on the tile kernel: L xi in the record's tiled layout */
     DeviceBuf err_n, err_mean, err_m2, aem_prec, aem_flags, cache_key, cache_val; /* AEM2 */
@@ -553,9 +555,17 @@ int launch_advance(ymc_run *r, uint64_t nsteps)
                 if (len <= nsteps && 2 * len >= nsteps && pieces < (1ull << 31)) {
                     if (r->handoff.bytes < G * sizeof(uint32_t)) YMC_TRY(r->handoff.alloc(G * sizeof(uint32_t)));
                     YMC_HIP(hipMemsetAsync(r->handoff.p, 0, G * sizeof(uint32_t), r->ctx->stream));
+                    if (!r->fault.p) { /* sticky for the run's lifetime: a record with a hole never turns good again */
+                        YMC_TRY(r->fault.reserve(sizeof(uint32_t)));
+                        *static_cast<volatile uint32_t *>(r->fault.p) = 0u;
+                    }
                     a.lv_pieces = (int32_t)pieces;
                     a.lv_piece_len = (uint32_t)len;
                     a.handoff = r->handoff.as<uint32_t>();
+                    a.fault = static_cast<uint32_t *>(r->fault.p);
+                    a.lv_poll_limit = 1u << 22;
+                    /* test-only: YMC_LV_POLL_LIMIT lowers the limit so that the give-up path runs (tests/test_gpu_parity.py) */
+                    if (const char *env = std::getenv("YMC_LV_POLL_LIMIT")) a.lv_poll_limit = (uint32_t)std::strtoul(env, nullptr, 10);
                 }
             }
         }
@@ -1118,6 +1128,19 @@ bool records_anything(uint32_t flags)
     return (flags & (YMC_RECORD_TRAJECTORY | YMC_RECORD_ACCEPT | YMC_RECORD_LOGPOST | YMC_RECORD_SUB_ACCEPT)) != 0;
 }
 
+/* An internal device error must not be delivered as data (the reference aborts a chain whose evaluation failed with
+ * an exception, model/forwardModel.py:15-19): after the stream has drained, a run whose launches were cut into
+ * hand-over pieces looks at its fault word (page-locked host memory; runs that never used pieces have none). */
+int check_internal_faults(ymc_run *r)
+{
+    if (!r->fault.p) return YMC_OK;
+    const uint32_t n = *static_cast<volatile const uint32_t *>(r->fault.p);
+    if (n)
+        return fail(YMC_ERR_DEVICE, "internal device error: %u chain waves gave up waiting for a hand-over "
+                                    "(YMC_CHAIN_HANDOFF): transitions are missing from the record of this run", n);
+    return YMC_OK;
+}
+
 int fetch_rows(ymc_run *r, const DeviceBuf &buf, uint32_t need_flag, const char *what, uint64_t first, uint64_t n,
                size_t row_bytes, void *dst, size_t dst_bytes)
 {
@@ -1129,6 +1152,7 @@ int fetch_rows(ymc_run *r, const DeviceBuf &buf, uint32_t need_flag, const char 
     if (dst_bytes < n * row_bytes) return fail(YMC_ERR_INVALID, "destination too small for %s", what);
     YMC_HIP(hipSetDevice(r->ctx->device));
     YMC_HIP(hipStreamSynchronize(r->ctx->stream));
+    YMC_TRY(check_internal_faults(r));
     if (n) YMC_HIP(hipMemcpy(dst, static_cast<const char *>(buf.p) + first * row_bytes, n * row_bytes, hipMemcpyDeviceToHost));
     return YMC_OK;
 }
@@ -1705,7 +1729,7 @@ int ymc_run_sync(ymc_run *run)
     if (!run) return fail(YMC_ERR_INVALID, "null argument");
     YMC_HIP(hipSetDevice(run->ctx->device));
     YMC_HIP(hipStreamSynchronize(run->ctx->stream));
-    return YMC_OK;
+    return check_internal_faults(run);
 }
 
 int ymc_run_kernel_time_ms(ymc_run *run, double *avg_ms, uint64_t *launches)
@@ -1859,6 +1883,7 @@ int ymc_run_fetch_state(ymc_run *run, double *state, double *logpost)
     if (!run) return fail(YMC_ERR_INVALID, "null argument");
     YMC_HIP(hipSetDevice(run->ctx->device));
     YMC_HIP(hipStreamSynchronize(run->ctx->stream));
+    YMC_TRY(check_internal_faults(run));
     if (state) YMC_HIP(hipMemcpy(state, run->x.p, run->x.bytes, hipMemcpyDeviceToHost));
     if (logpost) YMC_HIP(hipMemcpy(logpost, run->lp.p, run->lp.bytes, hipMemcpyDeviceToHost));
     return YMC_OK;
@@ -1942,6 +1967,7 @@ int ymc_run_egress_wait(ymc_run *run, int slot_index, ymc_egress_view *out)
     YMC_HIP(hipSetDevice(run->ctx->device));
     YMC_HIP(hipEventSynchronize(slot.done));
     slot.pending = false;
+    YMC_TRY(check_internal_faults(run));
     out->trajectory = (slot.what & YMC_RECORD_TRAJECTORY) ? static_cast<const double *>(slot.traj.p) : nullptr;
     out->accept = (slot.what & YMC_RECORD_ACCEPT) ? static_cast<const uint8_t *>(slot.acc.p) : nullptr;
     out->logpost = (slot.what & YMC_RECORD_LOGPOST) ? static_cast<const double *>(slot.lp.p) : nullptr;
@@ -2061,6 +2087,10 @@ int ymc_run_iat(ymc_run *run, uint64_t first, uint64_t n, int method, double sok
                     (unsigned long long)first, (unsigned long long)first, (unsigned long long)n,
                     (unsigned long long)run->recorded);
     YMC_HIP(hipSetDevice(run->ctx->device));
+    if (run->fault.p) {
+        YMC_HIP(hipStreamSynchronize(run->ctx->stream));
+        YMC_TRY(check_internal_faults(run));
+    }
     return iat_from_device_states(run->ctx, run->traj.as<double>(), first, n, run->K, run->problem->D, method,
                                   sokal_const, iat, run->problem->tile ? run->problem->tgt.KS : 0);
 }

@@ -23,6 +23,8 @@ struct ChainArgs {
     int32_t lv_pieces;
     uint32_t lv_piece_len;
     uint32_t *handoff;
+    uint32_t lv_poll_limit; /* polls of a predecessor's publication before a wave gives up (YMC_CHAIN_HANDOFF) */
+    uint32_t *fault;        /* the run's count of abandoned hand-overs: checked by ymc_run_sync and the fetch calls */
     int32_t split;       /* random walk, at most one wave of chains per SIMD: draws made by helper waves (same results) */
     uint32_t rec_stride, rec_since; /* thinned record (RecordClock): stride, transitions since the last recorded one */
     /* carried per-chain state */

@@ -610,7 +610,7 @@ __global__ __launch_bounds__(kBlock) void mrw_lv_rows_balanced_kernel(const Chai
                  * its working waves at every poll), one acquire fence after the loop */
                 while (__hip_atomic_load(a.handoff + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != nb) {
                     __builtin_amdgcn_s_sleep(127);
-                    if (++spins > (1u << 22)) {           /* tens of seconds: something is wrong, do not hang the device */
+                    if (++spins > a.lv_poll_limit) {      /* 2^22 polls = tens of seconds: something is wrong, do not hang the device */
                         ok = 0;
                         break;
                     }
@@ -622,6 +622,9 @@ __global__ __launch_bounds__(kBlock) void mrw_lv_rows_balanced_kernel(const Chai
                 const int nd = a.tgt.n_data, slot = lane / nd, row = lane - slot * nd;
                 const uint64_t k = g * cpw + slot;
                 if (slot < cpw && k < a.K && row == 0) a.status[k] |= YMC_CHAIN_HANDOFF;
+                /* the tail [nb, ne) of chain wave g is not run (nobody waits for a tail): the host turns the count
+                 * into a failed ymc_run_sync / fetch */
+                if (lane == 0) __hip_atomic_fetch_add(a.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 return;
             }
         }
