@@ -522,13 +522,17 @@ def test_aem_with_a_dense_prior_at_lane_sizes_vs_oracle(ffi, ctx):
     _same_error_model(dev, e)
 
 
+@pytest.mark.parametrize("build", ["matrix", "lds"])
 @pytest.mark.parametrize("name", ["f16_aem_linear_d128.npz", "f16b_aem_linear_d48_rows12.npz"])
-def test_f16_adaptive_error_model_d128_matrix_cores(ffi, ctx, golden, name):
+def test_f16_adaptive_error_model_d128_matrix_cores(ffi, ctx, golden, monkeypatch, name, build):
     """The adaptive error model on the matrix-core kernel (linear_tile_aem2_kernel: per-output error-model
     arrays in the tiled layout, cache keyed by the identity of the points): the live reference's chains at
     d = 128 (sha256) and at d = 48 with TWELVE data rows (two passes of eight rows over the coarse map), decisions of
-    both levels, what every chain learned; == oracle bit for bit."""
+    both levels, what every chain learned; == oracle bit for bit.  Both builds: the coarse matrix in LDS and the chains'
+    error model in HBM (default), and the error model in LDS with both matrices streamed (linear_tile_aem2_lds_kernel;
+    more than eight data rows keep the first)."""
     import hashlib
+    monkeypatch.setenv("YMC_TILE_AEM", build)
     g = golden(name)
     n, S = int(g["n_states"]), int(g["S"])
     common = dict(data=g["data"], noise_precision=g["noise_precision"], prior_mean=g["prior_mean"],
@@ -552,7 +556,9 @@ def test_f16_adaptive_error_model_d128_matrix_cores(ffi, ctx, golden, name):
 
 @pytest.mark.parametrize("d,m,nd,K", [(128, 128, 5, 70), (9, 3, 2, 33), (16, 40, 1, 64), (40, 70, 8, 50), (5, 30, 6, 40),
                                       (40, 70, 9, 50), (24, 33, 21, 40), (128, 96, 14, 36)])
-def test_tile_kernel_adaptive_error_model_other_shapes(ffi, ctx, d, m, nd, K):
+@pytest.mark.parametrize("build", ["matrix", "lds"])
+def test_tile_kernel_adaptive_error_model_other_shapes(ffi, ctx, monkeypatch, d, m, nd, K, build):
+    monkeypatch.setenv("YMC_TILE_AEM", build)
     rng = np.random.default_rng(40 + d + m)
     A = rng.normal(size=(m, d)) / np.sqrt(d)
     b = rng.normal(size=m) * 0.3

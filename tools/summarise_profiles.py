@@ -28,6 +28,9 @@ def main():
     wls = sys.argv[2:] or ["c2", "c3", "c3m", "c3a", "c5", "c4", "iat"]
     tpath = os.path.join(PROF, "pmc_traffic.json")
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    # YMC_PROFILE_VARIANT=name: a non-default build of the same workload (selected by an environment variable of the
+    # library while collecting) gets its own files and its own key, `<workload>_<name>_K..._T...`
+    variant = os.environ.get("YMC_PROFILE_VARIANT", "")
     for wl in wls:
         sdir = os.path.join(OUT, f"prof_{wl}_stats")
         if not os.path.isdir(sdir):
@@ -36,7 +39,8 @@ def main():
         cfg = line["config"]
         K = cfg["chains_per_gpu"]
         T = cfg.get("transitions_per_launch") or cfg.get("transitions_per_step") or cfg.get("states")
-        stem = os.path.join(PROF, f"{tag}_{wl}_K{K}_T{T}")
+        label = f"{wl}_{variant}" if variant else wl
+        stem = os.path.join(PROF, f"{tag}_{label}_K{K}_T{T}")
         rows = list(csv.DictReader(open(one(os.path.join(sdir, "**", "*_kernel_stats.csv")))))
         with open(stem + "_kernel_stats.csv", "w", newline="") as f:
             w = csv.DictWriter(f, fieldnames=list(rows[0].keys()), quoting=csv.QUOTE_NONNUMERIC)
@@ -70,7 +74,7 @@ def main():
         med = {k: sorted(v)[len(v) // 2] for k, v in sums.items()}
         if "WRITE_SIZE" in med and "FETCH_SIZE" in med:
             d = 128 if wl.startswith("c3") else 2
-            traffic[f"{wl}_K{K}_T{T}"] = {
+            traffic[f"{label}_K{K}_T{T}"] = {
                 "hbm_bytes_per_launch": med["WRITE_SIZE"] * 1024 + 2 * med["FETCH_SIZE"] * 1024,
                 "WRITE_SIZE_KB": med["WRITE_SIZE"], "FETCH_SIZE_KB_raw": med["FETCH_SIZE"],
                 "correction": "bytes = WRITE_SIZE*1024 + 2*FETCH_SIZE*1024 (gfx950: FETCH_SIZE reports half of a "

@@ -169,6 +169,7 @@ struct ymc_problem {
     int lvl_steps[YMC_MAX_LEVELS] = {};
     uint64_t lvl_cost[YMC_MAX_LEVELS] = {}; /* transitions one step of level e spans */
     DeviceBuf lvlP_dev, lvlQ_dev;                     /* DensityDev<D>[E] each */
+    DeviceBuf aem_pair_blob; /* matrix-core adaptive error model: both levels' A fragments interleaved pair by pair (TileArgs::blob_fc) */
     DeviceBuf tile_levels;                            /* matrix-core path: TileLevel[2 E], P / Q of level l at 2 l, 2 l + 1 */
 };
 
@@ -797,6 +798,21 @@ int build_aem_rows(DensityHost &h)
     return YMC_OK;
 }
 
+/* fine tiles 2p, 2p + 1 | coarse tiles 2p, 2p + 1 for every pair p: what the fine pass of linear_tile_aem2_lds_kernel streams */
+int build_aem_pair_blob(ymc_problem *p)
+{
+    const DensityHost &f = p->tgt, &c = p->sur;
+    if (f.MT != c.MT || f.KS != c.KS || (f.MT & 1)) return YMC_OK; /* the kernel then keeps the coarse matrix in LDS */
+    const size_t pair = 2 * (size_t)f.KS * 64 * sizeof(double);
+    YMC_TRY(p->aem_pair_blob.alloc(2 * (size_t)f.MT * f.KS * 64 * sizeof(double)));
+    for (int q = 0; q < f.MT / 2; ++q) {
+        char *dst = static_cast<char *>(p->aem_pair_blob.p) + 2 * (size_t)q * pair;
+        YMC_HIP(hipMemcpy(dst, static_cast<const char *>(f.tile_blob.p) + (size_t)q * pair, pair, hipMemcpyDeviceToDevice));
+        YMC_HIP(hipMemcpy(dst + pair, static_cast<const char *>(c.tile_blob.p) + (size_t)q * pair, pair, hipMemcpyDeviceToDevice));
+    }
+    return YMC_OK;
+}
+
 uint64_t tiled_row_doubles(const ymc_run *r)
 {
     return ((r->K + 15) / 16) * (uint64_t)r->problem->tgt.KS * 64;
@@ -1064,6 +1080,7 @@ int launch_advance_tile(ymc_run *r, uint64_t nsteps)
         a.min_data = p->aem_min_data;
         a.use_heuristic = p->aem_heuristic;
         a.aem_rows = h.aem_rows.as<double>();
+        a.blob_fc = p->aem_pair_blob.as<double>();
         a.err_n = r->err_n.as<uint64_t>();
         a.err_mean_t = r->err_mean.as<double>();
         a.err_m2_t = r->err_m2.as<double>();
@@ -1452,6 +1469,7 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
         if (rc == YMC_OK) rc = build_tile_blob(p, p->tgt);
         if (rc == YMC_OK && two) rc = build_tile_blob(p, p->sur);
         if (rc == YMC_OK && p->method == YMC_METHOD_AEM2) rc = build_aem_rows(p->sur);
+        if (rc == YMC_OK && p->method == YMC_METHOD_AEM2) rc = build_aem_pair_blob(p);
         if (rc == YMC_OK && p->method == YMC_METHOD_MLDA_NESTED) {
             /* level 0's posterior is staged in LDS whole where it fits (its matrix streamed otherwise); the posteriors
              * of the levels above are read from global memory through a table of blocks */

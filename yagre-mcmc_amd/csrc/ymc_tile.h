@@ -61,7 +61,10 @@ struct TileArgs {
     const double *aem_rows;  /* noise precision [m_pad] | data rows [n_data][m_pad] of the coarse level */
     uint64_t *err_n;         /* [K] accepted fine proposals */
     double *err_mean_t, *err_m2_t, *prec_t;
-    double *err_mean_alt_t, *err_m2_alt_t; /* the second copy of mean / M2 (the kernel updates into the copy a chain is not reading) */
+    double *err_mean_alt_t, *err_m2_alt_t; /* the second copy of mean / M2 (the kernel updates into the copy a chain is not reading;
+                                            * the LDS-resident build parks the model error of a fine proposal in the first) */
+    const double *blob_fc;   /* both levels' A fragments interleaved pair by pair: fine tiles 2p, 2p + 1, coarse tiles 2p, 2p + 1
+                              * ([2 MT][KS][64]; one stream for the fine pass), or null */
     int32_t *aem_flags;      /* [K][2] {precision set, cache fill} */
     uint64_t *cache_id;      /* [K][4]: the three cached points' ids (oldest first) and the carried state's id */
     double *cache_val;       /* [K][3] */

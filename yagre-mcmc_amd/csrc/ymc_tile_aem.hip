@@ -503,6 +503,415 @@ __global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_kernel(const Til
     }
 }
 
+/*
+ * The same sampler with the chains' ERROR MODEL resident in LDS (round 4).  The kernel above keeps the coarse matrix in
+ * LDS and reads a chain's learned state -- mean shift and inflated precision, 2 KB at 128 outputs -- from HBM at every
+ * coarse evaluation: 25 x the record's bytes at C3's shape, the state of 65 536 chains being far beyond any cache.
+ * Here the roles are swapped: what is PER CHAIN lives in LDS for the whole launch (mean | precision of the workgroup's 64
+ * chains: 128 KB), what is THE SAME FOR EVERY CHAIN -- both forward matrices, L2-resident -- streams through the
+ * workgroup's shared double buffer (ymc_stream_tile_pairs).  The Welford M2 stays in the run's array: only an ACCEPTED
+ * fine proposal touches it, so the update (estimation.py:36-53) is no longer prepared for every chain on every fine step
+ * but applied after the decision by the accepting chains, from the model error F_fine - F_coarse the fine pass parked in
+ * a scratch (1 KB per chain and fine step, the only per-step traffic besides the record).  The fine pass streams the two
+ * matrices interleaved pair by pair (blob_fc: fine tiles 2p, 2p + 1, coarse tiles 2p, 2p + 1), one stream for both maps.
+ * The four waves run in lockstep (every stream is a workgroup matter): a cache miss anywhere in the workgroup evaluates
+ * the current-model likelihood in all four waves, and only the chains that missed take the value -- per chain the same
+ * queries, the same values, the same bits as above.
+ */
+template <int KS, int DIV>
+__global__ __launch_bounds__(kAemThreads) void linear_tile_aem2_lds_kernel(const TileArgs a)
+{
+    static_assert(KS % DIV == 0, "staged units are whole k-steps");
+    ymc_stage_tables();
+    extern __shared__ double lds[];
+    const int MT = a.MT, m_pad = 16 * MT, d_pad = 4 * KS, Q = 4 * MT; /* both levels have a.m outputs */
+    /* constants: coarse bias | coarse prior mean | prior prec | sigma | fine bias | n * noise_prec | row mean | fine prior
+     * mean | prior prec | coarse noise precision | coarse data rows [n_data][m_pad] */
+    double *bias_c = lds;
+    double *pmean_c = bias_c + m_pad;
+    double *pprec_c = pmean_c + d_pad;
+    double *sigma = pprec_c + d_pad;
+    double *bias_f = sigma + d_pad;
+    const double *nprec_f = bias_f + m_pad;
+    const double *dbar_f = nprec_f + m_pad;
+    const double *pmean_f = dbar_f + m_pad;
+    const double *pprec_f = pmean_f + d_pad;
+    double *nprec_c = bias_f + 3 * m_pad + 2 * d_pad;
+    double *inv_nprec_c = nprec_c + m_pad;                    /* 1 / noise precision: the data variance of noise.py:51-53 */
+    double *data_c = inv_nprec_c + m_pad;
+    const size_t rows_c = (size_t)m_pad * (size_t)a.n_data;
+    double *em_all = data_c + rows_c;                         /* [waves][Q][64] mean of the model error */
+    double *ep_all = em_all + (size_t)kAemWaves * Q * 64;     /* [waves][Q][64] inflated precision */
+    double *stage = ep_all + (size_t)kAemWaves * Q * 64;      /* the streams' double buffer */
+    int *vote = reinterpret_cast<int *>(stage + 2 * ymc_stream_unit<KS, DIV>());
+
+    const int tid = threadIdx.x;
+    {
+        const double *cc = a.blob + (size_t)MT * KS * 64;       /* bias | n prec | row mean | prior mean | prior prec | sigma */
+        const double *fc = a.blob_f + (size_t)MT * KS * 64;
+        for (int i = tid; i < m_pad; i += kAemThreads) bias_c[i] = cc[i];
+        for (int i = tid; i < 3 * d_pad; i += kAemThreads) pmean_c[i] = cc[3 * (size_t)m_pad + i];
+        for (int i = tid; i < 3 * m_pad + 2 * d_pad; i += kAemThreads) bias_f[i] = fc[i];
+        for (int i = tid; i < m_pad; i += kAemThreads) {
+            const double np = a.aem_rows[i];
+            nprec_c[i] = np;
+            inv_nprec_c[i] = 1.0 / np; /* padding: 1 / 0, never read */
+        }
+        for (size_t i = tid; i < rows_c; i += kAemThreads) data_c[i] = a.aem_rows[(size_t)m_pad + i];
+        if (tid < 3) vote[tid] = 0;
+    }
+
+    const int lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
+    const uint64_t nct = (a.K + 15) / 16;
+    const uint64_t tile_raw = (uint64_t)blockIdx.x * kAemWaves + wave;
+    const bool wave_live = tile_raw < nct;
+    const uint64_t tile = wave_live ? tile_raw : 0; /* a wave past the last tile reads tile 0's arrays and writes nothing */
+    const uint64_t k = tile_raw * 16 + c;
+    const bool live = wave_live && k < a.K;
+    const uint64_t kk = live ? k : 0;
+    const uint32_t chain = (uint32_t)(a.chain0 + kk);
+    const int d = a.d, S = a.S, m_real = a.m;
+    const uint32_t pair_of_g = (g == 0) ? 0u : (g == 1) ? 2u : (g == 2) ? 1u : 3u;
+    double *xt = a.x_tiled + (tile * KS) * 64 + lane;
+    /* this lane's column of the per-output arrays: slot q = 4 mt + r <-> output 16 mt + 4 r + g */
+    double *const em = em_all + (size_t)wave * Q * 64 + lane, *const ep = ep_all + (size_t)wave * Q * 64 + lane;
+    double *const em_run = a.err_mean_t + (tile * Q) * 64 + lane, *const ep_run = a.prec_t + (tile * Q) * 64 + lane;
+    double *const e2 = a.err_m2_t + (tile * Q) * 64 + lane;
+    double *const escr = a.err_mean_alt_t + (tile * Q) * 64 + lane; /* F_fine - F_coarse of the current fine proposal */
+#pragma unroll 1
+    for (int q0 = 0; q0 < Q; q0 += 8) { /* Q is a multiple of 8 (MT is even) */
+        double mv[8], pv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mv[i] = em_run[(q0 + i) * 64], pv[i] = ep_run[(q0 + i) * 64];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) em[(q0 + i) * 64] = mv[i], ep[(q0 + i) * 64] = pv[i];
+    }
+    __syncthreads();
+
+    double z[KS], y[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int j = 4 * s + g;
+        z[s] = (live && j < d) ? a.x[k * d + j] : 0.0;
+        if (wave_live) xt[s * 64] = z[s];
+    }
+    double lpf = live ? a.lp[k] : 0.0;
+    uint64_t accepted = live ? a.acc_count[k] : 0;
+    uint32_t st = live ? a.status[k] : 0;
+    uint64_t n_err = a.err_n[kk];
+    bool has_prec = a.aem_flags[2 * kk] != 0;
+    AemCache cache;
+    cache.nkeys = a.aem_flags[2 * kk + 1];
+    cache.k0 = a.cache_id[kk * 4 + 0], cache.v0 = a.cache_val[kk * 3 + 0];
+    cache.k1 = a.cache_id[kk * 4 + 1], cache.v1 = a.cache_val[kk * 3 + 1];
+    cache.k2 = a.cache_id[kk * 4 + 2], cache.v2 = a.cache_val[kk * 3 + 2];
+    uint64_t x_id = a.cache_id[kk * 4 + 3];
+    UniformCache uc;
+    uc.valid = false;
+    uc.pair = 0;
+    RecordClock clk(a.rec_stride, a.rec_since);
+    uint32_t votes = 0;
+
+    /* does any chain of the WORKGROUP have `p`?  One barrier: call n writes slot n mod 3 and clears slot (n + 1) mod 3,
+     * which was last read before everybody's arrival at the previous call's barrier */
+    auto wg_any = [&](bool p) {
+        const uint32_t cur = votes % 3u, nxt = (votes + 1u) % 3u;
+        votes += 1u;
+        if (tid == 0) vote[nxt] = 0;
+        if (__builtin_amdgcn_ballot_w64(p) != 0 && lane == 0) vote[cur] = 1;
+        __syncthreads();
+        return vote[cur] != 0;
+    };
+    /* units of KS/8 k-steps (8 MFMAs) are shorter than a trip to L2: their fragments are requested two units ahead */
+    auto stream_pairs = [&](const double *A, int n_pairs, const double (&v)[KS], auto &&emit) {
+        if constexpr (DIV >= 8) ymc_stream_tile_pairs_ahead2<KS, DIV, kAemThreads>(A, n_pairs, stage, tid, lane, v, emit);
+        else ymc_stream_tile_pairs<KS, DIV, kAemThreads>(A, n_pairs, stage, tid, lane, v, emit);
+    };
+    /* AEMLikelihood.compute_log_likelihood under the CURRENT error model (likelihood.py:77-84, 128-133), the coarse matrix
+     * streamed: residual F - D_i (+ error mean once n >= minDataSize), norm in the (inflated) noise precision, row by row;
+     * every row's terms in the canonical four partial sums.  EVERY wave of the workgroup calls this together */
+    auto now = [&](const double (&v)[KS]) {
+        const bool shift = n_err >= (uint64_t)a.min_data;
+        static_assert(kAemRows == 8, "two 4-vectors of row sums");
+        const int nr = a.n_data;
+        d4 SA = {0.0, 0.0, 0.0, 0.0}, SB = {0.0, 0.0, 0.0, 0.0};
+        int row_off[kAemRows];
+#pragma unroll
+        for (int i = 0; i < kAemRows; ++i) row_off[i] = (i < nr ? i : nr - 1) * m_pad;
+        stream_pairs(a.blob, MT / 2, v, [&](int pair, const d4 &acc0, const d4 &acc1) {
+            const int mt = 2 * pair;
+            /* an output's reads wait for the sums of the one before the previous (the address passes through an empty asm
+             * that takes that sum as an input): two outputs' values in registers at most -- unbounded, the compiler hoists
+             * all 64 reads of a pair and spills (profiles/r03_tile_experiments.txt, experiment 9) */
+            double gate = 0.0, gate_next = 0.0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 16 * (mt + h) + 4 * r + g, q = 4 * (mt + h) + r;
+                    const double F = (h ? acc1[r] : acc0[r]) + bias_c[m];
+                    int mo = m;
+                    asm volatile("" : "+v"(mo) : "v"(gate));
+                    const double mean = shift ? em[q * 64] : 0.0;
+                    const double pe = has_prec ? ep[q * 64] : nprec_c[mo];
+                    double dv[kAemRows];
+#pragma unroll
+                    for (int i = 0; i < kAemRows; ++i) dv[i] = data_c[row_off[i] + mo];
+#pragma unroll
+                    for (int i = 0; i < kAemRows; ++i) {
+                        const double res = (F - dv[i]) + mean;
+                        const double px = pe * res;
+                        if (i < 4) SA[i & 3] = SA[i & 3] + res * px;
+                        else SB[i & 3] = SB[i & 3] + res * px;
+                    }
+                    gate = gate_next;
+                    gate_next = SA[0];
+                }
+            }
+        });
+        double total = 0.0;
+#pragma unroll
+        for (int i = 0; i < kAemRows; ++i)
+            if (i < nr) total = total + combine4(i < 4 ? SA[i & 3] : SB[i & 3]);
+        return -0.5 * total;
+    };
+    auto logprior = [&](const double *pmean, const double *pprec, const double (&v)[KS]) {
+        return ymc_tile_logprior<KS>(pmean, pprec, g, v);
+    };
+    auto any_differs = [&](const double (&p)[KS], const double (&q)[KS]) { return ymc_tile_any_differs<KS>(p, q); };
+    auto query = [&](uint64_t id, const double (&v)[KS], bool active) {
+        const int hit = cache.find(id);
+        const bool miss = active && hit < 0;
+        double fresh = 0.0;
+        if (wg_any(miss)) fresh = now(v);
+        return active ? cache.take(id, hit, fresh) : 0.0;
+    };
+    /* the fine likelihood of v (for the decision) and the model error F_fine(v) - F_coarse(v) (aem.py:44-56), parked for
+     * the chains that will accept: ONE stream of both matrices */
+    auto fine_likelihood_and_error = [&](const double (&v)[KS]) {
+        double Ssum = 0.0;
+        d4 f0 = {0.0, 0.0, 0.0, 0.0}, f1 = {0.0, 0.0, 0.0, 0.0};
+        stream_pairs(a.blob_fc, MT, v, [&](int P, const d4 &acc0, const d4 &acc1) {
+            if ((P & 1) == 0) {
+                f0 = acc0, f1 = acc1;
+                ymc_tile_add_residuals(P, acc0, acc1, bias_f, nprec_f, dbar_f, g, Ssum);
+            } else {
+                const int mt = P - 1;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = 16 * (mt + h) + 4 * r + g, q = 4 * (mt + h) + r;
+                        const double Ff = (h ? f1[r] : f0[r]) + bias_f[m];
+                        const double Fc = (h ? acc1[r] : acc0[r]) + bias_c[m];
+                        if (wave_live) escr[q * 64] = Ff - Fc;
+                    }
+                }
+            }
+        });
+        return -0.5 * (combine4(Ssum) + a.lik_const_f);
+    };
+    /* update_error_estimate for the chains with `mine` (likelihood.py:142-150, estimation.py:36-53): Welford step on every
+     * output from the parked model error, then -- beyond minDataSize -- the precision inflated from the new variances
+     * (noise.py:41-54) */
+    auto commit_error_model = [&](bool mine) {
+        const uint64_t n_new = n_err + 1;
+        const double dn = (double)n_new, nm1 = (double)(n_new - 1);
+        const bool inflate = n_new > (uint64_t)a.min_data;
+        double lo = 0.0, hi = 0.0;
+        bool first = true;
+        if (mine) {
+#pragma unroll 1
+            for (int q0 = 0; q0 < Q; q0 += 8) {
+                double ev[8], m2v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ev[i] = escr[(q0 + i) * 64], m2v[i] = e2[(q0 + i) * 64];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int q = q0 + i, m = 16 * (q >> 2) + 4 * (q & 3) + g;
+                    double mean = em[q * 64], m2 = m2v[i];
+                    const double delta = ev[i] - mean; /* estimation.py:36-53 */
+                    mean = mean + delta / dn;
+                    const double delta2 = ev[i] - mean;
+                    m2 = m2 + delta * delta2;
+                    if (m < m_real) {
+                        em[q * 64] = mean;
+                        e2[q * 64] = m2;
+                        m2v[i] = m2;
+                        const double mvar = m2 / nm1;
+                        lo = (first || mvar < lo) ? mvar : lo;
+                        hi = (first || mvar > hi) ? mvar : hi;
+                        first = false;
+                    }
+                }
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(mine && inflate) != 0) {
+            /* min / max of the marginal variances over ALL outputs of the chain: the four lanes' ranges joined
+             * (a lane without a real output holds none) */
+#pragma unroll
+            for (int mask = 16; mask <= 32; mask <<= 1) {
+                const double olo = shfl_xor_f64(lo, mask), ohi = shfl_xor_f64(hi, mask);
+                const int ofirst = __shfl_xor(first ? 1 : 0, mask, 64);
+                if (!ofirst) {
+                    lo = (first || olo < lo) ? olo : lo;
+                    hi = (first || ohi > hi) ? ohi : hi;
+                    first = false;
+                }
+            }
+            double scaling = 1.0;
+            if (a.use_heuristic) { /* noise.py:41-46 */
+                const double minval = lo > 1e-6 ? lo : 1e-6;
+                scaling = 2.0 * hi / minval;
+                scaling = scaling < 100.0 ? scaling : 100.0;
+            }
+            if (mine && inflate) {
+#pragma unroll 1
+                for (int q0 = 0; q0 < Q; q0 += 8) {
+                    double m2v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) m2v[i] = e2[(q0 + i) * 64];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int q = q0 + i, m = 16 * (q >> 2) + 4 * (q & 3) + g;
+                        if (m < m_real) {
+                            const double mvar = m2v[i] / nm1;
+                            ep[q * 64] = 1.0 / (scaling * mvar + inv_nprec_c[m]); /* noise.py:51-53, covariance.py:36-41 */
+                        }
+                    }
+                }
+                has_prec = true;
+            }
+        }
+        if (mine) n_err = n_new;
+    };
+
+    YMC_PROF_DECL;
+#pragma unroll 1
+    for (uint32_t n = 0; n < a.nsteps; ++n) {
+        const uint64_t tbase = (a.t0 + n) * (uint64_t)(S + 1);
+        uint64_t z_id = x_id;
+        YMC_PROF_START();
+        /* surrogate.run(S + 1, state), mlda.py:102-110 */
+#pragma unroll 1
+        for (int sub = 0; sub < S; ++sub) {
+            const uint64_t t = tbase + (uint64_t)sub;
+#pragma unroll
+            for (int q = 0; q < KS / 2; ++q) {
+                double xi0, xi1;
+                ymc_draw_normal_pair(a.seed, chain, t, 4u * (uint32_t)q + pair_of_g, &xi0, &xi1);
+                swap_odd_even_rows(xi0, xi1);
+                y[2 * q] = z[2 * q] + sigma[8 * q + g] * xi0;
+                y[2 * q + 1] = z[2 * q + 1] + sigma[8 * q + 4 + g] * xi1;
+            }
+            const double u = ymc_uniform_cached(uc, a.seed, chain, t);
+            const bool moved = wave_live && any_differs(y, z);
+            YMC_PROF(0);
+            /* mrw.py:51-57: evaluate_log(proposal), then evaluate_log(state) */
+            const uint64_t y_id = t + 1;
+            const double ly = query(y_id, y, moved) + logprior(pmean_c, pprec_c, y);
+            YMC_PROF(1);
+            const double lz = query(z_id, z, moved) + logprior(pmean_c, pprec_c, z);
+            YMC_PROF(2);
+            const bool acc = moved && ymc_accept(ly - lz, true, ymc_finite(ly), u, st);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) z[s] = acc ? y[s] : z[s];
+            z_id = acc ? y_id : z_id;
+            if (a.sub_acc && live && g == 0) a.sub_acc[((uint64_t)n * S + sub) * a.K + k] = acc ? 1 : 0;
+            YMC_PROF(3);
+        }
+        /* fine accept / reject, mlda.py:146-154: tgt(y), finest(x), finest(y), tgt(x); y <- the fine state x */
+#pragma unroll
+        for (int s = 0; s < KS; ++s) y[s] = wave_live ? xt[s * 64] : 0.0;
+        const double u = ymc_uniform_cached(uc, a.seed, chain, tbase + (uint64_t)S);
+        const bool moved = wave_live && any_differs(z, y);
+        YMC_PROF(4);
+        const double lpfy = fine_likelihood_and_error(z) + logprior(pmean_f, pprec_f, z);
+        YMC_PROF(5);
+        const double cx = query(x_id, y, moved) + logprior(pmean_c, pprec_c, y);
+        const double cy = query(z_id, z, moved) + logprior(pmean_c, pprec_c, z);
+        YMC_PROF(6);
+        const double log_ratio = ((lpfy + cx) - cy) - lpf;
+        const bool acc = wave_live && moved && ymc_accept(log_ratio, true, ymc_finite(lpfy) && ymc_finite(cy), u, st);
+        /* aem.py:26-56, before the chain moves */
+        if (__builtin_amdgcn_ballot_w64(acc) != 0) commit_error_model(acc);
+        YMC_PROF(7);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            z[s] = acc ? z[s] : y[s];
+            if (wave_live) xt[s * 64] = z[s];
+        }
+        lpf = acc ? lpfy : lpf;
+        x_id = acc ? z_id : x_id;
+        accepted += acc ? 1u : 0u;
+
+        const bool rec = clk.due();
+        if (rec && a.traj && wave_live) {
+            double *row = a.traj + (((uint64_t)clk.row * nct + tile) * KS) * 64 + lane;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) row[s * 64] = z[s];
+        }
+        if (live && g == 0) {
+            if (a.acc) a.acc[(uint64_t)n * a.K + k] = acc ? 1 : 0;
+            if (rec && a.lp_out) a.lp_out[(uint64_t)clk.row * a.K + k] = lpf;
+        }
+        if (rec) clk.wrote();
+        YMC_PROF(8);
+    }
+    YMC_PROF_FLUSH();
+
+    if (wave_live) { /* the learned state goes back to the run's arrays */
+#pragma unroll 1
+        for (int q0 = 0; q0 < Q; q0 += 8) {
+            double mv[8], pv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mv[i] = em[(q0 + i) * 64], pv[i] = ep[(q0 + i) * 64];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) em_run[(q0 + i) * 64] = mv[i], ep_run[(q0 + i) * 64] = pv[i];
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int j = 4 * s + g;
+            if (j < d) a.x[k * d + j] = z[s];
+        }
+        if (g == 0) {
+            a.lp[k] = lpf;
+            a.acc_count[k] = accepted;
+            a.status[k] = st;
+            a.err_n[k] = n_err;
+            a.aem_flags[2 * k] = has_prec ? 1 : 0;
+            a.aem_flags[2 * k + 1] = cache.nkeys;
+            a.cache_id[k * 4 + 0] = cache.k0, a.cache_val[k * 3 + 0] = cache.v0;
+            a.cache_id[k * 4 + 1] = cache.k1, a.cache_val[k * 3 + 1] = cache.v1;
+            a.cache_id[k * 4 + 2] = cache.k2, a.cache_val[k * 3 + 2] = cache.v2;
+            a.cache_id[k * 4 + 3] = x_id;
+        }
+    }
+}
+
+/* bytes of LDS the LDS-resident-error-model build wants with units of KS / div k-steps */
+size_t aem2_lds_resident_bytes(int KS, int MT, int n_data, int div)
+{
+    const size_t m_pad = 16 * (size_t)MT, d_pad = 4 * (size_t)KS, Q = 4 * (size_t)MT;
+    const size_t consts = 6 * m_pad + 5 * d_pad + m_pad * (size_t)n_data;
+    const size_t unit = 2 * (size_t)(KS / div) * 64;
+    return (consts + 2 * (size_t)kAemWaves * Q * 64 + 2 * unit) * sizeof(double) + 16;
+}
+
+template <int KS, int DIV>
+hipError_t launch_lds_model(const TileArgs &a, size_t lds, hipStream_t s)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_tile_aem2_lds_kernel<KS, DIV>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const uint64_t nct = (a.K + 15) / 16;
+    const unsigned grid = (unsigned)((nct + kAemWaves - 1) / kAemWaves);
+    hipLaunchKernelGGL((linear_tile_aem2_lds_kernel<KS, DIV>), dim3(grid), dim3(kAemThreads), lds, s, a);
+    return hipGetLastError();
+}
+
 template <int KS, int STG, bool ROWBLOCKS = false>
 hipError_t launch_staged(const TileArgs &a, size_t lds, hipStream_t s)
 {
@@ -522,6 +931,21 @@ hipError_t launch_as(const TileArgs &a, hipStream_t s)
      * results; YMC_TILE_STAGE=0 switches it off, the tests run both) */
     const size_t plain = ymc_tile_aem2_lds_bytes(KS, a.MT, a.n_data);
     if (a.n_data > kAemRows) return launch_staged<KS, 0, true>(a, plain, s);
+    /* YMC_TILE_AEM=lds: the chains' error model in LDS and both matrices streamed (identical results, the tests run both;
+     * 1/8 of the HBM traffic but 9 % slower at C3's shape -- profiles/r04_c3a_builds.txt -- so the coarse matrix in LDS
+     * stays the default) */
+    bool lds_model = false;
+    if (const char *env = std::getenv("YMC_TILE_AEM")) lds_model = a.blob_fc != nullptr && env[0] == 'l';
+    if (lds_model) {
+        /* the largest stream unit the LDS has room for (at d = m = 128: KS/8 k-steps; with the fine level's constants
+         * read from global memory instead KS/4 would fit -- measured: the fine pass then waits for them, 15.6 against
+         * 13.0 ms per launch of c3a) */
+        if (aem2_lds_resident_bytes(KS, a.MT, a.n_data, 4) <= kTileLdsLimit)
+            return launch_lds_model<KS, 4>(a, aem2_lds_resident_bytes(KS, a.MT, a.n_data, 4), s);
+        if constexpr (KS >= 8)
+            if (aem2_lds_resident_bytes(KS, a.MT, a.n_data, 8) <= kTileLdsLimit)
+                return launch_lds_model<KS, 8>(a, aem2_lds_resident_bytes(KS, a.MT, a.n_data, 8), s);
+    }
     const size_t unit4 = 2 * (size_t)ymc_stream_unit<KS, 4>() * sizeof(double);
     bool stage = true;
     if (const char *env = std::getenv("YMC_TILE_STAGE")) stage = env[0] != '0';

@@ -219,6 +219,54 @@ __device__ __forceinline__ void ymc_stream_tile_pairs(const double *__restrict__
     }
 }
 
+/* The same stream with every unit requested TWO units ahead (two register sets): with units of KS/8 k-steps the MFMAs of
+ * one unit (8 of them, ~530 cycles) are shorter than a trip to L2, so a request made one unit ahead is still in flight
+ * when its LDS write comes up and every unit stalls on it.  Same units, same buffers, same barrier, same MFMA order. */
+template <int KS, int DIV, int THREADS, typename Emit>
+__device__ __forceinline__ void ymc_stream_tile_pairs_ahead2(const double *__restrict__ A, int n_pairs, double *stage, int tid,
+                                                             int lane, const double (&v)[KS], Emit &&emit)
+{
+    static_assert(KS % DIV == 0, "staged units are whole k-steps");
+    static_assert(DIV % 2 == 0, "an even number of units per call (buffer and register-set parity)");
+    constexpr int kSteps = KS / DIV, kUnit = ymc_stream_unit<KS, DIV>(), kPer = (kUnit + THREADS - 1) / THREADS;
+    auto fetch = [&](int pair, int q, double (&r)[kPer]) {
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const int idx = tid + j * THREADS;
+            if (kUnit % THREADS == 0 || idx < kUnit) {
+                const int blk = idx / (kSteps * 64), off = idx % (kSteps * 64);
+                r[j] = A[((size_t)(2 * pair + blk) * KS + (size_t)q * kSteps) * 64 + off];
+            }
+        }
+    };
+    double r0[kPer], r1[kPer];
+    fetch(0, 0, r0);
+    if (DIV > 1) fetch(0, 1, r1);
+#pragma unroll 1
+    for (int pair = 0; pair < n_pairs; ++pair) {
+        d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < DIV; ++q) {
+            double *stg = stage + (q & 1) * kUnit;
+            double (&r)[kPer] = (q & 1) ? r1 : r0;
+#pragma unroll
+            for (int j = 0; j < kPer; ++j) {
+                const int idx = tid + j * THREADS;
+                if (kUnit % THREADS == 0 || idx < kUnit) stg[idx] = r[j];
+            }
+            __syncthreads();
+            if (q + 2 < DIV) fetch(pair, q + 2, r);
+            else if (pair + 1 < n_pairs) fetch(pair + 1, q + 2 - DIV, r);
+#pragma unroll
+            for (int sl = 0; sl < kSteps; ++sl) {
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(stg[sl * 64 + lane], v[q * kSteps + sl], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(stg[(kSteps + sl) * 64 + lane], v[q * kSteps + sl], acc1, 0, 0, 0);
+            }
+        }
+        emit(pair, acc0, acc1);
+    }
+}
+
 }  // namespace
 
 #endif /* YMC_TILE_DEV_H */
