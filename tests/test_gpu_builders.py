@@ -911,16 +911,18 @@ def _reference_iat(series, c=5.0):
     return 1
 
 
-@pytest.mark.parametrize("kernel", ["wave", "block"])
-@pytest.mark.parametrize("N", [2, 9, 77, 513, 1500, 4100])
+@pytest.mark.parametrize("kernel", ["resident", "wave", "block"])
+@pytest.mark.parametrize("N", [2, 9, 77, 513, 1500, 4100, 9800])
 def test_iat_kernels_on_ragged_series(monkeypatch, kernel, N):
-    """The wave-per-series kernel (register-blocked lags, LDS tiles of 512) and the workgroup-per-series one
+    """The persistent LDS-resident kernel (eight waves share a series' tiles, the next series requested into registers), the
+    wave-per-series kernel (register-blocked lags, LDS tiles of 512) and the workgroup-per-series one
     against the NumPy restatement of autocorrelation.py: lengths around the tile and lag-block sizes, slowly
-    and quickly decorrelating series (windows that close in the first block and after several)."""
+    and quickly decorrelating series (windows that close in the first block and after several), and more series than
+    the card has CUs (the persistent kernel's second lap)."""
     from yagremcmc_amd import _ffi
     monkeypatch.setenv("YMC_IAT_KERNEL", kernel)
     rng = np.random.default_rng(N)
-    S = 70
+    S = 70 if N != 1500 else 600
     phi = rng.uniform(0.0, 0.97, size=S)
     x = np.zeros((S, N))
     e = rng.standard_normal((S, N))
@@ -931,6 +933,26 @@ def test_iat_kernels_on_ragged_series(monkeypatch, kernel, N):
     got, _ = _ffi.default_context(0).iat_series(x)
     want = np.array([_reference_iat(x[s]) for s in range(S)])
     assert np.array_equal(got, want), (got - want)[got != want]
+
+
+@pytest.mark.parametrize("K,d,N", [(70, 1, 900), (300, 3, 700), (1000, 2, 2100)])
+def test_iat_of_many_chains_from_states(K, d, N):
+    """'max' and 'mean' on many chains through the transposition and the persistent LDS-resident kernel == the NumPy
+    restatement of autocorrelation.py per series (more series than the card has CUs: several laps per workgroup)."""
+    from yagremcmc_amd import _ffi
+    rng = np.random.default_rng(K + d)
+    phi = rng.uniform(0.0, 0.95, size=(K, d))
+    x = np.zeros((N, K, d))
+    e = rng.standard_normal((N, K, d))
+    x[0] = e[0]
+    for t in range(1, N):
+        x[t] = phi * x[t - 1] + e[t]
+    x += rng.normal(size=(1, K, d)) * 20.0
+    ctx = _ffi.default_context(0)
+    want = np.array([max(_reference_iat(x[:, k, j]) for j in range(d)) for k in range(K)])
+    assert np.array_equal(ctx.iat_states(x, 1), want)
+    want_mean = np.array([_reference_iat(np.mean(x[:, k, :], axis=1)) for k in range(K)])
+    assert np.array_equal(ctx.iat_states(x, 0), want_mean)
 
 
 @pytest.mark.parametrize("d", [8, 24, 128, 136, 200, 256])

@@ -2072,9 +2072,9 @@ int iat_from_device_states(ymc_ctx *ctx, const double *traj, uint64_t first, uin
     if (n < 2) return fail(YMC_ERR_INVALID, "a series needs at least two entries");
     const uint64_t per_chain = method == 0 ? 1 : (uint64_t)d, S = K * per_chain;
     DeviceBuf &series = ctx->post_series, &out = ctx->post_out;
-    if (series.bytes < S * n * sizeof(double)) YMC_TRY(series.alloc(S * n * sizeof(double)));
     if (out.bytes < S * sizeof(int32_t)) YMC_TRY(out.alloc(S * sizeof(int32_t)));
     hipStream_t st = ctx->stream;
+    if (series.bytes < S * n * sizeof(double)) YMC_TRY(series.alloc(S * n * sizeof(double)));
     YMC_HIP(ymc_launch_series_from_record(traj, first, n, K, d, tile_KS, method == 0, series.as<double>(), st));
     YMC_HIP(ymc_launch_iat(series.as<double>(), S, n, sokal_const, out.as<int32_t>(), nullptr, st));
     std::vector<int32_t> host(S);
@@ -2136,7 +2136,7 @@ int ymc_iat_series(ymc_ctx *ctx, const double *series, uint64_t n_series, uint64
     DeviceBuf dev, out, acf_dev;
     YMC_TRY(dev.alloc(n_series * length * sizeof(double)));
     YMC_TRY(out.alloc(n_series * sizeof(int32_t)));
-    YMC_HIP(hipMemcpyAsync(dev.p, series, dev.bytes, hipMemcpyHostToDevice, ctx->stream));
+    YMC_HIP(hipMemcpyAsync(dev.p, series, n_series * length * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     YMC_HIP(ymc_launch_iat(dev.as<double>(), n_series, length, sokal_const, out.as<int32_t>(), nullptr, ctx->stream));
     YMC_HIP(hipMemcpyAsync(iat, out.p, out.bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (acf && acf_lags) {

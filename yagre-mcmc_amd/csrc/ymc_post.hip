@@ -178,7 +178,7 @@ constexpr int kIatPer = 8;     /* consecutive elements per lane and tile */
 constexpr int kIatTile = 64 * kIatPer;
 constexpr int kIatNear = 96;   /* lag blocks starting at l0 <= kIatNear take both factors from one staged tile */
 
-__device__ __forceinline__ int iat_pad(int t) { return t + (t >> 3); } /* one spare double per 8: lane bases 9 apart */
+__host__ __device__ __forceinline__ int iat_pad(int t) { return t + (t >> 3); } /* one spare double per 8: lane bases 9 apart */
 
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -304,6 +304,173 @@ __global__ __launch_bounds__(64) void iat_wave_kernel(const double *__restrict__
     }
 }
 
+/*
+ * IAT of many series with every series read from HBM ONCE (round 4): a persistent workgroup of eight waves per CU keeps the
+ * centred series of the moment in LDS (padded as above: 88 KB for 9 800 states) and walks the lag blocks over it, the eight
+ * waves sharing a block's tiles; the NEXT series' elements are requested into registers before the lag sums start, so the
+ * trip to HBM hides behind them.  iat_wave_kernel re-reads its series once per block of 32 lags (4.0 x the algorithmic
+ * bytes at BASELINE's shape).  Per block: every wave reduces its 32 partial lag sums over its lanes (a butterfly that halves
+ * the values held at every step: v_permlane32_swap / v_permlane16_swap for the upper two), the eight waves' partials meet in
+ * LDS, and the window test runs lane-parallel (one division per lane, a prefix sum over the lags).  Sums are formed in
+ * another order than iat_wave_kernel's: values agree to rounding, the integer IAT except at exact ties.
+ */
+constexpr int kResWaves = 8, kResThreads = 64 * kResWaves;
+constexpr int kResTail = kIatTile + kIatLags + kIatPer + 8; /* zeros past the end: what a tile that still has partners reads */
+
+__device__ __forceinline__ double join_words(uint32_t lo, uint32_t hi) { return ymc_from_bits(((uint64_t)hi << 32) | lo); }
+
+/* 32 values per lane -> the sum over the wave's 64 lanes of value number lane / 2, in every lane */
+__device__ __forceinline__ double iat_butterfly(const double (&acc)[kIatLags], int lane)
+{
+    double r16[16], r8[8], r4[4], r2[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { /* lanes < 32 end up with value i of both halves, lanes >= 32 with value 16 + i */
+        const uint64_t a = ymc_bits(acc[i]), b = ymc_bits(acc[16 + i]);
+        const auto lo = __builtin_amdgcn_permlane32_swap((uint32_t)a, (uint32_t)b, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap((uint32_t)(a >> 32), (uint32_t)(b >> 32), false, false);
+        r16[i] = join_words(lo[0], hi[0]) + join_words(lo[1], hi[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { /* even rows of 16 lanes: value i, odd rows: value 8 + i */
+        const uint64_t a = ymc_bits(r16[i]), b = ymc_bits(r16[8 + i]);
+        const auto lo = __builtin_amdgcn_permlane16_swap((uint32_t)a, (uint32_t)b, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap((uint32_t)(a >> 32), (uint32_t)(b >> 32), false, false);
+        r8[i] = join_words(lo[0], hi[0]) + join_words(lo[1], hi[1]);
+    }
+    auto xchg = [&](double keep, double send, int mask) {
+        const uint64_t b = ymc_bits(send);
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)b, mask, 64);
+        const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(b >> 32), mask, 64);
+        return keep + join_words(lo, hi);
+    };
+    const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r4[i] = xchg(b3 ? r8[4 + i] : r8[i], b3 ? r8[i] : r8[4 + i], 8);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) r2[i] = xchg(b2 ? r4[2 + i] : r4[i], b2 ? r4[i] : r4[2 + i], 4);
+    const double r1 = xchg(b1 ? r2[1] : r2[0], b1 ? r2[0] : r2[1], 2);
+    return xchg(r1, r1, 1);
+}
+
+/* where the series live: element t of series s at base[s * series_step + t * stride]: the series-major scratch (N, 1).
+ * Measured and not kept (profiles/r04_iat.txt): 'max' mode straight from the record [row][K][d], whose column k d + j is
+ * series k d + j (1, K d), the workgroups of an XCD on neighbouring columns so that they share the 64-byte sectors in L2 --
+ * every element then sits on a row of its own a megabyte from the next, and the kernel took 21-23 ms where the transposition
+ * (4.9 ms) and the kernel on its output (10.3 ms) take 15 */
+struct SeriesSource {
+    const double *base;
+    uint64_t series_step, stride;
+};
+
+template <int NPER>
+__global__ __launch_bounds__(kResThreads) void iat_resident_kernel(const SeriesSource src, uint64_t n_series, uint64_t N64,
+                                                                   double sokal, int32_t *__restrict__ iat_out,
+                                                                   int32_t *__restrict__ lag_out)
+{
+    constexpr int L = kIatLags, P = kIatPer, TB = kIatTile, W = kResWaves;
+    extern __shared__ double xs[];          /* xs[iat_pad(t)] = x[t] - mean, 0 for N <= t < N + kResTail */
+    const int N = (int)N64;
+    double *part = xs + iat_pad(N + kResTail) + 8; /* [2][W][L]: the waves' partial lag sums of a block, by block parity */
+    double *wsum = part + 2 * W * L;               /* [W] */
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int t = N + tid; t < N + kResTail; t += kResThreads) xs[iat_pad(t)] = 0.0;
+
+    double nx[NPER];
+#pragma unroll
+    for (int j = 0; j < NPER; ++j) nx[j] = 0.0;
+    auto request = [&](uint64_t sidx) {
+        /* loads under the lanes' t < N and nothing else: a select on the loaded value would wait for it on the spot, and a
+         * spilled register anywhere in this kernel would too (scratch reloads count in vmcnt with these) */
+        const double *x = src.base + sidx * src.series_step + (uint64_t)tid * src.stride;
+#pragma unroll
+        for (int j = 0; j < NPER; ++j) {
+            if (tid + kResThreads * j < N) nx[j] = *x;
+            x += (uint64_t)kResThreads * src.stride;
+        }
+    };
+    const uint64_t G = gridDim.x, first = blockIdx.x;
+    uint64_t sidx = first;
+    if (sidx < n_series) request(sidx);
+    for (; sidx < n_series; sidx += G) {
+        double psum = 0.0;
+#pragma unroll
+        for (int j = 0; j < NPER; ++j) psum = psum + (tid + kResThreads * j < N ? nx[j] : 0.0);
+        const double ws = wave_sum(psum);
+        if (lane == 0) wsum[wave] = ws;
+        __syncthreads(); /* also: everybody has left the previous series */
+        const double mean = (((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) + ((wsum[4] + wsum[5]) + (wsum[6] + wsum[7]))) / (double)N;
+#pragma unroll
+        for (int j = 0; j < NPER; ++j) {
+            const int t = tid + kResThreads * j;
+            if (t < N) xs[iat_pad(t)] = nx[j] - mean;
+        }
+        __syncthreads();
+        if (sidx + G < n_series) request(sidx + G); /* in flight while this series is worked on */
+
+        double c0 = 0.0, cum = 1.0, iat_at = 1.0;
+        int stop = 0, par = 0;
+        bool found = false;
+        for (int l0 = 0; l0 < N && !found; l0 += L, par ^= 1) {
+            double acc[L];
+#pragma unroll
+            for (int l = 0; l < L; ++l) acc[l] = 0.0;
+            for (int T0 = wave * TB; T0 + l0 < N; T0 += W * TB) { /* tiles whose elements still have a partner at lag l0 */
+                const double *A = xs + iat_pad(T0 + P * lane), *B = xs + iat_pad(T0 + l0 + P * lane);
+                double a[P], w[L];
+#pragma unroll
+                for (int j = 0; j < P; ++j) a[j] = A[j];
+#pragma unroll
+                for (int l = 0; l < L; ++l) w[l] = B[iat_pad(l)];
+#pragma unroll
+                for (int j = 0; j < P; ++j) {
+                    /* w[(j + l) % L] holds x[T0 + l0 + P lane + j + l] for l = 0 .. L-1 */
+#pragma unroll
+                    for (int l = 0; l < L; ++l) acc[l] = ymc_fma(a[j], w[(j + l) % L], acc[l]);
+                    if (j + 1 < P) w[j % L] = B[iat_pad(j + L)];
+                }
+            }
+            const double mine = iat_butterfly(acc, lane);
+            if ((lane & 1) == 0) part[(par * W + wave) * L + (lane >> 1)] = mine;
+            __syncthreads();
+            /* the window test (autocorrelation.py:51-59, 85-89), lag l0 + (lane mod 32) in every lane */
+            const int li = lane & 31, lag = l0 + li;
+            const double *pp = part + par * W * L + li;
+            const double c = ((pp[0] + pp[L]) + (pp[2 * L] + pp[3 * L])) + ((pp[4 * L] + pp[5 * L]) + (pp[6 * L] + pp[7 * L]));
+            if (l0 == 0) c0 = join_words((uint32_t)__shfl((int)(uint32_t)ymc_bits(c), 0, 64),
+                                         (uint32_t)__shfl((int)(uint32_t)(ymc_bits(c) >> 32), 0, 64));
+            const bool counts = lag >= 1 && lag < N;
+            double pre = counts ? c / c0 : 0.0;
+#pragma unroll
+            for (int sft = 1; sft < 32; sft <<= 1) { /* inclusive prefix sum over the 32 lags */
+                const uint64_t b = ymc_bits(pre);
+                const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)b, sft, 32);
+                const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(b >> 32), sft, 32);
+                if (li >= sft) pre = pre + join_words(lo, hi);
+            }
+            const double cum_l = cum + pre, iat_l = 2.0 * cum_l - 1.0;
+            const bool closes = counts && !((double)lag < sokal * iat_l);
+            const uint32_t mask = (uint32_t)__builtin_amdgcn_ballot_w64(closes);
+            const int src = mask ? __builtin_ctz(mask) : 31;
+            const uint64_t pick = ymc_bits(mask ? iat_l : cum_l);
+            const double got = join_words((uint32_t)__shfl((int)(uint32_t)pick, src, 64),
+                                          (uint32_t)__shfl((int)(uint32_t)(pick >> 32), src, 64));
+            if (mask) {
+                found = true;
+                stop = l0 + src;
+                iat_at = got;
+            } else {
+                cum = got;
+            }
+        }
+        if (tid == 0) {
+            const double value = found ? iat_at : 1.0;
+            const bool defined = c0 > 0.0 && __builtin_fabs(value) < 2147483647.0;
+            iat_out[sidx] = defined ? (int32_t)__builtin_rint(value) : YMC_IAT_UNDEFINED;
+            if (lag_out) lag_out[sidx] = (int32_t)stop;
+        }
+    }
+}
+
 __global__ __launch_bounds__(kPostThreads) void iat_kernel(const double *__restrict__ series, uint64_t N, double sokal,
                                                            int32_t *__restrict__ iat_out, int32_t *__restrict__ lag_out)
 {
@@ -395,14 +562,42 @@ hipError_t ymc_launch_series_from_record(const double *traj, uint64_t row0, uint
     return hipGetLastError();
 }
 
+/* LDS of iat_resident_kernel for series of N states, or 0 if they do not fit */
+static size_t iat_resident_lds(uint64_t N)
+{
+    if (N > 20 * (uint64_t)kResThreads) return 0; /* the next series is held in 20 registers per thread while this one is worked on */
+    const size_t doubles = (size_t)iat_pad((int)N + kResTail) + 8 + 2 * kResWaves * kIatLags + kResWaves;
+    const size_t bytes = doubles * sizeof(double);
+    return bytes <= 160 * 1024 ? bytes : 0;
+}
+
+static hipError_t launch_resident(const SeriesSource &src, uint64_t S, uint64_t N, size_t lds, double sokal, int32_t *iat,
+                                  int32_t *lag, hipStream_t s)
+{
+    int dev = 0, cus = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return e;
+    const unsigned grid = (unsigned)(S < (uint64_t)cus ? S : (uint64_t)cus);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&iat_resident_kernel<20>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(iat_resident_kernel<20>, dim3(grid), dim3(kResThreads), lds, s, src, S, N, sokal, iat, lag);
+    return hipGetLastError();
+}
+
 hipError_t ymc_launch_iat(const double *series, uint64_t S, uint64_t N, double sokal, int32_t *iat, int32_t *lag,
                           hipStream_t s)
 {
-    /* many series: a wave each (register-blocked lags); a few long ones: a workgroup each with the series in LDS.
-     * YMC_IAT_KERNEL=wave|block overrides (tests run both) */
-    bool wave = S >= 64;
-    if (const char *env = std::getenv("YMC_IAT_KERNEL")) wave = env[0] == 'w';
-    if (wave) {
+    /* many series: a persistent workgroup per CU with the series of the moment in LDS (read from HBM once), or -- series
+     * that do not fit the LDS -- a wave each (register-blocked lags, the series re-read per block of lags); a few long
+     * ones: a workgroup each with the series in LDS.  YMC_IAT_KERNEL=resident|wave|block overrides (tests run all) */
+    const size_t res_lds = iat_resident_lds(N);
+    char pick = S >= 64 ? (res_lds ? 'r' : 'w') : 'b';
+    if (const char *env = std::getenv("YMC_IAT_KERNEL")) pick = env[0];
+    if (pick == 'r' && !res_lds) pick = 'w';
+    if (pick == 'r') return launch_resident(SeriesSource{series, N, 1}, S, N, res_lds, sokal, iat, lag, s);
+    if (pick == 'w') {
         hipLaunchKernelGGL(iat_wave_kernel, dim3((unsigned)S), dim3(64), 0, s, series, S, N, sokal, iat, lag);
         return hipGetLastError();
     }
