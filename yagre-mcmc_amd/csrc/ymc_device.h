@@ -303,6 +303,10 @@ struct UniformCache {
 
 __device__ __forceinline__ double ymc_uniform_cached(UniformCache &c, uint64_t seed, uint32_t chain, uint64_t t)
 {
+#if defined(YMC_DRAW_SPEC_V2X)
+    (void)c;
+    return ymc_draw_uniform(seed, chain, t); /* experiment: the transition's own block (shared with its first normal pair) */
+#endif
     uint64_t p = t >> 1;
     if (!c.valid || c.pair != p) { /* wave-uniform: t is the same in every lane */
         c.block = ymc_uniform_block(seed, chain, t);

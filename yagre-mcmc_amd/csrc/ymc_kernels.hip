@@ -153,9 +153,14 @@ __device__ __forceinline__ void mrw_body(const ChainArgs<D> &a)
     const uint32_t npairs = (a.nsteps - n) / 2;
 #pragma unroll 1
     for (uint32_t i = 0; i < npairs; ++i, n += 2) {
+#if defined(YMC_DRAW_SPEC_V2X)
+        transition(n, ymc_draw_uniform(a.seed, chain, a.t0 + n));
+        transition(n + 1, ymc_draw_uniform(a.seed, chain, a.t0 + n + 1));
+#else
         const ymc_u32x4 ub = ymc_uniform_block(a.seed, chain, a.t0 + n);
         transition(n, ymc_u01_co(ub.v[0], ub.v[1]));
         transition(n + 1, ymc_u01_co(ub.v[2], ub.v[3]));
+#endif
     }
     if (n < a.nsteps) transition(n, ymc_draw_uniform(a.seed, chain, a.t0 + n));
 
@@ -231,7 +236,11 @@ __global__ __launch_bounds__(256 * (NP + 1)) void mrw_split_kernel(const ChainAr
             const int q = 2 * p;
             const uint64_t t = a.t0 + (uint64_t)b * B + q;
             double u0, u1;
+#if defined(YMC_DRAW_SPEC_V2X)
+            if (false) {
+#else
             if (aligned) {
+#endif
                 const ymc_u32x4 ub = ymc_uniform_block(a.seed, chain, t);
                 u0 = ymc_u01_co(ub.v[0], ub.v[1]);
                 u1 = ymc_u01_co(ub.v[2], ub.v[3]);

@@ -151,8 +151,12 @@ __global__ __launch_bounds__(kBlock) YMC_MLDA2_ATTR void mlda2_static_kernel(con
             double lpcz = lpc;
             static_for<S + 1>([&](auto s_) {
                 constexpr int s = decltype(s_)::value, i = f * C + s;
+#if defined(YMC_DRAW_SPEC_V2X)
+                const double u = ymc_draw_uniform(a.seed, chain, tunit + i);
+#else
                 if constexpr ((i & 1) == 0) ub = ymc_uniform_block(a.seed, chain, tunit + i);
                 const double u = (i & 1) ? ymc_u01_co(ub.v[2], ub.v[3]) : ymc_u01_co(ub.v[0], ub.v[1]);
+#endif
                 if constexpr (s < S)
                     coarse(tunit + i, u, z, lpcz);
                 else

@@ -231,10 +231,26 @@ YMC_FN double ymc_uniform_from_block(ymc_u32x4 b, uint64_t t)
     return (t & 1u) ? ymc_u01_co(b.v[2], b.v[3]) : ymc_u01_co(b.v[0], b.v[1]);
 }
 
+#if defined(YMC_DRAW_SPEC_V2X)
+/* TIMING EXPERIMENT ONLY (make v2x, tools/ab_spec_v2.sh, profiles/r04_spec_v2.txt): a cheaper draw
+ * specification costed against the product's.  ONE Philox block per transition carries the first normal pair (two 42-bit
+ * mantissas: words 0, 1 + 10 bits each of word 3) AND the accept uniform (44 bits: word 2 + 12 bits of word 3); beyond the
+ * first pair three normal pairs share two blocks (40-bit mantissas).  Results differ from every fixture by construction. */
+YMC_FN double ymc_v2x_unit(uint32_t hi, uint32_t low, double low_scale, uint32_t add)
+{
+    return ymc_fma((double)hi, 0x1p-32, (double)(low + add) * low_scale);
+}
+#endif
+
 /* the accept/reject uniform of transition t (u ~ U[0,1), metropolisHastings.py:68) */
 YMC_FN double ymc_draw_uniform(uint64_t seed, uint32_t chain, uint64_t t)
 {
+#if defined(YMC_DRAW_SPEC_V2X)
+    ymc_u32x4 b = ymc_philox4x32_10(chain, 1u, (uint32_t)t, (uint32_t)(t >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
+    return ymc_v2x_unit(b.v[2], b.v[3] >> 20, 0x1p-44, 0u);
+#else
     return ymc_uniform_from_block(ymc_uniform_block(seed, chain, t), t);
+#endif
 }
 
 /* ------------------------------------------------------------------------ */
@@ -480,14 +496,43 @@ YMC_FN void ymc_draw_normal_pair(uint64_t seed, uint32_t chain, uint64_t t, uint
 {
     ymc_u32x4 b = ymc_philox4x32_10(chain, 1u + j, (uint32_t)t, (uint32_t)(t >> 32),
                                     (uint32_t)seed, (uint32_t)(seed >> 32));
+#if defined(YMC_DRAW_SPEC_V2X)
+    double u1 = ymc_v2x_unit(b.v[0], b.v[3] & 0x3ffu, 0x1p-42, 1u);
+    double u2 = ymc_v2x_unit(b.v[1], (b.v[3] >> 10) & 0x3ffu, 0x1p-42, 0u);
+#else
     double u1 = ymc_u01_oc(b.v[0], b.v[1]);           /* (0,1] */
     double u2 = ymc_u01_co(b.v[2], b.v[3]);           /* [0,1) */
+#endif
     double rad = ymc_sqrt_radius(-2.0 * ymc_log(u1));
     double sn, cs;
     ymc_sincospi(u2 + u2, &sn, &cs);
     *z0 = rad * cs;
     *z1 = rad * sn;
 }
+
+#if defined(YMC_DRAW_SPEC_V2X)
+/* experiment: the normal pairs j0, j0 + 1, j0 + 2 (as z[0..5]) of transition t from TWO blocks, 40-bit mantissas */
+YMC_FN void ymc_v2x_normal_triple(uint64_t seed, uint32_t chain, uint64_t t, uint32_t j0, double *za, double *zb, double *zc,
+                                  double *zd, double *ze, double *zf)
+{
+    ymc_u32x4 a = ymc_philox4x32_10(chain, 0x40000000u + j0, (uint32_t)t, (uint32_t)(t >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
+    ymc_u32x4 b = ymc_philox4x32_10(chain, 0x40000001u + j0, (uint32_t)t, (uint32_t)(t >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
+#define YMC_V2X_PAIR(o0, o1, h1, h2, l1, l2)                              \
+    {                                                                     \
+        double u1 = ymc_v2x_unit(h1, l1, 0x1p-40, 1u);                    \
+        double u2 = ymc_v2x_unit(h2, l2, 0x1p-40, 0u);                    \
+        double rad = ymc_sqrt_radius(-2.0 * ymc_log(u1));                 \
+        double sn, cs;                                                    \
+        ymc_sincospi(u2 + u2, &sn, &cs);                                  \
+        *(o0) = rad * cs;                                                 \
+        *(o1) = rad * sn;                                                 \
+    }
+    YMC_V2X_PAIR(za, zb, a.v[0], a.v[1], b.v[2] & 0xffu, (b.v[2] >> 8) & 0xffu)
+    YMC_V2X_PAIR(zc, zd, a.v[2], a.v[3], (b.v[2] >> 16) & 0xffu, b.v[2] >> 24)
+    YMC_V2X_PAIR(ze, zf, b.v[0], b.v[1], b.v[3] & 0xffu, (b.v[3] >> 8) & 0xffu)
+#undef YMC_V2X_PAIR
+}
+#endif
 
 /* ------------------------------------------------------------------------ */
 /* Gaussian-noise likelihood of a forward value F shared by all n data rows */

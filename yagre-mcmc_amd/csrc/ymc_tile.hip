@@ -115,13 +115,10 @@ __global__ __launch_bounds__(64 * WAVES) void linear_tile_kernel(const TileArgs 
         YMC_PHASE_DRAWS();
         /* proposal y = x + sigma * xi (mrw.py:32-38) in the MFMA operand layout */
         bool moved_l = false;
-#pragma unroll
-        for (int q = 0; q < KS / 2; ++q) {
-            /* even rows (g = 0, 2) drew the pair of components (8 q + g, 8 q + g + 1), odd rows that of
-             * (8 q + 3 + g, 8 q + 4 + g): an even row keeps its first normal and takes its partner's first,
-             * an odd row takes its partner's second and keeps its own second */
-            double xi0, xi1; /* components 8 q + g (s = 2 q) and 8 q + 4 + g (s = 2 q + 1) */
-            ymc_draw_normal_pair(a.seed, chain, t, 4u * (uint32_t)q + pair_of_g, &xi0, &xi1);
+        /* one pair of this lane: even rows (g = 0, 2) drew the pair of components (8 q + g, 8 q + g + 1), odd rows that of
+         * (8 q + 3 + g, 8 q + 4 + g): an even row keeps its first normal and takes its partner's first, an odd row takes
+         * its partner's second and keeps its own second */
+        auto place = [&](int q, double xi0, double xi1) { /* components 8 q + g (s = 2 q) and 8 q + 4 + g (s = 2 q + 1) */
             swap_odd_even_rows(xi0, xi1);
             if constexpr (DENSE) { /* dense proposal covariance: park xi in y, L xi follows below */
                 y[2 * q] = xi0;
@@ -136,7 +133,32 @@ __global__ __launch_bounds__(64 * WAVES) void linear_tile_kernel(const TileArgs 
                 y[2 * q + 1] = x[2 * q + 1] + sigma[8 * q + 4 + g] * xi1;
             }
             if constexpr (!DENSE) moved_l = moved_l || !(y[2 * q] == x[2 * q]) || !(y[2 * q + 1] == x[2 * q + 1]);
+        };
+#if defined(YMC_DRAW_SPEC_V2X)
+        /* experiment: this lane's pairs 3 i .. 3 i + 2 from two blocks, what is left over from blocks of their own */
+        constexpr int kTriples = (KS / 2) / 3;
+#pragma unroll
+        for (int i = 0; i < kTriples; ++i) {
+            double za, zb, zc, zd, ze, zf;
+            ymc_v2x_normal_triple(a.seed, chain, t, 64u * (uint32_t)i + pair_of_g, &za, &zb, &zc, &zd, &ze, &zf);
+            place(3 * i, za, zb);
+            place(3 * i + 1, zc, zd);
+            place(3 * i + 2, ze, zf);
         }
+#pragma unroll
+        for (int q = 3 * kTriples; q < KS / 2; ++q) {
+            double xi0, xi1;
+            ymc_draw_normal_pair(a.seed, chain, t, 4u * (uint32_t)q + pair_of_g, &xi0, &xi1);
+            place(q, xi0, xi1);
+        }
+#else
+#pragma unroll
+        for (int q = 0; q < KS / 2; ++q) {
+            double xi0, xi1;
+            ymc_draw_normal_pair(a.seed, chain, t, 4u * (uint32_t)q + pair_of_g, &xi0, &xi1);
+            place(q, xi0, xi1);
+        }
+#endif
         if constexpr (DENSE) {
             /* y = x + L xi (covariance.py:91-92, gaussian.py:66): row i of L xi is one k-ordered fma chain on the
              * matrix cores -- output 16 mt + 4 r + g of the accumulator IS component 4 s + g, s = 4 mt + r, of this
