@@ -1,96 +1,222 @@
-"""Linear forward model: random walk, two-level delayed acceptance over a model
-hierarchy, the same with the adaptive error model, and preconditioned
-Crank-Nicolson -- the ensemble version of the reference's
-example_inference_linearModel_twoLevel.py (same maps, prior, noise, proposal,
-minDataSize 100 with the noise heuristic)."""
+"""The reference's example_inference_linearModel_twoLevel.py on the device: the same sequence of calls with the
+builder imports switched and an ensemble size added --
+
+    target MRW -> surrogate MRW -> MLDA burn-in (sub-chain 2) from where the surrogate chains stopped
+    -> vanilla MLDA (sub-chain 5) from where the burn-in stopped -> MLDA with the adaptive error model from the same
+    states; every stage thinned by its integrated autocorrelation time ('mean' for the random walks, 'max' for the
+    delayed-acceptance chains) before its posterior mean is taken
+
+(/root/reference: example_inference_linearModel_twoLevel.py:24-304; same maps, data seed, prior, noise, proposal,
+minDataSize 100 with the noise heuristic).  K chains run each stage at once, a stage's chains start where THEIR
+predecessors stopped, and the IAT is taken per chain on the device from the record in HBM; the thinning stride of a stage
+is the median over its chains.  The plots of the reference's script need its host-side density grid and are left out.
+
+    python examples/example_inference_linearModel_twoLevel.py [nChains [nSteps]]
+"""
 import os
 import sys
 
 import numpy as np
+from numpy.random import seed, standard_normal
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-from yagremcmc_amd.chain.method.aem import AEMBuilder
-from yagremcmc_amd.chain.method.mlda import MLDABuilder
-from yagremcmc_amd.chain.method.mrw import MRWBuilder
-from yagremcmc_amd.chain.method.pcn import PCNBuilder
 from yagremcmc_amd.exampleSetup import ExampleLinearModelSolver
-from yagremcmc_amd.model.forwardModel import ForwardModel
 from yagremcmc_amd.parameter.vector import ParameterVector
-from yagremcmc_amd.statistics.bayesModel import BayesianRegressionModel
-from yagremcmc_amd.statistics.covariance import IIDCovarianceMatrix
+from yagremcmc_amd.model.forwardModel import ForwardModel
 from yagremcmc_amd.statistics.data import Data
+from yagremcmc_amd.statistics.covariance import IIDCovarianceMatrix
 from yagremcmc_amd.statistics.gaussian import Gaussian
-from yagremcmc_amd.statistics.likelihood import AdditiveGaussianNoiseLikelihood, AEMLikelihood
-from yagremcmc_amd.statistics.modelHierarchy import BayesianRegressionModelHierarchy
 from yagremcmc_amd.statistics.noise import CentredGaussianNoise
-from yagremcmc_amd.utility.hierarchy import Hierarchy, SharedComponent
+from yagremcmc_amd.statistics.likelihood import AdditiveGaussianNoiseLikelihood, AEMLikelihood
+from yagremcmc_amd.statistics.bayesModel import BayesianRegressionModel
+from yagremcmc_amd.statistics.modelHierarchy import BayesianRegressionModelHierarchy
+from yagremcmc_amd.utility.hierarchy import SharedComponent, Hierarchy
+from yagremcmc_amd.chain.method.mrw import MRWBuilder
+from yagremcmc_amd.chain.method.mlda import MLDABuilder
+from yagremcmc_amd.chain.method.aem import AEMBuilder
+from yagremcmc_amd.chain.diagnostics import FullDiagnostics
 
 nChains = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-nSteps = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
-np.random.seed(2222)
+nStepsAll = int(sys.argv[2]) if len(sys.argv) > 2 else 50000      # the reference's 50 000 per stage
+seed(2222)
 DIM = 2
 
+# -----------------------------------------------------------------------------
+#                             PROBLEM SETUP
+# -----------------------------------------------------------------------------
 tgtMap = np.array([[1.4, -0.2], [-0.6, 0.7]])
-surMap = tgtMap + np.array([[-0.6, -0.2], [0.4, 1.1]])
-tgtSolver = ExampleLinearModelSolver(tgtMap, np.zeros(DIM))
-surSolver = ExampleLinearModelSolver(surMap, np.array([0.5, -0.9]))
+tgtShift = np.zeros(DIM)
+tgtSolver = ExampleLinearModelSolver(tgtMap, tgtShift)
+
+surMapError = np.array([[-0.6, -0.2], [0.4, 1.1]])
+surMap = tgtMap + surMapError
+surShift = np.array([0.5, -0.9])
+surSolver = ExampleLinearModelSolver(surMap, surShift)
+
+tgtFwdModel = ForwardModel(tgtSolver)
+surFwdModel = ForwardModel(surSolver)
 
 trueParam = ParameterVector(np.array([1.5, 0.5]))
-noiseVar = 0.3
+dataNoiseStdDev = np.sqrt(0.3)
+nData = 5
+
 tgtSolver.interpolate(trueParam)
 tgtSolver.invoke()                                   # forward solve on the device
-data = Data(np.array([tgtSolver.evaluation + np.sqrt(noiseVar) * np.random.standard_normal(DIM) for _ in range(5)]))
+data = Data(np.array([tgtSolver.evaluation + dataNoiseStdDev * standard_normal(DIM) for _ in range(nData)]))
+assert data.size == nData and data.dim == DIM
 
-prior = Gaussian(ParameterVector(trueParam.coefficient + np.array([-0.2, 0.4])), IIDCovarianceMatrix(DIM, 5.))
-noise = CentredGaussianNoise(IIDCovarianceMatrix(DIM, noiseVar))
-surLikelihood = AdditiveGaussianNoiseLikelihood(data, ForwardModel(surSolver), noise)
-tgtLikelihood = AdditiveGaussianNoiseLikelihood(data, ForwardModel(tgtSolver), noise)
+# -----------------------------------------------------------------------------
+#                       BAYES MODEL DEFINITIONS
+# -----------------------------------------------------------------------------
+priorMean = ParameterVector(trueParam.coefficient + np.array([-0.2, 0.4]))
+prior = Gaussian(priorMean, IIDCovarianceMatrix(DIM, 5.))
+
+noiseModel = CentredGaussianNoise(IIDCovarianceMatrix(DIM, dataNoiseStdDev**2))
+
+vanillaSurLikelihood = AdditiveGaussianNoiseLikelihood(data, surFwdModel, noiseModel)
+vanillaTgtLikelihood = AdditiveGaussianNoiseLikelihood(data, tgtFwdModel, noiseModel)
+
+minDataSize = 100
+useNoiseHeuristic = True
+aemSurLikelihood = AEMLikelihood(data, surFwdModel, noiseModel, minDataSize, useNoiseHeuristic)
+aemTgtLikelihood = AEMLikelihood(data, tgtFwdModel, noiseModel, minDataSize, useNoiseHeuristic)
+
+nLevels = 2
+prior = SharedComponent(prior, nLevels)
+vanillaLikelihood = Hierarchy([vanillaSurLikelihood, vanillaTgtLikelihood])
+aemLikelihood = Hierarchy([aemSurLikelihood, aemTgtLikelihood])
+
+tgtModel = BayesianRegressionModel(vanillaTgtLikelihood, prior.level(0))
+surModel = BayesianRegressionModel(vanillaSurLikelihood, prior.level(0))
+vanillaModel = BayesianRegressionModelHierarchy(vanillaLikelihood, prior)
+aemModel = BayesianRegressionModelHierarchy(aemLikelihood, prior)
+
+# -----------------------------------------------------------------------------
+#                             MCMC SETUP
+# -----------------------------------------------------------------------------
 proposalCov = IIDCovarianceMatrix(DIM, 0.5)
-init = ParameterVector(np.zeros(DIM))
+
+tgtBuilder = MRWBuilder()
+tgtBuilder.proposalCovariance = proposalCov
+tgtBuilder.bayesModel = tgtModel
+tgtBuilder.nChains = nChains
+print("\nrequest building target mrw")
+tgtMRW = tgtBuilder.build_method()
+
+surBuilder = MRWBuilder()
+surBuilder.proposalCovariance = proposalCov
+surBuilder.bayesModel = surModel
+surBuilder.nChains = nChains
+print("\nrequest building surrogate mrw")
+surMRW = surBuilder.build_method()
+
+mldaBuilder = MLDABuilder()
+mldaBuilder.baseProposalCovariance = proposalCov
+mldaBuilder.subChainLengths = [2]
+mldaBuilder.bayesModel = vanillaModel
+mldaBuilder.nChains = nChains
+print("\nrequest building burn-in mlda")
+mldaBurnin = mldaBuilder.build_method()
+
+mldaBuilder = MLDABuilder()
+mldaBuilder.baseProposalCovariance = proposalCov
+mldaBuilder.subChainLengths = [5]
+mldaBuilder.bayesModel = vanillaModel
+mldaBuilder.nChains = nChains
+print("\nrequest building vanilla mlda")
+vanillaMLDA = mldaBuilder.build_method()
+
+aemBuilder = AEMBuilder()
+aemBuilder.baseProposalCovariance = proposalCov
+aemBuilder.subChainLengths = [5]
+aemBuilder.bayesModel = aemModel
+aemBuilder.targetDiagnostics = FullDiagnostics()
+aemBuilder.nChains = nChains
+print("\nrequest building aem mlda")
+aemMLDA = aemBuilder.build_method()
 
 
-def report(name, mc, burnin=None):
-    burnin = min(500, nSteps // 4) if burnin is None else burnin
-    states = mc.chain.ensemble_trajectory
-    # a chain that did not move after the burn-in has no autocorrelation (short runs of a sampler with a poor
-    # surrogate): ask for the marker instead of the error and say how many there were
-    iat = np.atleast_1d(mc.integrated_autocorrelation('mean', burnin=burnin, allowUndefined=True))
-    moved = iat != np.iinfo(np.int32).min
-    stuck = "" if moved.all() else f"   ({int((~moved).sum())} chains did not move after the burn-in)"
-    print(f"{name:28s} acceptance rate {mc.diagnostics.global_acceptance_rate():.3f}   posterior mean "
-          f"{states[burnin:].reshape(-1, DIM).mean(axis=0)}   median IAT {np.median(iat[moved]):.0f}{stuck}")
+# -----------------------------------------------------------------------------
+#                                INFERENCE
+# -----------------------------------------------------------------------------
+def thinned_mean(mc, method, burnin):
+    """the reference's `integrated_autocorrelation(states, method)` + `np.mean(states[burnin::thinning], axis=0)`,
+    per chain on the device; the stage's stride is the median over its chains, the mean is over all of them"""
+    iat = np.atleast_1d(mc.integrated_autocorrelation(method, allowUndefined=True))
+    moved = iat != np.iinfo(np.int32).min          # a chain that never moved has no autocorrelation
+    thinning = max(int(np.median(iat[moved])), 1) if moved.any() else 1
+    states = mc.chain.ensemble_trajectory          # (n, K, d)
+    return thinning, states[burnin::thinning].reshape(-1, DIM).mean(axis=0)
 
 
-mrw = MRWBuilder()
-mrw.proposalCovariance, mrw.bayesModel, mrw.nChains = proposalCov, BayesianRegressionModel(tgtLikelihood, prior), nChains
-tgtMRW = mrw.build_method()
-tgtMRW.run(nSteps, init, verbose=False)
-report("target MRW", tgtMRW)
+tgtNSteps = nStepsAll
+tgtBurnin = min(500, tgtNSteps // 4)
+initState = ParameterVector(np.zeros(DIM))
 
-mlda = MLDABuilder()
-mlda.baseProposalCovariance, mlda.subChainLengths, mlda.nChains = proposalCov, [5], nChains
-mlda.bayesModel = BayesianRegressionModelHierarchy(Hierarchy([surLikelihood, tgtLikelihood]), SharedComponent(prior, 2))
-vanillaMLDA = mlda.build_method()
-vanillaMLDA.run(nSteps, init, verbose=False)
-report("vanilla MLDA (sub-chain 5)", vanillaMLDA)
+print(f"\nRunning {tgtNSteps} steps of the target MRW ({nChains} chains)")
+tgtMRW.run(tgtNSteps, initState, verbose=False)
+tgtThinning, tgtMean = thinned_mean(tgtMRW, 'mean', tgtBurnin)
+tgtAccPr = tgtMRW.diagnostics.global_acceptance_rate()
 
-aemSur = AEMLikelihood(data, ForwardModel(surSolver), noise, 100, True)
-aemTgt = AEMLikelihood(data, ForwardModel(tgtSolver), noise, 100, True)
-aem = AEMBuilder()
-aem.baseProposalCovariance, aem.subChainLengths, aem.nChains = proposalCov, [5], nChains
-aem.bayesModel = BayesianRegressionModelHierarchy(Hierarchy([aemSur, aemTgt]), SharedComponent(prior, 2))
-aemMLDA = aem.build_method()
-aemMLDA.run(nSteps, init, verbose=False)
-report("MLDA + adaptive error model", aemMLDA)
-em = aemMLDA.error_model()
-print(f"{'':28s} chains past minDataSize: {int(em['has_precision'].sum())} of {nChains}; learned error mean "
-      f"(median over chains) {np.median(em['mean'], axis=0)}")
+surNSteps = nStepsAll
+surBurnin = min(500, surNSteps // 4)
+initState = ParameterVector(np.zeros(DIM))
 
-centred = Gaussian(ParameterVector(np.zeros(DIM)), IIDCovarianceMatrix(DIM, 5.))
-pcn = PCNBuilder()
-pcn.stepSize, pcn.bayesModel, pcn.nChains = 0.05, BayesianRegressionModel(tgtLikelihood, centred), nChains
-pcnChain = pcn.build_method()
-pcnChain.run(nSteps, init, verbose=False)
-report("pCN (centred prior, h=0.05)", pcnChain)
-print(f"true parameter: {trueParam.coefficient}")
+print(f"\nRunning {surNSteps} steps of the surrogate MRW ({nChains} chains)")
+surMRW.run(surNSteps, initState, verbose=False)
+surThinning, surMean = thinned_mean(surMRW, 'mean', surBurnin)
+surAccPr = surMRW.diagnostics.global_acceptance_rate()
+
+# start the actual burn-in chains where the surrogate chains left off (every chain from its own last state)
+initState = surMRW.chain.ensemble_trajectory[-1]
+nSteps = min(500, nStepsAll)
+print(f"\n\n\nBurning-in MLDA with {nSteps} steps, starting at the last surrogate chain positions")
+mldaBurnin.run(nSteps, initState, verbose=False)
+
+initState = mldaBurnin.chain.ensemble_trajectory[-1]
+initStateCopy = np.copy(initState)
+
+nSteps = nStepsAll
+print(f"\n\n\nRunning {nSteps} steps of vanilla MLDA")
+vanillaMLDA.run(nSteps, initState, verbose=False)
+vMLDAThinning, vMLDAPostMean = thinned_mean(vanillaMLDA, 'max', 0)
+vMLDAAccPr = vanillaMLDA.diagnostics.global_acceptance_rate()
+
+print(f"\n\n\nRunning {nSteps} steps of MLDA with an adaptive error model")
+assert np.array_equal(initState, initStateCopy)
+aemMLDA.run(nSteps, initState, verbose=False)
+aMLDAThinning, aMLDAPostMean = thinned_mean(aemMLDA, 'max', 0)
+aMLDAAccPr = aemMLDA.diagnostics.global_acceptance_rate()
+
+print("\n\nResults for target MRW")
+print("----------------------")
+print(f"\nacceptance rate: {tgtAccPr}")
+print(f"IAT estimate: {tgtThinning}")
+print(f"posterior mean: {tgtMean}")
+
+print("\n\nResults for surrogate MRW")
+print("----------------------")
+print(f"\nacceptance rate: {surAccPr}")
+print(f"IAT estimate: {surThinning}")
+print(f"posterior mean: {surMean}")
+
+print("\n\nResults for vanilla MLDA")
+print("-------------------------")
+print(f"acceptance rate: {vMLDAAccPr}")
+print(f"IAT estimate: {vMLDAThinning}")
+print(f"posterior mean: {vMLDAPostMean}")
+
+print("\n\nResults for AEM MLDA")
+print("---------------------")
+print(f"acceptance rate: {aMLDAAccPr}")
+print(f"IAT estimate: {aMLDAThinning}")
+print(f"posterior mean: {aMLDAPostMean}")
+em = aemMLDA.error_model()                          # per chain: what its coarse likelihood learned
+print(f"estimated mean error (median over chains): {np.median(em['mean'], axis=0)}")
+
+print("\nAEM DETAILS:")
+print(f"Estimated Marginal Variance of posterior: {aemMLDA.diagnostics.marginal_variance()}")
+print(f"chains past minDataSize = {minDataSize} accepted fine proposals: {int(em['has_precision'].sum())} of {nChains}")
+print(f"accepted fine proposals per chain (the error model's sample count), median: {int(np.median(em['n']))}")
+print(f"\ntrue parameter: {trueParam.coefficient}")

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CASES = [("example_mcmc_1d.py", []), ("example_mcmc_2d_singleLevel.py", ["256", "1200"]),
          ("example_mcmc_2d_twoLevel.py", ["256", "800"]), ("example_mcmc_2d_hierarchical.py", ["256", "600"]),
-         ("example_inference_linearModel_twoLevel.py", ["128", "600"]),
+         ("example_inference_linearModel_twoLevel.py", ["128", "1500"]),
          ("example_inference_lotkaVolterra_singleLevel.py", ["256", "400"]),
          ("example_inference_lotkaVolterra_singleLevel.py", ["256", "600", "adaptive"]),   # from the reference's own start
          ("example_inference_lotkaVolterra_twoLevel.py", ["256", "300"]),
@@ -29,3 +29,15 @@ def test_example_runs(script, args):
     assert "acceptance rate" in out and "nan" not in out, r.stdout[-1500:]
     if "adaptive" in args:
         assert "chains flagged non-finite: 0" in out, r.stdout[-1500:]
+    if script == "example_inference_linearModel_twoLevel.py":
+        # the reference's flow (example_inference_linearModel_twoLevel.py:157-236): four reported stages, each with its
+        # acceptance rate, its thinning stride from the device IAT and its posterior mean near the true parameter
+        import re
+        stages = re.findall(r"results for (target mrw|surrogate mrw|vanilla mlda|aem mlda)\n-+\n+acceptance rate: ([0-9.]+)\n"
+                            r"iat estimate: (\d+)\nposterior mean: \[\s*([-0-9.e]+)\s+([-0-9.e]+)\]", out)
+        assert [s[0] for s in stages] == ["target mrw", "surrogate mrw", "vanilla mlda", "aem mlda"], r.stdout[-2500:]
+        for name, rate, iat, m0, m1 in stages:
+            assert 0.05 < float(rate) < 0.95 and int(iat) >= 1, (name, rate, iat)
+            if name != "surrogate mrw":     # the surrogate's posterior is another one
+                assert abs(float(m0) - 1.5) < 0.6 and abs(float(m1) - 0.5) < 0.8, (name, m0, m1)
+        assert "burning-in mlda with" in out and "chains past mindatasize" in out
