@@ -34,7 +34,7 @@ def test_example_runs(script, args):
         # acceptance rate, its thinning stride from the device IAT and its posterior mean near the true parameter
         import re
         stages = re.findall(r"results for (target mrw|surrogate mrw|vanilla mlda|aem mlda)\n-+\n+acceptance rate: ([0-9.]+)\n"
-                            r"iat estimate: (\d+)\nposterior mean: \[\s*([-0-9.e]+)\s+([-0-9.e]+)\]", out)
+                            r"iat estimate: (\d+)\nposterior mean: \[\s*([-0-9.e]+)\s+([-0-9.e]+)\s*\]", out)
         assert [s[0] for s in stages] == ["target mrw", "surrogate mrw", "vanilla mlda", "aem mlda"], r.stdout[-2500:]
         for name, rate, iat, m0, m1 in stages:
             assert 0.05 < float(rate) < 0.95 and int(iat) >= 1, (name, rate, iat)
