@@ -347,6 +347,7 @@ def bench_iat(args, ffi, ctx, wl, K, info):
 LEGS_ONE_GPU = ("c3", "c3m", "c4", "c5")
 LEGS_SHARDED = ("c4", "c5")
 LEG_STEPS, LEG_WARMUP = 6, 1
+LAST_CLOCK_MHZ = [None]     # the clock this rank's GPU held in the last measured region (every rank, not only rank 0)
 INTERNAL_BITS = 2          # YMC_CHAIN_HANDOFF (include/ymc.h): an internal error, never a property of the problem
 
 
@@ -412,6 +413,7 @@ def measure(name, args, ffi, ctx, lowering, info, rank, world, comm, steps, warm
         elapsed = comm.allreduce_max(elapsed)
     kernel_ms, launches = run.kernel_time_ms()
     clock_mhz, probe_ran_ms = ctx.clock_probe_read()
+    LAST_CLOCK_MHZ[0] = clock_mhz
 
     # the single collective of a run: gather the per-chain summaries
     gather_ms = None
@@ -477,6 +479,13 @@ def main():
         device = 0  # a launcher that gives every rank its own single visible GPU (RCCL refuses a shared one loudly)
     if os.environ.get("YMC_BENCH_ALLOW_SHARED_GPU") == "1":
         device %= ffi.device_count()  # rehearsal of the N > 1 flow on a box with fewer GPUs than ranks
+    # N > 1: this rank's host process onto the cores of ITS GPU's NUMA node, before anything touches the GPU; the
+    # launch says once per rank which device / node / cores / power cap it got (stderr)
+    placement = None
+    if world > 1:
+        placement = distributed.pin_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))), device)
+        placement["rank"] = rank
+        print("bench.py: " + distributed.describe_rank(placement), file=sys.stderr, flush=True)
     ctx = ffi.Context(device)
     info = ctx.info()
     if args.workload == "iat":
@@ -494,6 +503,13 @@ def main():
             sys.exit(1)
 
     res, wl = measure(args.workload, args, ffi, ctx, lowering, info, rank, world, comm, args.steps, args.warmup, True)
+    local_clock_mhz = LAST_CLOCK_MHZ[0]
+    # every rank's placement and the clock ITS GPU held during the headline region: a drop under the node's power
+    # envelope shows per GPU (rank 0 alone would hide it)
+    per_rank = None
+    if comm is not None and getattr(comm, "store", None) is not None and placement is not None:
+        mine = dict(placement, sustained_clock_mhz=local_clock_mhz)
+        per_rank = [json.loads(p.decode()) for p in comm.store.allgather(json.dumps(mine).encode())]
     want_cpu = world == 1 and not args.no_cpu_baseline
     cpu = None
     if rank == 0 and want_cpu and not wl["spec"].get("aem"):
@@ -549,6 +565,8 @@ def main():
         "nranks_seen": nranks_seen,
         "device": info,
     }
+    if per_rank is not None:
+        out["ranks"] = per_rank
     if args.workload == "c5":
         out["coarse_sub_steps_per_s"] = res["value"] * 6
     if cpu is not None:

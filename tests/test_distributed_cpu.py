@@ -341,3 +341,82 @@ def test_rccl_failure_is_an_error_on_every_rank():
             distributed.make_communicator(None, 0, 1)
         finally:
             del os.environ["YMC_COMM"]
+
+
+# ---------------------------------------------------------------------------
+# rank -> GPU -> NUMA node -> cores: a faked sysfs
+# ---------------------------------------------------------------------------
+
+def _fake_node(root, nid, simd, minor=None, numa=None, cpulist=None, cap_uw=None, node_cpulist=None):
+    d = root / "class" / "kfd" / "kfd" / "topology" / "nodes" / str(nid)
+    d.mkdir(parents=True)
+    (d / "properties").write_text(f"cpu_cores_count {0 if simd else 48}\nsimd_count {simd}\ndrm_render_minor {minor if minor is not None else 0}\n")
+    if minor is None:
+        return
+    dev = root / "class" / "drm" / f"renderD{minor}" / "device"
+    dev.mkdir(parents=True)
+    if numa is not None:
+        (dev / "numa_node").write_text(f"{numa}\n")
+    if cpulist is not None:
+        (dev / "local_cpulist").write_text(cpulist + "\n")
+    if cap_uw is not None:
+        hw = dev / "hwmon" / "hwmon3"
+        hw.mkdir(parents=True)
+        (hw / "power1_cap").write_text(f"{cap_uw}\n")
+    if node_cpulist is not None:
+        nd = root / "devices" / "system" / "node" / f"node{numa}"
+        nd.mkdir(parents=True, exist_ok=True)
+        (nd / "cpulist").write_text(node_cpulist + "\n")
+
+
+def _eight_gpu_box(tmp_path):
+    """two CPU nodes (KFD nodes 0, 1: no SIMDs), eight GPUs on render minors 128..135: four per socket, 96 cores each
+    (hyper-threads as a second range), power cap 1400 W"""
+    _fake_node(tmp_path, 0, 0)
+    _fake_node(tmp_path, 1, 0)
+    for g in range(8):
+        sock = g // 4
+        cl = f"{96 * sock}-{96 * sock + 95},{192 + 96 * sock}-{192 + 96 * sock + 95}"
+        _fake_node(tmp_path, 2 + g, 1024, minor=128 + g, numa=sock, cpulist=cl, cap_uw=1400000000)
+    return str(tmp_path)
+
+
+def test_gpu_topology_from_sysfs(tmp_path, monkeypatch):
+    from yagremcmc_amd import distributed as d
+    for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    root = _eight_gpu_box(tmp_path)
+    topo = d.gpu_topology(root)
+    assert [g["index"] for g in topo] == list(range(8)) and [g["kfd_node"] for g in topo] == list(range(2, 10))
+    assert [g["numa_node"] for g in topo] == [0] * 4 + [1] * 4
+    assert topo[0]["cpus"] == set(range(0, 96)) | set(range(192, 288)) and topo[5]["power_cap_w"] == 1400.0
+    # a launcher that hands the job devices 6, 2: HIP's device 0 is the box's GPU 6
+    assert [g["kfd_node"] for g in d.gpu_topology(root, visible="6,2")] == [8, 4]
+    assert d.gpu_topology(str(tmp_path / "nowhere")) == []
+
+
+def test_ranks_are_pinned_to_their_gpus_socket_in_equal_shares(tmp_path, monkeypatch):
+    from yagremcmc_amd import distributed as d
+    for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "YMC_PIN_RANKS"):
+        monkeypatch.delenv(v, raising=False)
+    root = _eight_gpu_box(tmp_path)
+    topo = d.gpu_topology(root)
+    allowed = set(range(384))
+    sets = d.rank_cpu_sets(list(range(8)), topo, allowed)
+    assert all(len(s) == 48 for s in sets)                              # 192 hardware threads per socket, four ranks
+    assert set().union(*sets[:4]) == topo[0]["cpus"] and set().union(*sets[4:]) == topo[4]["cpus"]
+    assert all(sets[i].isdisjoint(sets[j]) for i in range(8) for j in range(i))
+    # a cgroup that allows the job 64 cores of socket 0 only: socket 0's ranks share those, socket 1's stay unpinned
+    sets = d.rank_cpu_sets(list(range(8)), topo, set(range(64)))
+    assert [len(s) if s else None for s in sets] == [16, 16, 16, 16, None, None, None, None]
+    # two ranks: one share each of the WHOLE socket's cores
+    assert [len(s) for s in d.rank_cpu_sets([0, 1], topo, allowed)] == [96, 96]
+    # the report of a rank (nothing applied: the test process keeps its affinity)
+    monkeypatch.setattr(d.os, "sched_getaffinity", lambda pid: allowed, raising=False)
+    info = d.pin_rank(5, 8, sysfs=root, apply=False)
+    assert info["device"] == 5 and info["numa_node"] == 1 and info["cpus"] == "144-191" and info["power_cap_w"] == 1400.0
+    assert d.describe_rank(info) == "rank 5 -> device 5 -> NUMA node 1 -> cores 144-191; power cap 1400 W"
+    # a box without the topology: nothing is pinned and the line says so
+    info = d.pin_rank(1, 2, sysfs=str(tmp_path / "nowhere"), apply=False)
+    assert info["cpus"] is None and "not pinned" in d.describe_rank(info)
+    assert d._format_cpulist(d._parse_cpulist("0-3,8,10-11")) == "0-3,8,10-11"

@@ -489,6 +489,144 @@ def spawn_local_ranks(n, argv=None, grace_s=10.0):
 
 
 # ---------------------------------------------------------------------------
+# rank -> GPU -> NUMA node -> host cores
+# ---------------------------------------------------------------------------
+# Eight host processes drive eight GPUs of one node: each is pinned to the cores of ITS GPU's NUMA node (the ctypes
+# calls, the page-locked egress buffers and the store's sockets then stay on the socket the GPU hangs off), and the
+# launch says once, on stderr, which rank got which device, node, cores and power cap -- so that a clock that drops
+# under the node's power envelope, or two ranks on one socket's cores, is visible in the first real run.  Everything
+# is read from sysfs (no GPU call: this runs before the rank creates its context); a box without that information
+# is left unpinned and says so.
+
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def _format_cpulist(cpus):
+    cpus = sorted(cpus)
+    out, i = [], 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else f"{cpus[i]}-{cpus[j]}")
+        i = j + 1
+    return ",".join(out)
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def gpu_topology(sysfs="/sys", visible=None):
+    """The GPUs in the order HIP numbers them -- the KFD topology nodes that have SIMDs, by node id, filtered and
+    re-ordered by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES when those are plain index lists -- each with its NUMA
+    node, that node's cores and its power cap: [{index, kfd_node, render_minor, numa_node, cpus (set), power_cap_w}].
+    -> [] when the box does not expose it."""
+    base = os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes")
+    try:
+        node_ids = sorted(int(n) for n in os.listdir(base) if n.isdigit())
+    except OSError:
+        return []
+    gpus = []
+    for nid in node_ids:
+        props = {}
+        for line in (_read(os.path.join(base, str(nid), "properties")) or "").splitlines():
+            k, _, v = line.partition(" ")
+            props[k] = v.strip()
+        if int(props.get("simd_count", "0") or 0) <= 0:
+            continue
+        minor = int(props.get("drm_render_minor", "-1") or -1)
+        dev = os.path.join(sysfs, "class", "drm", f"renderD{minor}", "device")
+        numa = _read(os.path.join(dev, "numa_node"))
+        cpulist = _read(os.path.join(dev, "local_cpulist"))
+        numa = int(numa) if numa not in (None, "") else -1
+        if (not cpulist) and numa >= 0:
+            cpulist = _read(os.path.join(sysfs, "devices", "system", "node", f"node{numa}", "cpulist"))
+        cap = None
+        hw = os.path.join(dev, "hwmon")
+        try:
+            for h in sorted(os.listdir(hw)):
+                v = _read(os.path.join(hw, h, "power1_cap"))
+                if v:
+                    cap = int(v) / 1e6          # microwatts
+                    break
+        except OSError:
+            pass
+        gpus.append(dict(kfd_node=nid, render_minor=minor, numa_node=numa,
+                         cpus=_parse_cpulist(cpulist) if cpulist else set(), power_cap_w=cap))
+    if visible is None:
+        visible = os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("HIP_VISIBLE_DEVICES") or ""
+    picks = [p.strip() for p in visible.split(",") if p.strip()]
+    if picks and all(p.isdigit() for p in picks):
+        gpus = [gpus[int(p)] for p in picks if int(p) < len(gpus)]
+    for i, g in enumerate(gpus):
+        g["index"] = i
+    return gpus
+
+
+def rank_cpu_sets(devices, topo, allowed):
+    """cores for the ranks that drive `devices` (device index per local rank): the rank's GPU's NUMA node's cores that
+    this process may use, cut into equal contiguous shares where several ranks' GPUs hang off one node.  A rank
+    whose device has no known node, or whose share would be empty, gets None (stays unpinned)."""
+    by_node = {}
+    for r, dev in enumerate(devices):
+        g = topo[dev] if 0 <= dev < len(topo) else None
+        if g is not None and g["cpus"]:
+            by_node.setdefault((g["numa_node"], frozenset(g["cpus"])), []).append(r)
+    out = [None] * len(devices)
+    for (_, cpus), ranks in by_node.items():
+        usable = sorted(set(cpus) & set(allowed))
+        share = len(usable) // len(ranks)
+        if share == 0:
+            continue
+        for i, r in enumerate(ranks):
+            out[r] = set(usable[i * share:(i + 1) * share])
+    return out
+
+
+def pin_rank(local_rank, local_world, device=None, sysfs="/sys", apply=True):
+    """Pin the calling process (a rank, before it touches the GPU) to its share of its GPU's NUMA node.
+    -> dict(rank, device, numa_node, cpus (cpulist string or None), power_cap_w): what the launch reports."""
+    topo = gpu_topology(sysfs)
+    devices = list(range(local_world))
+    if device is not None:
+        devices[local_rank] = device
+    allowed = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else set(range(os.cpu_count() or 1))
+    sets = rank_cpu_sets(devices, topo, allowed) if topo else [None] * local_world
+    mine = sets[local_rank]
+    dev = devices[local_rank]
+    g = topo[dev] if topo and dev < len(topo) else None
+    if apply and mine and os.environ.get("YMC_PIN_RANKS", "1") != "0" and hasattr(os, "sched_setaffinity"):
+        try:
+            os.sched_setaffinity(0, mine)
+        except OSError:
+            mine = None
+    elif os.environ.get("YMC_PIN_RANKS", "1") == "0":
+        mine = None
+    return dict(rank=local_rank, device=dev, numa_node=g["numa_node"] if g else None,
+                cpus=_format_cpulist(mine) if mine else None, power_cap_w=g["power_cap_w"] if g else None)
+
+
+def describe_rank(info):
+    cap = f"{info['power_cap_w']:.0f} W" if info.get("power_cap_w") else "unknown"
+    where = f"NUMA node {info['numa_node']}" if info.get("numa_node") is not None and info["numa_node"] >= 0 else "NUMA node unknown"
+    cpus = f"cores {info['cpus']}" if info.get("cpus") else "not pinned"
+    return f"rank {info['rank']} -> device {info['device']} -> {where} -> {cpus}; power cap {cap}"
+
+
+# ---------------------------------------------------------------------------
 # communicators
 # ---------------------------------------------------------------------------
 
