@@ -44,6 +44,9 @@ def _check_line(stdout, world, steps=2, warmup=1):
     assert out["value"] > 0 and out["scaling"] == "weak" and out["gather_ms"] is not None
     # the gather really carried every rank's chains: pooled over W shards == one run over all chains
     assert out["acceptance_rate"] == _expected(32 * world, 40 * (steps + warmup))
+    # every rank reports where it ran and the clock ITS device held (here: the stub's 2400 MHz, no topology to pin to)
+    assert [r["rank"] for r in out["ranks"]] == list(range(world))
+    assert all(r["sustained_clock_mhz"] == 2400.0 and "numa_node" in r and "cpus" in r for r in out["ranks"])
     return out
 
 
