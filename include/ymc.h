@@ -51,7 +51,12 @@ typedef enum ymc_density_kind {
     YMC_DENSITY_POSTERIOR_LINEAR = 3,
     /* the same over LotkaVolterraSolver (test/testSetup.py:61-141) with the
      * ODE integrated by fixed-step RK4 or, with lv_rtol > 0, adaptively */
-    YMC_DENSITY_POSTERIOR_LV = 4
+    YMC_DENSITY_POSTERIOR_LV = 4,
+    /* EXTENSION kinds (csrc/ymc_kinds.def; INTEGRATION.md "Adding a forward model"): the same posterior over another
+     * SolverInterface (model/interface.py:7-67) solved once per design row.  The worked example: logistic growth
+     * dx/dt = r x (1 - x / K), theta = (log r, log K), design = [n_data] initial populations, t_final, rk4_steps;
+     * data_dim = 1 (the population at t_final) */
+    YMC_DENSITY_POSTERIOR_LOGISTIC = 5
 } ymc_density_kind;
 
 typedef struct ymc_density_desc {
@@ -69,8 +74,8 @@ typedef struct ymc_density_desc {
     const double *prior_precision; /* [d] */
     const double *fwd_matrix;      /* POSTERIOR_LINEAR: A [data_dim][d] */
     const double *fwd_shift;       /* POSTERIOR_LINEAR: b [data_dim] */
-    const double *design;          /* POSTERIOR_LV: [n_data][2] initial conditions */
-    double t_final;                /* POSTERIOR_LV */
+    const double *design;          /* POSTERIOR_LV: [n_data][2] initial conditions; extension kinds: [n_data][their design columns] */
+    double t_final;                /* POSTERIOR_LV, POSTERIOR_LOGISTIC */
     double alpha;
     double gamma;
     int32_t rk4_steps;

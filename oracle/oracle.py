@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # YMC_ORACLE_LIB: another build of the same source (the sanitizer build of tests/test_sanitizers.py)
 _LIB_PATH = os.environ.get("YMC_ORACLE_LIB") or os.path.join(_HERE, "libymc_oracle.so")
 
-GAUSS_WHITENED, GAUSS_ISO1D, POST_LINEAR, POST_LV = 1, 2, 3, 4
+GAUSS_WHITENED, GAUSS_ISO1D, POST_LINEAR, POST_LV, POST_LOGISTIC = 1, 2, 3, 4, 5
 EQ_EXACT, EQ_ISCLOSE = 0, 1
 STATUS_NONFINITE = 1
 
@@ -186,6 +186,16 @@ def posterior_lv(design, t_final, alpha, gamma, rk4_steps, data, noise_precision
     return p
 
 
+def posterior_logistic(design, t_final, rk4_steps, data, noise_precision, prior_mean, prior_precision):
+    """The worked extension kind (csrc/kinds/logistic.h): logistic growth from the initial populations `design`
+    (n_data,), theta = (log r, log K), one forward output per design row."""
+    design = _f64(design).reshape(-1)
+    p = _posterior_common(POST_LOGISTIC, 2, data, noise_precision, prior_mean, prior_precision)
+    assert design.shape == (p["n_data"],) and p["data_dim"] == 1
+    p.update(design=design, t_final=float(t_final), rk4_steps=int(rk4_steps))
+    return p
+
+
 DMAX, MMAX = 2048, 8192     # YMO_DMAX, YMO_MMAX of ymc_oracle.c (its work arrays live on the stack)
 
 
@@ -298,7 +308,8 @@ def forward(problem, x):
         problem.pop("lin_tail", None)
     d, keep = _lower(problem)
     x = _f64(x).reshape(-1, problem["dim"])
-    m = problem["n_data"] * 2 if problem["kind"] == POST_LV else problem["data_dim"]
+    m = problem["n_data"] * 2 if problem["kind"] == POST_LV else problem["n_data"] if problem["kind"] == POST_LOGISTIC \
+        else problem["data_dim"]
     out = np.empty((x.shape[0], m))
     bad = lib().ymo_forward(C.byref(d), C.c_int64(x.shape[0]), _ptr(x), _ptr(out))
     if bad < 0:

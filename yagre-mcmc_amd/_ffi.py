@@ -19,7 +19,7 @@ ABI_VERSION = 4
 # ymc_status
 OK, ERR_INVALID, ERR_DEVICE, ERR_UNSUPPORTED, ERR_CAPACITY, ERR_COMM = 0, -1, -2, -3, -4, -5
 # ymc_density_kind
-GAUSS_WHITENED, GAUSS_ISO1D, POSTERIOR_LINEAR, POSTERIOR_LV = 1, 2, 3, 4
+GAUSS_WHITENED, GAUSS_ISO1D, POSTERIOR_LINEAR, POSTERIOR_LV, POSTERIOR_LOGISTIC = 1, 2, 3, 4, 5
 # ymc_method / ymc_state_eq
 METHOD_MRW, METHOD_MLDA2, METHOD_PCN, METHOD_MLDA_NESTED, METHOD_AEM2 = 1, 2, 3, 4, 5
 MAX_LEVELS = 8
@@ -312,7 +312,8 @@ class Problem(Handle):
 
     def forward(self, x, which=0):
         x = f64(x).reshape(-1, self.dim)
-        m = self._n_data[1] if self.kind == POSTERIOR_LINEAR else 2 * self._n_data[0]
+        # one evaluation for all data rows (linear map), or one solve per design row (Lotka-Volterra, extension kinds)
+        m = self._n_data[1] if self.kind == POSTERIOR_LINEAR else self._n_data[0] * self._n_data[1]
         out = np.empty((x.shape[0], m))
         check(lib().ymc_forward_eval(self.ctx.raw, self.raw, which, x.shape[0], vptr(x), vptr(out)))
         return out

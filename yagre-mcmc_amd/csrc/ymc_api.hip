@@ -16,6 +16,7 @@
 
 #include "ymc_aem.h"
 #include "ymc_kernels.h"
+#include "ymc_kinds.h"
 #include "ymc_nested.h"
 #include "ymc_post.h"
 #include "ymc_tile.h"
@@ -259,6 +260,9 @@ int lower_density(ymc_ctx *ctx, const ymc_density_desc &in, DensityHost &out, in
         if (!(in.variance > 0.0) || !std::isfinite(in.variance))
             return fail(YMC_ERR_INVALID, "variance must be positive and finite");
         break;
+    default: /* an extension kind (ymc_kinds.def) shares the posterior's common fields; anything else is unknown */
+        if (!ymc_ext_kind(in.kind)) return fail(YMC_ERR_UNSUPPORTED, "unknown density kind %d", in.kind);
+        [[fallthrough]];
     case YMC_DENSITY_POSTERIOR_LINEAR:
     case YMC_DENSITY_POSTERIOR_LV: {
         if (in.n_data < 1 || in.data_dim < 1)
@@ -362,6 +366,17 @@ int lower_density(ymc_ctx *ctx, const ymc_density_desc &in, DensityHost &out, in
                 out.prior_linv.clear();
                 out.d.data_dim = (int32_t)(m + (size_t)d);
             }
+        } else if (const ymc_ext_kind_info *ext = ymc_ext_kind(in.kind)) {
+            /* an extension kind: its dimension range, outputs per design row and design columns come from the registration
+             * table, what else its description must satisfy from its own check (kinds/<name>.h) */
+            if (d < ext->dmin || d > ext->dmax)
+                return fail(YMC_ERR_INVALID, "density kind %s needs a parameter dimension in [%d, %d], got %d", ext->name,
+                            ext->dmin, ext->dmax, d);
+            if ((int)m != ext->outputs)
+                return fail(YMC_ERR_INVALID, "density kind %s has %d forward outputs per design row, the data have %zu columns",
+                            ext->name, ext->outputs, m);
+            YMC_TRY(copy_array(out.design, in.design, nd * (size_t)ext->design_cols, "design"));
+            if (const char *why = ext->check(in)) return fail(YMC_ERR_INVALID, "density kind %s: %s", ext->name, why);
         } else {
             if (d != 2 || m != 2) return fail(YMC_ERR_INVALID, "Lotka-Volterra needs dim 2 and data_dim 2");
             if (in.lv_rtol < 0.0 || !std::isfinite(in.lv_rtol) || (in.lv_rtol > 0.0 && !(in.lv_atol >= 0.0)) ||
@@ -397,8 +412,6 @@ int lower_density(ymc_ctx *ctx, const ymc_density_desc &in, DensityHost &out, in
         YMC_HIP(hipMemcpy(out.dev.p, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice));
         break;
     }
-    default:
-        return fail(YMC_ERR_UNSUPPORTED, "unknown density kind %d", in.kind);
     }
     return YMC_OK;
 }
@@ -1433,7 +1446,7 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
     }
     if (rc == YMC_OK && desc->method == YMC_METHOD_PCN) {
         /* PreconditionedCrankNicolson.__init__, pcn.py:40-49; PCNBuilder, pcn.py:77-83 */
-        if (p->kind != YMC_DENSITY_POSTERIOR_LINEAR && p->kind != YMC_DENSITY_POSTERIOR_LV)
+        if (p->kind != YMC_DENSITY_POSTERIOR_LINEAR && p->kind != YMC_DENSITY_POSTERIOR_LV && !ymc_ext_kind(p->kind))
             rc = fail(YMC_ERR_INVALID, "PCN is only defined in relation to a Bayesian model");
         else if (desc->target.prior_chol_inv)
             rc = fail(YMC_ERR_UNSUPPORTED, "the pCN proposal draws from a diagonal prior covariance");
@@ -2039,6 +2052,7 @@ int ymc_forward_eval(ymc_ctx *ctx, const ymc_problem *problem, int which, uint64
     uint64_t m = 0;
     if (problem->kind == YMC_DENSITY_POSTERIOR_LINEAR) m = h.m_raw ? h.m_raw : h.d.data_dim;
     else if (problem->kind == YMC_DENSITY_POSTERIOR_LV) m = 2ull * h.d.n_data;
+    else if (const ymc_ext_kind_info *ext = ymc_ext_kind(problem->kind)) m = (uint64_t)ext->outputs * (uint64_t)h.d.n_data;
     else return fail(YMC_ERR_INVALID, "this density has no forward model");
     if (n == 0) return YMC_OK;
     YMC_HIP(hipSetDevice(ctx->device));

@@ -27,6 +27,7 @@
 #define YMC_EXP_WAVES 1, 2
 #endif
 #include "ymc_kernels.h"
+#include "ymc_kinds.h"
 
 /* This file is compiled four times (Makefile, -DYMC_KERNELS_PART=0..3): the dimensions are independent
  * instantiations and one translation unit with all of them takes two minutes to build.  Part 0 also holds the
@@ -677,6 +678,25 @@ __global__ __launch_bounds__(kBlock) void forward_linear_kernel(const DensityDev
         if (m < p.data_dim) out[i * p.data_dim + m] = F[m];
 }
 
+/* ForwardModel.evaluate for a batch, extension kinds: out[i][row][output] (Density<KIND, D>::forward_row) */
+template <int KIND, int D>
+__global__ __launch_bounds__(kBlock) void forward_rows_kernel(const DensityDev<D> p, uint64_t n,
+                                                              const double *__restrict__ xin,
+                                                              double *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    constexpr int M = Density<KIND, D>::kOutputs;
+    double th[D];
+    ymc_load_row<D>(xin, i, th);
+    for (int r = 0; r < p.n_data; ++r) {
+        double F[M];
+        Density<KIND, D>::forward_row(p, th, r, F);
+#pragma unroll
+        for (int j = 0; j < M; ++j) out[(i * p.n_data + r) * M + j] = F[j];
+    }
+}
+
 template <int UNUSED = 0> /* a template only so that the parts without d = 2 do not emit it */
 __global__ __launch_bounds__(kBlock) void forward_lv_kernel(const DensityDev<2> p, uint64_t n,
                                                             const double *__restrict__ xin,
@@ -798,11 +818,15 @@ __global__ __launch_bounds__(kBlock) void pack_summary_kernel(uint64_t K, int d,
 
 #endif /* part 0 */
 
+/* pCN is defined in relation to a Bayesian model (pcn.py:77-83): every kind but the two explicit Gaussian targets */
+template <int KIND>
+constexpr bool kKindIsPosterior = KIND != YMC_DENSITY_GAUSS_WHITENED && KIND != YMC_DENSITY_GAUSS_ISO1D;
+
 template <int KIND, int D, unsigned REC, int EQ>
 void launch_one(int method, const ChainArgs<D> &a, hipStream_t s)
 {
     if (method == YMC_METHOD_PCN) {
-        if constexpr (REC == kRuntimeRec && (KIND == YMC_DENSITY_POSTERIOR_LINEAR || KIND == YMC_DENSITY_POSTERIOR_LV))
+        if constexpr (REC == kRuntimeRec && kKindIsPosterior<KIND>)
             hipLaunchKernelGGL((mrw_kernel<KIND, D, REC, EQ, kPropPcn>), dim3(grid_for(a.K)), dim3(kBlock), 0, s, a);
     } else if (method == YMC_METHOD_MRW && a.chol) {
         if constexpr (REC == kRuntimeRec)
@@ -889,6 +913,13 @@ hipError_t ymc_launch_chain(int kind, int method, const ChainArgs<D> &a, hipStre
             return launch_chain<YMC_DENSITY_POSTERIOR_LV, 2>(method, a, s);
         }
         return hipErrorInvalidValue;
+    /* the extension kinds, generated from the registration table */
+#define YMC_EXT_KIND(ENUM, NAME, DMIN, DMAX, OUT, COLS)                                        \
+    case ENUM:                                                                                 \
+        if constexpr (D >= DMIN && D <= DMAX) return launch_chain<ENUM, D>(method, a, s);      \
+        return hipErrorInvalidValue;
+#include "ymc_kinds.def"
+#undef YMC_EXT_KIND
     default: return hipErrorInvalidValue;
     }
 }
@@ -917,6 +948,15 @@ hipError_t ymc_launch_logdensity(int kind, const DensityDev<D> &p, uint64_t n, c
         else
             return hipErrorInvalidValue;
         break;
+#define YMC_EXT_KIND(ENUM, NAME, DMIN, DMAX, OUT, COLS)                                                        \
+    case ENUM:                                                                                                 \
+        if constexpr (D >= DMIN && D <= DMAX)                                                                  \
+            hipLaunchKernelGGL((logdensity_kernel<ENUM, D>), g, b, 0, s, p, n, x, out, status);                \
+        else                                                                                                   \
+            return hipErrorInvalidValue;                                                                       \
+        break;
+#include "ymc_kinds.def"
+#undef YMC_EXT_KIND
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -935,7 +975,18 @@ hipError_t ymc_launch_forward(int kind, const DensityDev<D> &p, uint64_t n, cons
         else
             return hipErrorInvalidValue;
     } else {
-        return hipErrorInvalidValue;
+        switch (kind) {
+#define YMC_EXT_KIND(ENUM, NAME, DMIN, DMAX, OUT, COLS)                                              \
+    case ENUM:                                                                                       \
+        if constexpr (D >= DMIN && D <= DMAX)                                                        \
+            hipLaunchKernelGGL((forward_rows_kernel<ENUM, D>), g, b, 0, s, p, n, x, out);            \
+        else                                                                                         \
+            return hipErrorInvalidValue;                                                             \
+        break;
+#include "ymc_kinds.def"
+#undef YMC_EXT_KIND
+        default: return hipErrorInvalidValue;
+        }
     }
     return hipGetLastError();
 }

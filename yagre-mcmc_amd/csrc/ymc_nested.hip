@@ -25,6 +25,7 @@
  */
 #define YMC_COEFF_HOISTED 1
 #include "ymc_nested.h"
+#include "ymc_kinds.h"
 
 namespace {
 
@@ -267,6 +268,12 @@ hipError_t YMC_NESTED_ENTRY(int kind, const NestedArgs<D> &a, hipStream_t s)
     case YMC_DENSITY_POSTERIOR_LV:
         if constexpr (D == 2) return launch_kind<YMC_DENSITY_POSTERIOR_LV, 2>(a, s);
         return hipErrorInvalidValue;
+#define YMC_EXT_KIND(ENUM, NAME, DMIN, DMAX, OUT, COLS)                                \
+    case ENUM:                                                                         \
+        if constexpr (D >= DMIN && D <= DMAX) return launch_kind<ENUM, D>(a, s);       \
+        return hipErrorInvalidValue;
+#include "ymc_kinds.def"
+#undef YMC_EXT_KIND
     default: return hipErrorInvalidValue;
     }
 }

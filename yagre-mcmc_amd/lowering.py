@@ -156,9 +156,36 @@ def _lv_steps(solver, override):
     return rk4_steps_for_rtol(rtol) if rtol is not None else 50
 
 
+# The extension point for new forward models ("Adding a forward model"): a solver class whose device
+# kind is registered in csrc/ymc_kinds.def announces its lowering here.  Registered classes are matched by IDENTITY
+# (the class object itself, not its name), so nothing else can pass for them; a subclass is a different class and has
+# no lowering unless it registers one.
+_SOLVER_LOWERINGS = {}
+
+
+def register_solver(cls, lower, design_rows=None):
+    """`lower(solver, low, rk4_steps) -> (dim, data_dim)` fills the forward-model fields of `low.desc` (kind, design,
+    t_final, rk4_steps, ...) for instances of exactly `cls`.  `design_rows(solver) -> int`: one forward solve per
+    design row (the evaluation then has shape (rows, data_dim)); None: one evaluation for all data rows."""
+    if not isinstance(cls, type):
+        raise TypeError("register_solver takes the solver CLASS")
+    _SOLVER_LOWERINGS[cls] = (lower, design_rows)
+
+
+def solver_design_rows(solver):
+    """rows of the forward evaluation of a per-design-row solver, or None"""
+    if _name(solver) == "LotkaVolterraSolver" and hasattr(solver, "x_"):
+        return int(np.asarray(solver.x_).shape[0])
+    entry = _SOLVER_LOWERINGS.get(type(solver))
+    return int(entry[1](solver)) if entry and entry[1] else None
+
+
 def lower_solver(solver, low, rk4_steps=None):
     """SolverInterface -> forward-map fields of the descriptor."""
     n = _name(solver)
+    entry = _SOLVER_LOWERINGS.get(type(solver))
+    if entry is not None:
+        return entry[0](solver, low, rk4_steps)
     _require_stock(solver, "solver", "invoke", "interpolate", "evaluation", "flow__")
     if n == "ExampleLinearModelSolver" and _has(solver, "_A", "_b"):
         A = np.asarray(solver._A, dtype=np.float64)
@@ -185,8 +212,9 @@ def lower_solver(solver, low, rk4_steps=None):
                 raise ValueError(f"rtol must be positive, got {low.desc.lv_rtol}")
         return 2, 2
     raise UnsupportedPlugin(
-        f"solver {n} has no device lowering (known: ExampleLinearModelSolver, LotkaVolterraSolver); "
-        "there is no CPU fallback")
+        f"solver {n} has no device lowering (known: ExampleLinearModelSolver, LotkaVolterraSolver"
+        + "".join(f", {c.__name__}" for c in _SOLVER_LOWERINGS) + "); there is no CPU fallback -- a new forward model "
+        "needs a device kind and lowering.register_solver (INTEGRATION.md)")
 
 
 def lower_posterior(likelihood, prior, rk4_steps=None):
@@ -209,8 +237,10 @@ def lower_posterior(likelihood, prior, rk4_steps=None):
     data = np.asarray(likelihood._data.array, dtype=np.float64)
     if data.ndim != 2 or data.shape[1] != data_dim:
         raise ValueError(f"data has shape {data.shape}; the forward map has {data_dim} outputs")
-    if low.desc.kind == _ffi.POSTERIOR_LV and data.shape[0] != np.asarray(likelihood._fwdModel.solver_.x_).shape[0]:
-        raise ValueError("Lotka-Volterra: one data row per design row is required")
+    rows = solver_design_rows(likelihood._fwdModel.solver_)
+    if rows is not None and data.shape[0] != rows:
+        raise ValueError(f"{_name(likelihood._fwdModel.solver_)}: one data row per design row is required "
+                         f"({data.shape[0]} data rows, {rows} design rows)")
     low.desc.dim = dim
     low.desc.n_data, low.desc.data_dim = data.shape
     low.set_array("data", data)
@@ -387,7 +417,7 @@ def forward_only_problem(solver, device=0):
         low = Lowered(0, 0)
         dim, data_dim = lower_solver(solver, low)
         low.desc.dim = dim
-        rows = np.asarray(solver.x_).shape[0] if low.desc.kind == _ffi.POSTERIOR_LV else 1
+        rows = solver_design_rows(solver) or 1
         low.desc.n_data, low.desc.data_dim = rows, data_dim
         low.set_array("data", np.zeros((rows, data_dim)))
         low.set_array("noise_precision", np.ones(data_dim))
