@@ -1488,6 +1488,60 @@ def test_tile_mlda2_beyond_the_lds_and_d128_vs_oracle(ffi, ctx, d, mc, mf, K, S,
     assert 0 < dev["sub_acc"].mean() < 1
 
 
+@pytest.mark.parametrize("d,m,nd,K,method,stride", [(300, 40, 2, 70, "mrw", 1), (513, 700, 3, 20, "pcn", 1), (1000, 64, 2, 17, "mrw", 4),
+                                                    (257, 1, 1, 33, "mrw", 1), (320, 64, 2, 8229, "mrw", 1), (592, 48, 2, 8200, "pcn", 3),
+                                                    (512, 520, 1, 8192, "mrw", 2)])
+def test_wide_fused_kernel_vs_oracle_and_the_launch_per_stage_path(ffi, ctx, monkeypatch, d, m, nd, K, method, stride):
+    """linear_wide_fused_kernel (round 4): the random walk and pCN beyond 256 parameters as ONE persistent launch per advance
+    call -- the state in registers cut along k, the proposal in LDS, every wave its output tiles over all k, the sums handed
+    from wave to wave behind tickets.  Small ensembles (sixteen waves a tile), large ones (eight waves, two tiles; one tile
+    beyond 576 parameters), ragged tails, several rounds of output tiles, thinned records, launches cut in two: == oracle,
+    and == the launch-per-stage path (YMC_WIDE_FUSED=0) bit for bit."""
+    from yagremcmc_amd import lowering
+    rng = np.random.default_rng(4000 + d + m)
+    g = dict(data=rng.normal(size=(nd, m)), noise_precision=rng.uniform(0.5, 3, size=m), prior_mean=rng.normal(size=d) * 0.1,
+             prior_precision=rng.uniform(0.1, 2, size=d))
+    A, b = rng.normal(size=(m, d)) / np.sqrt(d), rng.normal(size=m)
+    x0 = rng.normal(size=(K, d)) * 0.3
+    n = 10
+    flags = ffi.RECORD_TRAJECTORY | ffi.RECORD_LOGPOST | (ffi.RECORD_ACCEPT if stride == 1 else 0)
+    if method == "pcn":
+        g["prior_mean"] = np.zeros(d)
+        low = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, g, fwd_matrix=A, fwd_shift=b)
+        low.desc.likelihood_only = 1
+        p = dict(o.posterior_linear(A, b, g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"]), likelihood_only=1)
+        sigma = 1.0 / np.sqrt(g["prior_precision"])
+        make = lambda: lowering.make_problem(ctx, ffi.METHOD_PCN, low, sigma, pcn_step_size=0.01)   # noqa: E731
+        e = o.Ensemble(p, sigma, x0, 17, chain0=40, pcn_step_size=0.01)
+    else:
+        low = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, g, fwd_matrix=A, fwd_shift=b)
+        p = o.posterior_linear(A, b, g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+        sigma = rng.uniform(0.01, 0.04, size=d)
+        make = lambda: lowering.make_problem(ctx, ffi.METHOD_MRW, low, sigma)   # noqa: E731
+        e = o.Ensemble(p, sigma, x0, 17, chain0=40)
+
+    def device(fused):
+        monkeypatch.setenv("YMC_WIDE_FUSED", "1" if fused else "0")
+        run = ffi.Run(make(), 17, K, x0, n, flags, 40, record_stride=stride)
+        run.advance(3)
+        run.advance(n - 3)
+        run.sync()
+        ms, launches = run.kernel_time_ms()
+        s_ = run.summary()
+        return dict(traj=run.trajectory(), lp=run.logpost(), acc=run.accept() if stride == 1 else None, state=run.state(),
+                    accepted=s_["accepted"], status=s_["status"], launches=launches)
+    fused, staged = device(True), device(False)
+    out = e.advance(n)
+    rows = slice(stride - 1, None, stride)
+    for dev in (fused, staged):
+        assert np.array_equal(dev["traj"], out["traj"][rows]) and np.array_equal(dev["lp"], out["logpost"][rows])
+        if stride == 1:
+            assert np.array_equal(dev["acc"], out["acc"])
+        assert np.array_equal(dev["state"][0], e.x) and np.array_equal(dev["state"][1], e.lp)
+        assert np.array_equal(dev["accepted"], e.acc_count) and np.array_equal(dev["status"], e.status)
+    assert 0 < out["acc"].mean() < 1
+
+
 @pytest.mark.parametrize("d,m,nd,K,method,stride", [(300, 40, 2, 70, "mrw", 1), (257, 1, 1, 33, "mrw", 1), (513, 700, 3, 20, "pcn", 1),
                                                     (1000, 64, 2, 17, "mrw", 4), (384, 384, 2, 40, "pcn", 3), (300, 20, 2, 30, "dense", 1)])
 def test_linear_posteriors_beyond_256_parameters_vs_oracle(ffi, ctx, d, m, nd, K, method, stride):

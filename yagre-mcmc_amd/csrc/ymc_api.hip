@@ -877,6 +877,37 @@ int launch_advance_wide(ymc_run *r, uint64_t nsteps)
         YMC_HIP(hipEventCreate(&ev.second));
     }
     YMC_HIP(hipEventRecord(ev.first, s));
+    /* the random walk with a diagonal proposal and pCN: the whole launch as ONE persistent kernel with the chains' state
+     * on the chip (linear_wide_fused_kernel) where the proposal tile fits the LDS -- identical results; moments are the
+     * launch-per-stage path's (they would be two more slices of registers per chain) */
+    const int cus = r->ctx->prop.multiProcessorCount;
+    if (!two && !p->chol_frag.p && !(r->flags & YMC_RECORD_MOMENTS) && nsteps < (1ull << 32) &&
+        ymc_wide_fused_lds_bytes(p->tgt.KS, p->tgt.MT, K, cus)) {
+        WideFusedArgs f{};
+        f.blob = p->tgt.tile_blob.as<double>();
+        f.lik_const = p->tgt.lik_const;
+        f.KS = p->tgt.KS, f.MT = p->tgt.MT, f.d = p->D;
+        f.likelihood_only = p->tgt.d.likelihood_only;
+        f.pcn = a.pcn, f.pcn_c1 = a.pcn_c1, f.pcn_c2 = a.pcn_c2;
+        f.seed = r->seed, f.chain0 = r->chain0, f.K = K, f.t0 = r->steps_done;
+        f.nsteps = (uint32_t)nsteps;
+        f.rec_stride = r->stride;
+        f.rec_since = (uint32_t)(r->steps_done % r->stride);
+        f.x = r->x.as<double>(), f.lp = r->lp.as<double>();
+        f.acc_count = r->acc_count.as<uint64_t>(), f.status = r->status.as<uint32_t>();
+        const uint64_t row = r->recorded;
+        if (r->flags & YMC_RECORD_TRAJECTORY) f.traj = r->traj.as<double>() + row * K * d;
+        if (r->flags & YMC_RECORD_ACCEPT) f.acc = r->acc.as<uint8_t>() + row * K;
+        if (r->flags & YMC_RECORD_LOGPOST) f.lp_out = r->lp_out.as<double>() + row * K;
+        hipError_t e = ymc_launch_wide_fused(f, cus, s);
+        if (e != hipSuccess) {
+            r->pool.push_back(ev);
+            return fail(YMC_ERR_DEVICE, "wide fused kernel launch failed: %s", hipGetErrorString(e));
+        }
+        YMC_HIP(hipEventRecord(ev.second, s));
+        r->timed.push_back(ev);
+        return YMC_OK;
+    }
     uint64_t rows = 0;
     for (uint64_t n = 0; n < nsteps; ++n) {
         const uint64_t step = r->steps_done + n;

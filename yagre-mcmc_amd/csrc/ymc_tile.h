@@ -118,6 +118,28 @@ struct WideArgs {
     double *wf_mean, *wf_m2;       /* [K][d] (null: no moments) */
     double wf_dn, wf_rdn;          /* the moments' sample count after this transition and RN(1 / count) */
 };
+/* The random walk (diagonal proposal) and pCN beyond 256 parameters as ONE persistent launch per advance call
+ * (linear_wide_fused_kernel, round 4): a workgroup owns NT tiles of 16 chains for the whole launch; the proposal of
+ * the moment lives in LDS in the matrix cores' B-operand layout, the state in registers, a slice of the k-steps per
+ * wave; every wave multiplies ITS output tiles over all k (the matrix's fragments from L2, each feeding NT MFMAs), and
+ * the residual terms join the chains' sums in the canonical order by a hand-over from wave to wave. */
+struct WideFusedArgs {
+    const double *blob;            /* TileArgs::blob layout with KS k-steps and MT output tiles, in global memory */
+    double lik_const;
+    int32_t KS, MT, d, likelihood_only, pcn, pad_;
+    double pcn_c1, pcn_c2;
+    uint64_t seed, chain0, K, t0;
+    uint32_t nsteps, rec_stride, rec_since, pad1_;
+    double *x, *lp;                /* [K][d], [K]: carried */
+    uint64_t *acc_count;
+    uint32_t *status;
+    double *traj;                  /* plain record rows of this launch [rows][K][d], or null */
+    uint8_t *acc;                  /* [nsteps][K] or null */
+    double *lp_out;                /* [rows][K] or null */
+};
+/* 0 = this shape / ensemble does not take the fused kernel (the caller runs the launch-per-stage path) */
+size_t ymc_wide_fused_lds_bytes(int KS, int MT, uint64_t K, int cus);
+hipError_t ymc_launch_wide_fused(const WideFusedArgs &a, int cus, hipStream_t s);
 hipError_t ymc_launch_wide_propose(const WideArgs &a, hipStream_t s);
 /* the normals of transition t in the matrix-core layout (xi_tiled) and the accept uniforms (a.u): the dense proposal's input */
 hipError_t ymc_launch_wide_draws(const WideArgs &a, uint64_t seed, uint64_t chain0, uint64_t t, double *xi_tiled, hipStream_t s);

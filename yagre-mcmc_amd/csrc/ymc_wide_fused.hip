@@ -1,0 +1,452 @@
+/*
+ * ymc_wide_fused.hip -- the random walk (diagonal proposal) and pCN over linear models beyond 256 parameters as ONE
+ * persistent launch per advance call (mrw.py:27-57, pcn.py:9-57, likelihood.py:74-84,
+ * exampleSetup.py:42-52).  A translation unit of its own: the draws' polynomial coefficients are plain literals here
+ * (ymc_numerics.h, ymc_fma_c) -- as SGPR pairs, the mode of ymc_tile.hip, they are spilled into VGPR lanes by this
+ * kernel's scalar pressure and cost two v_readlane per use.
+ */
+#include <cstdlib>
+
+#include "ymc_kernels.h"
+#include "ymc_tile.h"
+#include "ymc_tile_dev.h"
+
+namespace {
+
+/*
+ * The wide path as a GEMM, fused over the whole launch.  linear_wide_eval_kernel above is 65 536
+ * independent GEMVs -- every wave pulls every fragment of the matrix for its own 16 or 32 points, and a transition is four
+ * launches that carry the proposal and the state through HBM (7 x K d 8 bytes per transition against the record's one).
+ *
+ * Here a workgroup of W waves owns NT tiles of 16 chains from the first transition of the launch to the last:
+ *   state x      in registers, cut along k: wave w holds the k-steps of its q-range (a q = two k-steps = the eight
+ *                components a lane's normal pair lands on, as in linear_tile_kernel)
+ *   proposal y   in LDS, the MFMA B-operand layout [tile][k-step][lane]: every wave writes its slice, all read all of it
+ *   F = A y      OUTPUT tiles are dealt to the waves in chunks of TC (chunk i to wave i mod W): a wave runs the FULL k
+ *                loop for its chunk -- k ascending per accumulator: the bits of every other kernel -- with the matrix's
+ *                fragments requested from L2 a block of k-steps ahead, each fragment feeding NT MFMAs
+ *   sums         |F - Dbar|^2 and the prior join the chains' partial sums in the canonical order (outputs ascending,
+ *                components ascending) by a hand-over from wave to wave through LDS: phase w of a round belongs to wave w
+ *   decision     wave 0 (it carries log pi, the counters and the status of the chains) decides and posts the flags; every
+ *                wave moves its slice and writes its part of the record row
+ * Nothing but the record leaves the chip inside the launch.  Same draws, same arithmetic in the same order as the
+ * launch-per-stage path: bit-identical (F22b, the d <= 1000 shapes and the wide fuzz cases run both).
+ */
+template <int NT, int W, int QW, int TC>
+__global__ __launch_bounds__(64 * W) void linear_wide_fused_kernel(const WideFusedArgs a)
+{
+    ymc_stage_tables();
+    extern __shared__ double lds[];
+    constexpr int KB = TC >= 4 ? 1 : 4 / TC; /* k-steps per stage of fragments: ~4 fragments (more cost registers: spills) */
+    constexpr int PD = W >= 16 ? 2 : 4;      /* stages in flight */
+    const int KS = a.KS, MT = a.MT, m_pad = 16 * MT, d_pad = 4 * KS, d = a.d;
+    const int KSP = ((KS + PD * KB - 1) / (PD * KB)) * (PD * KB); /* the k-steps rounded up to whole rings of stages */
+    double *ylds = lds;                                   /* [NT][KSP][64], zero beyond KS */
+    double *bias = ylds + (size_t)NT * KSP * 64;          /* bias | n prec | row mean | prior mean | prior prec | sigma */
+    double *nprec = bias + m_pad, *dbar = nprec + m_pad;
+    double *pmean = dbar + m_pad, *pprec = pmean + d_pad, *sigma = pprec + d_pad;
+    double *handS = sigma + d_pad;                        /* [NT][64]: the residual sums on their way from wave to wave */
+    double *handP = handS + NT * 64;                      /* [NT][64]: the prior's */
+    int *movedf = reinterpret_cast<int *>(handP + NT * 64); /* [NT][16] */
+    int *accf = movedf + NT * 16;                         /* [NT][16] */
+    volatile uint32_t *ticket = reinterpret_cast<volatile uint32_t *>(accf + NT * 16);                /* [2]: hand-overs posted so far, of the prior's sums and of the residuals' */
+
+    /* the wave's number as a SCALAR: its q-range, its chunk and its phase are uniform branches and scalar address
+     * arithmetic (as tid >> 6 the compiler treats them as per-lane values: exec-masked branches around every pair's
+     * draws and a vector register per hoisted LDS address) */
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 15, g = lane >> 4;
+    {
+        const double *consts = a.blob + (size_t)MT * KS * 64;
+        for (int i = tid; i < 3 * m_pad + 3 * d_pad; i += 64 * W) bias[i] = consts[i];
+        for (int i = tid; i < NT * 16; i += 64 * W) movedf[i] = 0;
+        if (tid < 2) ticket[tid] = 0;
+        for (int i = tid; i < NT * (KSP - KS) * 64; i += 64 * W) {
+            const int nt = i / ((KSP - KS) * 64), r = i % ((KSP - KS) * 64);
+            ylds[(nt * KSP + KS) * 64 + r] = 0.0;
+        }
+    }
+    const uint64_t nct = (a.K + 15) / 16;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * NT;
+    const int Q = KS / 2, q0 = (wave * Q) / W, nq = ((wave + 1) * Q) / W - q0; /* this wave's q-range [q0, q0 + nq) */
+    const uint32_t pair_of_g = (g == 0) ? 0u : (g == 1) ? 2u : (g == 2) ? 1u : 3u;
+    /* everything the slice touches as ONE base per array + compile-time offsets (8 qi + 4 e components on, 2 qi + e k-steps
+     * on): per-pair addresses computed from q would be a hundred loop-invariant values for the compiler to hoist and spill */
+    const int j0 = 8 * q0 + g;                       /* this lane's first component */
+    const double *sig_w = sigma + j0, *pm_w = pmean + j0, *pp_w = pprec + j0;
+    double *y_w = ylds + (2 * q0) * 64 + lane;       /* + nt KSP 64 + (2 qi + e) 64 */
+    const int left = d - j0 - 4;                      /* pairs qi with 8 qi < left have both their components below d */
+    const int full_q = left > 0 ? (left + 7) / 8 : 0;
+
+    uint64_t kk[NT];
+    bool live[NT];
+    double xs[NT][2 * QW];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const uint64_t k = (tile0 + nt) * 16 + c;
+        live[nt] = tile0 + nt < nct && k < a.K;
+        kk[nt] = live[nt] ? k : 0;
+        const double *xr = a.x + kk[nt] * d + j0;
+#pragma unroll
+        for (int qi = 0; qi < QW; ++qi) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                xs[nt][2 * qi + e] = (live[nt] && qi < nq && j0 + 8 * qi + 4 * e < d) ? xr[8 * qi + 4 * e] : 0.0;
+        }
+    }
+    /* the LAST wave (the hand-overs end with it: it decides): what a chain carries besides its state */
+    double lp[NT];
+    uint64_t accepted[NT];
+    uint32_t st[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        lp[nt] = (wave == W - 1 && live[nt]) ? a.lp[kk[nt]] : 0.0;
+        accepted[nt] = (wave == W - 1 && live[nt]) ? a.acc_count[kk[nt]] : 0;
+        st[nt] = (wave == W - 1 && live[nt]) ? a.status[kk[nt]] : 0;
+    }
+    RecordClock clk(a.rec_stride, a.rec_since);
+    const int n_chunks = (MT + TC - 1) / TC, rounds = (n_chunks + W - 1) / W;
+    /* The accumulators are carried by a run-time k loop (KS is not a template parameter here), so the kernel must stay
+     * within the VGPR-form MFMA budget: built for one wave per SIMD (512 registers) the compiler puts them in AGPRs and
+     * copies every accumulator in and out per iteration (500 spilled registers at NT = 2, TC = 8); at two waves per SIMD
+     * everything is a VGPR */
+    __syncthreads();
+
+#pragma unroll 1
+    for (uint32_t n = 0; n < a.nsteps; ++n) {
+        const uint64_t t = a.t0 + n;
+        /* ---- proposal (mrw.py:32-38 / pcn.py:27-36) of this wave's slice, into LDS ---- */
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const uint32_t chain = (uint32_t)(a.chain0 + kk[nt]);
+            double *yt = y_w + nt * KSP * 64;
+            bool moved_l = false;
+#pragma unroll
+            for (int qi = 0; qi < QW; ++qi) {
+                if (qi < nq) {
+                    double xi0, xi1;
+#if defined(YMC_WF_NODRAW)   /* timing experiments only */
+                    xi0 = 1e-3 * (double)(qi + 1), xi1 = -1e-3 * (double)(chain & 7u);
+#else
+                    ymc_draw_normal_pair(a.seed, chain, t, 4u * (uint32_t)(q0 + qi) + pair_of_g, &xi0, &xi1);
+#endif
+                    swap_odd_even_rows(xi0, xi1);
+                    const double x0 = xs[nt][2 * qi], x1 = xs[nt][2 * qi + 1];
+                    double y0, y1;
+                    if (a.pcn) {
+                        const double p0 = pm_w[8 * qi] + sig_w[8 * qi] * xi0;
+                        const double p1 = pm_w[8 * qi + 4] + sig_w[8 * qi + 4] * xi1;
+                        y0 = a.pcn_c1 * x0 + a.pcn_c2 * p0;
+                        y1 = a.pcn_c1 * x1 + a.pcn_c2 * p1;
+                    } else {
+                        y0 = x0 + sig_w[8 * qi] * xi0;
+                        y1 = x1 + sig_w[8 * qi + 4] * xi1;
+                    }
+                    yt[(2 * qi) * 64] = y0;
+                    yt[(2 * qi + 1) * 64] = y1;
+                    moved_l = moved_l || !(y0 == x0) || !(y1 == x1);
+                }
+                __builtin_amdgcn_sched_barrier(0); /* one pair's draws at a time */
+            }
+            int mv = moved_l ? 1 : 0;
+            mv |= __shfl_xor(mv, 16, 64);
+            mv |= __shfl_xor(mv, 32, 64);
+            if (mv && g == 0) movedf[nt * 16 + c] = 1; /* every writer stores the same 1 */
+        }
+        __syncthreads();
+
+        /* ---- the sums travel from wave to wave behind TICKETS in LDS (no barrier: a wave spins only for its predecessor,
+         * which never waits for it): the prior's first -- components ascending, ymc_tile_logprior's order -- so that it
+         * hides under the matrix products of the waves that are through ---- */
+        auto wait_for = [&](int which, uint32_t value) {
+            if (lane == 0)
+                while (ticket[which] != value) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_wave_barrier();
+        };
+        {
+            /* the terms first (they depend on nobody), the wait, then nothing but the additions */
+            double pt[NT][2 * QW];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const double *yt = y_w + nt * KSP * 64;
+#pragma unroll
+                for (int qi = 0; qi < QW; ++qi) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        if (qi < nq) {
+                            const double dx = yt[(2 * qi + e) * 64] - pm_w[8 * qi + 4 * e];
+                            const double px = pp_w[8 * qi + 4 * e] * dx;
+                            pt[nt][2 * qi + e] = dx * px;
+                        } else {
+                            pt[nt][2 * qi + e] = 0.0;
+                        }
+                    }
+                }
+            }
+            const uint32_t tk = n * (uint32_t)W + (uint32_t)wave; /* modulo 2^32: only equality is tested */
+            double P[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) P[nt] = 0.0;
+            if (wave > 0) {
+                wait_for(0, tk);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) P[nt] = handP[nt * 64 + lane];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int qi = 0; qi < QW; ++qi) {
+                    if (qi < nq) {
+                        P[nt] = P[nt] + pt[nt][2 * qi];
+                        P[nt] = P[nt] + pt[nt][2 * qi + 1];
+                    }
+                }
+                handP[nt * 64 + lane] = P[nt];
+            }
+            if (lane == 0) ticket[0] = tk + 1; /* LDS operations of a wave are performed in order: the sums are there */
+        }
+
+        /* ---- F = A y on the matrix cores ---- */
+#pragma unroll 1
+        for (int r = 0; r < rounds; ++r) {
+            const int chunk = r * W + wave, t0 = chunk * TC; /* this wave's output tiles t0 .. t0 + TC - 1 (those < MT) */
+            d4 acc[NT][TC];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int tc = 0; tc < TC; ++tc) acc[nt][tc] = d4{0.0, 0.0, 0.0, 0.0};
+            if (t0 < MT) {
+                const double *A = a.blob + (size_t)t0 * KS * 64 + lane;
+                const double *yk = ylds + lane;
+                /* a ring of PD stages of KB k-steps: stage i is multiplied while stages i + 1 .. i + PD - 1 are on their way
+                 * from L2.  The loop body is ONE basic block -- no guard on the k-step -- so that the compiler counts the
+                 * loads in flight (with guards it drains them all, `s_waitcnt vmcnt(0)`, at every iteration): the k-steps run
+                 * to KSP, KS rounded up to whole rings; beyond KS the proposal tile holds zeros and the fragment read is
+                 * whatever follows in the block (the next tile's, or the constants': finite), so the products are +0 */
+                double fr[PD][KB][TC];
+                auto request = [&](double (&f)[KB][TC], int s0) {
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb) {
+                        const int s = s0 + kb < KSP ? s0 + kb : KSP - 1;
+#pragma unroll
+                        for (int tc = 0; tc < TC; ++tc) {
+                            const int tt = t0 + tc < MT ? tc : 0; /* a chunk's tail repeats its first tile (never summed) */
+                            f[kb][tc] = A[((size_t)tt * KS + s) * 64];
+                        }
+                    }
+                };
+#pragma unroll
+                for (int p = 0; p < PD; ++p) request(fr[p], p * KB);
+#pragma unroll 1
+                for (int s0 = 0; s0 < KSP; s0 += PD * KB) {
+#pragma unroll
+                    for (int p = 0; p < PD; ++p) {
+                        const int sb = s0 + p * KB;
+#pragma unroll
+                        for (int kb = 0; kb < KB; ++kb) {
+                            double yb[NT];
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) yb[nt] = yk[(nt * KSP + sb + kb) * 64];
+#pragma unroll
+                            for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt)
+                                    acc[nt][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[p][kb][tc], yb[nt], acc[nt][tc], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0); /* the stage's requests stay HERE, between its MFMAs and the next */
+                        request(fr[p], sb + PD * KB);      /* stage's (the scheduler otherwise gathers all 32 at the loop's end) */
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            /* the terms of this wave's outputs IN PLACE of their accumulators (ymc_tile_add_residuals, one tile at a time)
+             * and, in the first round, of its components' prior -- computed by all waves together, so that a phase of the
+             * hand-over below is nothing but the additions */
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int m = 16 * (t0 + tc < MT ? t0 + tc : 0) + 4 * rr + g;
+                        const double F = acc[nt][tc][rr] + bias[m];
+                        const double res = F - dbar[m];
+                        const double px = nprec[m] * res;
+                        acc[nt][tc][rr] = res * px;
+                    }
+            /* the residuals' hand-over: outputs ascending, chunk r W + w follows chunk r W + w - 1 */
+            {
+                const uint32_t tk = (n * (uint32_t)rounds + (uint32_t)r) * (uint32_t)W + (uint32_t)wave;
+                if (chunk > 0) wait_for(1, tk);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    double S = (chunk == 0) ? 0.0 : handS[nt * 64 + lane];
+#pragma unroll
+                    for (int tc = 0; tc < TC; ++tc) {
+                        if (t0 + tc < MT) {
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) S = S + acc[nt][tc][rr];
+                        }
+                    }
+                    handS[nt * 64 + lane] = S;
+                }
+                if (lane == 0) ticket[1] = tk + 1;
+            }
+        }
+
+        /* ---- the decision (metropolisHastings.py:55-73, mrw.py:51-57): the last wave, whose hand-over closed the sums ---- */
+        const bool rec = clk.due();
+        if (wave == W - 1) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const double logl = -0.5 * (combine4(handS[nt * 64 + lane]) + a.lik_const);
+                const double lpy = a.likelihood_only ? logl : logl + (-0.5 * combine4(handP[nt * 64 + lane]));
+                const uint32_t chain = (uint32_t)(a.chain0 + kk[nt]);
+                const double u = ymc_draw_uniform(a.seed, chain, t);
+                const bool moved = movedf[nt * 16 + c] != 0;
+                const bool acc1 = ymc_accept(lpy - lp[nt], moved, ymc_finite(lpy), u, st[nt]);
+                lp[nt] = acc1 ? lpy : lp[nt];
+                accepted[nt] += acc1 ? 1u : 0u;
+                if (g == 0) {
+                    accf[nt * 16 + c] = acc1 ? 1 : 0;
+                    movedf[nt * 16 + c] = 0;
+                    if (live[nt]) {
+                        if (a.acc) a.acc[(uint64_t)n * a.K + kk[nt]] = acc1 ? 1 : 0;
+                        if (rec && a.lp_out) a.lp_out[(uint64_t)clk.row * a.K + kk[nt]] = lp[nt];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        /* ---- the move and the record row, every wave its slice ---- */
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const bool acc1 = accf[nt * 16 + c] != 0;
+            const double *yt = y_w + nt * KSP * 64;
+#pragma unroll
+            for (int qi = 0; qi < QW; ++qi) {
+                if (qi < nq) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const double y = yt[(2 * qi + e) * 64];
+                        xs[nt][2 * qi + e] = acc1 ? y : xs[nt][2 * qi + e];
+                    }
+                }
+            }
+            if (rec && a.traj && live[nt]) { /* ONE masked region: the chains that exist */
+                double *row = a.traj + ((uint64_t)clk.row * a.K + kk[nt]) * (uint64_t)d + j0;
+#pragma unroll
+                for (int qi = 0; qi < QW; ++qi) {
+                    if (qi < nq) {
+                        if (qi < full_q) { /* both components exist in every lane's row */
+                            row[8 * qi] = xs[nt][2 * qi];
+                            row[8 * qi + 4] = xs[nt][2 * qi + 1];
+                        } else {
+                            if (j0 + 8 * qi < d) row[8 * qi] = xs[nt][2 * qi];
+                            if (j0 + 8 * qi + 4 < d) row[8 * qi + 4] = xs[nt][2 * qi + 1];
+                        }
+                    }
+                }
+            }
+        }
+        if (rec) clk.wrote();
+        /* no barrier here: the next proposal writes this wave's OWN slice of the LDS tile, which nobody else reads any more
+         * (every wave is through its products: the decision's barrier), and the flags it touches were read before that
+         * barrier */
+    }
+
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        if (!live[nt]) continue;
+        double *xr = a.x + kk[nt] * d + j0;
+#pragma unroll
+        for (int qi = 0; qi < QW; ++qi) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                if (qi < nq && j0 + 8 * qi + 4 * e < d) xr[8 * qi + 4 * e] = xs[nt][2 * qi + e];
+        }
+        if (wave == W - 1 && g == 0) {
+            a.lp[kk[nt]] = lp[nt];
+            a.acc_count[kk[nt]] = accepted[nt];
+            a.status[kk[nt]] = st[nt];
+        }
+    }
+}
+
+}  // namespace
+
+/* which build of linear_wide_fused_kernel an ensemble gets: large ensembles two tiles per workgroup of eight waves (two per
+ * SIMD, every fragment of the matrix feeding two MFMAs; one tile beyond 576 parameters, where two do not fit the LDS),
+ * small ones one tile per workgroup of sixteen (the chip is short of waves, not of registers); TC output tiles per wave
+ * and round by the number of output tiles */
+namespace {
+struct FusedPick {
+    int NT, W, QW, TC;
+};
+
+bool pick_fused(int KS, int MT, uint64_t K, int cus, FusedPick &f)
+{
+    const uint64_t nct = (K + 15) / 16;
+    const int Q = KS / 2;
+    if (nct >= 2ull * (uint64_t)cus) { /* eight waves = two per SIMD, 256 registers each */
+        f.W = 8;
+        f.NT = Q <= 72 ? 2 : 1;
+        f.QW = f.NT == 2 ? 9 : 18;
+    } else {                           /* sixteen waves = four per SIMD, 128 registers */
+        f.W = 16, f.NT = 1, f.QW = 9;
+    }
+    if ((Q + f.W - 1) / f.W > f.QW) return false;
+    const int per_wave = (MT + f.W - 1) / f.W;
+    const int cap = f.W == 16 ? 1 : 2; /* more output tiles per wave and round spill (the accumulators + the ring of fragments) */
+    f.TC = per_wave >= 8 ? 8 : per_wave >= 4 ? 4 : per_wave >= 2 ? 2 : 1;
+    if (f.TC > cap) f.TC = cap;
+    if (const char *env = std::getenv("YMC_WIDE_TC")) { /* experiments: tiles per wave and round */
+        const int want = std::atoi(env);
+        if ((want == 1 || want == 2 || want == 4 || want == 8) && want <= cap) f.TC = want;
+    }
+    return true;
+}
+
+size_t fused_lds(const FusedPick &f, int KS, int MT)
+{
+    const size_t m_pad = 16 * (size_t)MT, d_pad = 4 * (size_t)KS;
+    const int kb = f.TC >= 4 ? 1 : 4 / f.TC, pd = f.W >= 16 ? 2 : 4, ring = kb * pd;
+    const size_t ksp = (size_t)((KS + ring - 1) / ring) * ring; /* as the kernel rounds its k loop */
+    return ((size_t)f.NT * ksp * 64 + 3 * m_pad + 3 * d_pad + 2 * (size_t)f.NT * 64) * sizeof(double) + (2 * (size_t)f.NT * 16 + 4) * sizeof(int);
+}
+
+template <int NT, int W, int QW, int TC>
+hipError_t launch_fused(const WideFusedArgs &a, size_t lds, hipStream_t s)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_wide_fused_kernel<NT, W, QW, TC>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const uint64_t nct = (a.K + 15) / 16;
+    hipLaunchKernelGGL((linear_wide_fused_kernel<NT, W, QW, TC>), dim3((unsigned)((nct + NT - 1) / NT)), dim3(64 * W), lds, s, a);
+    return hipGetLastError();
+}
+}  // namespace
+
+size_t ymc_wide_fused_lds_bytes(int KS, int MT, uint64_t K, int cus)
+{
+    if (const char *env = std::getenv("YMC_WIDE_FUSED"))
+        if (env[0] == '0') return 0;
+    FusedPick f;
+    if (!pick_fused(KS, MT, K, cus, f)) return 0;
+    const size_t lds = fused_lds(f, KS, MT);
+    return lds <= kTileLdsLimit ? lds : 0;
+}
+
+hipError_t ymc_launch_wide_fused(const WideFusedArgs &a, int cus, hipStream_t s)
+{
+    FusedPick f;
+    if (!pick_fused(a.KS, a.MT, a.K, cus, f)) return hipErrorInvalidValue;
+    const size_t lds = fused_lds(f, a.KS, a.MT);
+#define YMC_FUSED(NT_, W_, QW_, TC_) \
+    if (f.NT == NT_ && f.W == W_ && f.TC == TC_) return launch_fused<NT_, W_, QW_, TC_>(a, lds, s);
+    YMC_FUSED(2, 8, 9, 2) YMC_FUSED(2, 8, 9, 1)
+    YMC_FUSED(1, 8, 18, 2) YMC_FUSED(1, 8, 18, 1)
+    YMC_FUSED(1, 16, 9, 1)
+#undef YMC_FUSED
+    return hipErrorInvalidValue;
+}
+
