@@ -1490,7 +1490,7 @@ def test_tile_mlda2_beyond_the_lds_and_d128_vs_oracle(ffi, ctx, d, mc, mf, K, S,
 
 @pytest.mark.parametrize("d,m,nd,K,method,stride", [(300, 40, 2, 70, "mrw", 1), (513, 700, 3, 20, "pcn", 1), (1000, 64, 2, 17, "mrw", 4),
                                                     (257, 1, 1, 33, "mrw", 1), (320, 64, 2, 8229, "mrw", 1), (592, 48, 2, 8200, "pcn", 3),
-                                                    (512, 520, 1, 8192, "mrw", 2)])
+                                                    (512, 520, 1, 8192, "mrw", 2), (1024, 256, 2, 8192, "mrw", 5), (1100, 30, 1, 40, "pcn", 1)])
 def test_wide_fused_kernel_vs_oracle_and_the_launch_per_stage_path(ffi, ctx, monkeypatch, d, m, nd, K, method, stride):
     """linear_wide_fused_kernel (round 4): the random walk and pCN beyond 256 parameters as ONE persistent launch per advance
     call -- the state in registers cut along k, the proposal in LDS, every wave its output tiles over all k, the sums handed

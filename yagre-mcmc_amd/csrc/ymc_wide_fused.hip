@@ -32,7 +32,7 @@ namespace {
  * Nothing but the record leaves the chip inside the launch.  Same draws, same arithmetic in the same order as the
  * launch-per-stage path: bit-identical (F22b, the d <= 1000 shapes and the wide fuzz cases run both).
  */
-template <int NT, int W, int QW, int TC>
+template <int NT, int W, int QW, int TC, bool CG>
 __global__ __launch_bounds__(64 * W) void linear_wide_fused_kernel(const WideFusedArgs a)
 {
     ymc_stage_tables();
@@ -44,8 +44,11 @@ __global__ __launch_bounds__(64 * W) void linear_wide_fused_kernel(const WideFus
     double *ylds = lds;                                   /* [NT][KSP][64], zero beyond KS */
     double *bias = ylds + (size_t)NT * KSP * 64;          /* bias | n prec | row mean | prior mean | prior prec | sigma */
     double *nprec = bias + m_pad, *dbar = nprec + m_pad;
-    double *pmean = dbar + m_pad, *pprec = pmean + d_pad, *sigma = pprec + d_pad;
-    double *handS = sigma + d_pad;                        /* [NT][64]: the residual sums on their way from wave to wave */
+    /* CG: the three per-component constants stay in the problem's block in global memory (L2): beyond ~900 parameters
+     * they no longer fit the LDS next to the proposal tile */
+    const double *pmean = CG ? a.blob + (size_t)MT * KS * 64 + 3 * (size_t)m_pad : dbar + m_pad;
+    const double *pprec = pmean + d_pad, *sigma = pprec + d_pad;
+    double *handS = dbar + m_pad + (CG ? 0 : 3 * d_pad);  /* [NT][64]: the residual sums on their way from wave to wave */
     double *handP = handS + NT * 64;                      /* [NT][64]: the prior's */
     int *movedf = reinterpret_cast<int *>(handP + NT * 64); /* [NT][16] */
     int *accf = movedf + NT * 16;                         /* [NT][16] */
@@ -57,7 +60,7 @@ __global__ __launch_bounds__(64 * W) void linear_wide_fused_kernel(const WideFus
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 15, g = lane >> 4;
     {
         const double *consts = a.blob + (size_t)MT * KS * 64;
-        for (int i = tid; i < 3 * m_pad + 3 * d_pad; i += 64 * W) bias[i] = consts[i];
+        for (int i = tid; i < 3 * m_pad + (CG ? 0 : 3 * d_pad); i += 64 * W) bias[i] = consts[i];
         for (int i = tid; i < NT * 16; i += 64 * W) movedf[i] = 0;
         if (tid < 2) ticket[tid] = 0;
         for (int i = tid; i < NT * (KSP - KS) * 64; i += 64 * W) {
@@ -381,6 +384,7 @@ __global__ __launch_bounds__(64 * W) void linear_wide_fused_kernel(const WideFus
 namespace {
 struct FusedPick {
     int NT, W, QW, TC;
+    bool CG; /* the per-component constants from global memory */
 };
 
 bool pick_fused(int KS, int MT, uint64_t K, int cus, FusedPick &f)
@@ -411,17 +415,31 @@ size_t fused_lds(const FusedPick &f, int KS, int MT)
     const size_t m_pad = 16 * (size_t)MT, d_pad = 4 * (size_t)KS;
     const int kb = f.TC >= 4 ? 1 : 4 / f.TC, pd = f.W >= 16 ? 2 : 4, ring = kb * pd;
     const size_t ksp = (size_t)((KS + ring - 1) / ring) * ring; /* as the kernel rounds its k loop */
-    return ((size_t)f.NT * ksp * 64 + 3 * m_pad + 3 * d_pad + 2 * (size_t)f.NT * 64) * sizeof(double) + (2 * (size_t)f.NT * 16 + 4) * sizeof(int);
+    return ((size_t)f.NT * ksp * 64 + 3 * m_pad + (f.CG ? 0 : 3 * d_pad) + 2 * (size_t)f.NT * 64) * sizeof(double) +
+           (2 * (size_t)f.NT * 16 + 4) * sizeof(int);
 }
 
-template <int NT, int W, int QW, int TC>
+/* the build and its LDS: constants in LDS if everything fits, else the per-component ones from global memory; 0 = no */
+size_t fused_fit(int KS, int MT, uint64_t K, int cus, FusedPick &f)
+{
+    if (!pick_fused(KS, MT, K, cus, f)) return 0;
+    f.CG = false;
+    size_t lds = fused_lds(f, KS, MT);
+    if (lds > kTileLdsLimit) {
+        f.CG = true;
+        lds = fused_lds(f, KS, MT);
+    }
+    return lds <= kTileLdsLimit ? lds : 0;
+}
+
+template <int NT, int W, int QW, int TC, bool CG>
 hipError_t launch_fused(const WideFusedArgs &a, size_t lds, hipStream_t s)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_wide_fused_kernel<NT, W, QW, TC>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_wide_fused_kernel<NT, W, QW, TC, CG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const uint64_t nct = (a.K + 15) / 16;
-    hipLaunchKernelGGL((linear_wide_fused_kernel<NT, W, QW, TC>), dim3((unsigned)((nct + NT - 1) / NT)), dim3(64 * W), lds, s, a);
+    hipLaunchKernelGGL((linear_wide_fused_kernel<NT, W, QW, TC, CG>), dim3((unsigned)((nct + NT - 1) / NT)), dim3(64 * W), lds, s, a);
     return hipGetLastError();
 }
 }  // namespace
@@ -431,22 +449,20 @@ size_t ymc_wide_fused_lds_bytes(int KS, int MT, uint64_t K, int cus)
     if (const char *env = std::getenv("YMC_WIDE_FUSED"))
         if (env[0] == '0') return 0;
     FusedPick f;
-    if (!pick_fused(KS, MT, K, cus, f)) return 0;
-    const size_t lds = fused_lds(f, KS, MT);
-    return lds <= kTileLdsLimit ? lds : 0;
+    return fused_fit(KS, MT, K, cus, f);
 }
 
 hipError_t ymc_launch_wide_fused(const WideFusedArgs &a, int cus, hipStream_t s)
 {
     FusedPick f;
-    if (!pick_fused(a.KS, a.MT, a.K, cus, f)) return hipErrorInvalidValue;
-    const size_t lds = fused_lds(f, a.KS, a.MT);
-#define YMC_FUSED(NT_, W_, QW_, TC_) \
-    if (f.NT == NT_ && f.W == W_ && f.TC == TC_) return launch_fused<NT_, W_, QW_, TC_>(a, lds, s);
+    const size_t lds = fused_fit(a.KS, a.MT, a.K, cus, f);
+    if (!lds) return hipErrorInvalidValue;
+#define YMC_FUSED(NT_, W_, QW_, TC_)                                                                      \
+    if (f.NT == NT_ && f.W == W_ && f.TC == TC_)                                                          \
+        return f.CG ? launch_fused<NT_, W_, QW_, TC_, true>(a, lds, s) : launch_fused<NT_, W_, QW_, TC_, false>(a, lds, s);
     YMC_FUSED(2, 8, 9, 2) YMC_FUSED(2, 8, 9, 1)
     YMC_FUSED(1, 8, 18, 2) YMC_FUSED(1, 8, 18, 1)
     YMC_FUSED(1, 16, 9, 1)
 #undef YMC_FUSED
     return hipErrorInvalidValue;
 }
-
