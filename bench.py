@@ -293,7 +293,7 @@ def roofline_block(name, stride, wl, K, T, kernel_ms, launches, clock_mhz, info)
         return dict(common, bound="mfma", achieved=tf, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / FP64_PEAK_TFLOPS,
                     algorithmic_flops_per_launch=flops, valu=valu,
                     note="per GPU (rank 0); v_mfma_f64_16x16x4_f64 GEMV (2 d m flop per transition); the 128 normal "
-                         "draws per transition are VALU work on top of it -- DESIGN.md")
+                         "draws per transition are VALU work on top of it -- DESIGN.md section 4")
     if name == "c4":
         flops = 10 * 50 * 50.0 * K * T   # n_data x rk4_steps x 50 flop (30 fp64 instructions, 20 of them fma)
         tf = flops / ksec / 1e12 if ksec > 0 else 0.0
@@ -305,7 +305,7 @@ def roofline_block(name, stride, wl, K, T, kernel_ms, launches, clock_mhz, info)
                 note="per GPU (rank 0); bytes = (8 d + 1) per transition per chain"
                      + (" (per FINE step; every fine step also makes 6 coarse transitions)" if name == "c5" else "")
                      + "; the kernel is VALU-issue bound (Philox + Box-Muller + exp per transition) -- see `valu` "
-                       "and DESIGN.md")
+                       "and DESIGN.md section 4")
 
 
 def bench_iat(args, ffi, ctx, wl, K, info):

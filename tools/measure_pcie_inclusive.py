@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The PCIe-inclusive rate quoted in DESIGN.md: C2 (65 536 chains, 2-D Gaussian target) when every recorded
+"""The PCIe-inclusive rate quoted in NOTEBOOK.md (rounds 1-3, section 5): C2 (65 536 chains, 2-D Gaussian target) when every recorded
 row is brought to the host, (a) the round-1 way -- synchronous fetch into pageable NumPy arrays after every
 launch -- and (b) through the egress path (ymc_run_egress_*: page-locked double buffer on a copy stream,
 overlapping the next launch), at record stride 1 and at stride = the median integrated autocorrelation time

@@ -15,7 +15,7 @@
  */
 /* Polynomial coefficients as loop-invariant VGPR pairs (ymc_numerics.h, ymc_fma_c): 11 % fewer
  * instructions per transition than re-materialising them, at the same or better occupancy. */
-/* Experiment switches (tools/exp_occupancy.sh; the results are in profiles/r02_exp_occupancy.txt and DESIGN.md
+/* Experiment switches (tools/exp_occupancy.sh; the results are in profiles/r02_exp_occupancy.txt and NOTEBOOK.md (rounds 1-3,
  * section 5): -DYMC_EXP_SGPR keeps the coefficients in SGPR pairs instead, -DYMC_EXP_WAVES=4,4 / 8,8 builds the
  * random-walk kernel for four / eight resident waves per SIMD instead of at most two. */
 #if defined(YMC_EXP_SGPR)
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(kBlock) void mrw_kernel(const ChainArgs<D> a)
  * scheduler interleaves the independent draw / density chains of a transition pair instead of
  * minimising registers for a third wave: the kernel is VALU-bound, so what counts is that the one
  * or two resident waves never stall on their own latencies.  Same instruction count, 170 instead of
- * 142 VGPRs; measured +8 % at 65 536 chains, +3 % at 131 072, +1 % at 1 M (tools: YMC A/B in DESIGN.md). */
+ * 142 VGPRs; measured +8 % at 65 536 chains, +3 % at 131 072, +1 % at 1 M (tools: YMC A/B in NOTEBOOK.md). */
 template <int KIND, int D, unsigned REC, int EQ>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(YMC_EXP_WAVES))) void mrw_kernel_two_waves(const ChainArgs<D> a)
 {
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(YMC_EXP_
  * handed over through an LDS ring of two blocks, one barrier per six transitions.  Every lane does the
  * arithmetic of mrw_body in the same order: same bits.  Measured +20 % at 65 536 chains (1.43e11 against
  * 1.18e11 transitions/s); what bounds it then is the chip's power limit (the clock drops from 2.39 to
- * ~2.0 GHz), the same wall the one-lane-per-chain kernel meets at 1 M chains.  The
+ * ~2.0 GHz), the same wall the one-lane-per-chain kernel meets at 1 M chains (NOTEBOOK.md (rounds 1-3, section 5)).  The
  * consumers of four 256-thread workgroups would all land on SIMD 0 -- hence one big workgroup.
  */
 constexpr int kSplitChains = 256;
