@@ -1504,7 +1504,8 @@ def test_wide_fused_kernel_vs_oracle_and_the_launch_per_stage_path(ffi, ctx, mon
     A, b = rng.normal(size=(m, d)) / np.sqrt(d), rng.normal(size=m)
     x0 = rng.normal(size=(K, d)) * 0.3
     n = 10
-    flags = ffi.RECORD_TRAJECTORY | ffi.RECORD_LOGPOST | (ffi.RECORD_ACCEPT if stride == 1 else 0)
+    # FullDiagnostics' moments where the record holds every transition (the fused kernel's are replayed from it)
+    flags = ffi.RECORD_TRAJECTORY | ffi.RECORD_LOGPOST | ((ffi.RECORD_ACCEPT | ffi.RECORD_MOMENTS) if stride == 1 else 0)
     if method == "pcn":
         g["prior_mean"] = np.zeros(d)
         low = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, g, fwd_matrix=A, fwd_shift=b)
@@ -1529,7 +1530,7 @@ def test_wide_fused_kernel_vs_oracle_and_the_launch_per_stage_path(ffi, ctx, mon
         ms, launches = run.kernel_time_ms()
         s_ = run.summary()
         return dict(traj=run.trajectory(), lp=run.logpost(), acc=run.accept() if stride == 1 else None, state=run.state(),
-                    accepted=s_["accepted"], status=s_["status"], launches=launches)
+                    accepted=s_["accepted"], status=s_["status"], launches=launches, wf=(s_["wf_mean"], s_["wf_m2"]))
     fused, staged = device(True), device(False)
     out = e.advance(n)
     rows = slice(stride - 1, None, stride)
@@ -1539,6 +1540,8 @@ def test_wide_fused_kernel_vs_oracle_and_the_launch_per_stage_path(ffi, ctx, mon
             assert np.array_equal(dev["acc"], out["acc"])
         assert np.array_equal(dev["state"][0], e.x) and np.array_equal(dev["state"][1], e.lp)
         assert np.array_equal(dev["accepted"], e.acc_count) and np.array_equal(dev["status"], e.status)
+        if stride == 1:
+            assert np.array_equal(dev["wf"][0], e.wf_mean) and np.array_equal(dev["wf"][1], e.wf_m2)
     assert 0 < out["acc"].mean() < 1
 
 

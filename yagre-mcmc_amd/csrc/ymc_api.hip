@@ -878,11 +878,18 @@ int launch_advance_wide(ymc_run *r, uint64_t nsteps)
     }
     YMC_HIP(hipEventRecord(ev.first, s));
     /* the random walk with a diagonal proposal and pCN: the whole launch as ONE persistent kernel with the chains' state
-     * on the chip (linear_wide_fused_kernel) where the proposal tile fits the LDS -- identical results; moments are the
-     * launch-per-stage path's (they would be two more slices of registers per chain) */
+     * on the chip (linear_wide_fused_kernel) where the proposal tile fits the LDS -- identical results; moments (they would
+     * be two more slices of registers per chain) are replayed from the record afterwards, as the tile kernels' are */
     const int cus = r->ctx->prop.multiProcessorCount;
-    if (!two && !p->chol_frag.p && !(r->flags & YMC_RECORD_MOMENTS) && nsteps < (1ull << 32) &&
+    const bool moments = (r->flags & YMC_RECORD_MOMENTS) != 0;
+    /* moments: replayed from the record the launch writes -- which must then hold every transition */
+    const bool replayable = !moments || ((r->flags & YMC_RECORD_TRAJECTORY) && r->stride == 1);
+    if (!two && !p->chol_frag.p && replayable && nsteps < (1ull << 32) &&
         ymc_wide_fused_lds_bytes(p->tgt.KS, p->tgt.MT, K, cus)) {
+        if (moments) {
+            if (!r->x_before.p) YMC_TRY(r->x_before.alloc(r->x.bytes));
+            YMC_HIP(hipMemcpyAsync(r->x_before.p, r->x.p, r->x.bytes, hipMemcpyDeviceToDevice, s));
+        }
         WideFusedArgs f{};
         f.blob = p->tgt.tile_blob.as<double>();
         f.lik_const = p->tgt.lik_const;
@@ -900,6 +907,9 @@ int launch_advance_wide(ymc_run *r, uint64_t nsteps)
         if (r->flags & YMC_RECORD_ACCEPT) f.acc = r->acc.as<uint8_t>() + row * K;
         if (r->flags & YMC_RECORD_LOGPOST) f.lp_out = r->lp_out.as<double>() + row * K;
         hipError_t e = ymc_launch_wide_fused(f, cus, s);
+        if (e == hipSuccess && moments)
+            e = ymc_launch_welford_replay_plain(f.traj, r->x_before.as<double>(), nsteps, K, p->D, r->steps_done,
+                                                r->wf_mean.as<double>(), r->wf_m2.as<double>(), s);
         if (e != hipSuccess) {
             r->pool.push_back(ev);
             return fail(YMC_ERR_DEVICE, "wide fused kernel launch failed: %s", hipGetErrorString(e));

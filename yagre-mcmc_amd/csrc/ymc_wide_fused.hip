@@ -377,6 +377,50 @@ __global__ __launch_bounds__(64 * W) void linear_wide_fused_kernel(const WideFus
 
 }  // namespace
 
+/* FullDiagnostics' moments (estimation.py:36-53, diagnostics.py:91-94) for the fused kernel: replayed after the launch from
+ * the plain record [rows][K][d] it wrote, one thread per chain and component -- the online update sequence per component,
+ * hence the bits of the kernels that update in place (welford_replay_kernel is the same for the tiled record).  The state
+ * before the launch's first transition is the carried state saved before the launch. */
+namespace {
+__global__ __launch_bounds__(256) void welford_replay_plain_kernel(const double *__restrict__ traj, const double *__restrict__ x_before,
+                                                                   uint64_t rows, uint64_t per_row, uint64_t wf_n0,
+                                                                   double *__restrict__ wf_mean, double *__restrict__ wf_m2)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= per_row) return;
+    double mean = wf_mean[i], m2 = wf_m2[i];
+    double v = x_before[i];
+    auto step = [&](uint64_t n, double next) {
+        const double dn = (double)(wf_n0 + n + 1);
+        const double delta = v - mean;
+        mean = mean + delta / dn;
+        const double delta2 = v - mean;
+        m2 = m2 + delta * delta2;
+        v = next;
+    };
+    uint64_t n = 0;
+    for (; n + 8 <= rows; n += 8) { /* eight rows requested together: the updates are sequential, the loads need not be */
+        double nx[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) nx[q] = traj[(n + q) * per_row + i];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) step(n + q, nx[q]);
+    }
+    for (; n < rows; ++n) step(n, traj[n * per_row + i]);
+    wf_mean[i] = mean;
+    wf_m2[i] = m2;
+}
+}  // namespace
+
+hipError_t ymc_launch_welford_replay_plain(const double *traj, const double *x_before, uint64_t rows, uint64_t K, int d,
+                                           uint64_t wf_n0, double *wf_mean, double *wf_m2, hipStream_t s)
+{
+    const uint64_t per_row = K * (uint64_t)d;
+    hipLaunchKernelGGL(welford_replay_plain_kernel, dim3((unsigned)((per_row + 255) / 256)), dim3(256), 0, s, traj, x_before, rows,
+                       per_row, wf_n0, wf_mean, wf_m2);
+    return hipGetLastError();
+}
+
 /* which build of linear_wide_fused_kernel an ensemble gets: large ensembles two tiles per workgroup of eight waves (two per
  * SIMD, every fragment of the matrix feeding two MFMAs; one tile beyond 576 parameters, where two do not fit the LDS),
  * small ones one tile per workgroup of sixteen (the chip is short of waves, not of registers); TC output tiles per wave
