@@ -39,13 +39,17 @@ chainBuilder.seed = 11
 mcmc = chainBuilder.build_method()
 mcmc.run(nSteps, ParameterVector(np.array([-8., -7.])))
 
+# the reference's post-processing (example_mcmc_2d_hierarchical.py:53-75): IATs per chain on the device, thinning by 'max'
 burnin = 100
 states = mcmc.chain.ensemble_trajectory
 meanIAT = mcmc.integrated_autocorrelation('mean', burnin)
 maxIAT = mcmc.integrated_autocorrelation('max', burnin)
+thinningStep = max(int(np.median(maxIAT)), 1)
+mcmcSamples = states[burnin::thinningStep].reshape(-1, 2)
 print("\nAnalytics")
 print("---------")
 print(f"acceptance rate (pooled): {mcmc.diagnostics.global_acceptance_rate():.4f}")
 print(f"acceptance rate per level (coarsest first): {[round(r, 4) for r in mcmc.level_acceptance_rates()]}")
 print(f"mean IAT (median over chains): {int(np.median(meanIAT))}   max IAT: {int(np.median(maxIAT))}")
-print(f"true mean: {tgtMeanCoeff}  mean estimate: {states[burnin:].reshape(-1, 2).mean(axis=0)}")
+print(f"true mean: {tgtMeanCoeff}  mean state: {states.reshape(-1, 2).mean(axis=0)}  "
+      f"mean estimate (thinned by {thinningStep}): {mcmcSamples.mean(axis=0)}")

@@ -9,6 +9,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from yagremcmc_amd.chain.diagnostics import FullDiagnostics
+import yagremcmc_amd.postprocessing.autocorrelation as ac
 from yagremcmc_amd.chain.method.mrw import MRWBuilder
 from yagremcmc_amd.parameter.vector import ParameterVector
 from yagremcmc_amd.statistics.covariance import IIDCovarianceMatrix
@@ -35,9 +36,15 @@ states = mcmc.chain.ensemble_trajectory          # (nSteps, nChains, 2)
 burnin = 1000
 samples = states[burnin:].reshape(-1, 2)
 
-# integrated autocorrelation time of every chain, computed on the device from the record
+# the reference's post-processing (example_mcmc_2d_singleLevel.py:62-82), per chain on the device from the record in HBM:
+# the autocorrelation function (of chain 0's components, as the reference plots it), both IATs, thinning by the 'max' one
+acf = [ac.estimate_autocorrelation_function_1d(states[burnin:, 0, j]) for j in range(tgtMean.dimension)]
 meanIAT = mcmc.integrated_autocorrelation('mean', burnin=burnin)
 maxIAT = mcmc.integrated_autocorrelation('max', burnin=burnin)
+thinningStep = max(int(np.median(maxIAT)), 1)
+mcmcSamples = states[burnin::thinningStep].reshape(-1, 2)
+meanState = states.reshape(-1, 2).mean(axis=0)
+meanEst = mcmcSamples.mean(axis=0)
 
 print("\nAnalytics")
 print("---------")
@@ -49,6 +56,9 @@ print("\nInference")
 print("---------")
 print(f"true mean: {tgtMean.coefficient}")
 print(f"mean state (Welford, pooled): {mcmc.diagnostics.mean()}")
-print(f"mean estimate after burn-in: {samples.mean(axis=0)}")
+print(f"mean state: {meanState}")
+print(f"mean estimate (burn-in {burnin}, thinned by {thinningStep}): {meanEst}")
+print(f"autocorrelation of chain 0 at lag {thinningStep}: {[round(float(a[min(thinningStep, a.size - 1)]), 3) for a in acf]}")
+print(f"mean estimate after burn-in, every state: {samples.mean(axis=0)}")
 print(f"true covariance:\n{tgtCov}")
 print(f"covariance estimate after burn-in:\n{np.cov(samples.T)}")

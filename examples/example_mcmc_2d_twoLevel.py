@@ -32,5 +32,19 @@ chainBuilder.seed = 7
 mcmc = chainBuilder.build_method()
 mcmc.run(nSteps, ParameterVector(np.array([-8., -7.])))
 states = mcmc.chain.ensemble_trajectory
+
+# the reference's post-processing (example_mcmc_2d_twoLevel.py:44-66): IATs per chain on the device, thinning by 'max'
+burnin = 100
+meanIAT = mcmc.integrated_autocorrelation('mean', burnin)
+maxIAT = mcmc.integrated_autocorrelation('max', burnin)
+thinningStep = max(int(np.median(maxIAT)), 1)
+mcmcSamples = states[burnin::thinningStep].reshape(-1, 2)
+print("\nAnalytics")
+print("---------")
 print(f"acceptance rate (fine level, pooled): {mcmc.diagnostics.global_acceptance_rate():.4f}")
-print(f"true mean: {tgtMeanCoeff}  mean estimate: {states[100:].reshape(-1, 2).mean(axis=0)}")
+print(f"mean IAT (median over chains): {int(np.median(meanIAT))}   max IAT: {int(np.median(maxIAT))}")
+print("\nInference")
+print("---------")
+print(f"true mean: {tgtMeanCoeff}")
+print(f"mean state: {states.reshape(-1, 2).mean(axis=0)}")
+print(f"mean estimate (thinned by {thinningStep}): {mcmcSamples.mean(axis=0)}")
