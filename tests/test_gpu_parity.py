@@ -1632,6 +1632,52 @@ def test_two_level_beyond_256_parameters_vs_oracle(ffi, ctx, d, mc, mf, K, S, de
     assert 0 < dev["sub_acc"].mean() < 1 and 0 < dev["acc"].mean()
 
 
+@pytest.mark.parametrize("d,mc,mf,K,S,stride", [(320, 32, 64, 4100, 3, 1), (600, 16, 48, 4096, 2, 2), (300, 40, 20, 50, 4, 1),
+                                                  (1040, 16, 32, 20, 2, 1)])
+def test_wide_fused_two_level_kernel_vs_oracle_and_the_launch_per_stage_path(ffi, ctx, monkeypatch, d, mc, mf, K, S, stride):
+    """linear_wide_fused2_kernel (round 4): two-level delayed acceptance beyond 256 parameters as one persistent launch --
+    x and z as slices of registers, the tile in LDS evaluated under the coarse posterior per sub-step and under the fine one
+    for the decision.  Large ensembles (eight waves a tile, both slice sizes), small ones (sixteen), a coarse level with more
+    outputs than the fine one, thinned records: == oracle and == the launch-per-stage path (YMC_WIDE_FUSED=0)."""
+    from yagremcmc_amd import lowering
+    rng = np.random.default_rng(5100 + d + mc)
+
+    def model(m, scale):
+        g = dict(data=rng.normal(size=(2, m)), noise_precision=rng.uniform(0.5, 3, size=m), prior_mean=rng.normal(size=d) * 0.1,
+                 prior_precision=rng.uniform(0.1, 2, size=d))
+        A, b = scale * rng.normal(size=(m, d)) / np.sqrt(d), rng.normal(size=m)
+        return (_posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, g, fwd_matrix=A, fwd_shift=b),
+                o.posterior_linear(A, b, g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"]))
+    (lf, pf), (lc, pc_) = model(mf, 1.0), model(mc, 0.95)
+    sigma, x0 = rng.uniform(0.01, 0.03, size=d), rng.normal(size=(K, d)) * 0.3
+    n = 8
+    flags = ffi.RECORD_TRAJECTORY | ffi.RECORD_LOGPOST | ((ffi.RECORD_ACCEPT | ffi.RECORD_SUB_ACCEPT | ffi.RECORD_MOMENTS) if stride == 1 else 0)
+
+    def device(fused):
+        monkeypatch.setenv("YMC_WIDE_FUSED", "1" if fused else "0")
+        prob = lowering.make_problem(ctx, ffi.METHOD_MLDA2, lf, sigma, surrogate=lc, sub_chain_length=S)
+        run = ffi.Run(prob, 995, K, x0, n, flags, 700, record_stride=stride)
+        run.advance(3)
+        run.advance(n - 3)
+        run.sync()
+        s_ = run.summary()
+        return dict(traj=run.trajectory(), lp=run.logpost(), acc=run.accept() if stride == 1 else None,
+                    sub=run.sub_accept() if stride == 1 else None, state=run.state(), accepted=s_["accepted"], status=s_["status"],
+                    wf=(s_["wf_mean"], s_["wf_m2"]))
+    fused, staged = device(True), device(False)
+    e = o.Ensemble(pf, sigma, x0, 995, chain0=700, surrogate=pc_, sub_chain_length=S)
+    out = e.advance(n, want_sub=True)
+    rows = slice(stride - 1, None, stride)
+    for dev in (fused, staged):
+        assert np.array_equal(dev["traj"], out["traj"][rows]) and np.array_equal(dev["lp"], out["logpost"][rows])
+        assert np.array_equal(dev["state"][0], e.x) and np.array_equal(dev["state"][1], e.lp)
+        assert np.array_equal(dev["accepted"], e.acc_count) and np.array_equal(dev["status"], e.status)
+        if stride == 1:
+            assert np.array_equal(dev["acc"], out["acc"]) and np.array_equal(dev["sub"], out["sub_acc"])
+            assert np.array_equal(dev["wf"][0], e.wf_mean) and np.array_equal(dev["wf"][1], e.wf_m2)
+    assert 0 < out["sub_acc"].mean() < 1
+
+
 @pytest.mark.parametrize("d,ms,K,E", [(300, (20, 30, 40), 33, 2), (260, (16, 8, 24, 12, 40), 20, 3), (400, (8,) * 8 + (16,), 17, 5)])
 def test_nested_levels_beyond_256_parameters_vs_oracle(ffi, ctx, d, ms, K, E):
     """The nest of levels beyond 256 parameters (the wide path: the walk as host recursion over plain kernels, every level

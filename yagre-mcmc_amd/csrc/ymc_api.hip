@@ -918,6 +918,40 @@ int launch_advance_wide(ymc_run *r, uint64_t nsteps)
         r->timed.push_back(ev);
         return YMC_OK;
     }
+    /* two-level delayed acceptance the same way: one persistent launch, x and z on the chip (linear_wide_fused2_kernel) */
+    if (two && !p->chol_frag.p && replayable && nsteps < (1ull << 32) && p->tgt.KS == p->sur.KS &&
+        ymc_wide_fused2_lds_bytes(p->tgt.KS, p->sur.MT, p->tgt.MT, K, cus)) {
+        if (moments) {
+            if (!r->x_before.p) YMC_TRY(r->x_before.alloc(r->x.bytes));
+            YMC_HIP(hipMemcpyAsync(r->x_before.p, r->x.p, r->x.bytes, hipMemcpyDeviceToDevice, s));
+        }
+        WideFused2Args f{};
+        f.blob_c = p->sur.tile_blob.as<double>(), f.blob_f = p->tgt.tile_blob.as<double>();
+        f.lik_const_c = p->sur.lik_const, f.lik_const_f = p->tgt.lik_const;
+        f.KS = p->tgt.KS, f.MT_c = p->sur.MT, f.MT_f = p->tgt.MT, f.d = p->D, f.S = p->S;
+        f.seed = r->seed, f.chain0 = r->chain0, f.K = K, f.t0 = r->steps_done;
+        f.nsteps = (uint32_t)nsteps;
+        f.rec_stride = r->stride;
+        f.rec_since = (uint32_t)(r->steps_done % r->stride);
+        f.x = r->x.as<double>(), f.lp = r->lp.as<double>(), f.lpc = r->lpc.as<double>();
+        f.acc_count = r->acc_count.as<uint64_t>(), f.status = r->status.as<uint32_t>();
+        const uint64_t row = r->recorded;
+        if (r->flags & YMC_RECORD_TRAJECTORY) f.traj = r->traj.as<double>() + row * K * d;
+        if (r->flags & YMC_RECORD_ACCEPT) f.acc = r->acc.as<uint8_t>() + row * K;
+        if (r->flags & YMC_RECORD_LOGPOST) f.lp_out = r->lp_out.as<double>() + row * K;
+        if (r->flags & YMC_RECORD_SUB_ACCEPT) f.sub_acc = r->sub_acc.as<uint8_t>() + row * S * K;
+        hipError_t e = ymc_launch_wide_fused2(f, cus, s);
+        if (e == hipSuccess && moments)
+            e = ymc_launch_welford_replay_plain(f.traj, r->x_before.as<double>(), nsteps, K, p->D, r->steps_done,
+                                                r->wf_mean.as<double>(), r->wf_m2.as<double>(), s);
+        if (e != hipSuccess) {
+            r->pool.push_back(ev);
+            return fail(YMC_ERR_DEVICE, "wide fused two-level kernel launch failed: %s", hipGetErrorString(e));
+        }
+        YMC_HIP(hipEventRecord(ev.second, s));
+        r->timed.push_back(ev);
+        return YMC_OK;
+    }
     uint64_t rows = 0;
     for (uint64_t n = 0; n < nsteps; ++n) {
         const uint64_t step = r->steps_done + n;

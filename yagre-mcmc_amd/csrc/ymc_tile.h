@@ -137,6 +137,25 @@ struct WideFusedArgs {
     uint8_t *acc;                  /* [nsteps][K] or null */
     double *lp_out;                /* [rows][K] or null */
 };
+/* Two-level delayed acceptance (mlda.py:100-110,146-154) beyond 256 parameters the same way (linear_wide_fused2_kernel):
+ * the fine state x and the sub-chain's state z as two slices of registers per wave, ONE tile of 16 chains per workgroup;
+ * the S coarse transitions and the fine decision each one evaluation of the tile in LDS (the fine one after z has been
+ * written into it). */
+struct WideFused2Args {
+    const double *blob_c, *blob_f; /* coarse / fine posterior, TileArgs::blob layout, same KS */
+    double lik_const_c, lik_const_f;
+    int32_t KS, MT_c, MT_f, d, S, pad_;
+    uint64_t seed, chain0, K, t0;  /* t0: fine steps done */
+    uint32_t nsteps, rec_stride, rec_since, pad1_;
+    double *x, *lp, *lpc;          /* [K][d]; fine and coarse log-density of the carried state */
+    uint64_t *acc_count;
+    uint32_t *status;
+    double *traj;
+    uint8_t *acc, *sub_acc;        /* [nsteps][K], [nsteps][S][K] or null */
+    double *lp_out;
+};
+size_t ymc_wide_fused2_lds_bytes(int KS, int MT_c, int MT_f, uint64_t K, int cus);
+hipError_t ymc_launch_wide_fused2(const WideFused2Args &a, int cus, hipStream_t s);
 /* 0 = this shape / ensemble does not take the fused kernel (the caller runs the launch-per-stage path) */
 size_t ymc_wide_fused_lds_bytes(int KS, int MT, uint64_t K, int cus);
 hipError_t ymc_launch_wide_fused(const WideFusedArgs &a, int cus, hipStream_t s);

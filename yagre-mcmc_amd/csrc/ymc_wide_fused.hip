@@ -32,6 +32,172 @@ namespace {
  * Nothing but the record leaves the chip inside the launch.  Same draws, same arithmetic in the same order as the
  * launch-per-stage path: bit-identical (F22b, the d <= 1000 shapes and the wide fuzz cases run both).
  */
+/* what an evaluation works with: the proposal tile and the hand-over slots in LDS, the wave's place in the workgroup */
+struct WideEvalCtx {
+    const double *ylds;        /* [NT][KSP][64] */
+    const double *y_w;         /* ylds + this wave's first k-step + lane */
+    double *handS, *handP;     /* [NT][64] each */
+    volatile uint32_t *ticket; /* [2] */
+    int KS, KSP, nq, lane, wave, g;
+};
+
+/* log-likelihood and prior sums of the NT tiles' proposals in LDS under ONE linear-model posterior (its matrix `blob`, MT
+ * output tiles, constants bias / nprec / dbar in LDS, prior constants at this lane's first component): afterwards handS /
+ * handP hold the chains' partial sums (per lane: its g), complete and visible to the LAST wave.  Every wave of the
+ * workgroup calls this at the same point; tkP / tkS are the running ticket numbers (uniform, advanced here). */
+template <int NT, int W, int QW, int TC, int KB, int PD>
+__device__ __forceinline__ void wide_evaluate(const WideEvalCtx &cx, const double *__restrict__ blob, int MT, const double *bias,
+                                              const double *nprec, const double *dbar, const double *pm_w, const double *pp_w,
+                                              uint32_t &tkP, uint32_t &tkS)
+{
+    const int KS = cx.KS, KSP = cx.KSP, nq = cx.nq, lane = cx.lane, wave = cx.wave, g = cx.g;
+    const double *ylds = cx.ylds, *y_w = cx.y_w;
+    double *handS = cx.handS, *handP = cx.handP;
+    volatile uint32_t *ticket = cx.ticket;
+    const int n_chunks = (MT + TC - 1) / TC, rounds = (n_chunks + W - 1) / W;
+    /* ---- the sums travel from wave to wave behind TICKETS in LDS (no barrier: a wave spins only for its predecessor,
+     * which never waits for it): the prior's first -- components ascending, ymc_tile_logprior's order -- so that it
+     * hides under the matrix products of the waves that are through ---- */
+    auto wait_for = [&](int which, uint32_t value) {
+        if (lane == 0)
+            while (ticket[which] != value) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_wave_barrier();
+    };
+    {
+        /* the terms first (they depend on nobody), the wait, then nothing but the additions */
+        double pt[NT][2 * QW];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const double *yt = y_w + nt * KSP * 64;
+#pragma unroll
+            for (int qi = 0; qi < QW; ++qi) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    if (qi < nq) {
+                        const double dx = yt[(2 * qi + e) * 64] - pm_w[8 * qi + 4 * e];
+                        const double px = pp_w[8 * qi + 4 * e] * dx;
+                        pt[nt][2 * qi + e] = dx * px;
+                    } else {
+                        pt[nt][2 * qi + e] = 0.0;
+                    }
+                }
+            }
+        }
+        const uint32_t tk = tkP + (uint32_t)wave; /* modulo 2^32: only equality is tested */
+        double P[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) P[nt] = 0.0;
+        if (wave > 0) {
+            wait_for(0, tk);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) P[nt] = handP[nt * 64 + lane];
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int qi = 0; qi < QW; ++qi) {
+                if (qi < nq) {
+                    P[nt] = P[nt] + pt[nt][2 * qi];
+                    P[nt] = P[nt] + pt[nt][2 * qi + 1];
+                }
+            }
+            handP[nt * 64 + lane] = P[nt];
+        }
+        if (lane == 0) ticket[0] = tk + 1; /* LDS operations of a wave are performed in order: the sums are there */
+    }
+
+    /* ---- F = A y on the matrix cores ---- */
+#pragma unroll 1
+    for (int r = 0; r < rounds; ++r) {
+        const int chunk = r * W + wave, t0 = chunk * TC; /* this wave's output tiles t0 .. t0 + TC - 1 (those < MT) */
+        d4 acc[NT][TC];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int tc = 0; tc < TC; ++tc) acc[nt][tc] = d4{0.0, 0.0, 0.0, 0.0};
+        if (t0 < MT) {
+            const double *A = blob + (size_t)t0 * KS * 64 + lane;
+            const double *yk = ylds + lane;
+            /* a ring of PD stages of KB k-steps: stage i is multiplied while stages i + 1 .. i + PD - 1 are on their way
+             * from L2.  The loop body is ONE basic block -- no guard on the k-step -- so that the compiler counts the
+             * loads in flight (with guards it drains them all, `s_waitcnt vmcnt(0)`, at every iteration): the k-steps run
+             * to KSP, KS rounded up to whole rings; beyond KS the proposal tile holds zeros and the fragment read is
+             * whatever follows in the block (the next tile's, or the constants': finite), so the products are +0 */
+            double fr[PD][KB][TC];
+            auto request = [&](double (&f)[KB][TC], int s0) {
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    const int s = s0 + kb < KSP ? s0 + kb : KSP - 1;
+#pragma unroll
+                    for (int tc = 0; tc < TC; ++tc) {
+                        const int tt = t0 + tc < MT ? tc : 0; /* a chunk's tail repeats its first tile (never summed) */
+                        f[kb][tc] = A[((size_t)tt * KS + s) * 64];
+                    }
+                }
+            };
+#pragma unroll
+            for (int p = 0; p < PD; ++p) request(fr[p], p * KB);
+#pragma unroll 1
+            for (int s0 = 0; s0 < KSP; s0 += PD * KB) {
+#pragma unroll
+                for (int p = 0; p < PD; ++p) {
+                    const int sb = s0 + p * KB;
+#pragma unroll
+                    for (int kb = 0; kb < KB; ++kb) {
+                        double yb[NT];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) yb[nt] = yk[(nt * KSP + sb + kb) * 64];
+#pragma unroll
+                        for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[nt][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[p][kb][tc], yb[nt], acc[nt][tc], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0); /* the stage's requests stay HERE, between its MFMAs and the next */
+                    request(fr[p], sb + PD * KB);      /* stage's (the scheduler otherwise gathers all 32 at the loop's end) */
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        /* the terms of this wave's outputs IN PLACE of their accumulators (ymc_tile_add_residuals, one tile at a time)
+         * and, in the first round, of its components' prior -- computed by all waves together, so that a phase of the
+         * hand-over below is nothing but the additions */
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int m = 16 * (t0 + tc < MT ? t0 + tc : 0) + 4 * rr + g;
+                    const double F = acc[nt][tc][rr] + bias[m];
+                    const double res = F - dbar[m];
+                    const double px = nprec[m] * res;
+                    acc[nt][tc][rr] = res * px;
+                }
+        /* the residuals' hand-over: outputs ascending, chunk r W + w follows chunk r W + w - 1 */
+        {
+            const uint32_t tk = tkS + (uint32_t)r * (uint32_t)W + (uint32_t)wave;
+            if (chunk > 0) wait_for(1, tk);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                double S = (chunk == 0) ? 0.0 : handS[nt * 64 + lane];
+#pragma unroll
+                for (int tc = 0; tc < TC; ++tc) {
+                    if (t0 + tc < MT) {
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) S = S + acc[nt][tc][rr];
+                    }
+                }
+                handS[nt * 64 + lane] = S;
+            }
+            if (lane == 0) ticket[1] = tk + 1;
+        }
+    }
+
+    tkP += (uint32_t)W;
+    tkS += (uint32_t)rounds * (uint32_t)W;
+}
+
 template <int NT, int W, int QW, int TC, bool CG>
 __global__ __launch_bounds__(64 * W) void linear_wide_fused_kernel(const WideFusedArgs a)
 {
@@ -107,12 +273,13 @@ __global__ __launch_bounds__(64 * W) void linear_wide_fused_kernel(const WideFus
         st[nt] = (wave == W - 1 && live[nt]) ? a.status[kk[nt]] : 0;
     }
     RecordClock clk(a.rec_stride, a.rec_since);
-    const int n_chunks = (MT + TC - 1) / TC, rounds = (n_chunks + W - 1) / W;
     /* The accumulators are carried by a run-time k loop (KS is not a template parameter here), so the kernel must stay
      * within the VGPR-form MFMA budget: built for one wave per SIMD (512 registers) the compiler puts them in AGPRs and
      * copies every accumulator in and out per iteration (500 spilled registers at NT = 2, TC = 8); at two waves per SIMD
      * everything is a VGPR */
     __syncthreads();
+    const WideEvalCtx cx{ylds, y_w, handS, handP, ticket, KS, KSP, nq, lane, wave, g};
+    uint32_t tkP = 0, tkS = 0;
 
 #pragma unroll 1
     for (uint32_t n = 0; n < a.nsteps; ++n) {
@@ -157,144 +324,8 @@ __global__ __launch_bounds__(64 * W) void linear_wide_fused_kernel(const WideFus
         }
         __syncthreads();
 
-        /* ---- the sums travel from wave to wave behind TICKETS in LDS (no barrier: a wave spins only for its predecessor,
-         * which never waits for it): the prior's first -- components ascending, ymc_tile_logprior's order -- so that it
-         * hides under the matrix products of the waves that are through ---- */
-        auto wait_for = [&](int which, uint32_t value) {
-            if (lane == 0)
-                while (ticket[which] != value) __builtin_amdgcn_s_sleep(1);
-            __builtin_amdgcn_wave_barrier();
-        };
-        {
-            /* the terms first (they depend on nobody), the wait, then nothing but the additions */
-            double pt[NT][2 * QW];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const double *yt = y_w + nt * KSP * 64;
-#pragma unroll
-                for (int qi = 0; qi < QW; ++qi) {
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        if (qi < nq) {
-                            const double dx = yt[(2 * qi + e) * 64] - pm_w[8 * qi + 4 * e];
-                            const double px = pp_w[8 * qi + 4 * e] * dx;
-                            pt[nt][2 * qi + e] = dx * px;
-                        } else {
-                            pt[nt][2 * qi + e] = 0.0;
-                        }
-                    }
-                }
-            }
-            const uint32_t tk = n * (uint32_t)W + (uint32_t)wave; /* modulo 2^32: only equality is tested */
-            double P[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) P[nt] = 0.0;
-            if (wave > 0) {
-                wait_for(0, tk);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) P[nt] = handP[nt * 64 + lane];
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-                for (int qi = 0; qi < QW; ++qi) {
-                    if (qi < nq) {
-                        P[nt] = P[nt] + pt[nt][2 * qi];
-                        P[nt] = P[nt] + pt[nt][2 * qi + 1];
-                    }
-                }
-                handP[nt * 64 + lane] = P[nt];
-            }
-            if (lane == 0) ticket[0] = tk + 1; /* LDS operations of a wave are performed in order: the sums are there */
-        }
-
-        /* ---- F = A y on the matrix cores ---- */
-#pragma unroll 1
-        for (int r = 0; r < rounds; ++r) {
-            const int chunk = r * W + wave, t0 = chunk * TC; /* this wave's output tiles t0 .. t0 + TC - 1 (those < MT) */
-            d4 acc[NT][TC];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int tc = 0; tc < TC; ++tc) acc[nt][tc] = d4{0.0, 0.0, 0.0, 0.0};
-            if (t0 < MT) {
-                const double *A = a.blob + (size_t)t0 * KS * 64 + lane;
-                const double *yk = ylds + lane;
-                /* a ring of PD stages of KB k-steps: stage i is multiplied while stages i + 1 .. i + PD - 1 are on their way
-                 * from L2.  The loop body is ONE basic block -- no guard on the k-step -- so that the compiler counts the
-                 * loads in flight (with guards it drains them all, `s_waitcnt vmcnt(0)`, at every iteration): the k-steps run
-                 * to KSP, KS rounded up to whole rings; beyond KS the proposal tile holds zeros and the fragment read is
-                 * whatever follows in the block (the next tile's, or the constants': finite), so the products are +0 */
-                double fr[PD][KB][TC];
-                auto request = [&](double (&f)[KB][TC], int s0) {
-#pragma unroll
-                    for (int kb = 0; kb < KB; ++kb) {
-                        const int s = s0 + kb < KSP ? s0 + kb : KSP - 1;
-#pragma unroll
-                        for (int tc = 0; tc < TC; ++tc) {
-                            const int tt = t0 + tc < MT ? tc : 0; /* a chunk's tail repeats its first tile (never summed) */
-                            f[kb][tc] = A[((size_t)tt * KS + s) * 64];
-                        }
-                    }
-                };
-#pragma unroll
-                for (int p = 0; p < PD; ++p) request(fr[p], p * KB);
-#pragma unroll 1
-                for (int s0 = 0; s0 < KSP; s0 += PD * KB) {
-#pragma unroll
-                    for (int p = 0; p < PD; ++p) {
-                        const int sb = s0 + p * KB;
-#pragma unroll
-                        for (int kb = 0; kb < KB; ++kb) {
-                            double yb[NT];
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) yb[nt] = yk[(nt * KSP + sb + kb) * 64];
-#pragma unroll
-                            for (int tc = 0; tc < TC; ++tc)
-#pragma unroll
-                                for (int nt = 0; nt < NT; ++nt)
-                                    acc[nt][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[p][kb][tc], yb[nt], acc[nt][tc], 0, 0, 0);
-                        }
-                        __builtin_amdgcn_sched_barrier(0); /* the stage's requests stay HERE, between its MFMAs and the next */
-                        request(fr[p], sb + PD * KB);      /* stage's (the scheduler otherwise gathers all 32 at the loop's end) */
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            }
-            /* the terms of this wave's outputs IN PLACE of their accumulators (ymc_tile_add_residuals, one tile at a time)
-             * and, in the first round, of its components' prior -- computed by all waves together, so that a phase of the
-             * hand-over below is nothing but the additions */
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int tc = 0; tc < TC; ++tc)
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const int m = 16 * (t0 + tc < MT ? t0 + tc : 0) + 4 * rr + g;
-                        const double F = acc[nt][tc][rr] + bias[m];
-                        const double res = F - dbar[m];
-                        const double px = nprec[m] * res;
-                        acc[nt][tc][rr] = res * px;
-                    }
-            /* the residuals' hand-over: outputs ascending, chunk r W + w follows chunk r W + w - 1 */
-            {
-                const uint32_t tk = (n * (uint32_t)rounds + (uint32_t)r) * (uint32_t)W + (uint32_t)wave;
-                if (chunk > 0) wait_for(1, tk);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    double S = (chunk == 0) ? 0.0 : handS[nt * 64 + lane];
-#pragma unroll
-                    for (int tc = 0; tc < TC; ++tc) {
-                        if (t0 + tc < MT) {
-#pragma unroll
-                            for (int rr = 0; rr < 4; ++rr) S = S + acc[nt][tc][rr];
-                        }
-                    }
-                    handS[nt * 64 + lane] = S;
-                }
-                if (lane == 0) ticket[1] = tk + 1;
-            }
-        }
+        /* ---- the evaluation: prior and residual sums handed from wave to wave behind tickets, F = A y on the matrix cores ---- */
+        wide_evaluate<NT, W, QW, TC, KB, PD>(cx, a.blob, MT, bias, nprec, dbar, pm_w, pp_w, tkP, tkS);
 
         /* ---- the decision (metropolisHastings.py:55-73, mrw.py:51-57): the last wave, whose hand-over closed the sums ---- */
         const bool rec = clk.due();
@@ -371,6 +402,222 @@ __global__ __launch_bounds__(64 * W) void linear_wide_fused_kernel(const WideFus
             a.lp[kk[nt]] = lp[nt];
             a.acc_count[kk[nt]] = accepted[nt];
             a.status[kk[nt]] = st[nt];
+        }
+    }
+}
+
+/*
+ * Two-level delayed acceptance on the same plan.  One tile of 16 chains per workgroup: the fine state x and the
+ * sub-chain's state z are two slices of registers per wave; a sub-step proposes from z into the LDS tile, evaluates the
+ * COARSE posterior and moves z; the fine step writes z into the tile, evaluates the FINE posterior and decides with
+ * ((pi_f(z) + pi_c(x)) - pi_c(z)) - pi_f(x) (mlda.py:146-154).  Fine step n owns transitions n (S + 1) + s, as everywhere.
+ * The three per-component constant arrays of each level stay in global memory (L2) when they do not fit the LDS.
+ */
+template <int W, int QW, int TC, bool CG>
+__global__ __launch_bounds__(64 * W) void linear_wide_fused2_kernel(const WideFused2Args a)
+{
+    ymc_stage_tables();
+    extern __shared__ double lds[];
+    constexpr int NT = 1;
+    constexpr int KB = TC >= 4 ? 1 : 4 / TC;
+    constexpr int PD = W >= 16 ? 2 : 4;
+    const int KS = a.KS, d_pad = 4 * KS, d = a.d, S = a.S;
+    const int MT_c = a.MT_c, MT_f = a.MT_f, mc_pad = 16 * MT_c, mf_pad = 16 * MT_f;
+    const int KSP = ((KS + PD * KB - 1) / (PD * KB)) * (PD * KB);
+    double *ylds = lds;                                   /* [KSP][64], zero beyond KS */
+    double *bias_c = ylds + (size_t)KSP * 64;             /* coarse: bias | n prec | row mean */
+    double *nprec_c = bias_c + mc_pad, *dbar_c = nprec_c + mc_pad;
+    double *bias_f = dbar_c + mc_pad;                     /* fine: bias | n prec | row mean */
+    double *nprec_f = bias_f + mf_pad, *dbar_f = nprec_f + mf_pad;
+    double *dconst = dbar_f + mf_pad;                     /* !CG: coarse prior mean | prec | sigma | fine prior mean | prec */
+    const double *cc = a.blob_c + (size_t)MT_c * KS * 64, *fc = a.blob_f + (size_t)MT_f * KS * 64;
+    const double *pmean_c = CG ? cc + 3 * (size_t)mc_pad : dconst;
+    const double *pprec_c = pmean_c + d_pad, *sigma = pprec_c + d_pad;
+    const double *pmean_f = CG ? fc + 3 * (size_t)mf_pad : dconst + 3 * d_pad;
+    const double *pprec_f = pmean_f + d_pad;
+    double *handS = dconst + (CG ? 0 : 5 * d_pad);
+    double *handP = handS + 64;
+    int *movedf = reinterpret_cast<int *>(handP + 64);    /* [16] */
+    int *accf = movedf + 16;                              /* [16] */
+    volatile uint32_t *ticket = reinterpret_cast<volatile uint32_t *>(accf + 16);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 15, g = lane >> 4;
+    {
+        for (int i = tid; i < 3 * mc_pad; i += 64 * W) bias_c[i] = cc[i];
+        for (int i = tid; i < 3 * mf_pad; i += 64 * W) bias_f[i] = fc[i];
+        if (!CG) {
+            for (int i = tid; i < 3 * d_pad; i += 64 * W) dconst[i] = cc[3 * (size_t)mc_pad + i];
+            for (int i = tid; i < 2 * d_pad; i += 64 * W) dconst[3 * d_pad + i] = fc[3 * (size_t)mf_pad + i];
+        }
+        for (int i = tid; i < 16; i += 64 * W) movedf[i] = 0;
+        if (tid < 2) ticket[tid] = 0;
+        for (int i = tid; i < (KSP - KS) * 64; i += 64 * W) ylds[KS * 64 + i] = 0.0;
+    }
+    const uint64_t nct = (a.K + 15) / 16, tile = blockIdx.x;
+    const int Q = KS / 2, q0 = (wave * Q) / W, nq = ((wave + 1) * Q) / W - q0;
+    const uint32_t pair_of_g = (g == 0) ? 0u : (g == 1) ? 2u : (g == 2) ? 1u : 3u;
+    const int j0 = 8 * q0 + g;
+    const double *sig_w = sigma + j0;
+    double *y_w = ylds + (2 * q0) * 64 + lane;
+    const int left = d - j0 - 4;
+    const int full_q = left > 0 ? (left + 7) / 8 : 0;
+
+    const uint64_t k = tile * 16 + c;
+    const bool live = tile < nct && k < a.K;
+    const uint64_t kk = live ? k : 0;
+    const uint32_t chain = (uint32_t)(a.chain0 + kk);
+    double xs[2 * QW], zs[2 * QW];
+    {
+        const double *xr = a.x + kk * d + j0;
+#pragma unroll
+        for (int qi = 0; qi < QW; ++qi)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                xs[2 * qi + e] = (live && qi < nq && j0 + 8 * qi + 4 * e < d) ? xr[8 * qi + 4 * e] : 0.0;
+    }
+    /* the last wave: what a chain carries besides its state */
+    const bool decider = wave == W - 1;
+    double lpf = (decider && live) ? a.lp[kk] : 0.0, lpc = (decider && live) ? a.lpc[kk] : 0.0;
+    uint64_t accepted = (decider && live) ? a.acc_count[kk] : 0;
+    uint32_t st = (decider && live) ? a.status[kk] : 0;
+    RecordClock clk(a.rec_stride, a.rec_since);
+    __syncthreads();
+    const WideEvalCtx cx{ylds, y_w, handS, handP, ticket, KS, KSP, nq, lane, wave, g};
+    uint32_t tkP = 0, tkS = 0;
+    auto any_moved = [&](bool moved_l) { /* the chain's flag from the lanes' (every writer stores the same 1) */
+        int mv = moved_l ? 1 : 0;
+        mv |= __shfl_xor(mv, 16, 64);
+        mv |= __shfl_xor(mv, 32, 64);
+        if (mv && g == 0) movedf[c] = 1;
+    };
+
+#pragma unroll 1
+    for (uint32_t n = 0; n < a.nsteps; ++n) {
+        const uint64_t tbase = (a.t0 + n) * (uint64_t)(S + 1);
+#pragma unroll
+        for (int i = 0; i < 2 * QW; ++i) zs[i] = xs[i];
+        double lpcz = lpc;
+        /* surrogate.run(S + 1, state), mlda.py:102-110: S random-walk transitions of z on the coarse posterior */
+#pragma unroll 1
+        for (int sub = 0; sub < S; ++sub) {
+            const uint64_t t = tbase + (uint64_t)sub;
+            bool moved_l = false;
+#pragma unroll
+            for (int qi = 0; qi < QW; ++qi) {
+                if (qi < nq) {
+                    double xi0, xi1;
+                    ymc_draw_normal_pair(a.seed, chain, t, 4u * (uint32_t)(q0 + qi) + pair_of_g, &xi0, &xi1);
+                    swap_odd_even_rows(xi0, xi1);
+                    const double y0 = zs[2 * qi] + sig_w[8 * qi] * xi0;
+                    const double y1 = zs[2 * qi + 1] + sig_w[8 * qi + 4] * xi1;
+                    y_w[(2 * qi) * 64] = y0;
+                    y_w[(2 * qi + 1) * 64] = y1;
+                    moved_l = moved_l || !(y0 == zs[2 * qi]) || !(y1 == zs[2 * qi + 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            any_moved(moved_l);
+            __syncthreads();
+            wide_evaluate<NT, W, QW, TC, KB, PD>(cx, a.blob_c, MT_c, bias_c, nprec_c, dbar_c, pmean_c + j0, pprec_c + j0, tkP, tkS);
+            if (decider) {
+                const double logl = -0.5 * (combine4(handS[lane]) + a.lik_const_c);
+                const double lpcy = logl + (-0.5 * combine4(handP[lane]));
+                const double u = ymc_draw_uniform(a.seed, chain, t);
+                const bool moved = movedf[c] != 0;
+                const bool acc1 = ymc_accept(lpcy - lpcz, moved, ymc_finite(lpcy), u, st);
+                lpcz = acc1 ? lpcy : lpcz;
+                if (g == 0) {
+                    accf[c] = acc1 ? 1 : 0;
+                    movedf[c] = 0;
+                    if (live && a.sub_acc) a.sub_acc[((uint64_t)n * S + sub) * a.K + kk] = acc1 ? 1 : 0;
+                }
+            }
+            __syncthreads();
+            {
+                const bool acc1 = accf[c] != 0;
+#pragma unroll
+                for (int qi = 0; qi < QW; ++qi) {
+                    if (qi < nq) {
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const double y = y_w[(2 * qi + e) * 64];
+                            zs[2 * qi + e] = acc1 ? y : zs[2 * qi + e];
+                        }
+                    }
+                }
+            }
+        }
+        /* the fine accept / reject, mlda.py:146-154: z into the tile, the fine posterior of z */
+        {
+            bool moved_l = false;
+#pragma unroll
+            for (int qi = 0; qi < QW; ++qi) {
+                if (qi < nq) {
+                    y_w[(2 * qi) * 64] = zs[2 * qi];
+                    y_w[(2 * qi + 1) * 64] = zs[2 * qi + 1];
+                    moved_l = moved_l || !(zs[2 * qi] == xs[2 * qi]) || !(zs[2 * qi + 1] == xs[2 * qi + 1]);
+                }
+            }
+            any_moved(moved_l);
+        }
+        __syncthreads();
+        wide_evaluate<NT, W, QW, TC, KB, PD>(cx, a.blob_f, MT_f, bias_f, nprec_f, dbar_f, pmean_f + j0, pprec_f + j0, tkP, tkS);
+        const bool rec = clk.due();
+        if (decider) {
+            const double logl = -0.5 * (combine4(handS[lane]) + a.lik_const_f);
+            const double lpfz = logl + (-0.5 * combine4(handP[lane]));
+            const double u = ymc_draw_uniform(a.seed, chain, tbase + (uint64_t)S);
+            const bool moved = movedf[c] != 0;
+            const double log_ratio = ((lpfz + lpc) - lpcz) - lpf;
+            const bool acc1 = ymc_accept(log_ratio, moved, ymc_finite(lpfz) && ymc_finite(lpcz), u, st);
+            lpf = acc1 ? lpfz : lpf;
+            lpc = acc1 ? lpcz : lpc;
+            accepted += acc1 ? 1u : 0u;
+            if (g == 0) {
+                accf[c] = acc1 ? 1 : 0;
+                movedf[c] = 0;
+                if (live) {
+                    if (a.acc) a.acc[(uint64_t)n * a.K + kk] = acc1 ? 1 : 0;
+                    if (rec && a.lp_out) a.lp_out[(uint64_t)clk.row * a.K + kk] = lpf;
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const bool acc1 = accf[c] != 0;
+#pragma unroll
+            for (int i = 0; i < 2 * QW; ++i) xs[i] = acc1 ? zs[i] : xs[i];
+            if (rec && a.traj && live) {
+                double *row = a.traj + ((uint64_t)clk.row * a.K + kk) * (uint64_t)d + j0;
+#pragma unroll
+                for (int qi = 0; qi < QW; ++qi) {
+                    if (qi < nq) {
+                        if (qi < full_q) {
+                            row[8 * qi] = xs[2 * qi];
+                            row[8 * qi + 4] = xs[2 * qi + 1];
+                        } else {
+                            if (j0 + 8 * qi < d) row[8 * qi] = xs[2 * qi];
+                            if (j0 + 8 * qi + 4 < d) row[8 * qi + 4] = xs[2 * qi + 1];
+                        }
+                    }
+                }
+            }
+        }
+        if (rec) clk.wrote();
+    }
+
+    if (live) {
+        double *xr = a.x + kk * d + j0;
+#pragma unroll
+        for (int qi = 0; qi < QW; ++qi)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                if (qi < nq && j0 + 8 * qi + 4 * e < d) xr[8 * qi + 4 * e] = xs[2 * qi + e];
+        if (decider && g == 0) {
+            a.lp[kk] = lpf;
+            a.lpc[kk] = lpc;
+            a.acc_count[kk] = accepted;
+            a.status[kk] = st;
         }
     }
 }
@@ -508,5 +755,71 @@ hipError_t ymc_launch_wide_fused(const WideFusedArgs &a, int cus, hipStream_t s)
     YMC_FUSED(1, 8, 18, 2) YMC_FUSED(1, 8, 18, 1)
     YMC_FUSED(1, 16, 9, 1)
 #undef YMC_FUSED
+    return hipErrorInvalidValue;
+}
+
+/* ---- two-level ---- */
+namespace {
+struct Fused2Pick {
+    int W, QW, TC;
+    bool CG;
+};
+
+size_t fused2_lds(const Fused2Pick &f, int KS, int MT_c, int MT_f)
+{
+    const size_t mc = 16 * (size_t)MT_c, mf = 16 * (size_t)MT_f, d_pad = 4 * (size_t)KS;
+    const int kb = f.TC >= 4 ? 1 : 4 / f.TC, pd = f.W >= 16 ? 2 : 4, ring = kb * pd;
+    const size_t ksp = (size_t)((KS + ring - 1) / ring) * ring;
+    return (ksp * 64 + 3 * mc + 3 * mf + (f.CG ? 0 : 5 * d_pad) + 2 * 64) * sizeof(double) + (2 * 16 + 4) * sizeof(int);
+}
+
+size_t fused2_fit(int KS, int MT_c, int MT_f, uint64_t K, int cus, Fused2Pick &f)
+{
+    const uint64_t nct = (K + 15) / 16;
+    const int Q = KS / 2;
+    if (nct >= (uint64_t)cus) f.W = 8, f.QW = (Q + 7) / 8 <= 9 ? 9 : 18; /* two slices of state: the smaller one where it does */
+    else f.W = 16, f.QW = (Q + 15) / 16 <= 5 ? 5 : 9;
+    if ((Q + f.W - 1) / f.W > f.QW) return 0;
+    const int per_wave = ((MT_f > MT_c ? MT_f : MT_c) + f.W - 1) / f.W;
+    f.TC = f.W == 16 ? 1 : (per_wave >= 2 ? 2 : 1);
+    f.CG = false;
+    size_t lds = fused2_lds(f, KS, MT_c, MT_f);
+    if (lds > kTileLdsLimit) {
+        f.CG = true;
+        lds = fused2_lds(f, KS, MT_c, MT_f);
+    }
+    return lds <= kTileLdsLimit ? lds : 0;
+}
+
+template <int W, int QW, int TC, bool CG>
+hipError_t launch_fused2(const WideFused2Args &a, size_t lds, hipStream_t s)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_wide_fused2_kernel<W, QW, TC, CG>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const uint64_t nct = (a.K + 15) / 16;
+    hipLaunchKernelGGL((linear_wide_fused2_kernel<W, QW, TC, CG>), dim3((unsigned)nct), dim3(64 * W), lds, s, a);
+    return hipGetLastError();
+}
+}  // namespace
+
+size_t ymc_wide_fused2_lds_bytes(int KS, int MT_c, int MT_f, uint64_t K, int cus)
+{
+    if (const char *env = std::getenv("YMC_WIDE_FUSED"))
+        if (env[0] == '0') return 0;
+    Fused2Pick f;
+    return fused2_fit(KS, MT_c, MT_f, K, cus, f);
+}
+
+hipError_t ymc_launch_wide_fused2(const WideFused2Args &a, int cus, hipStream_t s)
+{
+    Fused2Pick f;
+    const size_t lds = fused2_fit(a.KS, a.MT_c, a.MT_f, a.K, cus, f);
+    if (!lds) return hipErrorInvalidValue;
+#define YMC_FUSED2(W_, QW_, TC_)                     \
+    if (f.W == W_ && f.QW == QW_ && f.TC == TC_)     \
+        return f.CG ? launch_fused2<W_, QW_, TC_, true>(a, lds, s) : launch_fused2<W_, QW_, TC_, false>(a, lds, s);
+    YMC_FUSED2(8, 9, 2) YMC_FUSED2(8, 9, 1) YMC_FUSED2(8, 18, 2) YMC_FUSED2(8, 18, 1) YMC_FUSED2(16, 5, 1) YMC_FUSED2(16, 9, 1)
+#undef YMC_FUSED2
     return hipErrorInvalidValue;
 }
