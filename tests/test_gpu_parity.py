@@ -1521,8 +1521,9 @@ def test_wide_fused_kernel_vs_oracle_and_the_launch_per_stage_path(ffi, ctx, mon
         make = lambda: lowering.make_problem(ctx, ffi.METHOD_MRW, low, sigma)   # noqa: E731
         e = o.Ensemble(p, sigma, x0, 17, chain0=40)
 
-    def device(fused):
+    def device(fused, split=False):
         monkeypatch.setenv("YMC_WIDE_FUSED", "1" if fused else "0")
+        monkeypatch.setenv("YMC_WIDE_SPLIT", "1" if split else "0")
         run = ffi.Run(make(), 17, K, x0, n, flags, 40, record_stride=stride)
         run.advance(3)
         run.advance(n - 3)
@@ -1531,10 +1532,11 @@ def test_wide_fused_kernel_vs_oracle_and_the_launch_per_stage_path(ffi, ctx, mon
         s_ = run.summary()
         return dict(traj=run.trajectory(), lp=run.logpost(), acc=run.accept() if stride == 1 else None, state=run.state(),
                     accepted=s_["accepted"], status=s_["status"], launches=launches, wf=(s_["wf_mean"], s_["wf_m2"]))
-    fused, staged = device(True), device(False)
+    # small ensembles also as a tile over a group of workgroups (linear_wide_split_kernel; the same kernel where no group forms)
+    runs = [device(True), device(False)] + ([device(True, split=True)] if K <= 2048 else [])
     out = e.advance(n)
     rows = slice(stride - 1, None, stride)
-    for dev in (fused, staged):
+    for dev in runs:
         assert np.array_equal(dev["traj"], out["traj"][rows]) and np.array_equal(dev["lp"], out["logpost"][rows])
         if stride == 1:
             assert np.array_equal(dev["acc"], out["acc"])
@@ -1542,6 +1544,48 @@ def test_wide_fused_kernel_vs_oracle_and_the_launch_per_stage_path(ffi, ctx, mon
         assert np.array_equal(dev["accepted"], e.acc_count) and np.array_equal(dev["status"], e.status)
         if stride == 1:
             assert np.array_equal(dev["wf"][0], e.wf_mean) and np.array_equal(dev["wf"][1], e.wf_m2)
+    assert 0 < out["acc"].mean() < 1
+
+
+@pytest.mark.parametrize("d,m,K,env", [(512, 512, 256, {}), (512, 512, 256, {"YMC_WIDE_SPLIT_KERNEL": "stream"}), (512, 520, 16, {}),
+                                       (512, 520, 16, {"YMC_WIDE_SPLIT_KERNEL": "stream", "YMC_WIDE_SPLIT_W": "8"}),
+                                       (320, 200, 300, {"YMC_WIDE_SPLIT_G": "5"}), (600, 90, 2048, {}), (264, 16, 40, {"YMC_WIDE_SPLIT": "f"}),
+                                       (640, 2000, 20, {}), (300, 40, 1000, {"YMC_WIDE_SPLIT_KERNEL": "stream"}),
+                                       (700, 330, 100, {"YMC_WIDE_SPLIT_G": "3", "YMC_WIDE_SPLIT_W": "8"}), (1100, 60, 50, {})])
+def test_wide_split_kernel_vs_oracle(ffi, ctx, monkeypatch, d, m, K, env):
+    """linear_wide_split_kernel (round 4): small ensembles beyond 256 parameters with every tile of 16 chains over a GROUP of
+    workgroups -- each multiplies its share of the output tiles, the terms cross the chip once per transition (write-through
+    stores, one arrival counter per tile, one acquire per workgroup), every member adds them in the canonical order and
+    decides alike -- and linear_wide_systolic_kernel (up to 640 parameters, up to four output tiles per member): the member's
+    rows of the matrix in registers cut along k, an output tile's accumulator travelling down the waves, the decision taken
+    by the group's leader and published in one tagged word.  Groups of 32, 16, 5, 3, 2 and 1 (the protocol alone), output
+    tiles that do not divide among the members, the leader's sum in several chunks (m = 2000), every build, thinned record
+    with the launch cut in three, 40 transitions (the slots alternate): == oracle bit for bit."""
+    from yagremcmc_amd import lowering
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    rng = np.random.default_rng(4100 + d + m)
+    nd = 2
+    g = dict(data=rng.normal(size=(nd, m)), noise_precision=rng.uniform(0.5, 3, size=m), prior_mean=rng.normal(size=d) * 0.1,
+             prior_precision=rng.uniform(0.1, 2, size=d))
+    A, b = rng.normal(size=(m, d)) / np.sqrt(d), rng.normal(size=m)
+    x0 = rng.normal(size=(K, d)) * 0.3
+    low = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, g, fwd_matrix=A, fwd_shift=b)
+    p = o.posterior_linear(A, b, g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+    sigma = rng.uniform(0.01, 0.04, size=d)
+    n, stride = 40, 2
+    flags = ffi.RECORD_TRAJECTORY | ffi.RECORD_LOGPOST
+    run = ffi.Run(lowering.make_problem(ctx, ffi.METHOD_MRW, low, sigma), 23, K, x0, n // stride, flags, 7, record_stride=stride)
+    for part in (5, 14, 21):
+        run.advance(part)
+    run.sync()
+    e = o.Ensemble(p, sigma, x0, 23, chain0=7)
+    out = e.advance(n)
+    rows = slice(stride - 1, None, stride)
+    assert np.array_equal(run.trajectory(), out["traj"][rows]) and np.array_equal(run.logpost(), out["logpost"][rows])
+    s_ = run.summary()
+    assert np.array_equal(run.state()[0], e.x) and np.array_equal(run.state()[1], e.lp)
+    assert np.array_equal(s_["accepted"], e.acc_count) and np.array_equal(s_["status"], e.status)
     assert 0 < out["acc"].mean() < 1
 
 

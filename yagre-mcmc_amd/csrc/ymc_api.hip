@@ -191,6 +191,7 @@ struct ymc_run {
     DeviceBuf err_n, err_mean, err_m2, aem_prec, aem_flags, cache_key, cache_val; /* AEM2 */
     DeviceBuf err_mean_alt, err_m2_alt; /* AEM2 on the matrix cores: the kernel's second copy of mean / M2 (scratch) */
     DeviceBuf wide_xi, wide_u, wide_y, wide_yt, wide_lpy, wide_flag; /* the wide path's per-transition scratch */
+    DeviceBuf wide_xch, wide_arrived; /* small ensembles on the wide path: a group's exchange slots and arrival counters */
     DeviceBuf wide_z, wide_zt, wide_lpcz;                            /* ... and the two-level sampler's sub-chain state */
     DeviceBuf wide_differs;                                          /* [K] proposal-differs-from-state flags */
     DeviceBuf wide_terms;                                            /* small ensembles: the evaluation's residual terms */
@@ -884,8 +885,10 @@ int launch_advance_wide(ymc_run *r, uint64_t nsteps)
     const bool moments = (r->flags & YMC_RECORD_MOMENTS) != 0;
     /* moments: replayed from the record the launch writes -- which must then hold every transition */
     const bool replayable = !moments || ((r->flags & YMC_RECORD_TRAJECTORY) && r->stride == 1);
+    /* small ensembles: a tile over a group of workgroups (linear_wide_split_kernel), the same results again */
+    const int split_G = (!two && !p->chol_frag.p && replayable && nsteps < (1ull << 32)) ? ymc_wide_split_group(p->tgt.KS, p->tgt.MT, K, cus) : 0;
     if (!two && !p->chol_frag.p && replayable && nsteps < (1ull << 32) &&
-        ymc_wide_fused_lds_bytes(p->tgt.KS, p->tgt.MT, K, cus)) {
+        (split_G || ymc_wide_fused_lds_bytes(p->tgt.KS, p->tgt.MT, K, cus))) {
         if (moments) {
             if (!r->x_before.p) YMC_TRY(r->x_before.alloc(r->x.bytes));
             YMC_HIP(hipMemcpyAsync(r->x_before.p, r->x.p, r->x.bytes, hipMemcpyDeviceToDevice, s));
@@ -906,7 +909,26 @@ int launch_advance_wide(ymc_run *r, uint64_t nsteps)
         if (r->flags & YMC_RECORD_TRAJECTORY) f.traj = r->traj.as<double>() + row * K * d;
         if (r->flags & YMC_RECORD_ACCEPT) f.acc = r->acc.as<uint8_t>() + row * K;
         if (r->flags & YMC_RECORD_LOGPOST) f.lp_out = r->lp_out.as<double>() + row * K;
-        hipError_t e = ymc_launch_wide_fused(f, cus, s);
+        hipError_t e;
+        if (split_G) {
+            WideSplitArgs sp{};
+            sp.f = f;
+            const size_t xb = ymc_wide_split_exchange_bytes(p->tgt.MT, K), cb = ymc_wide_split_counter_bytes(K);
+            if (r->wide_xch.bytes < xb) YMC_TRY(r->wide_xch.alloc(xb));
+            if (r->wide_arrived.bytes < cb) YMC_TRY(r->wide_arrived.alloc(cb));
+            if (!r->fault.p) { /* sticky for the run's lifetime, as the hand-over pieces' */
+                YMC_TRY(r->fault.reserve(sizeof(uint32_t)));
+                *static_cast<volatile uint32_t *>(r->fault.p) = 0u;
+            }
+            sp.xch = r->wide_xch.as<double>();
+            sp.arrived = r->wide_arrived.as<uint32_t>();
+            sp.fault = static_cast<uint32_t *>(r->fault.p);
+            sp.poll_limit = 1u << 22;
+            if (const char *env = std::getenv("YMC_LV_POLL_LIMIT")) sp.poll_limit = (uint32_t)std::strtoul(env, nullptr, 10);
+            e = ymc_launch_wide_split(sp, cus, s);
+        } else {
+            e = ymc_launch_wide_fused(f, cus, s);
+        }
         if (e == hipSuccess && moments)
             e = ymc_launch_welford_replay_plain(f.traj, r->x_before.as<double>(), nsteps, K, p->D, r->steps_done,
                                                 r->wf_mean.as<double>(), r->wf_m2.as<double>(), s);
@@ -1241,7 +1263,7 @@ int check_internal_faults(ymc_run *r)
     if (!r->fault.p) return YMC_OK;
     const uint32_t n = *static_cast<volatile const uint32_t *>(r->fault.p);
     if (n)
-        return fail(YMC_ERR_DEVICE, "internal device error: %u chain waves gave up waiting for a hand-over "
+        return fail(YMC_ERR_DEVICE, "internal device error: %u waves gave up waiting for a hand-over "
                                     "(YMC_CHAIN_HANDOFF): transitions are missing from the record of this run", n);
     return YMC_OK;
 }

@@ -156,6 +156,22 @@ struct WideFused2Args {
 };
 size_t ymc_wide_fused2_lds_bytes(int KS, int MT_c, int MT_f, uint64_t K, int cus);
 hipError_t ymc_launch_wide_fused2(const WideFused2Args &a, int cus, hipStream_t s);
+/* Small ensembles (fewer tiles than half the CUs): a tile of 16 chains over a GROUP of workgroups, each multiplying its share of
+ * the output tiles, the per-output terms exchanged through global memory once per transition (linear_wide_split_kernel). */
+struct WideSplitArgs {
+    WideFusedArgs f;
+    int32_t G, chunk;              /* members of a group; output tiles per round of the leader's sum: set by the launch function */
+    double *xch;                   /* [tiles][2][MT][256]: the exchange slots, ymc_wide_split_exchange_bytes */
+    uint32_t *arrived;             /* [tiles][64]: word 0 = members through with their stores, words 32-33 = {transition, sixteen accept
+                                    * flags} from the group's leader (the systolic build); zeroed by the launch function */
+    uint32_t poll_limit, pad1_;
+    uint32_t *fault;               /* the run's count of abandoned hand-overs (page-locked) */
+};
+/* the group's size for this shape and ensemble; 0 = the fused kernel (or the launch-per-stage path) runs it */
+int ymc_wide_split_group(int KS, int MT, uint64_t K, int cus);
+size_t ymc_wide_split_exchange_bytes(int MT, uint64_t K);
+size_t ymc_wide_split_counter_bytes(uint64_t K);
+hipError_t ymc_launch_wide_split(WideSplitArgs a, int cus, hipStream_t s);
 /* 0 = this shape / ensemble does not take the fused kernel (the caller runs the launch-per-stage path) */
 size_t ymc_wide_fused_lds_bytes(int KS, int MT, uint64_t K, int cus);
 hipError_t ymc_launch_wide_fused(const WideFusedArgs &a, int cus, hipStream_t s);

@@ -41,6 +41,137 @@ struct WideEvalCtx {
     int KS, KSP, nq, lane, wave, g;
 };
 
+/* a wave spins only for its predecessor, which never waits for it (lane 0 polls, the wave follows) */
+__device__ __forceinline__ void wide_wait_ticket(volatile uint32_t *ticket, int which, uint32_t value, int lane)
+{
+    if (lane == 0)
+        while (ticket[which] != value) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_wave_barrier();
+}
+
+/* The prior's sums of the NT tiles' proposals in LDS, travelling from wave to wave behind TICKETS in LDS (no barrier) --
+ * components ascending, ymc_tile_logprior's order -- so that they hide under the matrix products of the waves that are
+ * through: afterwards handP holds the chains' partial sums, complete and visible to the LAST wave.  pm_w / pp_w: the prior's
+ * mean and precision at this lane's first component. */
+template <int NT, int W, int QW>
+__device__ __forceinline__ void wide_prior_chain(const WideEvalCtx &cx, const double *pm_w, const double *pp_w, uint32_t &tkP)
+{
+    const int KSP = cx.KSP, nq = cx.nq, lane = cx.lane, wave = cx.wave;
+    const double *y_w = cx.y_w;
+    double *handP = cx.handP;
+    volatile uint32_t *ticket = cx.ticket;
+    /* the terms first (they depend on nobody), the wait, then nothing but the additions */
+    double pt[NT][2 * QW];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const double *yt = y_w + nt * KSP * 64;
+#pragma unroll
+        for (int qi = 0; qi < QW; ++qi) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (qi < nq) {
+                    const double dx = yt[(2 * qi + e) * 64] - pm_w[8 * qi + 4 * e];
+                    const double px = pp_w[8 * qi + 4 * e] * dx;
+                    pt[nt][2 * qi + e] = dx * px;
+                } else {
+                    pt[nt][2 * qi + e] = 0.0;
+                }
+            }
+        }
+    }
+    const uint32_t tk = tkP + (uint32_t)wave; /* modulo 2^32: only equality is tested */
+    double P[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) P[nt] = 0.0;
+    if (wave > 0) {
+        wide_wait_ticket(ticket, 0, tk, lane);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) P[nt] = handP[nt * 64 + lane];
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int qi = 0; qi < QW; ++qi) {
+            if (qi < nq) {
+                P[nt] = P[nt] + pt[nt][2 * qi];
+                P[nt] = P[nt] + pt[nt][2 * qi + 1];
+            }
+        }
+        handP[nt * 64 + lane] = P[nt];
+    }
+    if (lane == 0) ticket[0] = tk + 1; /* LDS operations of a wave are performed in order: the sums are there */
+    tkP += (uint32_t)W;
+}
+
+/* F = A y on the matrix cores for the TC output tiles from t0 (those below MT) of the NT tiles' proposals in LDS: the FULL k
+ * loop, k ascending per accumulator. */
+template <int NT, int TC, int KB, int PD>
+__device__ __forceinline__ void wide_products(const WideEvalCtx &cx, const double *__restrict__ blob, int MT, int t0, d4 (&acc)[NT][TC])
+{
+    const int KS = cx.KS, KSP = cx.KSP, lane = cx.lane;
+    const double *A = blob + (size_t)t0 * KS * 64 + lane;
+    const double *yk = cx.ylds + lane;
+    /* a ring of PD stages of KB k-steps: stage i is multiplied while stages i + 1 .. i + PD - 1 are on their way
+     * from L2.  The loop body is ONE basic block -- no guard on the k-step -- so that the compiler counts the
+     * loads in flight (with guards it drains them all, `s_waitcnt vmcnt(0)`, at every iteration): the k-steps run
+     * to KSP, KS rounded up to whole rings; beyond KS the proposal tile holds zeros and the fragment read is
+     * whatever follows in the block (the next tile's, or the constants': finite), so the products are +0 */
+    double fr[PD][KB][TC];
+    auto request = [&](double (&f)[KB][TC], int s0) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int s = s0 + kb < KSP ? s0 + kb : KSP - 1;
+#pragma unroll
+            for (int tc = 0; tc < TC; ++tc) {
+                const int tt = t0 + tc < MT ? tc : 0; /* a chunk's tail repeats its first tile (never summed) */
+                f[kb][tc] = A[((size_t)tt * KS + s) * 64];
+            }
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < PD; ++p) request(fr[p], p * KB);
+#pragma unroll 1
+    for (int s0 = 0; s0 < KSP; s0 += PD * KB) {
+#pragma unroll
+        for (int p = 0; p < PD; ++p) {
+            const int sb = s0 + p * KB;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                double yb[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) yb[nt] = yk[(nt * KSP + sb + kb) * 64];
+#pragma unroll
+                for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[p][kb][tc], yb[nt], acc[nt][tc], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0); /* the stage's requests stay HERE, between its MFMAs and the next */
+            request(fr[p], sb + PD * KB);      /* stage's (the scheduler otherwise gathers all 32 at the loop's end) */
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+/* the terms of the outputs IN PLACE of their accumulators (ymc_tile_add_residuals, one tile at a time) */
+template <int NT, int TC>
+__device__ __forceinline__ void wide_terms(d4 (&acc)[NT][TC], int MT, int t0, int g, const double *bias, const double *nprec,
+                                           const double *dbar)
+{
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int m = 16 * (t0 + tc < MT ? t0 + tc : 0) + 4 * rr + g;
+                const double F = acc[nt][tc][rr] + bias[m];
+                const double res = F - dbar[m];
+                const double px = nprec[m] * res;
+                acc[nt][tc][rr] = res * px;
+            }
+}
+
 /* log-likelihood and prior sums of the NT tiles' proposals in LDS under ONE linear-model posterior (its matrix `blob`, MT
  * output tiles, constants bias / nprec / dbar in LDS, prior constants at this lane's first component): afterwards handS /
  * handP hold the chains' partial sums (per lane: its g), complete and visible to the LAST wave.  Every wave of the
@@ -50,61 +181,11 @@ __device__ __forceinline__ void wide_evaluate(const WideEvalCtx &cx, const doubl
                                               const double *nprec, const double *dbar, const double *pm_w, const double *pp_w,
                                               uint32_t &tkP, uint32_t &tkS)
 {
-    const int KS = cx.KS, KSP = cx.KSP, nq = cx.nq, lane = cx.lane, wave = cx.wave, g = cx.g;
-    const double *ylds = cx.ylds, *y_w = cx.y_w;
-    double *handS = cx.handS, *handP = cx.handP;
+    const int lane = cx.lane, wave = cx.wave, g = cx.g;
+    double *handS = cx.handS;
     volatile uint32_t *ticket = cx.ticket;
     const int n_chunks = (MT + TC - 1) / TC, rounds = (n_chunks + W - 1) / W;
-    /* ---- the sums travel from wave to wave behind TICKETS in LDS (no barrier: a wave spins only for its predecessor,
-     * which never waits for it): the prior's first -- components ascending, ymc_tile_logprior's order -- so that it
-     * hides under the matrix products of the waves that are through ---- */
-    auto wait_for = [&](int which, uint32_t value) {
-        if (lane == 0)
-            while (ticket[which] != value) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_wave_barrier();
-    };
-    {
-        /* the terms first (they depend on nobody), the wait, then nothing but the additions */
-        double pt[NT][2 * QW];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const double *yt = y_w + nt * KSP * 64;
-#pragma unroll
-            for (int qi = 0; qi < QW; ++qi) {
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    if (qi < nq) {
-                        const double dx = yt[(2 * qi + e) * 64] - pm_w[8 * qi + 4 * e];
-                        const double px = pp_w[8 * qi + 4 * e] * dx;
-                        pt[nt][2 * qi + e] = dx * px;
-                    } else {
-                        pt[nt][2 * qi + e] = 0.0;
-                    }
-                }
-            }
-        }
-        const uint32_t tk = tkP + (uint32_t)wave; /* modulo 2^32: only equality is tested */
-        double P[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) P[nt] = 0.0;
-        if (wave > 0) {
-            wait_for(0, tk);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) P[nt] = handP[nt * 64 + lane];
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-            for (int qi = 0; qi < QW; ++qi) {
-                if (qi < nq) {
-                    P[nt] = P[nt] + pt[nt][2 * qi];
-                    P[nt] = P[nt] + pt[nt][2 * qi + 1];
-                }
-            }
-            handP[nt * 64 + lane] = P[nt];
-        }
-        if (lane == 0) ticket[0] = tk + 1; /* LDS operations of a wave are performed in order: the sums are there */
-    }
+    wide_prior_chain<NT, W, QW>(cx, pm_w, pp_w, tkP);
 
     /* ---- F = A y on the matrix cores ---- */
 #pragma unroll 1
@@ -115,69 +196,13 @@ __device__ __forceinline__ void wide_evaluate(const WideEvalCtx &cx, const doubl
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int tc = 0; tc < TC; ++tc) acc[nt][tc] = d4{0.0, 0.0, 0.0, 0.0};
-        if (t0 < MT) {
-            const double *A = blob + (size_t)t0 * KS * 64 + lane;
-            const double *yk = ylds + lane;
-            /* a ring of PD stages of KB k-steps: stage i is multiplied while stages i + 1 .. i + PD - 1 are on their way
-             * from L2.  The loop body is ONE basic block -- no guard on the k-step -- so that the compiler counts the
-             * loads in flight (with guards it drains them all, `s_waitcnt vmcnt(0)`, at every iteration): the k-steps run
-             * to KSP, KS rounded up to whole rings; beyond KS the proposal tile holds zeros and the fragment read is
-             * whatever follows in the block (the next tile's, or the constants': finite), so the products are +0 */
-            double fr[PD][KB][TC];
-            auto request = [&](double (&f)[KB][TC], int s0) {
-#pragma unroll
-                for (int kb = 0; kb < KB; ++kb) {
-                    const int s = s0 + kb < KSP ? s0 + kb : KSP - 1;
-#pragma unroll
-                    for (int tc = 0; tc < TC; ++tc) {
-                        const int tt = t0 + tc < MT ? tc : 0; /* a chunk's tail repeats its first tile (never summed) */
-                        f[kb][tc] = A[((size_t)tt * KS + s) * 64];
-                    }
-                }
-            };
-#pragma unroll
-            for (int p = 0; p < PD; ++p) request(fr[p], p * KB);
-#pragma unroll 1
-            for (int s0 = 0; s0 < KSP; s0 += PD * KB) {
-#pragma unroll
-                for (int p = 0; p < PD; ++p) {
-                    const int sb = s0 + p * KB;
-#pragma unroll
-                    for (int kb = 0; kb < KB; ++kb) {
-                        double yb[NT];
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) yb[nt] = yk[(nt * KSP + sb + kb) * 64];
-#pragma unroll
-                        for (int tc = 0; tc < TC; ++tc)
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
-                                acc[nt][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[p][kb][tc], yb[nt], acc[nt][tc], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0); /* the stage's requests stay HERE, between its MFMAs and the next */
-                    request(fr[p], sb + PD * KB);      /* stage's (the scheduler otherwise gathers all 32 at the loop's end) */
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        /* the terms of this wave's outputs IN PLACE of their accumulators (ymc_tile_add_residuals, one tile at a time)
-         * and, in the first round, of its components' prior -- computed by all waves together, so that a phase of the
-         * hand-over below is nothing but the additions */
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int tc = 0; tc < TC; ++tc)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int m = 16 * (t0 + tc < MT ? t0 + tc : 0) + 4 * rr + g;
-                    const double F = acc[nt][tc][rr] + bias[m];
-                    const double res = F - dbar[m];
-                    const double px = nprec[m] * res;
-                    acc[nt][tc][rr] = res * px;
-                }
+        if (t0 < MT) wide_products<NT, TC, KB, PD>(cx, blob, MT, t0, acc);
+        /* computed by all waves together, so that a phase of the hand-over below is nothing but the additions */
+        wide_terms<NT, TC>(acc, MT, t0, g, bias, nprec, dbar);
         /* the residuals' hand-over: outputs ascending, chunk r W + w follows chunk r W + w - 1 */
         {
             const uint32_t tk = tkS + (uint32_t)r * (uint32_t)W + (uint32_t)wave;
-            if (chunk > 0) wait_for(1, tk);
+            if (chunk > 0) wide_wait_ticket(ticket, 1, tk, lane);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 double S = (chunk == 0) ? 0.0 : handS[nt * 64 + lane];
@@ -193,8 +218,6 @@ __device__ __forceinline__ void wide_evaluate(const WideEvalCtx &cx, const doubl
             if (lane == 0) ticket[1] = tk + 1;
         }
     }
-
-    tkP += (uint32_t)W;
     tkS += (uint32_t)rounds * (uint32_t)W;
 }
 
@@ -622,6 +645,660 @@ __global__ __launch_bounds__(64 * W) void linear_wide_fused2_kernel(const WideFu
     }
 }
 
+/*
+ * Small ensembles: ONE tile of 16 chains over G workgroups (G CUs).  With fewer tiles than CUs the fused kernel leaves most
+ * of the chip idle while each busy CU's matrix pipe runs a tile's whole product (4 096 MFMAs at d = m = 512: 31 us).  Here
+ * the G members of a tile's group all hold the tile's state and all build the SAME proposal (the draws are addressed, not
+ * consumed: every member computes the same bits), each multiplies its own share of the output tiles, and the per-output
+ * terms -- not sums: the canonical order is one sequential chain per lane -- go to every member of the group through L2 /
+ * the fabric in one all-to-all step per transition: write-through (sc1) stores, each storing wave drained, one agent-scope
+ * add per member on the tile's arrival counter; a member's last wave polls that ONE word, one agent-scope acquire, a
+ * workgroup barrier, plain loads into LDS (cdna_hip_programming.md Guideline 16, the R1 form).  Every member then adds the
+ * terms in the canonical order, draws the same uniform and takes the same decision; member 0 writes the record.  Two slots
+ * per tile by the parity of the transition: a member writes transition n + 2's terms only after it has seen every member's
+ * arrival for n + 1, which each posts after it has read n's.
+ * Every member of every group must be resident (grid <= CUs, one workgroup per CU by its LDS); a poll that does not end
+ * within the limit gives up, flags the chains (YMC_CHAIN_HANDOFF) and fails the run (check_internal_faults): every wave
+ * reaches the end of the launch whatever happens.
+ */
+template <int W, int QW, bool CG>
+__global__ __launch_bounds__(64 * W) void linear_wide_split_kernel(const WideSplitArgs sa)
+{
+    const WideFusedArgs &a = sa.f;
+    ymc_stage_tables();
+    extern __shared__ double lds[];
+    constexpr int NT = 1, TC = 1, KB = 4;
+    constexpr int PD = W >= 16 ? 2 : 4;
+    const int KS = a.KS, MT = a.MT, m_pad = 16 * MT, d_pad = 4 * KS, d = a.d, G = sa.G;
+    const int KSP = ((KS + PD * KB - 1) / (PD * KB)) * (PD * KB);
+    double *ylds = lds;                                   /* [KSP][64], zero beyond KS */
+    double *terms = ylds + (size_t)KSP * 64;              /* [4 MT][64]: every output's term of the 16 chains, as the MFMA leaves them */
+    double *dconst = terms + (size_t)MT * 256;            /* !CG: prior mean | prior prec | sigma */
+    const double *consts = a.blob + (size_t)MT * KS * 64; /* bias | n prec | row mean (| the three above) in global memory */
+    const double *pmean = CG ? consts + 3 * (size_t)m_pad : dconst;
+    const double *pprec = pmean + d_pad, *sigma = pprec + d_pad;
+    double *handP = dconst + (CG ? 0 : 3 * d_pad);        /* [64] */
+    int *movedf = reinterpret_cast<int *>(handP + 64);    /* [16] */
+    int *accf = movedf + 16;                              /* [16] */
+    volatile uint32_t *ticket = reinterpret_cast<volatile uint32_t *>(accf + 16); /* [2] */
+    uint32_t *arrive = const_cast<uint32_t *>(ticket) + 2; /* storing waves of this member through with their stores, so far */
+    volatile uint32_t *gave_up = ticket + 3;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 15, g = lane >> 4;
+    {
+        if (!CG)
+            for (int i = tid; i < 3 * d_pad; i += 64 * W) dconst[i] = consts[3 * (size_t)m_pad + i];
+        for (int i = tid; i < 16; i += 64 * W) movedf[i] = 0;
+        if (tid < 4) ticket[tid] = 0;
+        for (int i = tid; i < (KSP - KS) * 64; i += 64 * W) ylds[KS * 64 + i] = 0.0;
+    }
+    const uint64_t nct = (a.K + 15) / 16;
+    const uint64_t tile = blockIdx.x / (unsigned)G;
+    const int member = (int)(blockIdx.x % (unsigned)G);
+    const int first_t = (member * MT) / G, n_mine = ((member + 1) * MT) / G - first_t; /* this member's output tiles */
+    const int n_store = n_mine < W ? n_mine : W;                                       /* its waves that have some */
+    const int Q = KS / 2, q0 = (wave * Q) / W, nq = ((wave + 1) * Q) / W - q0;
+    const uint32_t pair_of_g = (g == 0) ? 0u : (g == 1) ? 2u : (g == 2) ? 1u : 3u;
+    const int j0 = 8 * q0 + g;
+    const double *sig_w = sigma + j0, *pm_w = pmean + j0, *pp_w = pprec + j0;
+    double *y_w = ylds + (2 * q0) * 64 + lane;
+    const int left = d - j0 - 4;
+    const int full_q = left > 0 ? (left + 7) / 8 : 0;
+
+    const uint64_t k = tile * 16 + c;
+    const bool live = tile < nct && k < a.K;
+    const uint64_t kk = live ? k : 0;
+    const uint32_t chain = (uint32_t)(a.chain0 + kk);
+    double xs[2 * QW];
+    {
+        const double *xr = a.x + kk * d + j0;
+#pragma unroll
+        for (int qi = 0; qi < QW; ++qi)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                xs[2 * qi + e] = (live && qi < nq && j0 + 8 * qi + 4 * e < d) ? xr[8 * qi + 4 * e] : 0.0;
+    }
+    const bool decider = wave == W - 1, scribe = member == 0;
+    double lp = (decider && live) ? a.lp[kk] : 0.0;
+    uint64_t accepted = (decider && live) ? a.acc_count[kk] : 0;
+    uint32_t st = (decider && live) ? a.status[kk] : 0;
+    RecordClock clk(a.rec_stride, a.rec_since);
+    __syncthreads();
+    const WideEvalCtx cx{ylds, y_w, nullptr, handP, ticket, KS, KSP, nq, lane, wave, g};
+    uint32_t tkP = 0;
+    uint32_t *arrived = sa.arrived + tile * 64; /* a tile's polled words on lines of their own (256 bytes a tile) */
+
+#pragma unroll 1
+    for (uint32_t n = 0; n < a.nsteps; ++n) {
+        const uint64_t t = a.t0 + n;
+        /* ---- the proposal of this wave's slice, into LDS: every member of the group the same ---- */
+        {
+            bool moved_l = false;
+#pragma unroll
+            for (int qi = 0; qi < QW; ++qi) {
+                if (qi < nq) {
+                    double xi0, xi1;
+#if defined(YMC_WS_NODRAW)   /* timing experiments only (tools/exp_wide_split.sh) */
+                    xi0 = 1e-3 * (double)(qi + 1), xi1 = -1e-3 * (double)(chain & 7u);
+#else
+                    ymc_draw_normal_pair(a.seed, chain, t, 4u * (uint32_t)(q0 + qi) + pair_of_g, &xi0, &xi1);
+#endif
+                    swap_odd_even_rows(xi0, xi1);
+                    const double x0 = xs[2 * qi], x1 = xs[2 * qi + 1];
+                    double y0, y1;
+                    if (a.pcn) {
+                        const double p0 = pm_w[8 * qi] + sig_w[8 * qi] * xi0;
+                        const double p1 = pm_w[8 * qi + 4] + sig_w[8 * qi + 4] * xi1;
+                        y0 = a.pcn_c1 * x0 + a.pcn_c2 * p0;
+                        y1 = a.pcn_c1 * x1 + a.pcn_c2 * p1;
+                    } else {
+                        y0 = x0 + sig_w[8 * qi] * xi0;
+                        y1 = x1 + sig_w[8 * qi + 4] * xi1;
+                    }
+                    y_w[(2 * qi) * 64] = y0;
+                    y_w[(2 * qi + 1) * 64] = y1;
+                    moved_l = moved_l || !(y0 == x0) || !(y1 == x1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            int mv = moved_l ? 1 : 0;
+            mv |= __shfl_xor(mv, 16, 64);
+            mv |= __shfl_xor(mv, 32, 64);
+            if (mv && g == 0) movedf[c] = 1;
+        }
+        __syncthreads();
+
+        /* the prior's sums first (every member its own: it has the whole proposal): the hand-over runs down the waves
+         * while the first ones multiply */
+#if !defined(YMC_WS_NOPRIOR)
+        wide_prior_chain<NT, W, QW>(cx, pm_w, pp_w, tkP);
+#endif
+
+        /* ---- this member's output tiles: products, terms, out to the group ---- */
+        const uint32_t epoch = n + 1;
+        double *slot = sa.xch + ((tile * 2 + (n & 1u)) * (uint64_t)MT) * 256;
+#pragma unroll 1
+        for (int ti = wave; ti < n_mine; ti += W) {
+            const int t_out = first_t + ti;
+            d4 acc[NT][TC];
+            acc[0][0] = d4{0.0, 0.0, 0.0, 0.0};
+#if !defined(YMC_WS_NOPROD)
+            wide_products<NT, TC, KB, PD>(cx, a.blob, MT, t_out, acc);
+#endif
+            wide_terms<NT, TC>(acc, MT, t_out, g, consts, consts + m_pad, consts + 2 * m_pad);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) /* write-through: the bytes leave this XCD's L2 with the store */
+                __hip_atomic_store(slot + (size_t)t_out * 256 + 64 * rr + lane, acc[0][0][rr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (wave < n_store) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* EVERY storing wave drains its stores before it counts */
+            if (lane == 0) {
+                const uint32_t before = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (before + 1 == epoch * (uint32_t)n_store) /* the member's last: ONE add for all its stores */
+                    __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        /* ---- the group's terms: the last wave waits for all G members, then everybody copies the slot into LDS ---- */
+#if !defined(YMC_WS_NOXCH)
+        if (decider) {
+            if (lane == 0 && !*gave_up) {
+                const uint32_t want = epoch * (uint32_t)G;
+                uint32_t spins = 0;
+                while ((int32_t)(__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > sa.poll_limit) { /* a member is not running: do not hang the device */
+                        *gave_up = 1;
+                        __hip_atomic_fetch_add(sa.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  /* ONE acquire after the match: this CU's stale lines go */
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    /* ... before the barrier lets the others load */
+        }
+        __syncthreads();
+        {
+            const int nterm = MT * 256;
+#pragma unroll 1
+            for (int i = tid; i < nterm; i += 4 * 64 * W) {
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = i + u * 64 * W;
+                    v[u] = slot[idx < nterm ? idx : i];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = i + u * 64 * W;
+                    if (idx < nterm) terms[idx] = v[u];
+                }
+            }
+        }
+        __syncthreads();
+#endif
+
+        /* ---- the decision: every member's last wave the same one ---- */
+        const bool rec = clk.due();
+        if (decider) {
+            double S = 0.0;
+            const double *tl = terms + lane;
+#pragma unroll 8
+            for (int i = 0; i < 4 * MT; ++i) S = S + tl[i * 64]; /* outputs ascending: the canonical order */
+            const double logl = -0.5 * (combine4(S) + a.lik_const);
+            const double lpy = a.likelihood_only ? logl : logl + (-0.5 * combine4(handP[lane]));
+            const double u = ymc_draw_uniform(a.seed, chain, t);
+            const bool moved = movedf[c] != 0;
+            if (*gave_up) st |= YMC_CHAIN_HANDOFF;
+            const bool acc1 = ymc_accept(lpy - lp, moved, ymc_finite(lpy), u, st);
+            lp = acc1 ? lpy : lp;
+            accepted += acc1 ? 1u : 0u;
+            if (g == 0) {
+                accf[c] = acc1 ? 1 : 0;
+                movedf[c] = 0;
+                if (live && scribe) {
+                    if (a.acc) a.acc[(uint64_t)n * a.K + kk] = acc1 ? 1 : 0;
+                    if (rec && a.lp_out) a.lp_out[(uint64_t)clk.row * a.K + kk] = lp;
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const bool acc1 = accf[c] != 0;
+#pragma unroll
+            for (int qi = 0; qi < QW; ++qi) {
+                if (qi < nq) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const double y = y_w[(2 * qi + e) * 64];
+                        xs[2 * qi + e] = acc1 ? y : xs[2 * qi + e];
+                    }
+                }
+            }
+            if (rec && a.traj && live && scribe) {
+                double *row = a.traj + ((uint64_t)clk.row * a.K + kk) * (uint64_t)d + j0;
+#pragma unroll
+                for (int qi = 0; qi < QW; ++qi) {
+                    if (qi < nq) {
+                        if (qi < full_q) {
+                            row[8 * qi] = xs[2 * qi];
+                            row[8 * qi + 4] = xs[2 * qi + 1];
+                        } else {
+                            if (j0 + 8 * qi < d) row[8 * qi] = xs[2 * qi];
+                            if (j0 + 8 * qi + 4 < d) row[8 * qi + 4] = xs[2 * qi + 1];
+                        }
+                    }
+                }
+            }
+        }
+        if (rec) clk.wrote();
+    }
+
+    if (live && scribe) {
+        double *xr = a.x + kk * d + j0;
+#pragma unroll
+        for (int qi = 0; qi < QW; ++qi)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                if (qi < nq && j0 + 8 * qi + 4 * e < d) xr[8 * qi + 4 * e] = xs[2 * qi + e];
+        if (decider && g == 0) {
+            a.lp[kk] = lp;
+            a.acc_count[kk] = accepted;
+            a.status[kk] = st;
+        }
+    }
+}
+
+/*
+ * The same group of workgroups as a SYSTOLIC pipeline (up to 640 parameters, up to four output tiles per member).  What a
+ * member multiplies never changes during a launch -- its own rows of the matrix -- and wave w's slice of the proposal
+ * (its q-range = the k-steps 2 q0 .. 2 (q0 + nq) - 1) is exactly the MFMA B operand of those k-steps, in the registers
+ * of the lanes that made it.  So a wave keeps, for each of the member's output tiles, the matrix fragments of ITS k-steps in
+ * registers for the whole launch; an output tile's accumulator starts in wave 0, takes each wave's k-steps in turn (k
+ * ascending: the bits of every other kernel) and travels on through LDS behind tickets; the last wave turns it into terms.
+ * No proposal tile in LDS, no matrix traffic at all after the first transition, the tiles of a member one stage apart in the
+ * pipeline, all four matrix pipes of the CU at work.
+ * The group's decision is taken ONCE, by member 0 (the leader): every member sends its terms (write-through stores, one
+ * arrival each), the leader's last wave waits for the G arrivals, the workgroup copies the slot into LDS (one acquire), the
+ * last wave adds in the canonical order, decides and publishes sixteen accept flags tagged with the transition in ONE
+ * 8-byte word per tile, which the other members' last waves poll (the data is the flag: Guideline 16, R2).  While a wave
+ * waits it draws the NEXT transition's normals: they are addressed by (chain, transition, component), not by the outcome.
+ */
+template <int QW, int NM>
+__global__ __launch_bounds__(512) void linear_wide_systolic_kernel(const WideSplitArgs sa)
+{
+    constexpr int W = 8;
+    const WideFusedArgs &a = sa.f;
+    ymc_stage_tables();
+    extern __shared__ double lds[];
+    const int KS = a.KS, MT = a.MT, m_pad = 16 * MT, d_pad = 4 * KS, d = a.d, G = sa.G;
+    const int TCH = sa.chunk;                             /* output tiles per staging chunk of the leader's sum */
+    const int stage = (W - 1) * NM * 256 > (MT < TCH ? MT : TCH) * 256 ? (W - 1) * NM * 256 : (MT < TCH ? MT : TCH) * 256;
+    double *hand = lds;                                   /* [W - 1][NM][4][64]: an accumulator between wave w and w + 1 */
+    double *terms = lds;                                  /* [<= TCH][4][64]: the leader's copy of the slot (the pipeline is empty then) */
+    double *xlds = lds + stage;                           /* [W][2 QW][64]: the chains' state, every wave its slice (registers
+                                                           * are for the matrix and the two sets of normals) */
+    double *dconst = xlds + W * 2 * QW * 64;              /* prior mean | prior prec | sigma */
+    const double *consts = a.blob + (size_t)MT * KS * 64; /* bias | n prec | row mean | the three above, in global memory */
+    const double *pmean = dconst, *pprec = pmean + d_pad, *sigma = pprec + d_pad;
+    double *mconst = dconst + 3 * d_pad;                  /* [3][NM][16]: bias | n prec | row mean of the member's outputs */
+    double *handP = mconst + 3 * NM * 16;                 /* [64] */
+    int *movedf = reinterpret_cast<int *>(handP + 64);    /* [16] */
+    int *accf = movedf + 16;                              /* [16] */
+    volatile uint32_t *ticket = reinterpret_cast<volatile uint32_t *>(accf + 16); /* [2]: [0] the prior's hand-over */
+    volatile uint32_t *gave_up = ticket + 1;
+    volatile uint32_t *passed = ticket + 2;               /* [W]: accumulators wave w has passed on so far */
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 15, g = lane >> 4;
+    {
+        for (int i = tid; i < 3 * d_pad; i += 64 * W) dconst[i] = consts[3 * (size_t)m_pad + i];
+        for (int i = tid; i < 16; i += 64 * W) movedf[i] = 0;
+        if (tid < 2 + W) ticket[tid] = 0;
+    }
+    const uint64_t nct = (a.K + 15) / 16;
+    const uint64_t tile = blockIdx.x / (unsigned)G;
+    const int member = (int)(blockIdx.x % (unsigned)G);
+    const bool leader = member == 0;
+    const int first_t = (member * MT) / G, n_mine = ((member + 1) * MT) / G - first_t; /* <= NM */
+    for (int i = tid; i < 3 * NM * 16; i += 64 * W) {
+        const int arr = i / (NM * 16), o = i % (NM * 16);
+        mconst[i] = o < 16 * n_mine ? consts[(size_t)arr * m_pad + 16 * first_t + o] : 0.0;
+    }
+    const int Q = KS / 2, q0 = (wave * Q) / W, nq = ((wave + 1) * Q) / W - q0;
+    const uint32_t pair_of_g = (g == 0) ? 0u : (g == 1) ? 2u : (g == 2) ? 1u : 3u;
+    const int j0 = 8 * q0 + g;
+    const int left = d - j0 - 4;
+    const int full_q = left > 0 ? (left + 7) / 8 : 0;
+
+    const uint64_t k = tile * 16 + c;
+    const bool live = tile < nct && k < a.K;
+    const uint64_t kk = live ? k : 0;
+    const uint32_t chain = (uint32_t)(a.chain0 + kk);
+    /* this wave's k-steps of the member's rows of the matrix: loaded ONCE */
+    double Ar[NM][2 * QW];
+#pragma unroll
+    for (int ti = 0; ti < NM; ++ti)
+#pragma unroll
+        for (int j = 0; j < 2 * QW; ++j)
+            Ar[ti][j] = (ti < n_mine && j < 2 * nq) ? a.blob[((size_t)(first_t + ti) * KS + 2 * q0 + j) * 64 + lane] : 0.0;
+    double ys[2 * QW], xin[2 * QW];
+    double *xl = xlds + (size_t)wave * 2 * QW * 64 + lane; /* + (2 qi + e) 64 */
+    {
+        const double *xr = a.x + kk * d + j0;
+#pragma unroll
+        for (int qi = 0; qi < QW; ++qi)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                xl[(2 * qi + e) * 64] = (live && qi < nq && j0 + 8 * qi + 4 * e < d) ? xr[8 * qi + 4 * e] : 0.0;
+    }
+    const bool decider = wave == W - 1;
+    double lp = (decider && leader && live) ? a.lp[kk] : 0.0;
+    uint64_t accepted = (decider && leader && live) ? a.acc_count[kk] : 0;
+    uint32_t st = (decider && leader && live) ? a.status[kk] : 0;
+    RecordClock clk(a.rec_stride, a.rec_since);
+    auto draw = [&](uint64_t t) { /* the normals of transition t for this wave's slice */
+#pragma unroll
+        for (int qi = 0; qi < QW; ++qi) {
+            if (qi < nq) {
+                double xi0, xi1;
+#if defined(YMC_WS_NODRAW)   /* timing experiments only (tools/exp_wide_split.sh) */
+                xi0 = 1e-3 * (double)(qi + 1), xi1 = -1e-3 * (double)((chain + t) & 7u);
+#else
+                ymc_draw_normal_pair(a.seed, chain, t, 4u * (uint32_t)(q0 + qi) + pair_of_g, &xi0, &xi1);
+#endif
+                swap_odd_even_rows(xi0, xi1);
+                xin[2 * qi] = xi0, xin[2 * qi + 1] = xi1;
+            } else {
+                xin[2 * qi] = 0.0, xin[2 * qi + 1] = 0.0;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto wait_lds = [&](volatile uint32_t *word, uint32_t want) { /* within the workgroup: never long */
+        if (lane == 0)
+            while ((int32_t)(*word - want) < 0) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_wave_barrier();
+    };
+    __syncthreads();
+    draw(a.t0);
+    uint32_t tkP = 0;
+    uint32_t *arrived = sa.arrived + tile * 64; /* a tile's polled words on lines of their own (256 bytes a tile) */
+    unsigned long long *decision = reinterpret_cast<unsigned long long *>(sa.arrived + tile * 64 + 32);
+
+#pragma unroll 1
+    for (uint32_t n = 0; n < a.nsteps; ++n) {
+        const uint64_t t = a.t0 + n;
+        const uint32_t epoch = n + 1;
+        /* ---- the proposal of this wave's slice: registers only ---- */
+        if (decider && n > 0) draw(t);
+        {
+            bool moved_l = false;
+            const double *sig_w = sigma + j0, *pm_w = pmean + j0;
+#pragma unroll
+            for (int qi = 0; qi < QW; ++qi) {
+                if (qi < nq) {
+                    const double x0 = xl[(2 * qi) * 64], x1 = xl[(2 * qi + 1) * 64];
+                    double y0, y1;
+                    if (a.pcn) {
+                        const double p0 = pm_w[8 * qi] + sig_w[8 * qi] * xin[2 * qi];
+                        const double p1 = pm_w[8 * qi + 4] + sig_w[8 * qi + 4] * xin[2 * qi + 1];
+                        y0 = a.pcn_c1 * x0 + a.pcn_c2 * p0;
+                        y1 = a.pcn_c1 * x1 + a.pcn_c2 * p1;
+                    } else {
+                        y0 = x0 + sig_w[8 * qi] * xin[2 * qi];
+                        y1 = x1 + sig_w[8 * qi + 4] * xin[2 * qi + 1];
+                    }
+                    ys[2 * qi] = y0, ys[2 * qi + 1] = y1;
+                    moved_l = moved_l || !(y0 == x0) || !(y1 == x1);
+                } else {
+                    ys[2 * qi] = 0.0, ys[2 * qi + 1] = 0.0;
+                }
+            }
+            if (leader) {
+                int mv = moved_l ? 1 : 0;
+                mv |= __shfl_xor(mv, 16, 64);
+                mv |= __shfl_xor(mv, 32, 64);
+                if (mv && g == 0) movedf[c] = 1;
+            }
+        }
+        /* ---- the leader's prior sums: components ascending, from wave to wave (wide_prior_chain, from registers) ---- */
+        if (leader && !a.likelihood_only) {
+            const double *pm_w = pmean + j0, *pp_w = pprec + j0;
+            double pt[2 * QW];
+#pragma unroll
+            for (int qi = 0; qi < QW; ++qi)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    if (qi < nq) {
+                        const double dx = ys[2 * qi + e] - pm_w[8 * qi + 4 * e];
+                        const double px = pp_w[8 * qi + 4 * e] * dx;
+                        pt[2 * qi + e] = dx * px;
+                    } else {
+                        pt[2 * qi + e] = 0.0;
+                    }
+                }
+            const uint32_t tk = tkP + (uint32_t)wave;
+            double P = 0.0;
+            if (wave > 0) {
+                wide_wait_ticket(ticket, 0, tk, lane);
+                P = handP[lane];
+            }
+#pragma unroll
+            for (int qi = 0; qi < QW; ++qi)
+                if (qi < nq) {
+                    P = P + pt[2 * qi];
+                    P = P + pt[2 * qi + 1];
+                }
+            handP[lane] = P;
+            if (lane == 0) ticket[0] = tk + 1;
+            tkP += (uint32_t)W;
+        }
+
+        /* ---- the pipeline: tile ti's accumulator arrives from wave w - 1, takes this wave's k-steps, moves on ---- */
+        double *slot = sa.xch + ((tile * 2 + (n & 1u)) * (uint64_t)MT) * 256;
+        const uint32_t base = n * (uint32_t)n_mine;
+#pragma unroll
+        for (int ti = 0; ti < NM; ++ti) {
+            if (ti < n_mine) {
+                d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+                if (wave > 0) {
+                    wait_lds(passed + wave - 1, base + (uint32_t)ti + 1u);
+                    const double *h = hand + ((size_t)(wave - 1) * NM + ti) * 256 + lane;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) acc[rr] = h[64 * rr];
+                }
+#if !defined(YMC_WS_NOPROD)
+#pragma unroll
+                for (int j = 0; j < 2 * QW; ++j)
+                    if (j < 2 * nq) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ar[ti][j], ys[j], acc, 0, 0, 0);
+#endif
+                if (wave < W - 1) {
+                    double *h = hand + ((size_t)wave * NM + ti) * 256 + lane;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) h[64 * rr] = acc[rr];
+                    if (lane == 0) passed[wave] = base + (uint32_t)ti + 1u; /* a wave's LDS operations are performed in order */
+                } else {
+                    d4 tacc[1][1];
+                    tacc[0][0] = acc;
+                    const double *mc = mconst - 16 * first_t; /* wide_terms indexes by the output's number */
+                    wide_terms<1, 1>(tacc, MT, first_t + ti, g, mc, mc + NM * 16, mc + 2 * NM * 16);
+                    /* write-through (sc1): the bytes leave this XCD's L2 with the store.  The slot is lane-major
+                     * [tile][lane][4] so that a lane's four terms are two 16-byte stores (8-byte write-through stores cost
+                     * 2.7 x per byte); the data registers must outlive the issue: the s_nop */
+                    {
+                        typedef double d2 __attribute__((ext_vector_type(2)));
+                        double *dst = slot + (size_t)(first_t + ti) * 256 + 4 * lane;
+                        const d2 lo = {tacc[0][0][0], tacc[0][0][1]}, hi = {tacc[0][0][2], tacc[0][0][3]};
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1\n\ts_nop 1"
+                                     :: "v"(dst), "v"(lo), "v"(hi) : "memory");
+                    }
+                }
+            }
+        }
+        if (decider) { /* the only storing wave of the member: drained, then ONE arrival for all its stores */
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        /* ---- meanwhile: the next transition's normals (the last wave has the group to attend to: it draws its own while
+         * the next transition's accumulators come down the pipeline) ---- */
+        if (!decider && n + 1 < a.nsteps) draw(t + 1);
+
+        const bool rec = clk.due();
+        if (leader) {
+            /* ---- the leader: all G arrivals, the slot into LDS (a chunk at a time), the sum, the decision ---- */
+            const double u = decider ? ymc_draw_uniform(a.seed, chain, t) : 0.0; /* before the wait, not after it */
+#if !defined(YMC_WS_NOXCH)
+            if (decider) {
+                if (lane == 0 && !*gave_up) {
+                    const uint32_t want = epoch * (uint32_t)G;
+                    uint32_t spins = 0;
+                    while ((int32_t)(__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > sa.poll_limit) { /* a member is not running: do not hang the device */
+                            *gave_up = 1;
+                            __hip_atomic_fetch_add(sa.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            break;
+                        }
+                    }
+                }
+#if defined(YMC_WS_SC1LOAD)  /* experiment: every load of the slot write-through-aware (sc1), no acquire (Guideline 16, Rule) */
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  /* ONE acquire after the match: this CU's stale lines go */
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    /* ... before the barrier lets the others load */
+#endif
+            }
+#endif
+            double S = 0.0;
+#if defined(YMC_WS_NOXCH)
+            __syncthreads();
+#else
+#pragma unroll 1
+            for (int c0 = 0; c0 < MT; c0 += TCH) {
+                const int nterm = (MT - c0 < TCH ? MT - c0 : TCH) * 256;
+                const double *src = slot + (size_t)c0 * 256;
+                __syncthreads();
+                /* 16-byte units (tile, lane, half) -> LDS [tile][4][64]; eight units per thread requested together */
+                typedef double d2 __attribute__((ext_vector_type(2)));
+                const d2 *src2 = reinterpret_cast<const d2 *>(src);
+                const int nunit = nterm / 2;
+#pragma unroll 1
+                for (int i = tid; i < nunit; i += 8 * 64 * W) {
+                    d2 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int idx = i + u * 64 * W;
+#if defined(YMC_WS_SC1LOAD)
+                        const double *s8 = src + 2 * (size_t)(idx < nunit ? idx : i);
+                        v[u][0] = __hip_atomic_load(s8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        v[u][1] = __hip_atomic_load(s8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+                        v[u] = src2[idx < nunit ? idx : i];
+#endif
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int idx = i + u * 64 * W;
+                        if (idx < nunit) {
+                            double *dst = terms + (idx >> 7) * 256 + (idx & 1) * 128 + ((idx & 127) >> 1);
+                            dst[0] = v[u][0];
+                            dst[64] = v[u][1];
+                        }
+                    }
+                }
+                __syncthreads();
+                if (decider) {
+                    const double *tl = terms + lane;
+#pragma unroll 8
+                    for (int i = 0; i < nterm / 64; ++i) S = S + tl[i * 64]; /* outputs ascending: the canonical order */
+                }
+            }
+#endif
+            if (decider) {
+                const double logl = -0.5 * (combine4(S) + a.lik_const);
+                const double lpy = a.likelihood_only ? logl : logl + (-0.5 * combine4(handP[lane]));
+                const bool moved = movedf[c] != 0;
+                if (*gave_up) st |= YMC_CHAIN_HANDOFF;
+                const bool acc1 = ymc_accept(lpy - lp, moved, ymc_finite(lpy), u, st);
+                const unsigned long long flags = __ballot(acc1) & 0xffffull; /* lanes 0 .. 15: g = 0, chain c */
+                if (lane == 0) /* ONE aligned 8-byte write-through store: the transition is the tag */
+                    __hip_atomic_store(decision, ((unsigned long long)epoch << 32) | flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lp = acc1 ? lpy : lp;
+                accepted += acc1 ? 1u : 0u;
+                if (g == 0) {
+                    accf[c] = acc1 ? 1 : 0;
+                    movedf[c] = 0;
+                    if (live) {
+                        if (a.acc) a.acc[(uint64_t)n * a.K + kk] = acc1 ? 1 : 0;
+                        if (rec && a.lp_out) a.lp_out[(uint64_t)clk.row * a.K + kk] = lp;
+                    }
+                }
+            }
+        } else if (decider) {
+            /* ---- the others: the leader's word for this transition ---- */
+            unsigned long long v = 0;
+#if defined(YMC_WS_NOXCH)
+            v = 0x5a5aull;
+#endif
+            if (lane == 0 && !*gave_up && v == 0) {
+                uint32_t spins = 0;
+                while (((v = __hip_atomic_load(decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != epoch) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > sa.poll_limit) {
+                        *gave_up = 1;
+                        __hip_atomic_fetch_add(sa.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        v = 0;
+                        break;
+                    }
+                }
+            }
+            const uint32_t fl = (uint32_t)__shfl((int)(uint32_t)v, 0, 64);
+            if (g == 0) accf[c] = (int)((fl >> c) & 1u);
+        }
+        __syncthreads();
+        /* ---- the move, every wave its slice; the leader writes the record row ---- */
+        {
+            const bool acc1 = accf[c] != 0;
+            if (acc1) {
+#pragma unroll
+                for (int i = 0; i < 2 * QW; ++i) xl[i * 64] = ys[i];
+            }
+            if (rec && a.traj && live && leader) {
+                double *row = a.traj + ((uint64_t)clk.row * a.K + kk) * (uint64_t)d + j0;
+#pragma unroll
+                for (int qi = 0; qi < QW; ++qi) {
+                    if (qi < nq) {
+                        const double x0 = xl[(2 * qi) * 64], x1 = xl[(2 * qi + 1) * 64];
+                        if (qi < full_q) {
+                            row[8 * qi] = x0;
+                            row[8 * qi + 4] = x1;
+                        } else {
+                            if (j0 + 8 * qi < d) row[8 * qi] = x0;
+                            if (j0 + 8 * qi + 4 < d) row[8 * qi + 4] = x1;
+                        }
+                    }
+                }
+            }
+        }
+        if (rec) clk.wrote();
+        /* no barrier here: the flags are rewritten only behind the next transition's pipeline and exchange, and the hand-over
+         * slots are written in the order they are read */
+    }
+
+    if (live && leader) {
+        double *xr = a.x + kk * d + j0;
+#pragma unroll
+        for (int qi = 0; qi < QW; ++qi)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                if (qi < nq && j0 + 8 * qi + 4 * e < d) xr[8 * qi + 4 * e] = xl[(2 * qi + e) * 64];
+        if (decider && g == 0) {
+            a.lp[kk] = lp;
+            a.acc_count[kk] = accepted;
+            a.status[kk] = st;
+        }
+    }
+}
+
 }  // namespace
 
 /* FullDiagnostics' moments (estimation.py:36-53, diagnostics.py:91-94) for the fused kernel: replayed after the launch from
@@ -756,6 +1433,123 @@ hipError_t ymc_launch_wide_fused(const WideFusedArgs &a, int cus, hipStream_t s)
     YMC_FUSED(1, 16, 9, 1)
 #undef YMC_FUSED
     return hipErrorInvalidValue;
+}
+
+/* ---- small ensembles: a tile over G workgroups ---- */
+namespace {
+struct SplitPick {
+    int W, QW, G, NM; /* NM > 0: the systolic build with room for NM output tiles per member */
+    int chunk;        /* ... and the output tiles its leader stages per round of its sum */
+    bool CG;
+};
+
+size_t split_lds(const SplitPick &f, int KS, int MT)
+{
+    const size_t d_pad = 4 * (size_t)KS;
+    if (f.NM) {
+        const size_t chunk = (size_t)(MT < f.chunk ? MT : f.chunk) * 256, hand = (size_t)7 * f.NM * 256;
+        return ((hand > chunk ? hand : chunk) + (size_t)8 * 2 * f.QW * 64 + 3 * d_pad + 3 * (size_t)f.NM * 16 + 64) * sizeof(double) +
+               (2 * 16 + 2 + 8) * sizeof(int);
+    }
+    const int ring = 4 * (f.W >= 16 ? 2 : 4);
+    const size_t ksp = (size_t)((KS + ring - 1) / ring) * ring;
+    return (ksp * 64 + (size_t)MT * 256 + (f.CG ? 0 : 3 * d_pad) + 64) * sizeof(double) + (2 * 16 + 4) * sizeof(int);
+}
+
+size_t split_fit(int KS, int MT, uint64_t K, int cus, SplitPick &f)
+{
+    const char *env = std::getenv("YMC_WIDE_SPLIT");
+    if (env && env[0] == '0') return 0;
+    if (const char *ef = std::getenv("YMC_WIDE_FUSED")) /* the launch-per-stage path asked for */
+        if (ef[0] == '0') return 0;
+    const uint64_t nct = (K + 15) / 16;
+    if (nct == 0 || nct * 2 > (uint64_t)cus) return 0; /* every member resident: one workgroup per CU */
+    int G = (int)((uint64_t)cus / nct);
+    if (G > MT) G = MT;
+    if (G > 32) G = 32;
+    if (const char *eg = std::getenv("YMC_WIDE_SPLIT_G")) { /* experiments and tests: the group's size */
+        const int want = std::atoi(eg);
+        if (want >= 1 && want <= G) G = want;
+    }
+    if (G < 2 && !(env && env[0] == 'f')) return 0;     /* 'f'orce: a group of one runs the protocol alone (tests) */
+    f.G = G;
+    const int Q = KS / 2;
+    /* the systolic build where a wave's k-steps of the member's rows fit its registers; YMC_WIDE_SPLIT_KERNEL=stream: the other */
+    const char *ek = std::getenv("YMC_WIDE_SPLIT_KERNEL");
+    const int per_member = (MT + G - 1) / G, qw8 = (Q + 7) / 8;
+    if (!(ek && ek[0] == 's' && ek[1] == 't') && qw8 <= 10 && per_member <= 4) {
+        f.W = 8, f.QW = qw8 <= 8 ? 8 : 10, f.NM = per_member <= 1 ? 1 : per_member <= 2 ? 2 : 4, f.CG = false;
+        for (f.chunk = 32; f.chunk >= 8; f.chunk /= 2) {
+            const size_t lds = split_lds(f, KS, MT);
+            if (lds <= kTileLdsLimit) return lds;
+        }
+    }
+    f.NM = 0, f.chunk = 0;
+    f.W = 16, f.QW = 9;
+    if (const char *ew = std::getenv("YMC_WIDE_SPLIT_W"))
+        if (std::atoi(ew) == 8) f.W = 8, f.QW = 18;
+    if ((Q + f.W - 1) / f.W > f.QW) return 0;
+    f.CG = false;
+    size_t lds = split_lds(f, KS, MT);
+    if (lds > kTileLdsLimit) {
+        f.CG = true;
+        lds = split_lds(f, KS, MT);
+    }
+    return lds <= kTileLdsLimit ? lds : 0;
+}
+
+template <int W, int QW, bool CG>
+hipError_t launch_split(const WideSplitArgs &a, size_t lds, hipStream_t s)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_wide_split_kernel<W, QW, CG>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const uint64_t nct = (a.f.K + 15) / 16;
+    hipLaunchKernelGGL((linear_wide_split_kernel<W, QW, CG>), dim3((unsigned)(nct * (uint64_t)a.G)), dim3(64 * W), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int QW, int NM>
+hipError_t launch_systolic(const WideSplitArgs &a, size_t lds, hipStream_t s)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_wide_systolic_kernel<QW, NM>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const uint64_t nct = (a.f.K + 15) / 16;
+    hipLaunchKernelGGL((linear_wide_systolic_kernel<QW, NM>), dim3((unsigned)(nct * (uint64_t)a.G)), dim3(512), lds, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+int ymc_wide_split_group(int KS, int MT, uint64_t K, int cus)
+{
+    SplitPick f;
+    return split_fit(KS, MT, K, cus, f) ? f.G : 0;
+}
+
+size_t ymc_wide_split_exchange_bytes(int MT, uint64_t K) { return ((K + 15) / 16) * 2 * (size_t)MT * 256 * sizeof(double); }
+
+/* the polled words of a launch, one block, 256 bytes a tile (its arrival counter and, 128 bytes on, its decision word: a
+ * group's pollers and arrivals meet nobody else's on a line) */
+size_t ymc_wide_split_counter_bytes(uint64_t K) { return ((K + 15) / 16) * 256; }
+
+hipError_t ymc_launch_wide_split(WideSplitArgs a, int cus, hipStream_t s)
+{
+    SplitPick f;
+    const size_t lds = split_fit(a.f.KS, a.f.MT, a.f.K, cus, f);
+    if (!lds) return hipErrorInvalidValue;
+    a.G = f.G;
+    a.chunk = f.chunk;
+    /* every polled word zeroed before EVERY launch (arrivals and tags count within the launch) */
+    hipError_t e = hipMemsetAsync(a.arrived, 0, ymc_wide_split_counter_bytes(a.f.K), s);
+    if (e != hipSuccess) return e;
+#define YMC_SYSTOLIC(QW_, NM_) \
+    if (f.NM == NM_ && f.QW == QW_) return launch_systolic<QW_, NM_>(a, lds, s);
+    YMC_SYSTOLIC(8, 1) YMC_SYSTOLIC(8, 2) YMC_SYSTOLIC(8, 4) YMC_SYSTOLIC(10, 1) YMC_SYSTOLIC(10, 2) YMC_SYSTOLIC(10, 4)
+#undef YMC_SYSTOLIC
+    if (f.W == 16) return f.CG ? launch_split<16, 9, true>(a, lds, s) : launch_split<16, 9, false>(a, lds, s);
+    return f.CG ? launch_split<8, 18, true>(a, lds, s) : launch_split<8, 18, false>(a, lds, s);
 }
 
 /* ---- two-level ---- */
