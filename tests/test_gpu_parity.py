@@ -1550,13 +1550,13 @@ def test_wide_fused_kernel_vs_oracle_and_the_launch_per_stage_path(ffi, ctx, mon
 @pytest.mark.parametrize("d,m,K,env", [(512, 512, 256, {}), (512, 512, 256, {"YMC_WIDE_SPLIT_KERNEL": "stream"}), (512, 520, 16, {}),
                                        (512, 520, 16, {"YMC_WIDE_SPLIT_KERNEL": "stream", "YMC_WIDE_SPLIT_W": "8"}),
                                        (320, 200, 300, {"YMC_WIDE_SPLIT_G": "5"}), (600, 90, 2048, {}), (264, 16, 40, {"YMC_WIDE_SPLIT": "f"}),
-                                       (640, 2000, 20, {}), (300, 40, 1000, {"YMC_WIDE_SPLIT_KERNEL": "stream"}),
+                                       (640, 2000, 20, {}), (300, 40, 1000, {"YMC_WIDE_SPLIT_KERNEL": "stream"}), (600, 700, 20, {}), (600, 460, 30, {}),
                                        (700, 330, 100, {"YMC_WIDE_SPLIT_G": "3", "YMC_WIDE_SPLIT_W": "8"}), (1100, 60, 50, {})])
 def test_wide_split_kernel_vs_oracle(ffi, ctx, monkeypatch, d, m, K, env):
     """linear_wide_split_kernel (round 4): small ensembles beyond 256 parameters with every tile of 16 chains over a GROUP of
     workgroups -- each multiplies its share of the output tiles, the terms cross the chip once per transition (write-through
     stores, one arrival counter per tile, one acquire per workgroup), every member adds them in the canonical order and
-    decides alike -- and linear_wide_systolic_kernel (up to 640 parameters, up to four output tiles per member): the member's
+    decides alike -- and linear_wide_systolic_kernel (up to 640 parameters, one or two output tiles per member): the member's
     rows of the matrix in registers cut along k, an output tile's accumulator travelling down the waves, the decision taken
     by the group's leader and published in one tagged word.  Groups of 32, 16, 5, 3, 2 and 1 (the protocol alone), output
     tiles that do not divide among the members, the leader's sum in several chunks (m = 2000), every build, thinned record
@@ -1587,6 +1587,41 @@ def test_wide_split_kernel_vs_oracle(ffi, ctx, monkeypatch, d, m, K, env):
     assert np.array_equal(run.state()[0], e.x) and np.array_equal(run.state()[1], e.lp)
     assert np.array_equal(s_["accepted"], e.acc_count) and np.array_equal(s_["status"], e.status)
     assert 0 < out["acc"].mean() < 1
+
+
+@pytest.mark.parametrize("kernel", ["systolic", "stream"])
+def test_an_abandoned_group_exchange_fails_the_run(ffi, ctx, monkeypatch, kernel):
+    """The group kernels wait for other workgroups inside a launch (arrival counters, the leader's decision word): a wait
+    that does not end within the poll limit gives up -- every wave still reaches the end of the launch -- and the run fails
+    with YMC_ERR_DEVICE instead of delivering a record made from terms that never arrived (the limit is lowered through the
+    test-only knob so that the give-up path really runs); a fresh run with the product's limit is fine."""
+    from yagremcmc_amd import lowering
+    if kernel == "stream":
+        monkeypatch.setenv("YMC_WIDE_SPLIT_KERNEL", "stream")
+    d, m, K = 400, 300, 64
+    rng = np.random.default_rng(77)
+    g = dict(data=rng.normal(size=(2, m)), noise_precision=rng.uniform(0.5, 3, size=m), prior_mean=rng.normal(size=d) * 0.1,
+             prior_precision=rng.uniform(0.1, 2, size=d))
+    A, b = rng.normal(size=(m, d)) / np.sqrt(d), rng.normal(size=m)
+    low = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, g, fwd_matrix=A, fwd_shift=b)
+    sigma, x0 = np.full(d, 0.02), rng.normal(size=(K, d)) * 0.3
+    prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, sigma)
+    monkeypatch.setenv("YMC_LV_POLL_LIMIT", "0")
+    run = ffi.Run(prob, 5, K, x0, 30, ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT, 0)
+    run.advance(30)
+    with pytest.raises(ffi.YmcError, match="internal device error") as err:
+        run.sync()
+    assert err.value.code == ffi.ERR_DEVICE
+    with pytest.raises(ffi.YmcError, match="internal device error"):
+        run.trajectory()
+    monkeypatch.delenv("YMC_LV_POLL_LIMIT")
+    good = ffi.Run(prob, 5, K, x0, 30, ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT, 0)
+    good.advance(30)
+    good.sync()
+    p = o.posterior_linear(A, b, g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+    e = o.Ensemble(p, sigma, x0, 5, chain0=0)
+    out = e.advance(30)
+    assert np.array_equal(good.trajectory(), out["traj"]) and not good.summary()["status"].any()
 
 
 @pytest.mark.parametrize("d,m,nd,K,method,stride", [(300, 40, 2, 70, "mrw", 1), (257, 1, 1, 33, "mrw", 1), (513, 700, 3, 20, "pcn", 1),

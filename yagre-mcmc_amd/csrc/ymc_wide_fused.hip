@@ -646,20 +646,135 @@ __global__ __launch_bounds__(64 * W) void linear_wide_fused2_kernel(const WideFu
 }
 
 /*
- * Small ensembles: ONE tile of 16 chains over G workgroups (G CUs).  With fewer tiles than CUs the fused kernel leaves most
- * of the chip idle while each busy CU's matrix pipe runs a tile's whole product (4 096 MFMAs at d = m = 512: 31 us).  Here
- * the G members of a tile's group all hold the tile's state and all build the SAME proposal (the draws are addressed, not
- * consumed: every member computes the same bits), each multiplies its own share of the output tiles, and the per-output
- * terms -- not sums: the canonical order is one sequential chain per lane -- go to every member of the group through L2 /
- * the fabric in one all-to-all step per transition: write-through (sc1) stores, each storing wave drained, one agent-scope
- * add per member on the tile's arrival counter; a member's last wave polls that ONE word, one agent-scope acquire, a
- * workgroup barrier, plain loads into LDS (cdna_hip_programming.md Guideline 16, the R1 form).  Every member then adds the
- * terms in the canonical order, draws the same uniform and takes the same decision; member 0 writes the record.  Two slots
- * per tile by the parity of the transition: a member writes transition n + 2's terms only after it has seen every member's
- * arrival for n + 1, which each posts after it has read n's.
+ * ---- a tile of 16 chains over a GROUP of workgroups: what the two kernels below share ----
+ * Every member of a group holds the tile's state and builds the SAME proposal (the draws are addressed, not consumed: every
+ * member computes the same bits); each multiplies its own share of the output tiles and sends the per-output TERMS -- not
+ * sums: the canonical order is one sequential chain per lane -- to the group's LEADER (member 0): write-through (sc1)
+ * stores, every storing wave drained, ONE agent-scope add per member on the tile's arrival counter.  The leader's last wave
+ * polls that ONE word, one agent-scope acquire, a workgroup barrier, plain loads into LDS (cdna_hip_programming.md
+ * Guideline 16, the R1 form), adds in the canonical order, decides, and publishes the sixteen accept flags tagged with the
+ * transition in ONE aligned 8-byte word, which the other members' last waves poll (the data is the flag: R2).  A member
+ * writes transition n + 1's terms only after it has read decision n, which the leader publishes after it has read all of
+ * n's terms (the two slots by parity are a margin, not a need).  A tile's polled words have 256 bytes to themselves: all
+ * tiles' words on one line cost 6 us per transition at 256 workgroups (every poll and every arrival queue at one channel).
  * Every member of every group must be resident (grid <= CUs, one workgroup per CU by its LDS); a poll that does not end
  * within the limit gives up, flags the chains (YMC_CHAIN_HANDOFF) and fails the run (check_internal_faults): every wave
  * reaches the end of the launch whatever happens.
+ */
+/* a lane's four terms of output tile t into the slot, lane-major [tile][lane][4]: two 16-byte write-through stores (8-byte
+ * write-through stores cost 2.7 x per byte); the data registers must outlive the issue: the s_nop.  The caller drains. */
+__device__ __forceinline__ void wide_send_terms(double *slot, int t, int lane, const d4 &terms)
+{
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    double *dst = slot + (size_t)t * 256 + 4 * lane;
+    const d2 lo = {terms[0], terms[1]}, hi = {terms[2], terms[3]};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1\n\ts_nop 1"
+                 :: "v"(dst), "v"(lo), "v"(hi) : "memory");
+}
+
+/* the leader's last wave: all G members' arrivals for this transition (bounded), then ONE acquire */
+__device__ __forceinline__ void wide_await_arrivals(uint32_t *arrived, uint32_t want, const WideSplitArgs &sa, volatile uint32_t *gave_up, int lane)
+{
+    if (lane == 0 && !*gave_up) {
+        uint32_t spins = 0;
+        while ((int32_t)(__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > sa.poll_limit) { /* a member is not running: do not hang the device */
+                *gave_up = 1;
+                __hip_atomic_fetch_add(sa.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
+#if defined(YMC_WS_SC1LOAD)  /* experiment: every load of the slot write-through-aware (sc1), no acquire (Guideline 16, Rule) */
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  /* ONE acquire after the match: this CU's stale lines go */
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    /* ... before the barrier lets the others load */
+#endif
+}
+
+/* the leader, every wave: the slot into LDS a chunk of TCH output tiles at a time (16-byte units (tile, lane, half) -> LDS
+ * [tile][4][64], eight units per thread requested together), the last wave adding each chunk in the canonical order --
+ * outputs ascending.  Two barriers per chunk; the sum is the last wave's. */
+template <int W>
+__device__ __forceinline__ double wide_gather_sum(const double *slot, int MT, int TCH, double *terms, int tid, int lane, bool decider)
+{
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    double S = 0.0;
+#pragma unroll 1
+    for (int c0 = 0; c0 < MT; c0 += TCH) {
+        const int nterm = (MT - c0 < TCH ? MT - c0 : TCH) * 256;
+        const double *src = slot + (size_t)c0 * 256;
+        const d2 *src2 = reinterpret_cast<const d2 *>(src);
+        const int nunit = nterm / 2;
+        __syncthreads();
+#pragma unroll 1
+        for (int i = tid; i < nunit; i += 8 * 64 * W) {
+            d2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = i + u * 64 * W;
+#if defined(YMC_WS_SC1LOAD)
+                const double *s8 = src + 2 * (size_t)(idx < nunit ? idx : i);
+                v[u][0] = __hip_atomic_load(s8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v[u][1] = __hip_atomic_load(s8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+                v[u] = src2[idx < nunit ? idx : i];
+#endif
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = i + u * 64 * W;
+                if (idx < nunit) {
+                    double *dst = terms + (idx >> 7) * 256 + (idx & 1) * 128 + ((idx & 127) >> 1);
+                    dst[0] = v[u][0];
+                    dst[64] = v[u][1];
+                }
+            }
+        }
+        __syncthreads();
+        if (decider) {
+            const double *tl = terms + lane;
+#pragma unroll 8
+            for (int i = 0; i < nterm / 64; ++i) S = S + tl[i * 64];
+        }
+    }
+    return S;
+}
+
+/* the leader's last wave: the chains' accept flags of this transition, ONE aligned 8-byte write-through store */
+__device__ __forceinline__ void wide_publish_decision(unsigned long long *decision, uint32_t epoch, bool acc1, int lane)
+{
+    const unsigned long long flags = __ballot(acc1) & 0xffffull; /* lanes 0 .. 15: g = 0, chain c */
+    if (lane == 0) __hip_atomic_store(decision, ((unsigned long long)epoch << 32) | flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+/* the other members' last wave: the leader's word for this transition (bounded); the sixteen flags, in every lane */
+__device__ __forceinline__ uint32_t wide_await_decision(unsigned long long *decision, uint32_t epoch, const WideSplitArgs &sa,
+                                                        volatile uint32_t *gave_up, int lane)
+{
+    unsigned long long v = 0;
+    if (lane == 0 && !*gave_up) {
+        uint32_t spins = 0;
+        while (((v = __hip_atomic_load(decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != epoch) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > sa.poll_limit) {
+                *gave_up = 1;
+                __hip_atomic_fetch_add(sa.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                v = 0;
+                break;
+            }
+        }
+    }
+    return (uint32_t)__shfl((int)(uint32_t)v, 0, 64);
+}
+
+/*
+ * Small ensembles: ONE tile of 16 chains over G workgroups (G CUs).  With fewer tiles than CUs the fused kernel leaves most
+ * of the chip idle while each busy CU's matrix pipe runs a tile's whole product (4 096 MFMAs at d = m = 512: 31 us).  This
+ * build is the fused kernel's evaluation cut along the OUTPUT tiles: the proposal tile in LDS, a wave per output tile of the
+ * member's share, the matrix's fragments streamed from L2 (any d the proposal tile fits, any number of output tiles).
  */
 template <int W, int QW, bool CG>
 __global__ __launch_bounds__(64 * W) void linear_wide_split_kernel(const WideSplitArgs sa)
@@ -672,8 +787,9 @@ __global__ __launch_bounds__(64 * W) void linear_wide_split_kernel(const WideSpl
     const int KS = a.KS, MT = a.MT, m_pad = 16 * MT, d_pad = 4 * KS, d = a.d, G = sa.G;
     const int KSP = ((KS + PD * KB - 1) / (PD * KB)) * (PD * KB);
     double *ylds = lds;                                   /* [KSP][64], zero beyond KS */
-    double *terms = ylds + (size_t)KSP * 64;              /* [4 MT][64]: every output's term of the 16 chains, as the MFMA leaves them */
-    double *dconst = terms + (size_t)MT * 256;            /* !CG: prior mean | prior prec | sigma */
+    const int TCH = sa.chunk;                             /* output tiles per staging chunk of the leader's sum */
+    double *terms = ylds + (size_t)KSP * 64;              /* [<= TCH][4][64]: the leader's copy of the slot */
+    double *dconst = terms + (size_t)(MT < TCH ? MT : TCH) * 256; /* !CG: prior mean | prior prec | sigma */
     const double *consts = a.blob + (size_t)MT * KS * 64; /* bias | n prec | row mean (| the three above) in global memory */
     const double *pmean = CG ? consts + 3 * (size_t)m_pad : dconst;
     const double *pprec = pmean + d_pad, *sigma = pprec + d_pad;
@@ -695,6 +811,7 @@ __global__ __launch_bounds__(64 * W) void linear_wide_split_kernel(const WideSpl
     const uint64_t nct = (a.K + 15) / 16;
     const uint64_t tile = blockIdx.x / (unsigned)G;
     const int member = (int)(blockIdx.x % (unsigned)G);
+    const bool leader = member == 0;
     const int first_t = (member * MT) / G, n_mine = ((member + 1) * MT) / G - first_t; /* this member's output tiles */
     const int n_store = n_mine < W ? n_mine : W;                                       /* its waves that have some */
     const int Q = KS / 2, q0 = (wave * Q) / W, nq = ((wave + 1) * Q) / W - q0;
@@ -718,15 +835,16 @@ __global__ __launch_bounds__(64 * W) void linear_wide_split_kernel(const WideSpl
             for (int e = 0; e < 2; ++e)
                 xs[2 * qi + e] = (live && qi < nq && j0 + 8 * qi + 4 * e < d) ? xr[8 * qi + 4 * e] : 0.0;
     }
-    const bool decider = wave == W - 1, scribe = member == 0;
-    double lp = (decider && live) ? a.lp[kk] : 0.0;
-    uint64_t accepted = (decider && live) ? a.acc_count[kk] : 0;
-    uint32_t st = (decider && live) ? a.status[kk] : 0;
+    const bool decider = wave == W - 1;
+    double lp = (decider && leader && live) ? a.lp[kk] : 0.0;
+    uint64_t accepted = (decider && leader && live) ? a.acc_count[kk] : 0;
+    uint32_t st = (decider && leader && live) ? a.status[kk] : 0;
     RecordClock clk(a.rec_stride, a.rec_since);
     __syncthreads();
     const WideEvalCtx cx{ylds, y_w, nullptr, handP, ticket, KS, KSP, nq, lane, wave, g};
     uint32_t tkP = 0;
     uint32_t *arrived = sa.arrived + tile * 64; /* a tile's polled words on lines of their own (256 bytes a tile) */
+    unsigned long long *decision = reinterpret_cast<unsigned long long *>(sa.arrived + tile * 64 + 32);
 
 #pragma unroll 1
     for (uint32_t n = 0; n < a.nsteps; ++n) {
@@ -764,14 +882,14 @@ __global__ __launch_bounds__(64 * W) void linear_wide_split_kernel(const WideSpl
             int mv = moved_l ? 1 : 0;
             mv |= __shfl_xor(mv, 16, 64);
             mv |= __shfl_xor(mv, 32, 64);
-            if (mv && g == 0) movedf[c] = 1;
+            if (leader && mv && g == 0) movedf[c] = 1;
         }
         __syncthreads();
 
         /* the prior's sums first (every member its own: it has the whole proposal): the hand-over runs down the waves
          * while the first ones multiply */
 #if !defined(YMC_WS_NOPRIOR)
-        wide_prior_chain<NT, W, QW>(cx, pm_w, pp_w, tkP);
+        if (leader && !a.likelihood_only) wide_prior_chain<NT, W, QW>(cx, pm_w, pp_w, tkP);
 #endif
 
         /* ---- this member's output tiles: products, terms, out to the group ---- */
@@ -786,9 +904,7 @@ __global__ __launch_bounds__(64 * W) void linear_wide_split_kernel(const WideSpl
             wide_products<NT, TC, KB, PD>(cx, a.blob, MT, t_out, acc);
 #endif
             wide_terms<NT, TC>(acc, MT, t_out, g, consts, consts + m_pad, consts + 2 * m_pad);
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) /* write-through: the bytes leave this XCD's L2 with the store */
-                __hip_atomic_store(slot + (size_t)t_out * 256 + 64 * rr + lane, acc[0][0][rr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            wide_send_terms(slot, t_out, lane, acc[0][0]);
         }
         if (wave < n_store) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* EVERY storing wave drains its stores before it counts */
@@ -798,68 +914,40 @@ __global__ __launch_bounds__(64 * W) void linear_wide_split_kernel(const WideSpl
                     __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        /* ---- the group's terms: the last wave waits for all G members, then everybody copies the slot into LDS ---- */
+        /* ---- the leader: the group's terms and the decision; the others: its word ---- */
+        const bool rec = clk.due();
+        if (leader) {
+            const double u = decider ? ymc_draw_uniform(a.seed, chain, t) : 0.0; /* before the wait, not after it */
+            double S = 0.0;
 #if !defined(YMC_WS_NOXCH)
-        if (decider) {
-            if (lane == 0 && !*gave_up) {
-                const uint32_t want = epoch * (uint32_t)G;
-                uint32_t spins = 0;
-                while ((int32_t)(__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > sa.poll_limit) { /* a member is not running: do not hang the device */
-                        *gave_up = 1;
-                        __hip_atomic_fetch_add(sa.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        break;
+            if (decider) wide_await_arrivals(arrived, epoch * (uint32_t)G, sa, gave_up, lane);
+            S = wide_gather_sum<W>(slot, MT, TCH, terms, tid, lane, decider);
+#endif
+            if (decider) {
+                const double logl = -0.5 * (combine4(S) + a.lik_const);
+                const double lpy = a.likelihood_only ? logl : logl + (-0.5 * combine4(handP[lane]));
+                const bool moved = movedf[c] != 0;
+                if (*gave_up) st |= YMC_CHAIN_HANDOFF;
+                const bool acc1 = ymc_accept(lpy - lp, moved, ymc_finite(lpy), u, st);
+                wide_publish_decision(decision, epoch, acc1, lane);
+                lp = acc1 ? lpy : lp;
+                accepted += acc1 ? 1u : 0u;
+                if (g == 0) {
+                    accf[c] = acc1 ? 1 : 0;
+                    movedf[c] = 0;
+                    if (live) {
+                        if (a.acc) a.acc[(uint64_t)n * a.K + kk] = acc1 ? 1 : 0;
+                        if (rec && a.lp_out) a.lp_out[(uint64_t)clk.row * a.K + kk] = lp;
                     }
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  /* ONE acquire after the match: this CU's stale lines go */
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    /* ... before the barrier lets the others load */
-        }
-        __syncthreads();
-        {
-            const int nterm = MT * 256;
-#pragma unroll 1
-            for (int i = tid; i < nterm; i += 4 * 64 * W) {
-                double v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int idx = i + u * 64 * W;
-                    v[u] = slot[idx < nterm ? idx : i];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int idx = i + u * 64 * W;
-                    if (idx < nterm) terms[idx] = v[u];
-                }
-            }
-        }
-        __syncthreads();
+        } else if (decider) {
+#if defined(YMC_WS_NOXCH)
+            const uint32_t fl = 0x5a5au;
+#else
+            const uint32_t fl = wide_await_decision(decision, epoch, sa, gave_up, lane);
 #endif
-
-        /* ---- the decision: every member's last wave the same one ---- */
-        const bool rec = clk.due();
-        if (decider) {
-            double S = 0.0;
-            const double *tl = terms + lane;
-#pragma unroll 8
-            for (int i = 0; i < 4 * MT; ++i) S = S + tl[i * 64]; /* outputs ascending: the canonical order */
-            const double logl = -0.5 * (combine4(S) + a.lik_const);
-            const double lpy = a.likelihood_only ? logl : logl + (-0.5 * combine4(handP[lane]));
-            const double u = ymc_draw_uniform(a.seed, chain, t);
-            const bool moved = movedf[c] != 0;
-            if (*gave_up) st |= YMC_CHAIN_HANDOFF;
-            const bool acc1 = ymc_accept(lpy - lp, moved, ymc_finite(lpy), u, st);
-            lp = acc1 ? lpy : lp;
-            accepted += acc1 ? 1u : 0u;
-            if (g == 0) {
-                accf[c] = acc1 ? 1 : 0;
-                movedf[c] = 0;
-                if (live && scribe) {
-                    if (a.acc) a.acc[(uint64_t)n * a.K + kk] = acc1 ? 1 : 0;
-                    if (rec && a.lp_out) a.lp_out[(uint64_t)clk.row * a.K + kk] = lp;
-                }
-            }
+            if (g == 0) accf[c] = (int)((fl >> c) & 1u);
         }
         __syncthreads();
         {
@@ -874,7 +962,7 @@ __global__ __launch_bounds__(64 * W) void linear_wide_split_kernel(const WideSpl
                     }
                 }
             }
-            if (rec && a.traj && live && scribe) {
+            if (rec && a.traj && live && leader) {
                 double *row = a.traj + ((uint64_t)clk.row * a.K + kk) * (uint64_t)d + j0;
 #pragma unroll
                 for (int qi = 0; qi < QW; ++qi) {
@@ -893,7 +981,7 @@ __global__ __launch_bounds__(64 * W) void linear_wide_split_kernel(const WideSpl
         if (rec) clk.wrote();
     }
 
-    if (live && scribe) {
+    if (live && leader) {
         double *xr = a.x + kk * d + j0;
 #pragma unroll
         for (int qi = 0; qi < QW; ++qi)
@@ -909,7 +997,7 @@ __global__ __launch_bounds__(64 * W) void linear_wide_split_kernel(const WideSpl
 }
 
 /*
- * The same group of workgroups as a SYSTOLIC pipeline (up to 640 parameters, up to four output tiles per member).  What a
+ * The same group of workgroups as a SYSTOLIC pipeline (up to 640 parameters, one or two output tiles per member).  What a
  * member multiplies never changes during a launch -- its own rows of the matrix -- and wave w's slice of the proposal
  * (its q-range = the k-steps 2 q0 .. 2 (q0 + nq) - 1) is exactly the MFMA B operand of those k-steps, in the registers
  * of the lanes that made it.  So a wave keeps, for each of the member's output tiles, the matrix fragments of ITS k-steps in
@@ -917,11 +1005,10 @@ __global__ __launch_bounds__(64 * W) void linear_wide_split_kernel(const WideSpl
  * ascending: the bits of every other kernel) and travels on through LDS behind tickets; the last wave turns it into terms.
  * No proposal tile in LDS, no matrix traffic at all after the first transition, the tiles of a member one stage apart in the
  * pipeline, all four matrix pipes of the CU at work.
- * The group's decision is taken ONCE, by member 0 (the leader): every member sends its terms (write-through stores, one
- * arrival each), the leader's last wave waits for the G arrivals, the workgroup copies the slot into LDS (one acquire), the
- * last wave adds in the canonical order, decides and publishes sixteen accept flags tagged with the transition in ONE
- * 8-byte word per tile, which the other members' last waves poll (the data is the flag: Guideline 16, R2).  While a wave
- * waits it draws the NEXT transition's normals: they are addressed by (chain, transition, component), not by the outcome.
+ * While a wave waits for the group it draws the NEXT transition's normals: they are addressed by (chain, transition,
+ * component), not by the outcome (the last wave, which has the group to attend to, draws its own while the next
+ * transition's accumulators come down the pipeline).  The chains' state lives in LDS, every wave its slice: the registers are
+ * for the matrix and the two sets of normals.
  */
 template <int QW, int NM>
 __global__ __launch_bounds__(512) void linear_wide_systolic_kernel(const WideSplitArgs sa)
@@ -1121,16 +1208,7 @@ __global__ __launch_bounds__(512) void linear_wide_systolic_kernel(const WideSpl
                     tacc[0][0] = acc;
                     const double *mc = mconst - 16 * first_t; /* wide_terms indexes by the output's number */
                     wide_terms<1, 1>(tacc, MT, first_t + ti, g, mc, mc + NM * 16, mc + 2 * NM * 16);
-                    /* write-through (sc1): the bytes leave this XCD's L2 with the store.  The slot is lane-major
-                     * [tile][lane][4] so that a lane's four terms are two 16-byte stores (8-byte write-through stores cost
-                     * 2.7 x per byte); the data registers must outlive the issue: the s_nop */
-                    {
-                        typedef double d2 __attribute__((ext_vector_type(2)));
-                        double *dst = slot + (size_t)(first_t + ti) * 256 + 4 * lane;
-                        const d2 lo = {tacc[0][0][0], tacc[0][0][1]}, hi = {tacc[0][0][2], tacc[0][0][3]};
-                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1\n\ts_nop 1"
-                                     :: "v"(dst), "v"(lo), "v"(hi) : "memory");
-                    }
+                    wide_send_terms(slot, first_t + ti, lane, tacc[0][0]);
                 }
             }
         }
@@ -1146,72 +1224,12 @@ __global__ __launch_bounds__(512) void linear_wide_systolic_kernel(const WideSpl
         if (leader) {
             /* ---- the leader: all G arrivals, the slot into LDS (a chunk at a time), the sum, the decision ---- */
             const double u = decider ? ymc_draw_uniform(a.seed, chain, t) : 0.0; /* before the wait, not after it */
-#if !defined(YMC_WS_NOXCH)
-            if (decider) {
-                if (lane == 0 && !*gave_up) {
-                    const uint32_t want = epoch * (uint32_t)G;
-                    uint32_t spins = 0;
-                    while ((int32_t)(__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
-                        __builtin_amdgcn_s_sleep(1);
-                        if (++spins > sa.poll_limit) { /* a member is not running: do not hang the device */
-                            *gave_up = 1;
-                            __hip_atomic_fetch_add(sa.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                            break;
-                        }
-                    }
-                }
-#if defined(YMC_WS_SC1LOAD)  /* experiment: every load of the slot write-through-aware (sc1), no acquire (Guideline 16, Rule) */
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#else
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  /* ONE acquire after the match: this CU's stale lines go */
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    /* ... before the barrier lets the others load */
-#endif
-            }
-#endif
             double S = 0.0;
 #if defined(YMC_WS_NOXCH)
             __syncthreads();
 #else
-#pragma unroll 1
-            for (int c0 = 0; c0 < MT; c0 += TCH) {
-                const int nterm = (MT - c0 < TCH ? MT - c0 : TCH) * 256;
-                const double *src = slot + (size_t)c0 * 256;
-                __syncthreads();
-                /* 16-byte units (tile, lane, half) -> LDS [tile][4][64]; eight units per thread requested together */
-                typedef double d2 __attribute__((ext_vector_type(2)));
-                const d2 *src2 = reinterpret_cast<const d2 *>(src);
-                const int nunit = nterm / 2;
-#pragma unroll 1
-                for (int i = tid; i < nunit; i += 8 * 64 * W) {
-                    d2 v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int idx = i + u * 64 * W;
-#if defined(YMC_WS_SC1LOAD)
-                        const double *s8 = src + 2 * (size_t)(idx < nunit ? idx : i);
-                        v[u][0] = __hip_atomic_load(s8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        v[u][1] = __hip_atomic_load(s8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-                        v[u] = src2[idx < nunit ? idx : i];
-#endif
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int idx = i + u * 64 * W;
-                        if (idx < nunit) {
-                            double *dst = terms + (idx >> 7) * 256 + (idx & 1) * 128 + ((idx & 127) >> 1);
-                            dst[0] = v[u][0];
-                            dst[64] = v[u][1];
-                        }
-                    }
-                }
-                __syncthreads();
-                if (decider) {
-                    const double *tl = terms + lane;
-#pragma unroll 8
-                    for (int i = 0; i < nterm / 64; ++i) S = S + tl[i * 64]; /* outputs ascending: the canonical order */
-                }
-            }
+            if (decider) wide_await_arrivals(arrived, epoch * (uint32_t)G, sa, gave_up, lane);
+            S = wide_gather_sum<W>(slot, MT, TCH, terms, tid, lane, decider);
 #endif
             if (decider) {
                 const double logl = -0.5 * (combine4(S) + a.lik_const);
@@ -1219,9 +1237,7 @@ __global__ __launch_bounds__(512) void linear_wide_systolic_kernel(const WideSpl
                 const bool moved = movedf[c] != 0;
                 if (*gave_up) st |= YMC_CHAIN_HANDOFF;
                 const bool acc1 = ymc_accept(lpy - lp, moved, ymc_finite(lpy), u, st);
-                const unsigned long long flags = __ballot(acc1) & 0xffffull; /* lanes 0 .. 15: g = 0, chain c */
-                if (lane == 0) /* ONE aligned 8-byte write-through store: the transition is the tag */
-                    __hip_atomic_store(decision, ((unsigned long long)epoch << 32) | flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                wide_publish_decision(decision, epoch, acc1, lane);
                 lp = acc1 ? lpy : lp;
                 accepted += acc1 ? 1u : 0u;
                 if (g == 0) {
@@ -1235,23 +1251,11 @@ __global__ __launch_bounds__(512) void linear_wide_systolic_kernel(const WideSpl
             }
         } else if (decider) {
             /* ---- the others: the leader's word for this transition ---- */
-            unsigned long long v = 0;
 #if defined(YMC_WS_NOXCH)
-            v = 0x5a5aull;
+            const uint32_t fl = 0x5a5au;
+#else
+            const uint32_t fl = wide_await_decision(decision, epoch, sa, gave_up, lane);
 #endif
-            if (lane == 0 && !*gave_up && v == 0) {
-                uint32_t spins = 0;
-                while (((v = __hip_atomic_load(decision, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != epoch) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > sa.poll_limit) {
-                        *gave_up = 1;
-                        __hip_atomic_fetch_add(sa.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        v = 0;
-                        break;
-                    }
-                }
-            }
-            const uint32_t fl = (uint32_t)__shfl((int)(uint32_t)v, 0, 64);
             if (g == 0) accf[c] = (int)((fl >> c) & 1u);
         }
         __syncthreads();
@@ -1453,7 +1457,7 @@ size_t split_lds(const SplitPick &f, int KS, int MT)
     }
     const int ring = 4 * (f.W >= 16 ? 2 : 4);
     const size_t ksp = (size_t)((KS + ring - 1) / ring) * ring;
-    return (ksp * 64 + (size_t)MT * 256 + (f.CG ? 0 : 3 * d_pad) + 64) * sizeof(double) + (2 * 16 + 4) * sizeof(int);
+    return (ksp * 64 + (size_t)(MT < f.chunk ? MT : f.chunk) * 256 + (f.CG ? 0 : 3 * d_pad) + 64) * sizeof(double) + (2 * 16 + 4) * sizeof(int);
 }
 
 size_t split_fit(int KS, int MT, uint64_t K, int cus, SplitPick &f)
@@ -1477,25 +1481,26 @@ size_t split_fit(int KS, int MT, uint64_t K, int cus, SplitPick &f)
     /* the systolic build where a wave's k-steps of the member's rows fit its registers; YMC_WIDE_SPLIT_KERNEL=stream: the other */
     const char *ek = std::getenv("YMC_WIDE_SPLIT_KERNEL");
     const int per_member = (MT + G - 1) / G, qw8 = (Q + 7) / 8;
-    if (!(ek && ek[0] == 's' && ek[1] == 't') && qw8 <= 10 && per_member <= 4) {
-        f.W = 8, f.QW = qw8 <= 8 ? 8 : 10, f.NM = per_member <= 1 ? 1 : per_member <= 2 ? 2 : 4, f.CG = false;
+    /* (with four output tiles per member the fragments no longer fit the registers beside the draws: the other build is faster) */
+    if (!(ek && ek[0] == 's' && ek[1] == 't') && qw8 <= 10 && per_member <= 2) {
+        f.W = 8, f.QW = qw8 <= 8 ? 8 : 10, f.NM = per_member, f.CG = false;
         for (f.chunk = 32; f.chunk >= 8; f.chunk /= 2) {
             const size_t lds = split_lds(f, KS, MT);
             if (lds <= kTileLdsLimit) return lds;
         }
     }
-    f.NM = 0, f.chunk = 0;
+    f.NM = 0;
     f.W = 16, f.QW = 9;
     if (const char *ew = std::getenv("YMC_WIDE_SPLIT_W"))
         if (std::atoi(ew) == 8) f.W = 8, f.QW = 18;
     if ((Q + f.W - 1) / f.W > f.QW) return 0;
-    f.CG = false;
-    size_t lds = split_lds(f, KS, MT);
-    if (lds > kTileLdsLimit) {
-        f.CG = true;
-        lds = split_lds(f, KS, MT);
-    }
-    return lds <= kTileLdsLimit ? lds : 0;
+    for (f.chunk = 32; f.chunk >= 8; f.chunk /= 2)
+        for (int cg = 0; cg < 2; ++cg) {
+            f.CG = cg != 0;
+            const size_t lds = split_lds(f, KS, MT);
+            if (lds <= kTileLdsLimit) return lds;
+        }
+    return 0;
 }
 
 template <int W, int QW, bool CG>
@@ -1546,7 +1551,7 @@ hipError_t ymc_launch_wide_split(WideSplitArgs a, int cus, hipStream_t s)
     if (e != hipSuccess) return e;
 #define YMC_SYSTOLIC(QW_, NM_) \
     if (f.NM == NM_ && f.QW == QW_) return launch_systolic<QW_, NM_>(a, lds, s);
-    YMC_SYSTOLIC(8, 1) YMC_SYSTOLIC(8, 2) YMC_SYSTOLIC(8, 4) YMC_SYSTOLIC(10, 1) YMC_SYSTOLIC(10, 2) YMC_SYSTOLIC(10, 4)
+    YMC_SYSTOLIC(8, 1) YMC_SYSTOLIC(8, 2) YMC_SYSTOLIC(10, 1) YMC_SYSTOLIC(10, 2)
 #undef YMC_SYSTOLIC
     if (f.W == 16) return f.CG ? launch_split<16, 9, true>(a, lds, s) : launch_split<16, 9, false>(a, lds, s);
     return f.CG ? launch_split<8, 18, true>(a, lds, s) : launch_split<8, 18, false>(a, lds, s);
