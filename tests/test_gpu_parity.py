@@ -1490,14 +1490,19 @@ def test_tile_mlda2_beyond_the_lds_and_d128_vs_oracle(ffi, ctx, d, mc, mf, K, S,
 
 @pytest.mark.parametrize("d,m,nd,K,method,stride", [(300, 40, 2, 70, "mrw", 1), (513, 700, 3, 20, "pcn", 1), (1000, 64, 2, 17, "mrw", 4),
                                                     (257, 1, 1, 33, "mrw", 1), (320, 64, 2, 8229, "mrw", 1), (592, 48, 2, 8200, "pcn", 3),
-                                                    (512, 520, 1, 8192, "mrw", 2), (1024, 256, 2, 8192, "mrw", 5), (1100, 30, 1, 40, "pcn", 1)])
+                                                    (512, 520, 1, 8192, "mrw", 2), (1024, 256, 2, 8192, "mrw", 5), (1100, 30, 1, 40, "pcn", 1),
+                                                    (544, 100, 2, 8210, "beyond-L2", 1)])
 def test_wide_fused_kernel_vs_oracle_and_the_launch_per_stage_path(ffi, ctx, monkeypatch, d, m, nd, K, method, stride):
     """linear_wide_fused_kernel (round 4): the random walk and pCN beyond 256 parameters as ONE persistent launch per advance
     call -- the state in registers cut along k, the proposal in LDS, every wave its output tiles over all k, the sums handed
     from wave to wave behind tickets.  Small ensembles (sixteen waves a tile), large ones (eight waves, two tiles; one tile
-    beyond 576 parameters), ragged tails, several rounds of output tiles, thinned records, launches cut in two: == oracle,
-    and == the launch-per-stage path (YMC_WIDE_FUSED=0) bit for bit."""
+    beyond 576 parameters; two workgroups of eight waves per CU, the build for matrices no L2 holds, forced on a small one),
+    ragged tails, several rounds of output tiles, thinned records, launches cut in two: == oracle, and == the
+    launch-per-stage path (YMC_WIDE_FUSED=0) bit for bit."""
     from yagremcmc_amd import lowering
+    if method == "beyond-L2":
+        monkeypatch.setenv("YMC_WIDE_W", "88")
+        method = "mrw"
     rng = np.random.default_rng(4000 + d + m)
     g = dict(data=rng.normal(size=(nd, m)), noise_precision=rng.uniform(0.5, 3, size=m), prior_mean=rng.normal(size=d) * 0.1,
              prior_precision=rng.uniform(0.1, 2, size=d))

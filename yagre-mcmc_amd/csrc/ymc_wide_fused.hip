@@ -222,7 +222,7 @@ __device__ __forceinline__ void wide_evaluate(const WideEvalCtx &cx, const doubl
 }
 
 template <int NT, int W, int QW, int TC, bool CG>
-__global__ __launch_bounds__(64 * W) void linear_wide_fused_kernel(const WideFusedArgs a)
+__global__ __launch_bounds__(64 * W, (NT == 1 && W == 8 && QW == 9) ? 4 : 1) void linear_wide_fused_kernel(const WideFusedArgs a)
 {
     ymc_stage_tables();
     extern __shared__ double lds[];
@@ -1363,7 +1363,14 @@ bool pick_fused(int KS, int MT, uint64_t K, int cus, FusedPick &f)
 {
     const uint64_t nct = (K + 15) / 16;
     const int Q = KS / 2;
-    if (nct >= 2ull * (uint64_t)cus) { /* eight waves = two per SIMD, 256 registers each */
+    /* a matrix that no XCD's L2 holds (8 MB and more) is streamed from the memory side by every workgroup: two workgroups of
+     * eight waves per CU (128 registers a wave, one tile each) keep more requests in flight -- 0.50 -> 0.57 of the fp64 peak at
+     * d = 512, m = 2 048; below that size the build for 256 registers is faster (profiles/r04_wide_shapes.txt) */
+    const char *ew = std::getenv("YMC_WIDE_W");
+    const bool beyond_l2 = (size_t)KS * (size_t)MT * 512 >= ((size_t)8 << 20);
+    if (nct >= 2ull * (uint64_t)cus && Q <= 72 && (ew ? std::atoi(ew) == 88 : beyond_l2)) {
+        f.W = 8, f.NT = 1, f.QW = 9;
+    } else if (nct >= 2ull * (uint64_t)cus) { /* eight waves = two per SIMD, 256 registers each */
         f.W = 8;
         f.NT = Q <= 72 ? 2 : 1;
         f.QW = f.NT == 2 ? 9 : 18;
@@ -1379,6 +1386,7 @@ bool pick_fused(int KS, int MT, uint64_t K, int cus, FusedPick &f)
         const int want = std::atoi(env);
         if ((want == 1 || want == 2 || want == 4 || want == 8) && want <= cap) f.TC = want;
     }
+    if (f.W == 8 && f.NT == 1 && f.QW == 9) f.TC = 1; /* the build for 128 registers has one */
     return true;
 }
 
@@ -1432,6 +1440,8 @@ hipError_t ymc_launch_wide_fused(const WideFusedArgs &a, int cus, hipStream_t s)
 #define YMC_FUSED(NT_, W_, QW_, TC_)                                                                      \
     if (f.NT == NT_ && f.W == W_ && f.TC == TC_)                                                          \
         return f.CG ? launch_fused<NT_, W_, QW_, TC_, true>(a, lds, s) : launch_fused<NT_, W_, QW_, TC_, false>(a, lds, s);
+    if (f.NT == 1 && f.W == 8 && f.QW == 9)
+        return f.CG ? launch_fused<1, 8, 9, 1, true>(a, lds, s) : launch_fused<1, 8, 9, 1, false>(a, lds, s);
     YMC_FUSED(2, 8, 9, 2) YMC_FUSED(2, 8, 9, 1)
     YMC_FUSED(1, 8, 18, 2) YMC_FUSED(1, 8, 18, 1)
     YMC_FUSED(1, 16, 9, 1)
