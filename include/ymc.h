@@ -177,7 +177,9 @@ typedef struct ymc_problem_desc {
 /* per-chain status bits */
 #define YMC_CHAIN_NONFINITE 1u    /* a proposal's log-density was not finite; it was rejected */
 #define YMC_CHAIN_HANDOFF 2u      /* internal error: a launch cut into hand-over pieces (Lotka-Volterra, small ensembles)
-                                     never received this chain's state from the preceding piece; the chain stopped there */
+                                     never received this chain's state from the preceding piece and the chain stopped there,
+                                     or a group of workgroups sharing this chain's tile (linear models beyond 256
+                                     parameters, small ensembles) gave up waiting for one of its members */
 
 /* MetropolisHastings.run(chainLength, initialState) for n_chains chains
  * (metropolisHastings.py:103-110): chain k of this run is GLOBAL chain
