@@ -667,3 +667,58 @@ def test_random_wide_path_matches_oracle(case, monkeypatch):
         assert np.array_equal(acc, e.level_acc)
     x, lp = run.state()
     assert np.array_equal(x, e.x) and np.array_equal(lp, e.lp)
+
+
+@pytest.mark.parametrize("case", range(32))
+def test_random_group_kernels_match_oracle(case, monkeypatch):
+    """Round 4's group kernels (a tile of 16 chains over several workgroups: linear_wide_systolic_kernel, linear_wide_split_kernel),
+    fuzzed against the oracle: random walk and pCN beyond 256 parameters on small ensembles; group sizes forced to odd values,
+    both builds, both workgroup sizes of the streaming build, output counts from 1 to beyond one staging chunk, ragged
+    ensembles, chain offsets, thinned records, launches cut at random (the exchange slots alternate across the cut)."""
+    from yagremcmc_amd import _ffi as ffi, lowering
+    ctx = ffi.default_context(0)
+    rng = np.random.default_rng(17000 + case + _SEED_SHIFT)
+    method = ["mrw", "pcn"][case % 2]
+    d = int(rng.integers(257, 1100))
+    K = int(rng.choice([1, 16, 40, 130, 600, 2048]))
+    n = int(rng.integers(2, 15))
+    m_cap = max(1, min(2100, int(2.5e9 / (K * n * d))))
+    m = int(rng.integers(1, m_cap + 1)) if case % 4 else min(m_cap, int(rng.integers(500, 2100)))
+    seed, chain0 = int(rng.integers(0, 2**62)), int(rng.choice([0, 9, 2**31 + 7]))
+    cut = int(rng.integers(0, n + 1))
+    g_force = rng.choice(["", "2", "3", "7", "13"])
+    if g_force:
+        monkeypatch.setenv("YMC_WIDE_SPLIT_G", str(g_force))
+    if rng.random() < 0.4:
+        monkeypatch.setenv("YMC_WIDE_SPLIT_KERNEL", "stream")
+    if rng.random() < 0.5:
+        monkeypatch.setenv("YMC_WIDE_SPLIT_W", "8")
+    x0 = rng.normal(size=(K, d)) * 0.3
+    sigma = rng.uniform(0.01, 0.03, size=d)
+    low, p = _linear_pair(ffi, d, m, int(rng.integers(1, 4)), rng)
+    stride = int(rng.choice([1, 1, 3]))
+    flags = ffi.RECORD_TRAJECTORY | ffi.RECORD_LOGPOST | ((ffi.RECORD_ACCEPT | ffi.RECORD_MOMENTS) if stride == 1 else 0)
+    if method == "pcn":
+        low.set_array("prior_mean", np.zeros(d))
+        low.desc.likelihood_only = 1
+        p = dict(p, prior_mean=np.zeros(d), likelihood_only=1)
+        sigma = 1.0 / np.sqrt(p["prior_precision"])
+        h = float(rng.uniform(0.005, 0.05))
+        prob = lowering.make_problem(ctx, ffi.METHOD_PCN, low, sigma, pcn_step_size=h)
+        e = o.Ensemble(p, sigma, x0, seed, chain0=chain0, pcn_step_size=h)
+    else:
+        prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, sigma)
+        e = o.Ensemble(p, sigma, x0, seed, chain0=chain0)
+    run = ffi.Run(prob, seed, K, x0, n, flags, chain0, record_stride=stride)
+    run.advance(cut)
+    run.advance(n - cut)
+    out = e.advance(n)
+    rows = slice(stride - 1, None, stride)
+    assert np.array_equal(run.trajectory(), out["traj"][rows]) and np.array_equal(run.logpost(), out["logpost"][rows])
+    s_ = run.summary()
+    if stride == 1:
+        assert np.array_equal(run.accept(), out["acc"])
+        assert np.array_equal(s_["wf_mean"], e.wf_mean) and np.array_equal(s_["wf_m2"], e.wf_m2)
+    assert np.array_equal(s_["accepted"], e.acc_count) and np.array_equal(s_["status"], e.status)
+    x, lp = run.state()
+    assert np.array_equal(x, e.x) and np.array_equal(lp, e.lp)
