@@ -1594,6 +1594,48 @@ def test_wide_split_kernel_vs_oracle(ffi, ctx, monkeypatch, d, m, K, env):
     assert 0 < out["acc"].mean() < 1
 
 
+@pytest.mark.parametrize("d,m,K,stride", [(300, 20, 30, 1), (512, 128, 4100, 1), (417, 300, 50, 3), (590, 40, 17, 1), (264, 1, 16, 2)])
+def test_wide_fused_dense_proposal_vs_oracle_and_the_launch_per_stage_path(ffi, ctx, monkeypatch, d, m, K, stride):
+    """The random walk with a dense proposal covariance beyond 256 parameters as ONE persistent launch (linear_wide_fused_kernel's
+    dense build: the normals in a second LDS tile, L xi one more product on the matrix cores, written straight into the
+    proposal tile's B layout): == oracle and == the launch-per-stage path (YMC_WIDE_FUSED=0) bit for bit; moments replayed
+    from the record, thinned records, launches cut in two."""
+    from yagremcmc_amd import lowering
+    rng = np.random.default_rng(4300 + d + m)
+    g = dict(data=rng.normal(size=(2, m)), noise_precision=rng.uniform(0.5, 3, size=m), prior_mean=rng.normal(size=d) * 0.1,
+             prior_precision=rng.uniform(0.1, 2, size=d))
+    A, b = rng.normal(size=(m, d)) / np.sqrt(d), rng.normal(size=m)
+    low = _posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, g, fwd_matrix=A, fwd_shift=b)
+    p = o.posterior_linear(A, b, g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"])
+    B = rng.normal(size=(d, d)) * 0.02 / np.sqrt(d)
+    L = np.linalg.cholesky(B @ B.T + 0.0005 * np.eye(d))
+    x0 = rng.normal(size=(K, d)) * 0.3
+    n = 9
+    flags = ffi.RECORD_TRAJECTORY | ffi.RECORD_LOGPOST | ((ffi.RECORD_ACCEPT | ffi.RECORD_MOMENTS) if stride == 1 else 0)
+
+    def device(fused):
+        monkeypatch.setenv("YMC_WIDE_FUSED", "1" if fused else "0")
+        run = ffi.Run(lowering.make_problem(ctx, ffi.METHOD_MRW, low, np.ones(d), chol=np.tril(L)), 31, K, x0, n, flags, 5, record_stride=stride)
+        run.advance(4)
+        run.advance(n - 4)
+        run.sync()
+        s_ = run.summary()
+        return dict(traj=run.trajectory(), lp=run.logpost(), acc=run.accept() if stride == 1 else None, state=run.state(),
+                    accepted=s_["accepted"], wf=(s_["wf_mean"], s_["wf_m2"]))
+    fused, staged = device(True), device(False)
+    e = o.Ensemble(p, np.ones(d), x0, 31, chain0=5, chol=L)
+    out = e.advance(n)
+    rows = slice(stride - 1, None, stride)
+    for dev in (fused, staged):
+        assert np.array_equal(dev["traj"], out["traj"][rows]) and np.array_equal(dev["lp"], out["logpost"][rows])
+        assert np.array_equal(dev["state"][0], e.x) and np.array_equal(dev["state"][1], e.lp)
+        assert np.array_equal(dev["accepted"], e.acc_count)
+        if stride == 1:
+            assert np.array_equal(dev["acc"], out["acc"])
+            assert np.array_equal(dev["wf"][0], e.wf_mean) and np.array_equal(dev["wf"][1], e.wf_m2)
+    assert 0 < out["acc"].mean() < 1
+
+
 @pytest.mark.parametrize("kernel", ["systolic", "stream"])
 def test_an_abandoned_group_exchange_fails_the_run(ffi, ctx, monkeypatch, kernel):
     """The group kernels wait for other workgroups inside a launch (arrival counters, the leader's decision word): a wait

@@ -887,8 +887,10 @@ int launch_advance_wide(ymc_run *r, uint64_t nsteps)
     const bool replayable = !moments || ((r->flags & YMC_RECORD_TRAJECTORY) && r->stride == 1);
     /* small ensembles: a tile over a group of workgroups (linear_wide_split_kernel), the same results again */
     const int split_G = (!two && !p->chol_frag.p && replayable && nsteps < (1ull << 32)) ? ymc_wide_split_group(p->tgt.KS, p->tgt.MT, K, cus) : 0;
-    if (!two && !p->chol_frag.p && replayable && nsteps < (1ull << 32) &&
-        (split_G || ymc_wide_fused_lds_bytes(p->tgt.KS, p->tgt.MT, K, cus))) {
+    const bool dense_fused = !two && p->chol_frag.p && !a.pcn && replayable && nsteps < (1ull << 32) &&
+                             ymc_wide_fused_dense_lds_bytes(p->tgt.KS, p->tgt.MT, p->MT_L) != 0;
+    if (dense_fused || (!two && !p->chol_frag.p && replayable && nsteps < (1ull << 32) &&
+                        (split_G || ymc_wide_fused_lds_bytes(p->tgt.KS, p->tgt.MT, K, cus)))) {
         if (moments) {
             if (!r->x_before.p) YMC_TRY(r->x_before.alloc(r->x.bytes));
             YMC_HIP(hipMemcpyAsync(r->x_before.p, r->x.p, r->x.bytes, hipMemcpyDeviceToDevice, s));
@@ -910,7 +912,11 @@ int launch_advance_wide(ymc_run *r, uint64_t nsteps)
         if (r->flags & YMC_RECORD_ACCEPT) f.acc = r->acc.as<uint8_t>() + row * K;
         if (r->flags & YMC_RECORD_LOGPOST) f.lp_out = r->lp_out.as<double>() + row * K;
         hipError_t e;
-        if (split_G) {
+        if (dense_fused) {
+            f.chol_frag = p->chol_frag.as<double>();
+            f.MT_L = p->MT_L;
+            e = ymc_launch_wide_fused_dense(f, s);
+        } else if (split_G) {
             WideSplitArgs sp{};
             sp.f = f;
             const size_t xb = ymc_wide_split_exchange_bytes(p->tgt.MT, K), cb = ymc_wide_split_counter_bytes(K);
@@ -1526,7 +1532,8 @@ int ymc_problem_create(ymc_ctx *ctx, const ymc_problem_desc *desc, ymc_problem *
                     const int KS = p->tgt.KS, d = p->D;
                     p->MT_L = (d + 15) / 16;
                     p->MT_L += p->MT_L & 1;
-                    std::vector<double> frag((size_t)p->MT_L * KS * 64, 0.0);
+                    /* + one ring of k-steps of zeros: the fused kernel's padded k loop reads (and multiplies by zero) past KS */
+                    std::vector<double> frag((size_t)p->MT_L * KS * 64 + 16 * 64, 0.0);
                     for (int mt = 0; mt < p->MT_L; ++mt)
                         for (int s = 0; s < KS; ++s)
                             for (int l = 0; l < 64; ++l) {

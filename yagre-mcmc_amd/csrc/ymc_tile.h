@@ -136,6 +136,8 @@ struct WideFusedArgs {
     double *traj;                  /* plain record rows of this launch [rows][K][d], or null */
     uint8_t *acc;                  /* [nsteps][K] or null */
     double *lp_out;                /* [rows][K] or null */
+    const double *chol_frag;       /* dense proposal: the factor as A-operand fragments [MT_L][KS][64], else null */
+    int32_t MT_L, pad2_;
 };
 /* Two-level delayed acceptance (mlda.py:100-110,146-154) beyond 256 parameters the same way (linear_wide_fused2_kernel):
  * the fine state x and the sub-chain's state z as two slices of registers per wave, ONE tile of 16 chains per workgroup;
@@ -175,6 +177,9 @@ hipError_t ymc_launch_wide_split(WideSplitArgs a, int cus, hipStream_t s);
 /* 0 = this shape / ensemble does not take the fused kernel (the caller runs the launch-per-stage path) */
 size_t ymc_wide_fused_lds_bytes(int KS, int MT, uint64_t K, int cus);
 hipError_t ymc_launch_wide_fused(const WideFusedArgs &a, int cus, hipStream_t s);
+/* the random walk with a dense proposal covariance as one persistent launch (0 = does not fit: launches per stage) */
+size_t ymc_wide_fused_dense_lds_bytes(int KS, int MT, int MT_L);
+hipError_t ymc_launch_wide_fused_dense(const WideFusedArgs &a, hipStream_t s);
 /* the moments of a launch replayed from the plain record it wrote (rows = its transitions, record_stride 1) */
 hipError_t ymc_launch_welford_replay_plain(const double *traj, const double *x_before, uint64_t rows, uint64_t K, int d,
                                            uint64_t wf_n0, double *wf_mean, double *wf_m2, hipStream_t s);

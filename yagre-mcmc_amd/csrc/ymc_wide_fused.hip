@@ -106,9 +106,12 @@ __device__ __forceinline__ void wide_prior_chain(const WideEvalCtx &cx, const do
 /* F = A y on the matrix cores for the TC output tiles from t0 (those below MT) of the NT tiles' proposals in LDS: the FULL k
  * loop, k ascending per accumulator. */
 template <int NT, int TC, int KB, int PD>
-__device__ __forceinline__ void wide_products(const WideEvalCtx &cx, const double *__restrict__ blob, int MT, int t0, d4 (&acc)[NT][TC])
+__device__ __forceinline__ void wide_products(const WideEvalCtx &cx, const double *__restrict__ blob, int MT, int t0, d4 (&acc)[NT][TC],
+                                              int k_end = 0)
 {
-    const int KS = cx.KS, KSP = cx.KSP, lane = cx.lane;
+    /* k_end: whole rings of k-steps to run (0 = all KSP): a lower-triangular factor's rows have nothing but zeros beyond their
+     * diagonal block, and a zero product added to an accumulator changes no bit of it */
+    const int KS = cx.KS, KSP = k_end ? k_end : cx.KSP, lane = cx.lane;
     const double *A = blob + (size_t)t0 * KS * 64 + lane;
     const double *yk = cx.ylds + lane;
     /* a ring of PD stages of KB k-steps: stage i is multiplied while stages i + 1 .. i + PD - 1 are on their way
@@ -221,9 +224,14 @@ __device__ __forceinline__ void wide_evaluate(const WideEvalCtx &cx, const doubl
     tkS += (uint32_t)rounds * (uint32_t)W;
 }
 
-template <int NT, int W, int QW, int TC, bool CG>
+/* DENSE: the random walk with a dense proposal covariance (covariance.py:91-92), y = x + 1 (L xi): the normals go into a
+ * second LDS tile, L xi is one more product on the matrix cores (the factor's rows as output tiles, dealt to the waves like
+ * the forward map's; an output tile's accumulator IS the B-operand fragment of its four k-steps: lane (c, g), register rr
+ * = row 16 t + 4 rr + g = k-step 4 t + rr, component g), the slices' owners add their state. */
+template <int NT, int W, int QW, int TC, bool CG, bool DENSE = false>
 __global__ __launch_bounds__(64 * W, (NT == 1 && W == 8 && QW == 9) ? 4 : 1) void linear_wide_fused_kernel(const WideFusedArgs a)
 {
+    static_assert(!DENSE || NT == 1, "the dense proposal's build holds one tile");
     ymc_stage_tables();
     extern __shared__ double lds[];
     constexpr int KB = TC >= 4 ? 1 : 4 / TC; /* k-steps per stage of fragments: ~4 fragments (more cost registers: spills) */
@@ -231,7 +239,8 @@ __global__ __launch_bounds__(64 * W, (NT == 1 && W == 8 && QW == 9) ? 4 : 1) voi
     const int KS = a.KS, MT = a.MT, m_pad = 16 * MT, d_pad = 4 * KS, d = a.d;
     const int KSP = ((KS + PD * KB - 1) / (PD * KB)) * (PD * KB); /* the k-steps rounded up to whole rings of stages */
     double *ylds = lds;                                   /* [NT][KSP][64], zero beyond KS */
-    double *bias = ylds + (size_t)NT * KSP * 64;          /* bias | n prec | row mean | prior mean | prior prec | sigma */
+    double *xilds = ylds + (size_t)NT * KSP * 64;         /* DENSE: [KSP][64], the normals, zero beyond KS */
+    double *bias = xilds + (DENSE ? (size_t)KSP * 64 : 0); /* bias | n prec | row mean | prior mean | prior prec | sigma */
     double *nprec = bias + m_pad, *dbar = nprec + m_pad;
     /* CG: the three per-component constants stay in the problem's block in global memory (L2): beyond ~900 parameters
      * they no longer fit the LDS next to the proposal tile */
@@ -256,6 +265,8 @@ __global__ __launch_bounds__(64 * W, (NT == 1 && W == 8 && QW == 9) ? 4 : 1) voi
             const int nt = i / ((KSP - KS) * 64), r = i % ((KSP - KS) * 64);
             ylds[(nt * KSP + KS) * 64 + r] = 0.0;
         }
+        if (DENSE)
+            for (int i = tid; i < (KSP - KS) * 64; i += 64 * W) xilds[KS * 64 + i] = 0.0;
     }
     const uint64_t nct = (a.K + 15) / 16;
     const uint64_t tile0 = (uint64_t)blockIdx.x * NT;
@@ -323,6 +334,12 @@ __global__ __launch_bounds__(64 * W, (NT == 1 && W == 8 && QW == 9) ? 4 : 1) voi
                     ymc_draw_normal_pair(a.seed, chain, t, 4u * (uint32_t)(q0 + qi) + pair_of_g, &xi0, &xi1);
 #endif
                     swap_odd_even_rows(xi0, xi1);
+                    if (DENSE) { /* the normals into their tile; the proposal follows the product below */
+                        double *xw = xilds + (2 * q0) * 64 + lane;
+                        xw[(2 * qi) * 64] = xi0;
+                        xw[(2 * qi + 1) * 64] = xi1;
+                        continue;
+                    }
                     const double x0 = xs[nt][2 * qi], x1 = xs[nt][2 * qi + 1];
                     double y0, y1;
                     if (a.pcn) {
@@ -340,12 +357,60 @@ __global__ __launch_bounds__(64 * W, (NT == 1 && W == 8 && QW == 9) ? 4 : 1) voi
                 }
                 __builtin_amdgcn_sched_barrier(0); /* one pair's draws at a time */
             }
-            int mv = moved_l ? 1 : 0;
-            mv |= __shfl_xor(mv, 16, 64);
-            mv |= __shfl_xor(mv, 32, 64);
-            if (mv && g == 0) movedf[nt * 16 + c] = 1; /* every writer stores the same 1 */
+            if (!DENSE) {
+                int mv = moved_l ? 1 : 0;
+                mv |= __shfl_xor(mv, 16, 64);
+                mv |= __shfl_xor(mv, 32, 64);
+                if (mv && g == 0) movedf[nt * 16 + c] = 1; /* every writer stores the same 1 */
+            }
         }
         __syncthreads();
+        if constexpr (DENSE) {
+            /* ---- L xi on the matrix cores, into the proposal tile in the B layout ---- */
+            {
+                const WideEvalCtx cl{xilds, xilds + (2 * q0) * 64 + lane, nullptr, nullptr, ticket, KS, KSP, nq, lane, wave, g};
+                const int MT_L = a.MT_L, n_chunks = (MT_L + TC - 1) / TC, rounds = (n_chunks + W - 1) / W;
+#pragma unroll 1
+                for (int r = 0; r < rounds; ++r) {
+                    const int t0 = (r * W + wave) * TC;
+                    if (t0 >= MT_L) break;
+                    d4 acc[1][TC];
+#pragma unroll
+                    for (int tc = 0; tc < TC; ++tc) acc[0][tc] = d4{0.0, 0.0, 0.0, 0.0};
+                    /* the rows of output tiles t0 .. t0 + TC - 1 end with column 16 (t0 + TC) - 1 = k-step 4 (t0 + TC) - 1 */
+                    const int ring = PD * KB, k_need = 4 * (t0 + TC), k_run = ((k_need + ring - 1) / ring) * ring;
+                    wide_products<1, TC, KB, PD>(cl, a.chol_frag, MT_L, t0, acc, k_run < KSP ? k_run : KSP);
+#pragma unroll
+                    for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const int sk = 4 * (t0 + tc) + rr;
+                            if (t0 + tc < MT_L && sk < KS) ylds[sk * 64 + lane] = acc[0][tc][rr];
+                        }
+                }
+            }
+            __syncthreads();
+            /* ---- y = x + sigma (L xi) (covariance.py:91-92, mrw.py:32-38: sigma is one), every wave its slice, in place ---- */
+            {
+                bool moved_l = false;
+#pragma unroll
+                for (int qi = 0; qi < QW; ++qi) {
+                    if (qi < nq) {
+                        const double x0 = xs[0][2 * qi], x1 = xs[0][2 * qi + 1];
+                        const double y0 = x0 + sig_w[8 * qi] * y_w[(2 * qi) * 64];
+                        const double y1 = x1 + sig_w[8 * qi + 4] * y_w[(2 * qi + 1) * 64];
+                        y_w[(2 * qi) * 64] = y0;
+                        y_w[(2 * qi + 1) * 64] = y1;
+                        moved_l = moved_l || !(y0 == x0) || !(y1 == x1);
+                    }
+                }
+                int mv = moved_l ? 1 : 0;
+                mv |= __shfl_xor(mv, 16, 64);
+                mv |= __shfl_xor(mv, 32, 64);
+                if (mv && g == 0) movedf[c] = 1;
+            }
+            __syncthreads();
+        }
 
         /* ---- the evaluation: prior and residual sums handed from wave to wave behind tickets, F = A y on the matrix cores ---- */
         wide_evaluate<NT, W, QW, TC, KB, PD>(cx, a.blob, MT, bias, nprec, dbar, pm_w, pp_w, tkP, tkS);
@@ -1412,17 +1477,52 @@ size_t fused_fit(int KS, int MT, uint64_t K, int cus, FusedPick &f)
     return lds <= kTileLdsLimit ? lds : 0;
 }
 
-template <int NT, int W, int QW, int TC, bool CG>
+template <int NT, int W, int QW, int TC, bool CG, bool DENSE = false>
 hipError_t launch_fused(const WideFusedArgs &a, size_t lds, hipStream_t s)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_wide_fused_kernel<NT, W, QW, TC, CG>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&linear_wide_fused_kernel<NT, W, QW, TC, CG, DENSE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const uint64_t nct = (a.K + 15) / 16;
-    hipLaunchKernelGGL((linear_wide_fused_kernel<NT, W, QW, TC, CG>), dim3((unsigned)((nct + NT - 1) / NT)), dim3(64 * W), lds, s, a);
+    hipLaunchKernelGGL((linear_wide_fused_kernel<NT, W, QW, TC, CG, DENSE>), dim3((unsigned)((nct + NT - 1) / NT)), dim3(64 * W), lds, s, a);
     return hipGetLastError();
 }
+
+/* the dense proposal's build: one tile per workgroup of eight waves, two LDS tiles (the normals, the proposal) */
+size_t dense_fit(int KS, int MT, int MT_L, FusedPick &f)
+{
+    const int Q = KS / 2;
+    f.NT = 1, f.W = 8, f.QW = 18;
+    if ((Q + f.W - 1) / f.W > f.QW) return 0;
+    const int most = MT > MT_L ? MT : MT_L;
+    f.TC = (most + f.W - 1) / f.W >= 2 ? 2 : 1;
+    for (int cg = 0; cg < 2; ++cg) {
+        f.CG = cg != 0;
+        const int kb = 4 / f.TC, ring = kb * 4;
+        const size_t ksp = (size_t)((KS + ring - 1) / ring) * ring;
+        const size_t lds = fused_lds(f, KS, MT) + ksp * 64 * sizeof(double);
+        if (lds <= kTileLdsLimit) return lds;
+    }
+    return 0;
+}
 }  // namespace
+
+size_t ymc_wide_fused_dense_lds_bytes(int KS, int MT, int MT_L)
+{
+    if (const char *env = std::getenv("YMC_WIDE_FUSED"))
+        if (env[0] == '0') return 0;
+    FusedPick f;
+    return dense_fit(KS, MT, MT_L, f);
+}
+
+hipError_t ymc_launch_wide_fused_dense(const WideFusedArgs &a, hipStream_t s)
+{
+    FusedPick f;
+    const size_t lds = dense_fit(a.KS, a.MT, a.MT_L, f);
+    if (!lds || !a.chol_frag || a.pcn) return hipErrorInvalidValue;
+    if (f.TC == 2) return f.CG ? launch_fused<1, 8, 18, 2, true, true>(a, lds, s) : launch_fused<1, 8, 18, 2, false, true>(a, lds, s);
+    return f.CG ? launch_fused<1, 8, 18, 1, true, true>(a, lds, s) : launch_fused<1, 8, 18, 1, false, true>(a, lds, s);
+}
 
 size_t ymc_wide_fused_lds_bytes(int KS, int MT, uint64_t K, int cus)
 {
