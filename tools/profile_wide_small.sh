@@ -24,7 +24,7 @@ for rep in range(6):
     run.rewind_record()
     run.advance(n); run.sync()
 ms, launches = run.kernel_time_ms()
-print("256 chains d = m = 512: %.3f ms per launch of %d transitions (HIP events, %d launches)" % (ms / launches, n, launches))
+print("256 chains d = m = 512: %.3f ms per launch of %d transitions (HIP events, %d launches)" % (ms, n, launches))
 PY
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/r04_wsmall_stats -- python3 /tmp/wide_small_one.py > $OUT/r04_wsmall_stats.txt 2>&1 || exit 1
