@@ -1637,6 +1637,47 @@ def test_wide_fused_dense_proposal_vs_oracle_and_the_launch_per_stage_path(ffi, 
 
 
 @pytest.mark.parametrize("kernel", ["systolic", "stream"])
+def test_group_kernels_beside_another_launch(ffi, ctx, monkeypatch, kernel):
+    """The group kernels' exchange under UNEVEN load: a second context (its own stream) keeps the chip busy with the d = 128
+    matrix-core sampler while the group kernel runs -- its workgroups become resident at different times, every member's L1
+    is warm with the slot's previous contents (the slots alternate for 60 transitions) -- and the chains still equal the
+    oracle's bit for bit; then the other way round (the group kernel first)."""
+    from yagremcmc_amd import lowering
+    if kernel == "stream":
+        monkeypatch.setenv("YMC_WIDE_SPLIT_KERNEL", "stream")
+    rng = np.random.default_rng(91)
+
+    def linear(d, m):
+        g = dict(data=rng.normal(size=(2, m)), noise_precision=rng.uniform(0.5, 3, size=m), prior_mean=rng.normal(size=d) * 0.1,
+                 prior_precision=rng.uniform(0.1, 2, size=d))
+        A, b = rng.normal(size=(m, d)) / np.sqrt(d), rng.normal(size=m)
+        return (_posterior_low(ffi, ffi.POSTERIOR_LINEAR, d, g, fwd_matrix=A, fwd_shift=b),
+                o.posterior_linear(A, b, g["data"], g["noise_precision"], g["prior_mean"], g["prior_precision"]))
+    other = ffi.Context(ctx.device)
+    low_b, _ = linear(128, 128)
+    Kb = 65536
+    busy = ffi.Run(lowering.make_problem(other, ffi.METHOD_MRW, low_b, np.full(128, 0.03)), 3, Kb, rng.normal(size=(Kb, 128)) * 0.1, 1, 0, 0)
+    d, m, K, n = 400, 300, 128, 60
+    low, p = linear(d, m)
+    sigma, x0 = rng.uniform(0.01, 0.03, size=d), rng.normal(size=(K, d)) * 0.3
+    prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, sigma)
+    e = o.Ensemble(p, sigma, x0, 8, chain0=3)
+    out = e.advance(n)
+    for group_first in (False, True):
+        run = ffi.Run(prob, 8, K, x0, n, ffi.RECORD_TRAJECTORY | ffi.RECORD_ACCEPT | ffi.RECORD_LOGPOST, 3)
+        if group_first:
+            run.advance(n)
+        for _ in range(6):
+            busy.advance(40)      # asynchronous: ~3 ms each on the other stream
+        if not group_first:
+            run.advance(n)
+        run.sync()
+        busy.sync()
+        assert np.array_equal(run.trajectory(), out["traj"]) and np.array_equal(run.accept(), out["acc"])
+        assert np.array_equal(run.logpost(), out["logpost"]) and not run.summary()["status"].any()
+
+
+@pytest.mark.parametrize("kernel", ["systolic", "stream"])
 def test_an_abandoned_group_exchange_fails_the_run(ffi, ctx, monkeypatch, kernel):
     """The group kernels wait for other workgroups inside a launch (arrival counters, the leader's decision word): a wait
     that does not end within the poll limit gives up -- every wave still reaches the end of the launch -- and the run fails
