@@ -181,6 +181,10 @@ struct ymc_run {
     uint32_t flags = 0;
     uint64_t capacity = 0, recorded = 0, steps_done = 0;
     uint32_t stride = 1; /* record_stride: rows hold the states after transitions stride, 2 stride, ... of the run */
+    /* beyond 256 parameters: which kernel advances this run -- fixed at creation, because the persistent kernels write the
+     * trajectory in the matrix-core kernels' TILED layout and the launches per stage in plain rows */
+    enum WideKind { WIDE_STAGED = 0, WIDE_FUSED, WIDE_FUSED2, WIDE_DENSE, WIDE_GROUP } wide_kind = WIDE_STAGED;
+    bool traj_tiled() const { return problem->tile || wide_kind != WIDE_STAGED; }
     DeviceBuf x, lp, lpc, acc_count, wf_mean, wf_m2, status, traj, acc, lp_out, sub_acc, summary, x_before, recip;
     DeviceBuf level_acc; /* MLDA_NESTED: [E-1][K] */
     DeviceBuf handoff;   /* Lotka-Volterra rows kernel in hand-over pieces: transitions published per chain wave */
@@ -832,6 +836,26 @@ uint64_t tiled_row_doubles(const ymc_run *r)
     return ((r->K + 15) / 16) * (uint64_t)r->problem->tgt.KS * 64;
 }
 
+/* the wide path's kernel for a run (launch_advance_wide): the persistent ones where the shape, the ensemble and what the run
+ * records allow -- moments are replayed from the record, which must then hold every transition */
+ymc_run::WideKind pick_wide_kind(const ymc_run *r)
+{
+    const ymc_problem *p = r->problem;
+    if (!p->wide || p->method == YMC_METHOD_MLDA_NESTED) return ymc_run::WIDE_STAGED;
+    const bool two = p->method == YMC_METHOD_MLDA2;
+    const int cus = r->ctx->prop.multiProcessorCount;
+    const bool moments = (r->flags & YMC_RECORD_MOMENTS) != 0;
+    if (moments && !((r->flags & YMC_RECORD_TRAJECTORY) && r->stride == 1)) return ymc_run::WIDE_STAGED;
+    if (two)
+        return (!p->chol_frag.p && p->tgt.KS == p->sur.KS && ymc_wide_fused2_lds_bytes(p->tgt.KS, p->sur.MT, p->tgt.MT, r->K, cus))
+                   ? ymc_run::WIDE_FUSED2 : ymc_run::WIDE_STAGED;
+    if (p->chol_frag.p)
+        return (p->method != YMC_METHOD_PCN && ymc_wide_fused_dense_lds_bytes(p->tgt.KS, p->tgt.MT, p->MT_L)) ? ymc_run::WIDE_DENSE
+                                                                                                              : ymc_run::WIDE_STAGED;
+    if (ymc_wide_split_group(p->tgt.KS, p->tgt.MT, r->K, cus)) return ymc_run::WIDE_GROUP;
+    return ymc_wide_fused_lds_bytes(p->tgt.KS, p->tgt.MT, r->K, cus) ? ymc_run::WIDE_FUSED : ymc_run::WIDE_STAGED;
+}
+
 /* Beyond 256 parameters (random walk with a diagonal proposal, pCN over a linear model): a transition is five plain
  * launches over [K][d] arrays -- the draws, the proposal, the canonical-order evaluation (linear_big_eval_kernel, the
  * kernel behind evaluate_log at these sizes), the decision per chain, the move with record and moments.  The same
@@ -884,13 +908,13 @@ int launch_advance_wide(ymc_run *r, uint64_t nsteps)
     const int cus = r->ctx->prop.multiProcessorCount;
     const bool moments = (r->flags & YMC_RECORD_MOMENTS) != 0;
     /* moments: replayed from the record the launch writes -- which must then hold every transition */
-    const bool replayable = !moments || ((r->flags & YMC_RECORD_TRAJECTORY) && r->stride == 1);
-    /* small ensembles: a tile over a group of workgroups (linear_wide_split_kernel), the same results again */
-    const int split_G = (!two && !p->chol_frag.p && replayable && nsteps < (1ull << 32)) ? ymc_wide_split_group(p->tgt.KS, p->tgt.MT, K, cus) : 0;
-    const bool dense_fused = !two && p->chol_frag.p && !a.pcn && replayable && nsteps < (1ull << 32) &&
-                             ymc_wide_fused_dense_lds_bytes(p->tgt.KS, p->tgt.MT, p->MT_L) != 0;
-    if (dense_fused || (!two && !p->chol_frag.p && replayable && nsteps < (1ull << 32) &&
-                        (split_G || ymc_wide_fused_lds_bytes(p->tgt.KS, p->tgt.MT, K, cus)))) {
+    if (r->wide_kind != ymc_run::WIDE_STAGED && nsteps >= (1ull << 32))
+        return fail(YMC_ERR_INVALID, "more than 2^32 transitions in one launch");
+    const bool dense_fused = r->wide_kind == ymc_run::WIDE_DENSE;
+    const int split_G = r->wide_kind == ymc_run::WIDE_GROUP ? ymc_wide_split_group(p->tgt.KS, p->tgt.MT, K, cus) : 0;
+    if (r->wide_kind == ymc_run::WIDE_GROUP && !split_G)
+        return fail(YMC_ERR_INVALID, "the kernel selection changed under a live run (YMC_WIDE_* are read when the run is created)");
+    if (r->wide_kind == ymc_run::WIDE_FUSED || r->wide_kind == ymc_run::WIDE_DENSE || r->wide_kind == ymc_run::WIDE_GROUP) {
         if (moments) {
             if (!r->x_before.p) YMC_TRY(r->x_before.alloc(r->x.bytes));
             YMC_HIP(hipMemcpyAsync(r->x_before.p, r->x.p, r->x.bytes, hipMemcpyDeviceToDevice, s));
@@ -908,7 +932,7 @@ int launch_advance_wide(ymc_run *r, uint64_t nsteps)
         f.x = r->x.as<double>(), f.lp = r->lp.as<double>();
         f.acc_count = r->acc_count.as<uint64_t>(), f.status = r->status.as<uint32_t>();
         const uint64_t row = r->recorded;
-        if (r->flags & YMC_RECORD_TRAJECTORY) f.traj = r->traj.as<double>() + row * K * d;
+        if (r->flags & YMC_RECORD_TRAJECTORY) f.traj = r->traj.as<double>() + row * tiled_row_doubles(r); /* tiled rows */
         if (r->flags & YMC_RECORD_ACCEPT) f.acc = r->acc.as<uint8_t>() + row * K;
         if (r->flags & YMC_RECORD_LOGPOST) f.lp_out = r->lp_out.as<double>() + row * K;
         hipError_t e;
@@ -936,8 +960,8 @@ int launch_advance_wide(ymc_run *r, uint64_t nsteps)
             e = ymc_launch_wide_fused(f, cus, s);
         }
         if (e == hipSuccess && moments)
-            e = ymc_launch_welford_replay_plain(f.traj, r->x_before.as<double>(), nsteps, K, p->D, r->steps_done,
-                                                r->wf_mean.as<double>(), r->wf_m2.as<double>(), s);
+            e = ymc_launch_welford_replay(f.traj, r->x_before.as<double>(), nsteps, K, p->D, p->tgt.KS, r->steps_done,
+                                          r->wf_mean.as<double>(), r->wf_m2.as<double>(), s);
         if (e != hipSuccess) {
             r->pool.push_back(ev);
             return fail(YMC_ERR_DEVICE, "wide fused kernel launch failed: %s", hipGetErrorString(e));
@@ -947,8 +971,7 @@ int launch_advance_wide(ymc_run *r, uint64_t nsteps)
         return YMC_OK;
     }
     /* two-level delayed acceptance the same way: one persistent launch, x and z on the chip (linear_wide_fused2_kernel) */
-    if (two && !p->chol_frag.p && replayable && nsteps < (1ull << 32) && p->tgt.KS == p->sur.KS &&
-        ymc_wide_fused2_lds_bytes(p->tgt.KS, p->sur.MT, p->tgt.MT, K, cus)) {
+    if (r->wide_kind == ymc_run::WIDE_FUSED2) {
         if (moments) {
             if (!r->x_before.p) YMC_TRY(r->x_before.alloc(r->x.bytes));
             YMC_HIP(hipMemcpyAsync(r->x_before.p, r->x.p, r->x.bytes, hipMemcpyDeviceToDevice, s));
@@ -964,14 +987,14 @@ int launch_advance_wide(ymc_run *r, uint64_t nsteps)
         f.x = r->x.as<double>(), f.lp = r->lp.as<double>(), f.lpc = r->lpc.as<double>();
         f.acc_count = r->acc_count.as<uint64_t>(), f.status = r->status.as<uint32_t>();
         const uint64_t row = r->recorded;
-        if (r->flags & YMC_RECORD_TRAJECTORY) f.traj = r->traj.as<double>() + row * K * d;
+        if (r->flags & YMC_RECORD_TRAJECTORY) f.traj = r->traj.as<double>() + row * tiled_row_doubles(r); /* tiled rows */
         if (r->flags & YMC_RECORD_ACCEPT) f.acc = r->acc.as<uint8_t>() + row * K;
         if (r->flags & YMC_RECORD_LOGPOST) f.lp_out = r->lp_out.as<double>() + row * K;
         if (r->flags & YMC_RECORD_SUB_ACCEPT) f.sub_acc = r->sub_acc.as<uint8_t>() + row * S * K;
         hipError_t e = ymc_launch_wide_fused2(f, cus, s);
         if (e == hipSuccess && moments)
-            e = ymc_launch_welford_replay_plain(f.traj, r->x_before.as<double>(), nsteps, K, p->D, r->steps_done,
-                                                r->wf_mean.as<double>(), r->wf_m2.as<double>(), s);
+            e = ymc_launch_welford_replay(f.traj, r->x_before.as<double>(), nsteps, K, p->D, p->tgt.KS, r->steps_done,
+                                          r->wf_mean.as<double>(), r->wf_m2.as<double>(), s);
         if (e != hipSuccess) {
             r->pool.push_back(ev);
             return fail(YMC_ERR_DEVICE, "wide fused two-level kernel launch failed: %s", hipGetErrorString(e));
@@ -1703,8 +1726,9 @@ int ymc_run_create(ymc_ctx *ctx, const ymc_problem *problem, const ymc_run_desc 
         YMC_HIP(hipMemsetAsync(r->wf_mean.p, 0, r->wf_mean.bytes, ctx->stream));
         YMC_HIP(hipMemsetAsync(r->wf_m2.p, 0, r->wf_m2.bytes, ctx->stream));
         YMC_HIP(hipMemsetAsync(r->status.p, 0, r->status.bytes, ctx->stream));
+        r->wide_kind = pick_wide_kind(r);
         if (r->flags & YMC_RECORD_TRAJECTORY)
-            YMC_TRY(r->traj.alloc(r->capacity * (problem->tile ? tiled_row_doubles(r) : K * D) * sizeof(double)));
+            YMC_TRY(r->traj.alloc(r->capacity * (r->traj_tiled() ? tiled_row_doubles(r) : K * D) * sizeof(double)));
         if (r->flags & YMC_RECORD_ACCEPT) YMC_TRY(r->acc.alloc(r->capacity * K));
         if (r->flags & YMC_RECORD_LOGPOST) YMC_TRY(r->lp_out.alloc(r->capacity * K * sizeof(double)));
         if ((r->flags & YMC_RECORD_SUB_ACCEPT) &&
@@ -1904,7 +1928,7 @@ int ymc_run_steps_done(const ymc_run *run, uint64_t *total, uint64_t *recorded)
 int ymc_run_fetch_trajectory(ymc_run *run, uint64_t first, uint64_t n, double *dst, size_t dst_bytes)
 {
     if (!run) return fail(YMC_ERR_INVALID, "null argument");
-    if (run->problem->tile) {
+    if (run->traj_tiled()) {
         /* the record is in the kernel's tiled layout: untile on the device, chunk by chunk */
         if (!dst) return fail(YMC_ERR_INVALID, "null argument");
         if (!(run->flags & YMC_RECORD_TRAJECTORY)) return fail(YMC_ERR_INVALID, "the run does not record the trajectory");
@@ -1913,6 +1937,10 @@ int ymc_run_fetch_trajectory(ymc_run *run, uint64_t first, uint64_t n, double *d
         const uint64_t row_doubles = run->K * (uint64_t)run->problem->D;
         if (dst_bytes < n * row_doubles * sizeof(double)) return fail(YMC_ERR_INVALID, "destination too small");
         YMC_HIP(hipSetDevice(run->ctx->device));
+        if (run->fault.p) { /* an internal device error is never delivered as data (fetch_rows does the same) */
+            YMC_HIP(hipStreamSynchronize(run->ctx->stream));
+            YMC_TRY(check_internal_faults(run));
+        }
         const uint64_t chunk_rows = std::max<uint64_t>(1, (256ull << 20) / (row_doubles * sizeof(double)));
         DeviceBuf stage;
         YMC_TRY(stage.alloc(std::min(chunk_rows, std::max<uint64_t>(n, 1)) * row_doubles * sizeof(double)));
@@ -2066,7 +2094,7 @@ int ymc_run_egress_begin(ymc_run *run, int slot_index, uint64_t first, uint64_t 
     if (what & YMC_RECORD_LOGPOST) YMC_TRY(slot.lp.reserve(n * K * sizeof(double)));
     const double *traj_src = nullptr;
     if (what & YMC_RECORD_TRAJECTORY) {
-        if (run->problem->tile) {
+        if (run->traj_tiled()) {
             if (slot.untiled.bytes < n * traj_row) YMC_TRY(slot.untiled.alloc(n * traj_row));
             YMC_HIP(ymc_launch_untile(run->traj.as<double>(), first, n, K, D, run->problem->tgt.KS,
                                       slot.untiled.as<double>(), run->ctx->stream));
@@ -2228,7 +2256,7 @@ int ymc_run_iat(ymc_run *run, uint64_t first, uint64_t n, int method, double sok
         YMC_TRY(check_internal_faults(run));
     }
     return iat_from_device_states(run->ctx, run->traj.as<double>(), first, n, run->K, run->problem->D, method,
-                                  sokal_const, iat, run->problem->tile ? run->problem->tgt.KS : 0);
+                                  sokal_const, iat, run->traj_tiled() ? run->problem->tgt.KS : 0);
 }
 
 int ymc_iat_states(ymc_ctx *ctx, const double *states, uint64_t n, uint64_t n_chains, int32_t d, int method,

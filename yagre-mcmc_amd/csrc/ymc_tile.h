@@ -180,9 +180,6 @@ hipError_t ymc_launch_wide_fused(const WideFusedArgs &a, int cus, hipStream_t s)
 /* the random walk with a dense proposal covariance as one persistent launch (0 = does not fit: launches per stage) */
 size_t ymc_wide_fused_dense_lds_bytes(int KS, int MT, int MT_L);
 hipError_t ymc_launch_wide_fused_dense(const WideFusedArgs &a, hipStream_t s);
-/* the moments of a launch replayed from the plain record it wrote (rows = its transitions, record_stride 1) */
-hipError_t ymc_launch_welford_replay_plain(const double *traj, const double *x_before, uint64_t rows, uint64_t K, int d,
-                                           uint64_t wf_n0, double *wf_mean, double *wf_m2, hipStream_t s);
 hipError_t ymc_launch_wide_propose(const WideArgs &a, hipStream_t s);
 /* the normals of transition t in the matrix-core layout (xi_tiled) and the accept uniforms (a.u): the dense proposal's input */
 hipError_t ymc_launch_wide_draws(const WideArgs &a, uint64_t seed, uint64_t chain0, uint64_t t, double *xi_tiled, hipStream_t s);

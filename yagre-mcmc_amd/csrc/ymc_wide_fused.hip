@@ -188,7 +188,9 @@ __device__ __forceinline__ void wide_evaluate(const WideEvalCtx &cx, const doubl
     double *handS = cx.handS;
     volatile uint32_t *ticket = cx.ticket;
     const int n_chunks = (MT + TC - 1) / TC, rounds = (n_chunks + W - 1) / W;
+#if !defined(YMC_WF_NOPRIOR)
     wide_prior_chain<NT, W, QW>(cx, pm_w, pp_w, tkP);
+#endif
 
     /* ---- F = A y on the matrix cores ---- */
 #pragma unroll 1
@@ -199,7 +201,9 @@ __device__ __forceinline__ void wide_evaluate(const WideEvalCtx &cx, const doubl
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int tc = 0; tc < TC; ++tc) acc[nt][tc] = d4{0.0, 0.0, 0.0, 0.0};
+#if !defined(YMC_WF_NOPROD)   /* timing experiments only (tools/exp_wide_stages.sh) */
         if (t0 < MT) wide_products<NT, TC, KB, PD>(cx, blob, MT, t0, acc);
+#endif
         /* computed by all waves together, so that a phase of the hand-over below is nothing but the additions */
         wide_terms<NT, TC>(acc, MT, t0, g, bias, nprec, dbar);
         /* the residuals' hand-over: outputs ascending, chunk r W + w follows chunk r W + w - 1 */
@@ -277,8 +281,6 @@ __global__ __launch_bounds__(64 * W, (NT == 1 && W == 8 && QW == 9) ? 4 : 1) voi
     const int j0 = 8 * q0 + g;                       /* this lane's first component */
     const double *sig_w = sigma + j0, *pm_w = pmean + j0, *pp_w = pprec + j0;
     double *y_w = ylds + (2 * q0) * 64 + lane;       /* + nt KSP 64 + (2 qi + e) 64 */
-    const int left = d - j0 - 4;                      /* pairs qi with 8 qi < left have both their components below d */
-    const int full_q = left > 0 ? (left + 7) / 8 : 0;
 
     uint64_t kk[NT];
     bool live[NT];
@@ -412,6 +414,14 @@ __global__ __launch_bounds__(64 * W, (NT == 1 && W == 8 && QW == 9) ? 4 : 1) voi
             __syncthreads();
         }
 
+        /* the accept uniforms BEFORE the evaluation: the deciding wave ends both hand-over chains, and nothing of the draw
+         * depends on them (the empty asm keeps the compiler from sinking it back behind the last ticket) */
+        double u_dec[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            u_dec[nt] = wave == W - 1 ? ymc_draw_uniform(a.seed, (uint32_t)(a.chain0 + kk[nt]), t) : 0.0;
+            asm volatile("" : "+v"(u_dec[nt]));
+        }
         /* ---- the evaluation: prior and residual sums handed from wave to wave behind tickets, F = A y on the matrix cores ---- */
         wide_evaluate<NT, W, QW, TC, KB, PD>(cx, a.blob, MT, bias, nprec, dbar, pm_w, pp_w, tkP, tkS);
 
@@ -422,8 +432,7 @@ __global__ __launch_bounds__(64 * W, (NT == 1 && W == 8 && QW == 9) ? 4 : 1) voi
             for (int nt = 0; nt < NT; ++nt) {
                 const double logl = -0.5 * (combine4(handS[nt * 64 + lane]) + a.lik_const);
                 const double lpy = a.likelihood_only ? logl : logl + (-0.5 * combine4(handP[nt * 64 + lane]));
-                const uint32_t chain = (uint32_t)(a.chain0 + kk[nt]);
-                const double u = ymc_draw_uniform(a.seed, chain, t);
+                const double u = u_dec[nt];
                 const bool moved = movedf[nt * 16 + c] != 0;
                 const bool acc1 = ymc_accept(lpy - lp[nt], moved, ymc_finite(lpy), u, st[nt]);
                 lp[nt] = acc1 ? lpy : lp[nt];
@@ -454,20 +463,17 @@ __global__ __launch_bounds__(64 * W, (NT == 1 && W == 8 && QW == 9) ? 4 : 1) voi
                     }
                 }
             }
-            if (rec && a.traj && live[nt]) { /* ONE masked region: the chains that exist */
-                double *row = a.traj + ((uint64_t)clk.row * a.K + kk[nt]) * (uint64_t)d + j0;
+            /* the record row in the TILED layout of the matrix-core kernels, [tile][k-step][lane]: a wave's store of one k-step
+             * is 512 contiguous bytes (rows of 8 d bytes a chain would make it sixteen 32-byte pieces: 10 % of a transition at
+             * m = 64, profiles/r04_wide_shapes.txt); the host untiles on fetch.  Padding lanes are written like the others. */
+            if (rec && a.traj && tile0 + nt < nct) {
+                double *rowt = a.traj + (((uint64_t)clk.row * nct + tile0 + nt) * (uint64_t)KS + 2 * q0) * 64 + lane;
 #pragma unroll
-                for (int qi = 0; qi < QW; ++qi) {
+                for (int qi = 0; qi < QW; ++qi)
                     if (qi < nq) {
-                        if (qi < full_q) { /* both components exist in every lane's row */
-                            row[8 * qi] = xs[nt][2 * qi];
-                            row[8 * qi + 4] = xs[nt][2 * qi + 1];
-                        } else {
-                            if (j0 + 8 * qi < d) row[8 * qi] = xs[nt][2 * qi];
-                            if (j0 + 8 * qi + 4 < d) row[8 * qi + 4] = xs[nt][2 * qi + 1];
-                        }
+                        rowt[(2 * qi) * 64] = xs[nt][2 * qi];
+                        rowt[(2 * qi + 1) * 64] = xs[nt][2 * qi + 1];
                     }
-                }
             }
         }
         if (rec) clk.wrote();
@@ -547,8 +553,6 @@ __global__ __launch_bounds__(64 * W) void linear_wide_fused2_kernel(const WideFu
     const int j0 = 8 * q0 + g;
     const double *sig_w = sigma + j0;
     double *y_w = ylds + (2 * q0) * 64 + lane;
-    const int left = d - j0 - 4;
-    const int full_q = left > 0 ? (left + 7) / 8 : 0;
 
     const uint64_t k = tile * 16 + c;
     const bool live = tile < nct && k < a.K;
@@ -606,11 +610,12 @@ __global__ __launch_bounds__(64 * W) void linear_wide_fused2_kernel(const WideFu
             }
             any_moved(moved_l);
             __syncthreads();
+            double u = decider ? ymc_draw_uniform(a.seed, chain, t) : 0.0; /* before the evaluation: see linear_wide_fused_kernel */
+            asm volatile("" : "+v"(u));
             wide_evaluate<NT, W, QW, TC, KB, PD>(cx, a.blob_c, MT_c, bias_c, nprec_c, dbar_c, pmean_c + j0, pprec_c + j0, tkP, tkS);
             if (decider) {
                 const double logl = -0.5 * (combine4(handS[lane]) + a.lik_const_c);
                 const double lpcy = logl + (-0.5 * combine4(handP[lane]));
-                const double u = ymc_draw_uniform(a.seed, chain, t);
                 const bool moved = movedf[c] != 0;
                 const bool acc1 = ymc_accept(lpcy - lpcz, moved, ymc_finite(lpcy), u, st);
                 lpcz = acc1 ? lpcy : lpcz;
@@ -649,12 +654,13 @@ __global__ __launch_bounds__(64 * W) void linear_wide_fused2_kernel(const WideFu
             any_moved(moved_l);
         }
         __syncthreads();
+        double u = decider ? ymc_draw_uniform(a.seed, chain, tbase + (uint64_t)S) : 0.0;
+        asm volatile("" : "+v"(u));
         wide_evaluate<NT, W, QW, TC, KB, PD>(cx, a.blob_f, MT_f, bias_f, nprec_f, dbar_f, pmean_f + j0, pprec_f + j0, tkP, tkS);
         const bool rec = clk.due();
         if (decider) {
             const double logl = -0.5 * (combine4(handS[lane]) + a.lik_const_f);
             const double lpfz = logl + (-0.5 * combine4(handP[lane]));
-            const double u = ymc_draw_uniform(a.seed, chain, tbase + (uint64_t)S);
             const bool moved = movedf[c] != 0;
             const double log_ratio = ((lpfz + lpc) - lpcz) - lpf;
             const bool acc1 = ymc_accept(log_ratio, moved, ymc_finite(lpfz) && ymc_finite(lpcz), u, st);
@@ -675,20 +681,14 @@ __global__ __launch_bounds__(64 * W) void linear_wide_fused2_kernel(const WideFu
             const bool acc1 = accf[c] != 0;
 #pragma unroll
             for (int i = 0; i < 2 * QW; ++i) xs[i] = acc1 ? zs[i] : xs[i];
-            if (rec && a.traj && live) {
-                double *row = a.traj + ((uint64_t)clk.row * a.K + kk) * (uint64_t)d + j0;
+            if (rec && a.traj && tile < nct) { /* tiled, as linear_wide_fused_kernel's */
+                double *rowt = a.traj + (((uint64_t)clk.row * nct + tile) * (uint64_t)KS + 2 * q0) * 64 + lane;
 #pragma unroll
-                for (int qi = 0; qi < QW; ++qi) {
+                for (int qi = 0; qi < QW; ++qi)
                     if (qi < nq) {
-                        if (qi < full_q) {
-                            row[8 * qi] = xs[2 * qi];
-                            row[8 * qi + 4] = xs[2 * qi + 1];
-                        } else {
-                            if (j0 + 8 * qi < d) row[8 * qi] = xs[2 * qi];
-                            if (j0 + 8 * qi + 4 < d) row[8 * qi + 4] = xs[2 * qi + 1];
-                        }
+                        rowt[(2 * qi) * 64] = xs[2 * qi];
+                        rowt[(2 * qi + 1) * 64] = xs[2 * qi + 1];
                     }
-                }
             }
         }
         if (rec) clk.wrote();
@@ -884,8 +884,6 @@ __global__ __launch_bounds__(64 * W) void linear_wide_split_kernel(const WideSpl
     const int j0 = 8 * q0 + g;
     const double *sig_w = sigma + j0, *pm_w = pmean + j0, *pp_w = pprec + j0;
     double *y_w = ylds + (2 * q0) * 64 + lane;
-    const int left = d - j0 - 4;
-    const int full_q = left > 0 ? (left + 7) / 8 : 0;
 
     const uint64_t k = tile * 16 + c;
     const bool live = tile < nct && k < a.K;
@@ -1027,20 +1025,14 @@ __global__ __launch_bounds__(64 * W) void linear_wide_split_kernel(const WideSpl
                     }
                 }
             }
-            if (rec && a.traj && live && leader) {
-                double *row = a.traj + ((uint64_t)clk.row * a.K + kk) * (uint64_t)d + j0;
+            if (rec && a.traj && leader && tile < nct) { /* tiled, as linear_wide_fused_kernel's */
+                double *rowt = a.traj + (((uint64_t)clk.row * nct + tile) * (uint64_t)KS + 2 * q0) * 64 + lane;
 #pragma unroll
-                for (int qi = 0; qi < QW; ++qi) {
+                for (int qi = 0; qi < QW; ++qi)
                     if (qi < nq) {
-                        if (qi < full_q) {
-                            row[8 * qi] = xs[2 * qi];
-                            row[8 * qi + 4] = xs[2 * qi + 1];
-                        } else {
-                            if (j0 + 8 * qi < d) row[8 * qi] = xs[2 * qi];
-                            if (j0 + 8 * qi + 4 < d) row[8 * qi + 4] = xs[2 * qi + 1];
-                        }
+                        rowt[(2 * qi) * 64] = xs[2 * qi];
+                        rowt[(2 * qi + 1) * 64] = xs[2 * qi + 1];
                     }
-                }
             }
         }
         if (rec) clk.wrote();
@@ -1118,8 +1110,6 @@ __global__ __launch_bounds__(512) void linear_wide_systolic_kernel(const WideSpl
     const int Q = KS / 2, q0 = (wave * Q) / W, nq = ((wave + 1) * Q) / W - q0;
     const uint32_t pair_of_g = (g == 0) ? 0u : (g == 1) ? 2u : (g == 2) ? 1u : 3u;
     const int j0 = 8 * q0 + g;
-    const int left = d - j0 - 4;
-    const int full_q = left > 0 ? (left + 7) / 8 : 0;
 
     const uint64_t k = tile * 16 + c;
     const bool live = tile < nct && k < a.K;
@@ -1331,21 +1321,14 @@ __global__ __launch_bounds__(512) void linear_wide_systolic_kernel(const WideSpl
 #pragma unroll
                 for (int i = 0; i < 2 * QW; ++i) xl[i * 64] = ys[i];
             }
-            if (rec && a.traj && live && leader) {
-                double *row = a.traj + ((uint64_t)clk.row * a.K + kk) * (uint64_t)d + j0;
+            if (rec && a.traj && leader && tile < nct) { /* tiled, as linear_wide_fused_kernel's */
+                double *rowt = a.traj + (((uint64_t)clk.row * nct + tile) * (uint64_t)KS + 2 * q0) * 64 + lane;
 #pragma unroll
-                for (int qi = 0; qi < QW; ++qi) {
+                for (int qi = 0; qi < QW; ++qi)
                     if (qi < nq) {
-                        const double x0 = xl[(2 * qi) * 64], x1 = xl[(2 * qi + 1) * 64];
-                        if (qi < full_q) {
-                            row[8 * qi] = x0;
-                            row[8 * qi + 4] = x1;
-                        } else {
-                            if (j0 + 8 * qi < d) row[8 * qi] = x0;
-                            if (j0 + 8 * qi + 4 < d) row[8 * qi + 4] = x1;
-                        }
+                        rowt[(2 * qi) * 64] = xl[(2 * qi) * 64];
+                        rowt[(2 * qi + 1) * 64] = xl[(2 * qi + 1) * 64];
                     }
-                }
             }
         }
         if (rec) clk.wrote();
@@ -1369,50 +1352,6 @@ __global__ __launch_bounds__(512) void linear_wide_systolic_kernel(const WideSpl
 }
 
 }  // namespace
-
-/* FullDiagnostics' moments (estimation.py:36-53, diagnostics.py:91-94) for the fused kernel: replayed after the launch from
- * the plain record [rows][K][d] it wrote, one thread per chain and component -- the online update sequence per component,
- * hence the bits of the kernels that update in place (welford_replay_kernel is the same for the tiled record).  The state
- * before the launch's first transition is the carried state saved before the launch. */
-namespace {
-__global__ __launch_bounds__(256) void welford_replay_plain_kernel(const double *__restrict__ traj, const double *__restrict__ x_before,
-                                                                   uint64_t rows, uint64_t per_row, uint64_t wf_n0,
-                                                                   double *__restrict__ wf_mean, double *__restrict__ wf_m2)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= per_row) return;
-    double mean = wf_mean[i], m2 = wf_m2[i];
-    double v = x_before[i];
-    auto step = [&](uint64_t n, double next) {
-        const double dn = (double)(wf_n0 + n + 1);
-        const double delta = v - mean;
-        mean = mean + delta / dn;
-        const double delta2 = v - mean;
-        m2 = m2 + delta * delta2;
-        v = next;
-    };
-    uint64_t n = 0;
-    for (; n + 8 <= rows; n += 8) { /* eight rows requested together: the updates are sequential, the loads need not be */
-        double nx[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) nx[q] = traj[(n + q) * per_row + i];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) step(n + q, nx[q]);
-    }
-    for (; n < rows; ++n) step(n, traj[n * per_row + i]);
-    wf_mean[i] = mean;
-    wf_m2[i] = m2;
-}
-}  // namespace
-
-hipError_t ymc_launch_welford_replay_plain(const double *traj, const double *x_before, uint64_t rows, uint64_t K, int d,
-                                           uint64_t wf_n0, double *wf_mean, double *wf_m2, hipStream_t s)
-{
-    const uint64_t per_row = K * (uint64_t)d;
-    hipLaunchKernelGGL(welford_replay_plain_kernel, dim3((unsigned)((per_row + 255) / 256)), dim3(256), 0, s, traj, x_before, rows,
-                       per_row, wf_n0, wf_mean, wf_m2);
-    return hipGetLastError();
-}
 
 /* which build of linear_wide_fused_kernel an ensemble gets: large ensembles two tiles per workgroup of eight waves (two per
  * SIMD, every fragment of the matrix feeding two MFMAs; one tile beyond 576 parameters, where two do not fit the LDS),
@@ -1686,7 +1625,9 @@ size_t fused2_fit(int KS, int MT_c, int MT_f, uint64_t K, int cus, Fused2Pick &f
 {
     const uint64_t nct = (K + 15) / 16;
     const int Q = KS / 2;
-    if (nct >= (uint64_t)cus) f.W = 8, f.QW = (Q + 7) / 8 <= 9 ? 9 : 18; /* two slices of state: the smaller one where it does */
+    bool big = nct >= (uint64_t)cus;
+    if (const char *env = std::getenv("YMC_WIDE2_W")) big = std::atoi(env) != 16; /* experiments: the workgroup's size */
+    if (big) f.W = 8, f.QW = (Q + 7) / 8 <= 9 ? 9 : 18; /* two slices of state: the smaller one where it does */
     else f.W = 16, f.QW = (Q + 15) / 16 <= 5 ? 5 : 9;
     if ((Q + f.W - 1) / f.W > f.QW) return 0;
     const int per_wave = ((MT_f > MT_c ? MT_f : MT_c) + f.W - 1) / f.W;
