@@ -1498,12 +1498,12 @@ def test_wide_fused_kernel_vs_oracle_and_the_launch_per_stage_path(ffi, ctx, mon
     """linear_wide_fused_kernel (round 4): the random walk and pCN beyond 256 parameters as ONE persistent launch per advance
     call -- the state in registers cut along k, the proposal in LDS, every wave its output tiles over all k, the sums handed
     from wave to wave behind tickets.  Small ensembles (sixteen waves a tile), large ones (eight waves, two tiles; one tile
-    beyond 576 parameters; two workgroups of eight waves per CU, the build for matrices no L2 holds, forced on a small one),
+    beyond 576 parameters; sixteen waves, also the build for matrices no L2 holds, forced on a small one),
     ragged tails, several rounds of output tiles, thinned records, launches cut in two: == oracle, and == the
     launch-per-stage path (YMC_WIDE_FUSED=0) bit for bit."""
     from yagremcmc_amd import lowering
     if method == "beyond-L2":
-        monkeypatch.setenv("YMC_WIDE_W", "88")
+        monkeypatch.setenv("YMC_WIDE_W", "16")
         method = "mrw"
     rng = np.random.default_rng(4000 + d + m)
     g = dict(data=rng.normal(size=(nd, m)), noise_precision=rng.uniform(0.5, 3, size=m), prior_mean=rng.normal(size=d) * 0.1,

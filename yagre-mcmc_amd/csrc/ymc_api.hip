@@ -985,6 +985,8 @@ int launch_advance_wide(ymc_run *r, uint64_t nsteps)
         f.rec_stride = r->stride;
         f.rec_since = (uint32_t)(r->steps_done % r->stride);
         f.x = r->x.as<double>(), f.lp = r->lp.as<double>(), f.lpc = r->lpc.as<double>();
+        if (r->x_tiled.bytes < tiled_row_doubles(r) * sizeof(double)) YMC_TRY(r->x_tiled.alloc(tiled_row_doubles(r) * sizeof(double)));
+        f.x_park = r->x_tiled.as<double>();
         f.acc_count = r->acc_count.as<uint64_t>(), f.status = r->status.as<uint32_t>();
         const uint64_t row = r->recorded;
         if (r->flags & YMC_RECORD_TRAJECTORY) f.traj = r->traj.as<double>() + row * tiled_row_doubles(r); /* tiled rows */

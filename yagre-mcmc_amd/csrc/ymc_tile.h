@@ -150,6 +150,7 @@ struct WideFused2Args {
     uint64_t seed, chain0, K, t0;  /* t0: fine steps done */
     uint32_t nsteps, rec_stride, rec_since, pad1_;
     double *x, *lp, *lpc;          /* [K][d]; fine and coarse log-density of the carried state */
+    double *x_park;                /* [tiles][KS][64] scratch: the fine state during a fine step's sub-chain (tiled layout) */
     uint64_t *acc_count;
     uint32_t *status;
     double *traj;

@@ -233,7 +233,7 @@ __device__ __forceinline__ void wide_evaluate(const WideEvalCtx &cx, const doubl
  * the forward map's; an output tile's accumulator IS the B-operand fragment of its four k-steps: lane (c, g), register rr
  * = row 16 t + 4 rr + g = k-step 4 t + rr, component g), the slices' owners add their state. */
 template <int NT, int W, int QW, int TC, bool CG, bool DENSE = false>
-__global__ __launch_bounds__(64 * W, (NT == 1 && W == 8 && QW == 9) ? 4 : 1) void linear_wide_fused_kernel(const WideFusedArgs a)
+__global__ __launch_bounds__(64 * W) void linear_wide_fused_kernel(const WideFusedArgs a)
 {
     static_assert(!DENSE || NT == 1, "the dense proposal's build holds one tile");
     ymc_stage_tables();
@@ -558,14 +558,21 @@ __global__ __launch_bounds__(64 * W) void linear_wide_fused2_kernel(const WideFu
     const bool live = tile < nct && k < a.K;
     const uint64_t kk = live ? k : 0;
     const uint32_t chain = (uint32_t)(a.chain0 + kk);
-    double xs[2 * QW], zs[2 * QW];
+    /* The fine state x is PARKED in global memory (a.x_park, this tile's [KS][64] in the tiled layout, this wave's slice):
+     * it is needed only after the fine evaluation -- for `proposal == state`, the move and the record -- and as a second
+     * slice of registers it was live across every evaluation's matrix loop (170 spilled registers at 18 pairs per wave).
+     * zs is the sub-chain's state; between fine steps it IS the fine state. */
+    double zs[2 * QW];
+    double *park_w = a.x_park + ((uint64_t)tile * KS + 2 * q0) * 64 + lane;
     {
         const double *xr = a.x + kk * d + j0;
 #pragma unroll
         for (int qi = 0; qi < QW; ++qi)
 #pragma unroll
-            for (int e = 0; e < 2; ++e)
-                xs[2 * qi + e] = (live && qi < nq && j0 + 8 * qi + 4 * e < d) ? xr[8 * qi + 4 * e] : 0.0;
+            for (int e = 0; e < 2; ++e) {
+                zs[2 * qi + e] = (live && qi < nq && j0 + 8 * qi + 4 * e < d) ? xr[8 * qi + 4 * e] : 0.0;
+                if (qi < nq) park_w[(2 * qi + e) * 64] = zs[2 * qi + e];
+            }
     }
     /* the last wave: what a chain carries besides its state */
     const bool decider = wave == W - 1;
@@ -586,8 +593,6 @@ __global__ __launch_bounds__(64 * W) void linear_wide_fused2_kernel(const WideFu
 #pragma unroll 1
     for (uint32_t n = 0; n < a.nsteps; ++n) {
         const uint64_t tbase = (a.t0 + n) * (uint64_t)(S + 1);
-#pragma unroll
-        for (int i = 0; i < 2 * QW; ++i) zs[i] = xs[i];
         double lpcz = lpc;
         /* surrogate.run(S + 1, state), mlda.py:102-110: S random-walk transitions of z on the coarse posterior */
 #pragma unroll 1
@@ -641,22 +646,29 @@ __global__ __launch_bounds__(64 * W) void linear_wide_fused2_kernel(const WideFu
             }
         }
         /* the fine accept / reject, mlda.py:146-154: z into the tile, the fine posterior of z */
-        {
-            bool moved_l = false;
 #pragma unroll
-            for (int qi = 0; qi < QW; ++qi) {
-                if (qi < nq) {
-                    y_w[(2 * qi) * 64] = zs[2 * qi];
-                    y_w[(2 * qi + 1) * 64] = zs[2 * qi + 1];
-                    moved_l = moved_l || !(zs[2 * qi] == xs[2 * qi]) || !(zs[2 * qi + 1] == xs[2 * qi + 1]);
-                }
+        for (int qi = 0; qi < QW; ++qi) {
+            if (qi < nq) {
+                y_w[(2 * qi) * 64] = zs[2 * qi];
+                y_w[(2 * qi + 1) * 64] = zs[2 * qi + 1];
             }
-            any_moved(moved_l);
         }
         __syncthreads();
         double u = decider ? ymc_draw_uniform(a.seed, chain, tbase + (uint64_t)S) : 0.0;
         asm volatile("" : "+v"(u));
         wide_evaluate<NT, W, QW, TC, KB, PD>(cx, a.blob_f, MT_f, bias_f, nprec_f, dbar_f, pmean_f + j0, pprec_f + j0, tkP, tkS);
+        /* the fine state back from its parking place: did the sub-chain move at all (metropolisHastings.py:60-61)? */
+        double xs[2 * QW];
+        {
+            bool moved_l = false;
+#pragma unroll
+            for (int i = 0; i < 2 * QW; ++i) xs[i] = i < 2 * nq ? park_w[i * 64] : 0.0;
+#pragma unroll
+            for (int i = 0; i < 2 * QW; ++i)
+                if (i < 2 * nq) moved_l = moved_l || !(zs[i] == xs[i]);
+            any_moved(moved_l);
+        }
+        __syncthreads();
         const bool rec = clk.due();
         if (decider) {
             const double logl = -0.5 * (combine4(handS[lane]) + a.lik_const_f);
@@ -680,14 +692,17 @@ __global__ __launch_bounds__(64 * W) void linear_wide_fused2_kernel(const WideFu
         {
             const bool acc1 = accf[c] != 0;
 #pragma unroll
-            for (int i = 0; i < 2 * QW; ++i) xs[i] = acc1 ? zs[i] : xs[i];
+            for (int i = 0; i < 2 * QW; ++i) {
+                zs[i] = acc1 ? zs[i] : xs[i];
+                if (acc1 && i < 2 * nq) park_w[i * 64] = zs[i]; /* a rejected chain's parked state stays */
+            }
             if (rec && a.traj && tile < nct) { /* tiled, as linear_wide_fused_kernel's */
                 double *rowt = a.traj + (((uint64_t)clk.row * nct + tile) * (uint64_t)KS + 2 * q0) * 64 + lane;
 #pragma unroll
                 for (int qi = 0; qi < QW; ++qi)
                     if (qi < nq) {
-                        rowt[(2 * qi) * 64] = xs[2 * qi];
-                        rowt[(2 * qi + 1) * 64] = xs[2 * qi + 1];
+                        rowt[(2 * qi) * 64] = zs[2 * qi];
+                        rowt[(2 * qi + 1) * 64] = zs[2 * qi + 1];
                     }
             }
         }
@@ -700,7 +715,7 @@ __global__ __launch_bounds__(64 * W) void linear_wide_fused2_kernel(const WideFu
         for (int qi = 0; qi < QW; ++qi)
 #pragma unroll
             for (int e = 0; e < 2; ++e)
-                if (qi < nq && j0 + 8 * qi + 4 * e < d) xr[8 * qi + 4 * e] = xs[2 * qi + e];
+                if (qi < nq && j0 + 8 * qi + 4 * e < d) xr[8 * qi + 4 * e] = zs[2 * qi + e];
         if (decider && g == 0) {
             a.lp[kk] = lpf;
             a.lpc[kk] = lpc;
@@ -1367,13 +1382,13 @@ bool pick_fused(int KS, int MT, uint64_t K, int cus, FusedPick &f)
 {
     const uint64_t nct = (K + 15) / 16;
     const int Q = KS / 2;
-    /* a matrix that no XCD's L2 holds (8 MB and more) is streamed from the memory side by every workgroup: two workgroups of
-     * eight waves per CU (128 registers a wave, one tile each) keep more requests in flight -- 0.50 -> 0.57 of the fp64 peak at
-     * d = 512, m = 2 048; below that size the build for 256 registers is faster (profiles/r04_wide_shapes.txt) */
+    /* a matrix that no XCD's L2 holds (8 MB and more) is streamed from the memory side by every workgroup: sixteen waves a
+     * workgroup (four per SIMD, 128 registers a wave, one tile) keep more requests in flight -- 0.50 -> 0.64 of the fp64 peak
+     * at d = 512, m = 2 048; below that size the builds for 256 registers are faster (profiles/r04_wide_shapes.txt) */
     const char *ew = std::getenv("YMC_WIDE_W");
     const bool beyond_l2 = (size_t)KS * (size_t)MT * 512 >= ((size_t)8 << 20);
-    if (nct >= 2ull * (uint64_t)cus && Q <= 72 && (ew ? std::atoi(ew) == 88 : beyond_l2)) {
-        f.W = 8, f.NT = 1, f.QW = 9;
+    if (Q <= 144 && (ew ? std::atoi(ew) == 16 : (beyond_l2 && nct >= 2ull * (uint64_t)cus))) {
+        f.W = 16, f.NT = 1, f.QW = 9;
     } else if (nct >= 2ull * (uint64_t)cus) { /* eight waves = two per SIMD, 256 registers each */
         f.W = 8;
         f.NT = Q <= 72 ? 2 : 1;
@@ -1390,7 +1405,6 @@ bool pick_fused(int KS, int MT, uint64_t K, int cus, FusedPick &f)
         const int want = std::atoi(env);
         if ((want == 1 || want == 2 || want == 4 || want == 8) && want <= cap) f.TC = want;
     }
-    if (f.W == 8 && f.NT == 1 && f.QW == 9) f.TC = 1; /* the build for 128 registers has one */
     return true;
 }
 
@@ -1479,8 +1493,6 @@ hipError_t ymc_launch_wide_fused(const WideFusedArgs &a, int cus, hipStream_t s)
 #define YMC_FUSED(NT_, W_, QW_, TC_)                                                                      \
     if (f.NT == NT_ && f.W == W_ && f.TC == TC_)                                                          \
         return f.CG ? launch_fused<NT_, W_, QW_, TC_, true>(a, lds, s) : launch_fused<NT_, W_, QW_, TC_, false>(a, lds, s);
-    if (f.NT == 1 && f.W == 8 && f.QW == 9)
-        return f.CG ? launch_fused<1, 8, 9, 1, true>(a, lds, s) : launch_fused<1, 8, 9, 1, false>(a, lds, s);
     YMC_FUSED(2, 8, 9, 2) YMC_FUSED(2, 8, 9, 1)
     YMC_FUSED(1, 8, 18, 2) YMC_FUSED(1, 8, 18, 1)
     YMC_FUSED(1, 16, 9, 1)
@@ -1625,9 +1637,13 @@ size_t fused2_fit(int KS, int MT_c, int MT_f, uint64_t K, int cus, Fused2Pick &f
 {
     const uint64_t nct = (K + 15) / 16;
     const int Q = KS / 2;
-    bool big = nct >= (uint64_t)cus;
-    if (const char *env = std::getenv("YMC_WIDE2_W")) big = std::atoi(env) != 16; /* experiments: the workgroup's size */
-    if (big) f.W = 8, f.QW = (Q + 7) / 8 <= 9 ? 9 : 18; /* two slices of state: the smaller one where it does */
+    /* sixteen waves (four per SIMD, 128 registers) beat eight at every shape measured but the smallest forward maps
+     * (profiles/r04_wide_shapes.txt: d = 640, outputs 64 / 256: 11.3 -> 8.5 ms per 4 fine steps; d = 320, outputs 32 / 64: 4.0 -> 4.7):
+     * an evaluation is a chain of hand-overs and barriers, and more waves hide more of it */
+    bool eight = MT_f <= 4 && nct >= (uint64_t)cus;
+    if (const char *env = std::getenv("YMC_WIDE2_W")) eight = std::atoi(env) != 16; /* experiments and tests: the workgroup's size */
+    if ((Q + 15) / 16 > 9) eight = true;
+    if (eight) f.W = 8, f.QW = (Q + 7) / 8 <= 9 ? 9 : 18;
     else f.W = 16, f.QW = (Q + 15) / 16 <= 5 ? 5 : 9;
     if ((Q + f.W - 1) / f.W > f.QW) return 0;
     const int per_wave = ((MT_f > MT_c ? MT_f : MT_c) + f.W - 1) / f.W;
