@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "c4", "iat", "c3m", "c3a"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "c4", "iat", "c3m", "c3a", "wide", "widek"])
     ap.add_argument("--chains", type=int, default=0, help="chains per GPU (default: the workload's)")
     ap.add_argument("--transitions", type=int, default=0, help="MH transitions per chain per launch")
     ap.add_argument("--launches-per-step", type=int, default=0, help="kernel launches per bench step")
@@ -102,6 +102,9 @@ def _lv_lowered(ffi, lowering, design, data, noise_prec, prior_mean, prior_prec)
     return low
 
 
+MFMA_WORKLOADS = ("c3", "c3m", "c3a", "wide", "widek")   # linear models on the matrix cores: roofline = fp64 MFMA
+
+
 def make_workload(name, ffi, ctx, lowering):
     """-> dict(problem, x0 (1,d), K, T, L, desc, d, spec): defaults of chains / GPU, transitions / launch and
     launches / step; `spec` holds the arrays that describe the same problem to the cpu_baseline leg."""
@@ -121,9 +124,10 @@ def make_workload(name, ffi, ctx, lowering):
         return dict(problem=prob, x0=x0, K=131072, T=1000, L=100, d=2,
                     desc="C5: two-level delayed acceptance (example_mcmc_2d_twoLevel.py), S=6",
                     spec=dict(target=s_fine, sigma=sigma, surrogate=s_coarse, S=6))
-    if name in ("c3", "c3m", "c3a"):
-        # linear forward model, d = m = 128, nData = 5
-        d = 128
+    if name in MFMA_WORKLOADS:
+        # linear forward model, d = m = 128, nData = 5; "wide" / "widek": the same construction at d = m = 512
+        # (beyond the BASELINE configs: the persistent wide kernels on 65 536 chains, the group kernels on 256)
+        d = 512 if name in ("wide", "widek") else 128
         rng = np.random.default_rng(7)
         A = rng.standard_normal((d, d)) / np.sqrt(d)
         b = rng.standard_normal(d)
@@ -136,7 +140,7 @@ def make_workload(name, ffi, ctx, lowering):
         for k, v in (("data", data), ("noise_precision", noise_prec), ("prior_mean", prior_mean),
                      ("prior_precision", prior_prec), ("fwd_matrix", A), ("fwd_shift", b)):
             low.set_array(k, v)
-        sigma = np.sqrt(np.reciprocal(np.reciprocal(np.full(d, 1.1e-3))))
+        sigma = np.sqrt(np.reciprocal(np.reciprocal(np.full(d, 1.1e-3 * 128 / d))))
         if name == "c3a":
             # the adaptive error model over two models of C3's size: S = 4 coarse transitions per fine step,
             # the coarse likelihood learning the model error F_fine - F_coarse (minDataSize 8, noise heuristic on)
@@ -169,6 +173,14 @@ def make_workload(name, ffi, ctx, lowering):
                              "(fp64 MFMA tile kernel; steps = FINE steps, each with 5 coarse transitions)",
                         spec=dict(target=lin(A, b), surrogate=lin(A_c, b_c), S=S, sigma=sigma))
         prob = lowering.make_problem(ctx, ffi.METHOD_MRW, low, sigma)
+        if name in ("wide", "widek"):
+            small = name == "widek"
+            return dict(problem=prob, x0=np.zeros((1, d)), K=256 if small else 65536, T=1000 if small else 30, L=25 if small else 24, d=d,
+                        desc="linear forward model posterior d = m = 512, nData = 5 (" +
+                             ("a tile of 16 chains over a group of 16 workgroups: linear_wide_systolic_kernel)" if small
+                              else "one persistent launch per advance call: linear_wide_fused_kernel)"),
+                        spec=dict(target=dict(kind="linear", A=A, b=b, data=data, noise_prec=noise_prec,
+                                              prior_mean=prior_mean, prior_prec=prior_prec), sigma=sigma))
         return dict(problem=prob, x0=np.zeros((1, d)), K=262144, T=100, L=25, d=d,
                     desc="C3: linear forward model posterior d = m = 128, nData = 5 (fp64 MFMA tile kernel)",
                     spec=dict(target=dict(kind="linear", A=A, b=b, data=data, noise_prec=noise_prec,
@@ -269,7 +281,7 @@ def roofline_block(name, stride, wl, K, T, kernel_ms, launches, clock_mhz, info)
     sq = rec.get("sq_per_launch") or {}
     valu = None
     if sq.get("SQ_INSTS_VALU") and clock_mhz and ksec > 0:
-        waves = math.ceil(K / (16 if name in ("c3", "c3m", "c3a") else 64))   # waves' worth of chains
+        waves = math.ceil(K / (16 if name in MFMA_WORKLOADS else 64))   # waves' worth of chains
         simds = 4 * info["compute_units"]
         avail = ksec * clock_mhz * 1e6 * simds          # SIMD issue cycles in one launch
         mfma = sq.get("SQ_INSTS_MFMA", 0.0)
@@ -285,14 +297,14 @@ def roofline_block(name, stride, wl, K, T, kernel_ms, launches, clock_mhz, info)
                         "and a VALU instruction never execute together on gfx950: SQ_VALU_MFMA_COEXEC_CYCLES = 0); "
                         "instruction counts per wave of chains and transition",
                 "source": {"instr": rec.get("source"), "kernel_time_and_clock": "this run"}}
-    if name in ("c3", "c3m", "c3a"):
+    if name in MFMA_WORKLOADS:
         # c3m: S = 5 coarse + 1 fine forward map per fine step; c3a: S = 4 coarse + the fine matrix twice (likelihood, model error)
         maps = wl["spec"].get("fine_maps", 1) + wl["spec"].get("S", 0)
         flops = 2.0 * d * d * K * T * maps
         tf = flops / ksec / 1e12 if ksec > 0 else 0.0
         return dict(common, bound="mfma", achieved=tf, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=tf / FP64_PEAK_TFLOPS,
                     algorithmic_flops_per_launch=flops, valu=valu,
-                    note="per GPU (rank 0); v_mfma_f64_16x16x4_f64 GEMV (2 d m flop per transition); the 128 normal "
+                    note="per GPU (rank 0); v_mfma_f64_16x16x4_f64 GEMV (2 d m flop per transition); the d normal "
                          "draws per transition are VALU work on top of it -- DESIGN.md section 4")
     if name == "c4":
         flops = 10 * 50 * 50.0 * K * T   # n_data x rk4_steps x 50 flop (30 fp64 instructions, 20 of them fma)
@@ -366,7 +378,7 @@ def measure(name, args, ffi, ctx, lowering, info, rank, world, comm, steps, warm
     T = (args.transitions if headline else 0) or wl["T"]
     L = (args.launches_per_step if headline else 0) or wl["L"]
     d, x0 = wl["d"], wl["x0"]
-    no_moments = args.no_moments or name in ("c3", "c3m", "c3a")   # the tile kernels keep no Welford state (the
+    no_moments = args.no_moments or name in MFMA_WORKLOADS   # the tile kernels keep no Welford state (the
     #                                                                 reference's default diagnostics)
     stride = max(args.record_stride, 1) if headline else 1
     flags = ffi.RECORD_TRAJECTORY | (ffi.RECORD_ACCEPT if stride == 1 else 0) | (0 if no_moments else ffi.RECORD_MOMENTS)
@@ -402,9 +414,13 @@ def measure(name, args, ffi, ctx, lowering, info, rank, world, comm, steps, warm
         run.kernel_time_ms()
     probe_ms = min(max(0.8 * expect_s * 1e3, 1.0), 20000.0)
 
+    # "widek" keeps every CU busy with ONE resident workgroup of a group that meets once per transition: the probe's wave
+    # would share a CU with one of them and hold its whole group back (24 against 18 us per transition) -- not probed
+    probed = name != "widek"
     barrier()
     t0 = time.perf_counter()
-    ctx.clock_probe_start(probe_ms)
+    if probed:
+        ctx.clock_probe_start(probe_ms)
     for _ in range(steps):
         step()
     run.sync()
@@ -412,7 +428,7 @@ def measure(name, args, ffi, ctx, lowering, info, rank, world, comm, steps, warm
     if comm is not None:
         elapsed = comm.allreduce_max(elapsed)
     kernel_ms, launches = run.kernel_time_ms()
-    clock_mhz, probe_ran_ms = ctx.clock_probe_read()
+    clock_mhz, probe_ran_ms = ctx.clock_probe_read() if probed else (None, None)
     LAST_CLOCK_MHZ[0] = clock_mhz
 
     # the single collective of a run: gather the per-chain summaries
