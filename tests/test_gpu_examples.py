@@ -4,6 +4,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -16,7 +17,8 @@ CASES = [("example_mcmc_1d.py", []), ("example_mcmc_2d_singleLevel.py", ["256", 
          ("example_inference_lotkaVolterra_singleLevel.py", ["256", "400"]),
          ("example_inference_lotkaVolterra_singleLevel.py", ["256", "600", "adaptive"]),   # from the reference's own start
          ("example_inference_lotkaVolterra_twoLevel.py", ["256", "300"]),
-         ("example_inference_lotkaVolterra_twoLevel.py", ["256", "400", "adaptive"])]
+         ("example_inference_lotkaVolterra_twoLevel.py", ["256", "400", "adaptive"]),
+         ("example_inference_logisticGrowth_singleLevel.py", ["256", "600"])]    # the extension point's worked example
 
 
 @pytest.mark.parametrize("script,args", CASES, ids=["-".join([c[0]] + c[1][2:]) for c in CASES])
@@ -29,6 +31,12 @@ def test_example_runs(script, args):
     assert "acceptance rate" in out and "nan" not in out, r.stdout[-1500:]
     if "adaptive" in args:
         assert "chains flagged non-finite: 0" in out, r.stdout[-1500:]
+    if script == "example_inference_logisticGrowth_singleLevel.py":
+        import re
+        m = re.search(r"posterior mean: \[\s*([-0-9.e]+)\s+([-0-9.e]+)\s*\]", out)
+        truth = np.log(np.array([0.9, 2.5]))
+        assert m and abs(float(m.group(1)) - truth[0]) < 0.3 and abs(float(m.group(2)) - truth[1]) < 0.15, r.stdout[-1500:]
+        assert "chains flagged non-finite: 0" in out
     if script == "example_inference_linearModel_twoLevel.py":
         # the reference's flow (example_inference_linearModel_twoLevel.py:157-236): four reported stages, each with its
         # acceptance rate, its thinning stride from the device IAT and its posterior mean near the true parameter
