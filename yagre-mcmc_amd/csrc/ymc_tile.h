@@ -140,7 +140,7 @@ struct WideFusedArgs {
     int32_t MT_L, pad2_;
 };
 /* Two-level delayed acceptance (mlda.py:100-110,146-154) beyond 256 parameters the same way (linear_wide_fused2_kernel):
- * the fine state x and the sub-chain's state z as two slices of registers per wave, ONE tile of 16 chains per workgroup;
+ * the sub-chain's state z as a slice of registers per wave (the fine state x parked in x_park meanwhile), ONE tile of 16 chains per workgroup;
  * the S coarse transitions and the fine decision each one evaluation of the tile in LDS (the fine one after z has been
  * written into it). */
 struct WideFused2Args {

@@ -501,9 +501,10 @@ __global__ __launch_bounds__(64 * W) void linear_wide_fused_kernel(const WideFus
 }
 
 /*
- * Two-level delayed acceptance on the same plan.  One tile of 16 chains per workgroup: the fine state x and the
- * sub-chain's state z are two slices of registers per wave; a sub-step proposes from z into the LDS tile, evaluates the
- * COARSE posterior and moves z; the fine step writes z into the tile, evaluates the FINE posterior and decides with
+ * Two-level delayed acceptance on the same plan.  One tile of 16 chains per workgroup: the sub-chain's state z is a slice
+ * of registers per wave, the fine state x waits in global memory while the sub-chain runs (see x_park below); a sub-step
+ * proposes from z into the LDS tile, evaluates the COARSE posterior and moves z; the fine step writes z into the tile,
+ * evaluates the FINE posterior, fetches x, and decides with
  * ((pi_f(z) + pi_c(x)) - pi_c(z)) - pi_f(x) (mlda.py:146-154).  Fine step n owns transitions n (S + 1) + s, as everywhere.
  * The three per-component constant arrays of each level stay in global memory (L2) when they do not fit the LDS.
  */
