@@ -297,3 +297,24 @@ def test_module_paths_of_the_reference_resolve():
         m = importlib.import_module("yagremcmc_amd." + mod)
         for n in names:
             assert hasattr(m, n), f"{mod}.{n}"
+
+
+def test_every_build_selection_switch_is_documented_and_swept():
+    """The kernels' alternative builds are selected through YMC_* environment variables read in csrc/: each one is listed in
+    INTEGRATION.md ("Which kernel runs") and -- unless it only exists for a test or an experiment harness -- appears in
+    tools/env_sweep.sh, which runs the whole GPU suite under it (profiles/r04_env_sweep.txt)."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for f in glob.glob(os.path.join(root, "yagre-mcmc_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "yagre-mcmc_amd", "csrc", "*.h")):
+        names |= set(re.findall(r'getenv\("(YMC_[A-Z0-9_]+)"\)', open(f).read()))
+    assert len(names) >= 15, names
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    sweep = open(os.path.join(root, "tools", "env_sweep.sh")).read()
+    missing_doc = sorted(n for n in names if n not in doc)
+    assert not missing_doc, f"not in INTEGRATION.md: {missing_doc}"
+    not_swept_on_purpose = {"YMC_LV_POLL_LIMIT",      # test-only knob of the give-up paths
+                            "YMC_SPLIT_NP"}           # swept together with YMC_SPLIT
+    missing_sweep = sorted(n for n in names - not_swept_on_purpose if n not in sweep)
+    assert not missing_sweep, f"not in tools/env_sweep.sh: {missing_sweep}"
