@@ -206,9 +206,10 @@ __device__ __forceinline__ void wide_evaluate(const WideEvalCtx &cx, const doubl
 #endif
         /* computed by all waves together, so that a phase of the hand-over below is nothing but the additions */
         wide_terms<NT, TC>(acc, MT, t0, g, bias, nprec, dbar);
-        /* the residuals' hand-over: outputs ascending, chunk r W + w follows chunk r W + w - 1 */
-        {
-            const uint32_t tk = tkS + (uint32_t)r * (uint32_t)W + (uint32_t)wave;
+        /* the residuals' hand-over: outputs ascending, chunk c follows chunk c - 1; a wave whose chunk holds no output tile
+         * takes no part (with 64 outputs on eight waves that is half the hops) */
+        if (chunk < n_chunks) {
+            const uint32_t tk = tkS + (uint32_t)chunk;
             if (chunk > 0) wide_wait_ticket(ticket, 1, tk, lane);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -225,7 +226,9 @@ __device__ __forceinline__ void wide_evaluate(const WideEvalCtx &cx, const doubl
             if (lane == 0) ticket[1] = tk + 1;
         }
     }
-    tkS += (uint32_t)rounds * (uint32_t)W;
+    /* the LAST wave reads the sums next (it decides): unless the last chunk was its own it waits for that chunk's wave */
+    if (wave == W - 1 && rounds * W > n_chunks) wide_wait_ticket(ticket, 1, tkS + (uint32_t)n_chunks, lane);
+    tkS += (uint32_t)n_chunks;
 }
 
 /* DENSE: the random walk with a dense proposal covariance (covariance.py:91-92), y = x + 1 (L xi): the normals go into a
